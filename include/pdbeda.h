@@ -1,0 +1,179 @@
+/*
+ * pdbeda.h -- C-ABI of libpdbeda_hip.so: the MI355X (gfx950) electron-density voxel core.
+ *
+ * This is the drop-in boundary for the one accelerated path of pdb_eda: everything the
+ * reference routes through its `utils` seam (`from . import cutils as utils`,
+ * /root/reference/pdb_eda/ccp4.py:16-19 and densityAnalysis.py:26-29).  A per-voxel
+ * Python-tuple API cannot cross a device boundary, so the seam sits one level up:
+ * ccp4.py hands over the raw [s][r][c] grid and the unit-cell basis once
+ * (pdbeda_map_upload) and each entry point below replaces one reference call chain,
+ * cited per function (paths relative to /root/reference/pdb_eda/).
+ *
+ * Conventions
+ *   - plain C types only; all functions return 0 on success or a negative pdbeda_status;
+ *     pdbeda_last_error(ctx) gives the message.  No exception crosses the ABI.
+ *   - the caller owns every host buffer; the library owns device memory behind the
+ *     opaque handles.  A context is bound to ONE device and ONE HIP stream; N contexts
+ *     = N streams.  Calls on one context are not re-entrant; different contexts may be
+ *     used from different threads concurrently.
+ *   - crs triples are (column, row, section) = the reference's crsCoord order.
+ *   - "cutoff"/"radius" parameters are C floats on purpose: the reference's Cython
+ *     declares them `float` (cutils.pyx:28,185,205,220,250,273), i.e. the Python double
+ *     is rounded to float32 before use.
+ *   - there is no CPU fallback: without a usable gfx950 device every entry point fails
+ *     with PDBEDA_ERR_DEVICE.
+ */
+#ifndef PDBEDA_H
+#define PDBEDA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum pdbeda_status {
+    PDBEDA_OK = 0,
+    PDBEDA_ERR_DEVICE = -1,   /* no device / HIP runtime error */
+    PDBEDA_ERR_ARGUMENT = -2, /* bad argument */
+    PDBEDA_ERR_MEMORY = -3,   /* device or host allocation failed */
+    PDBEDA_ERR_CAPACITY = -4, /* caller buffer too small */
+    PDBEDA_ERR_STATE = -5     /* handle used in the wrong state */
+} pdbeda_status;
+
+typedef struct pdbeda_ctx pdbeda_ctx;           /* device + stream + reusable workspace */
+typedef struct pdbeda_map pdbeda_map;           /* one density grid resident in HBM */
+typedef struct pdbeda_bloblist pdbeda_bloblist; /* result of a labelling call */
+
+/* The "unit-cell basis" ccp4.py computes on the host (DensityHeader, ccp4.py:225-286). */
+typedef struct pdbeda_geometry {
+    int32_t ncrs[3];         /* header.ncrs                                   ccp4.py:168   */
+    int32_t crs_start[3];    /* header.crsStart                               ccp4.py:186   */
+    int32_t xyz_interval[3]; /* header.xyzInterval                            ccp4.py:227   */
+    int32_t map2xyz[3];      /* header.map2xyz                                ccp4.py:230-234 */
+    int32_t map2crs[3];      /* header.map2crs                                ccp4.py:235   */
+    int32_t orthogonal;      /* alpha == beta == gamma == 90                  ccp4.py:297   */
+    double ortho[9];         /* header.orthoMat (row major)                   ccp4.py:248-250 */
+    double deortho[9];       /* header.deOrthoMat (row major)                 ccp4.py:252-253 */
+    double origin[3];        /* header.origin                                 ccp4.py:272-286 */
+    double grid_len[3];      /* header.gridLength                             ccp4.py:228   */
+    double unit_volume;      /* header.unitVolume                             ccp4.py:243-244 */
+} pdbeda_geometry;
+
+/* ---- library / context ------------------------------------------------------------ */
+const char *pdbeda_version(void);
+int pdbeda_device_count(void);
+int pdbeda_ctx_create(int device_id, pdbeda_ctx **out);
+/* Bind to an existing hipStream_t (e.g. torch's current stream); stream == NULL -> new stream. */
+int pdbeda_ctx_create_on_stream(int device_id, void *hip_stream, pdbeda_ctx **out);
+int pdbeda_ctx_destroy(pdbeda_ctx *ctx);
+int pdbeda_ctx_synchronize(pdbeda_ctx *ctx);
+void *pdbeda_ctx_stream(pdbeda_ctx *ctx); /* the hipStream_t the kernels are launched on */
+const char *pdbeda_last_error(pdbeda_ctx *ctx);
+
+/* ---- map residency: replaces DensityMatrix.__init__ (ccp4.py:322-341) ------------- */
+/* density: host float32 [ns][nr][nc] (c fastest); copied to HBM. */
+int pdbeda_map_upload(pdbeda_ctx *ctx, const float *density, const pdbeda_geometry *geom, pdbeda_map **out);
+/* density_dev: a device pointer the caller keeps alive (zero-copy, e.g. a torch tensor). */
+int pdbeda_map_from_device(pdbeda_ctx *ctx, const float *density_dev, const pdbeda_geometry *geom, pdbeda_map **out);
+int pdbeda_map_free(pdbeda_map *map);
+
+/* ---- whole-map reductions --------------------------------------------------------- */
+/* DensityMatrix.meanDensity / stdDensity: np.mean / np.std (population) over ALL stored
+ * voxels in fp64 (ccp4.py:343-363). */
+int pdbeda_map_stats(pdbeda_map *map, double *mean, double *std);
+/* utils.sumOfAbs via getTotalAbsDensity: sum |v| for |v| > cutoff, strict (cutils.pyx:28-39,
+ * ccp4.py:365-376). */
+int pdbeda_sum_of_abs(pdbeda_map *map, float cutoff, double *out);
+
+/* ---- point / geometry helpers (batched) ------------------------------------------- */
+/* utils.getPointDensityFromCrs (cutils.pyx:125-145): periodic wrap, 0 outside the data. */
+int pdbeda_point_density(pdbeda_map *map, const int32_t *crs, int64_t n, double *out);
+/* utils.testValidCrs (cutils.pyx:147-167). */
+int pdbeda_valid_crs(pdbeda_map *map, const int32_t *crs, int64_t n, uint8_t *out);
+/* DensityHeader.crs2xyzCoord / xyz2crsCoord evaluated by the DEVICE code (ccp4.py:288-316);
+ * exposed so the parity tests can pin the kernels' geometry arithmetic. */
+int pdbeda_crs2xyz(pdbeda_map *map, const int32_t *crs, int64_t n, double *xyz);
+int pdbeda_xyz2crs(pdbeda_map *map, const double *xyz, int64_t n, int32_t *crs);
+
+/* ---- blob labelling --------------------------------------------------------------- */
+#define PDBEDA_FLAG_LABELS 1u /* also materialise the dense int32 label volume in HBM */
+
+/* DensityMatrix.createFullBlobList(cutoff) = utils.createFullCrsList + utils.createCrsLists
+ * + DensityBlob.fromCrsList (ccp4.py:463-485, 522-545; cutils.pyx:185-203, 44-70):
+ * inclusive threshold over the non-repeating box header.uniqueNcrs, 26-connected
+ * components (non-periodic), per-blob fp64 statistics, blobs ordered by the c-major
+ * position of their first voxel (the reference's emission order).  Asynchronous: returns
+ * after enqueueing; the first accessor synchronises.  cutoff == 0 -> PDBEDA_ERR_ARGUMENT
+ * (the reference returns None). */
+int pdbeda_full_blobs(pdbeda_map *map, float cutoff, uint32_t flags, pdbeda_bloblist **out);
+/* Fused green/red: ONE pass over the grid labels density >= cutoff_pos and
+ * density <= cutoff_neg (densityAnalysis.py:392-412 calls the above twice). */
+int pdbeda_full_blobs_pm(pdbeda_map *map, float cutoff_pos, float cutoff_neg, uint32_t flags,
+                         pdbeda_bloblist **green, pdbeda_bloblist **red);
+
+/* DensityMatrix.findAberrantBlobs (ccp4.py:437-461) = utils.getSphereCrsFromXyz[List]
+ * (cutils.pyx:220-271) + createBlobList, batched: atoms [group_offsets[g], group_offsets[g+1])
+ * form group g whose sphere voxels are unioned on RAW crs (a one-atom group is the
+ * single-coordinate call).  xyz: n_atoms x 3 doubles (float32 atom coordinates promoted
+ * exactly); radii: per atom.  Blobs come back sorted by (group, c-major first voxel of the
+ * group's bounding box). */
+int pdbeda_sphere_blobs(pdbeda_map *map, const double *xyz, const float *radii, int64_t n_atoms,
+                        const int64_t *group_offsets, int64_t n_groups, float density_cutoff,
+                        pdbeda_bloblist **out);
+
+/* DensityMatrix.createBlobList(crsList) (ccp4.py:475-485) on explicit raw voxel sets:
+ * voxels [group_offsets[g], group_offsets[g+1]) of crs (n x 3) form group g (duplicates
+ * collapse, as in DensityBlob's set).  Used for DensityBlob.merge / fromCrsList and for
+ * the residue / domain cloud unions of aggregateCloud (densityAnalysis.py:646-708). */
+int pdbeda_list_blobs(pdbeda_map *map, const int32_t *crs, int64_t n, const int64_t *group_offsets,
+                      int64_t n_groups, pdbeda_bloblist **out);
+
+/* ---- blob list accessors ---------------------------------------------------------- */
+int64_t pdbeda_bloblist_count(pdbeda_bloblist *bl);      /* number of blobs (synchronises) */
+int64_t pdbeda_bloblist_num_voxels(pdbeda_bloblist *bl); /* total voxels in all blobs */
+/* Per blob, any pointer may be NULL: n voxels, totalDensity, centroid[3], coordCenter[3],
+ * volume (= unitVolume * n), first_key (c-major position of the first voxel), group. */
+int pdbeda_bloblist_stats(pdbeda_bloblist *bl, int64_t *n, double *total_density, double *centroid,
+                          double *coord_center, double *volume, int64_t *first_key, int32_t *group);
+/* Voxel membership: crs (N x 3, raw coordinates) grouped by blob in blob order;
+ * blob_offsets has count+1 entries. */
+int pdbeda_bloblist_voxels(pdbeda_bloblist *bl, int32_t *crs, int64_t *blob_offsets);
+/* Dense labels of a full-map list: int32 [us][ur][uc] over header.uniqueNcrs, blob index or
+ * -1.  Computed on first use unless PDBEDA_FLAG_LABELS was given. */
+int pdbeda_bloblist_labels(pdbeda_bloblist *bl, int32_t *labels_host);
+int pdbeda_bloblist_free(pdbeda_bloblist *bl);
+
+/* ---- regional sums ---------------------------------------------------------------- */
+/* The voxel part of calculateRegionDiscrepancy / calculateRegionDensity
+ * (densityAnalysis.py:1037-1068, 1160-1211): per group (atom or residue sphere-union,
+ * deduplicated on raw crs): pos = sum of density > cutoff, neg = sum of density < -cutoff
+ * (strict, cutils.pyx:245), n_region = |sphere union| with no density filter
+ * (densityAnalysis.py:1198), valid = utils.testValidXyzList (cutils.pyx:273-313).
+ * Any output pointer may be NULL. */
+int pdbeda_region_sums(pdbeda_map *map, const double *xyz, const float *radii, int64_t n_atoms,
+                       const int64_t *group_offsets, int64_t n_groups, float cutoff,
+                       double *pos, double *neg, int64_t *n_region, uint8_t *valid);
+
+/* ---- voxel-set adjacency ---------------------------------------------------------- */
+/* utils.testOverlap (cutils.pyx:8-25) batched: pair p tests set a_idx[p] against set
+ * b_idx[p]; sets are slices [set_offsets[i], set_offsets[i+1]) of crs. */
+int pdbeda_test_overlap(pdbeda_ctx *ctx, const int32_t *crs, const int64_t *set_offsets, int64_t n_sets,
+                        const int32_t *a_idx, const int32_t *b_idx, int64_t n_pairs, uint8_t *out);
+
+/* ---- symmetry atoms --------------------------------------------------------------- */
+/* utils.createSymmetryAtoms (cutils.pyx:73-103): x' = R x + t + orthoMat (i,j,k) for
+ * (i,j,k) in {-1,0,1}^3 x ops, kept when inside bbox +- 5 A; the identity keeps all.
+ * Outputs in the reference's order; returns the count through n_out (capacity cap). */
+int pdbeda_symmetry_atoms(pdbeda_ctx *ctx, const double *xyz, int64_t n_atoms, const double *rot /* n_ops x 12 */,
+                          int32_t n_ops, const double ortho[9], const double bbox_lo[3], const double bbox_hi[3],
+                          int32_t *atom_index, int32_t *symmetry /* x4 */, double *out_xyz, int64_t cap, int64_t *n_out);
+/* calculateAtomSpecificBlobStatistics inner step (densityAnalysis.py:932-935): for every
+ * centroid the nearest atom (first index on ties, fp64 Euclidean as scipy cdist). */
+int pdbeda_nearest_atom(pdbeda_ctx *ctx, const double *centroids, int64_t n_centroids, const double *atom_xyz,
+                        int64_t n_atoms, int64_t *index, double *distance);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDBEDA_H */

@@ -1,0 +1,1045 @@
+// pdbeda_hip.hip -- host side of libpdbeda_hip.so: contexts, device arenas, job setup and the
+// extern "C" entry points declared in include/pdbeda.h.  gfx950 only, no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "pdbeda_kernels.h"
+#include "pdbeda_tile.h"
+
+using namespace pdbeda;
+
+// ------------------------------------------------------------------------------------
+// Handles
+// ------------------------------------------------------------------------------------
+struct Arena {
+    char *base = nullptr;
+    size_t cap = 0;
+};
+
+struct pdbeda_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    std::multimap<size_t, Arena> pool;  // free device arenas by capacity (reused: no hipMalloc in steady state)
+    double *partials = nullptr;         // reduction partials (N_PARTIAL doubles) + 4 result slots
+    void *pinned = nullptr;             // small pinned staging buffer
+    size_t pinned_cap = 0;
+    int live_handles = 0;
+};
+
+struct pdbeda_map {
+    pdbeda_ctx *ctx = nullptr;
+    const float *dens = nullptr;
+    bool own_dens = false;
+    Geom geom;
+    Geom *geom_dev = nullptr;
+    int64_t n_vox = 0;
+};
+
+struct pdbeda_bloblist {
+    pdbeda_ctx *ctx = nullptr;
+    pdbeda_map *map = nullptr;
+    Arena arena;
+    Job job;
+    int vol_lo = 0, vol_hi = 0;      // volumes of the job that belong to this list
+    bool owns_arena = true;          // the "red" list of a fused call shares the green list's arena
+    pdbeda_bloblist *sibling = nullptr;
+    bool freed = false;
+    // resolved lazily
+    bool have_counts = false;
+    int64_t rank_lo = 0, rank_hi = 0;  // blob rank range of this list inside the job's table
+    int64_t n_voxels = -1;
+    int32_t *labels_dev = nullptr;     // inside arena when requested
+    bool labels_done = false;
+    int64_t *offsets_dev = nullptr;
+    int32_t *crs_dev = nullptr;
+    unsigned int *cursor_dev = nullptr;
+    bool voxels_done = false;
+    Arena vox_arena;
+    bool whole_map = false;
+};
+
+static const int N_PARTIAL = 2048;
+
+static int fail(pdbeda_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(ctx, PDBEDA_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+static int arena_get(pdbeda_ctx *ctx, size_t bytes, Arena *out) {
+    bytes = align_up(std::max<size_t>(bytes, 256));
+    auto it = ctx->pool.lower_bound(bytes);
+    if (it != ctx->pool.end() && it->first <= bytes * 2 + (1u << 20)) {
+        *out = it->second;
+        ctx->pool.erase(it);
+        return 0;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        // drop the cache and retry once
+        for (auto &kv : ctx->pool) (void)hipFree(kv.second.base);
+        ctx->pool.clear();
+        e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return fail(ctx, PDBEDA_ERR_MEMORY, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
+    out->base = (char *)p;
+    out->cap = bytes;
+    return 0;
+}
+
+static void arena_put(pdbeda_ctx *ctx, Arena &a) {
+    if (a.base) ctx->pool.emplace(a.cap, a);
+    a.base = nullptr;
+    a.cap = 0;
+}
+
+struct Carver {
+    char *base;
+    size_t off = 0;
+    explicit Carver(char *b) : base(b) {}
+    template <typename T> T *take(size_t n) {
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += align_up(n * sizeof(T));
+        return p;
+    }
+};
+
+static int pinned_get(pdbeda_ctx *ctx, size_t bytes, void **out) {
+    if (ctx->pinned_cap < bytes) {
+        if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+        ctx->pinned = nullptr;
+        ctx->pinned_cap = 0;
+        size_t cap = std::max<size_t>(bytes, 1 << 16);
+        HIP_TRY(ctx, hipHostMalloc(&ctx->pinned, cap, hipHostMallocDefault));
+        ctx->pinned_cap = cap;
+    }
+    *out = ctx->pinned;
+    return 0;
+}
+
+static inline unsigned grid_for(int64_t n, int block, int64_t cap = 1 << 20) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+// ------------------------------------------------------------------------------------
+// Library / context
+// ------------------------------------------------------------------------------------
+extern "C" const char *pdbeda_version(void) { return "pdbeda-hip 0.1 (gfx950)"; }
+
+extern "C" int pdbeda_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int pdbeda_ctx_create_on_stream(int device_id, void *hip_stream, pdbeda_ctx **out) {
+    if (!out) return PDBEDA_ERR_ARGUMENT;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return PDBEDA_ERR_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) return PDBEDA_ERR_DEVICE;
+    pdbeda_ctx *ctx = new pdbeda_ctx();
+    ctx->device = device_id;
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDBEDA_ERR_DEVICE; }
+        ctx->own_stream = true;
+    }
+    if (hipMalloc((void **)&ctx->partials, sizeof(double) * (N_PARTIAL + 8)) != hipSuccess) {
+        if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return PDBEDA_ERR_MEMORY;
+    }
+    *out = ctx;
+    return PDBEDA_OK;
+}
+
+extern "C" int pdbeda_ctx_create(int device_id, pdbeda_ctx **out) { return pdbeda_ctx_create_on_stream(device_id, nullptr, out); }
+
+extern "C" int pdbeda_ctx_destroy(pdbeda_ctx *ctx) {
+    if (!ctx) return PDBEDA_ERR_ARGUMENT;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->pool) (void)hipFree(kv.second.base);
+    ctx->pool.clear();
+    if (ctx->partials) (void)hipFree(ctx->partials);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PDBEDA_OK;
+}
+
+extern "C" int pdbeda_ctx_synchronize(pdbeda_ctx *ctx) {
+    if (!ctx) return PDBEDA_ERR_ARGUMENT;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PDBEDA_OK;
+}
+
+extern "C" void *pdbeda_ctx_stream(pdbeda_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" const char *pdbeda_last_error(pdbeda_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+// ------------------------------------------------------------------------------------
+// Maps
+// ------------------------------------------------------------------------------------
+static int fill_geom(pdbeda_ctx *ctx, const pdbeda_geometry *in, Geom *g) {
+    for (int k = 0; k < 3; ++k) {
+        g->ncrs[k] = in->ncrs[k];
+        g->crs_start[k] = in->crs_start[k];
+        g->xyz_interval[k] = in->xyz_interval[k];
+        g->map2xyz[k] = in->map2xyz[k];
+        g->map2crs[k] = in->map2crs[k];
+        g->origin[k] = in->origin[k];
+        g->grid_len[k] = in->grid_len[k];
+        if (in->ncrs[k] <= 0) return fail(ctx, PDBEDA_ERR_ARGUMENT, "ncrs[%d] = %d", k, in->ncrs[k]);
+        if (in->xyz_interval[k] <= 0) return fail(ctx, PDBEDA_ERR_ARGUMENT, "xyz_interval[%d] = %d", k, in->xyz_interval[k]);
+        if (in->map2xyz[k] < 0 || in->map2xyz[k] > 2 || in->map2crs[k] < 0 || in->map2crs[k] > 2)
+            return fail(ctx, PDBEDA_ERR_ARGUMENT, "axis map out of range");
+    }
+    for (int k = 0; k < 9; ++k) { g->ortho[k] = in->ortho[k]; g->deortho[k] = in->deortho[k]; }
+    g->orthogonal = in->orthogonal;
+    g->unit_volume = in->unit_volume;
+    for (int k = 0; k < 3; ++k) {
+        g->crs_interval[k] = g->xyz_interval[g->map2crs[k]];                  // ccp4.py:237
+        g->unique_ncrs[k] = std::min(g->ncrs[k], g->crs_interval[k]);         // ccp4.py:262-269
+    }
+    return 0;
+}
+
+static int map_create(pdbeda_ctx *ctx, const float *host, const float *dev, const pdbeda_geometry *geom, pdbeda_map **out) {
+    if (!ctx || !geom || !out || (!host && !dev)) return PDBEDA_ERR_ARGUMENT;
+    *out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    pdbeda_map *m = new pdbeda_map();
+    m->ctx = ctx;
+    int rc = fill_geom(ctx, geom, &m->geom);
+    if (rc) { delete m; return rc; }
+    m->n_vox = (int64_t)geom->ncrs[0] * geom->ncrs[1] * geom->ncrs[2];
+    if (m->n_vox >= (1ll << 32)) { delete m; return fail(ctx, PDBEDA_ERR_ARGUMENT, "grids of 2^32 voxels or more are not supported"); }
+    hipError_t e = hipMalloc((void **)&m->geom_dev, sizeof(Geom));
+    if (e != hipSuccess) { delete m; return fail(ctx, PDBEDA_ERR_MEMORY, "hipMalloc geom: %s", hipGetErrorString(e)); }
+    e = hipMemcpyAsync(m->geom_dev, &m->geom, sizeof(Geom), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && host) {
+        float *d = nullptr;
+        e = hipMalloc((void **)&d, sizeof(float) * (size_t)m->n_vox);
+        if (e == hipSuccess) {
+            m->dens = d;
+            m->own_dens = true;
+            e = hipMemcpyAsync(d, host, sizeof(float) * (size_t)m->n_vox, hipMemcpyHostToDevice, ctx->stream);
+        }
+    } else if (e == hipSuccess) {
+        if (((uintptr_t)dev & 15u) != 0) {
+            (void)hipFree(m->geom_dev);
+            delete m;
+            return fail(ctx, PDBEDA_ERR_ARGUMENT, "device density pointer must be 16-byte aligned");
+        }
+        m->dens = dev;
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // host buffers may be released on return
+    if (e != hipSuccess) {
+        if (m->own_dens) (void)hipFree((void *)m->dens);
+        (void)hipFree(m->geom_dev);
+        delete m;
+        return fail(ctx, PDBEDA_ERR_DEVICE, "map upload: %s", hipGetErrorString(e));
+    }
+    ctx->live_handles++;
+    *out = m;
+    return PDBEDA_OK;
+}
+
+extern "C" int pdbeda_map_upload(pdbeda_ctx *ctx, const float *density, const pdbeda_geometry *geom, pdbeda_map **out) {
+    return map_create(ctx, density, nullptr, geom, out);
+}
+extern "C" int pdbeda_map_from_device(pdbeda_ctx *ctx, const float *density_dev, const pdbeda_geometry *geom, pdbeda_map **out) {
+    return map_create(ctx, nullptr, density_dev, geom, out);
+}
+
+extern "C" int pdbeda_map_free(pdbeda_map *m) {
+    if (!m) return PDBEDA_ERR_ARGUMENT;
+    pdbeda_ctx *ctx = m->ctx;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (m->own_dens) (void)hipFree((void *)m->dens);
+    (void)hipFree(m->geom_dev);
+    ctx->live_handles--;
+    delete m;
+    return PDBEDA_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Whole-map reductions
+// ------------------------------------------------------------------------------------
+static int reduce_launch(pdbeda_map *m, int mode, const double *mean_dev, double cutoff, double scale, int take_sqrt, double *out_dev) {
+    pdbeda_ctx *ctx = m->ctx;
+    hipLaunchKernelGGL(k_reduce_partials, dim3(N_PARTIAL), dim3(256), 0, ctx->stream, m->dens, m->n_vox, mode, mean_dev, cutoff, ctx->partials);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, N_PARTIAL, scale, take_sqrt, out_dev);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+extern "C" int pdbeda_map_stats(pdbeda_map *m, double *mean, double *std) {
+    if (!m) return PDBEDA_ERR_ARGUMENT;
+    pdbeda_ctx *ctx = m->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    double *res = ctx->partials + N_PARTIAL;
+    const double inv_n = 1.0 / (double)m->n_vox;
+    int rc = reduce_launch(m, 0, nullptr, 0.0, inv_n, 0, res);
+    if (rc) return rc;
+    rc = reduce_launch(m, 1, res, 0.0, inv_n, 1, res + 1);
+    if (rc) return rc;
+    double host[2];
+    HIP_TRY(ctx, hipMemcpyAsync(host, res, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (mean) *mean = host[0];
+    if (std) *std = host[1];
+    return PDBEDA_OK;
+}
+
+extern "C" int pdbeda_sum_of_abs(pdbeda_map *m, float cutoff, double *out) {
+    if (!m || !out) return PDBEDA_ERR_ARGUMENT;
+    pdbeda_ctx *ctx = m->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    double *res = ctx->partials + N_PARTIAL + 2;
+    int rc = reduce_launch(m, 2, nullptr, (double)cutoff, 1.0, 0, res);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out, res, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PDBEDA_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Small batched helpers: stage host arrays through a scratch arena
+// ------------------------------------------------------------------------------------
+template <typename Fn>
+static int with_scratch(pdbeda_ctx *ctx, size_t bytes, Fn fn) {
+    Arena a;
+    int rc = arena_get(ctx, bytes, &a);
+    if (rc) return rc;
+    rc = fn(a.base);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    arena_put(ctx, a);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(ctx, PDBEDA_ERR_DEVICE, "stream sync: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int pdbeda_point_density(pdbeda_map *m, const int32_t *crs, int64_t n, double *out) {
+    if (!m || (n > 0 && (!crs || !out)) || n < 0) return PDBEDA_ERR_ARGUMENT;
+    if (n == 0) return PDBEDA_OK;
+    pdbeda_ctx *ctx = m->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return with_scratch(ctx, align_up(12 * n) + align_up(8 * n), [&](char *base) -> int {
+        Carver cv(base);
+        int32_t *d_crs = cv.take<int32_t>(3 * n);
+        double *d_out = cv.take<double>(n);
+        HIP_TRY(ctx, hipMemcpyAsync(d_crs, crs, 12 * n, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_point_density, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->geom_dev, m->dens, d_crs, n, d_out, (uint8_t *)nullptr);
+        HIP_TRY(ctx, hipMemcpyAsync(out, d_out, 8 * n, hipMemcpyDeviceToHost, ctx->stream));
+        return 0;
+    });
+}
+
+extern "C" int pdbeda_valid_crs(pdbeda_map *m, const int32_t *crs, int64_t n, uint8_t *out) {
+    if (!m || (n > 0 && (!crs || !out)) || n < 0) return PDBEDA_ERR_ARGUMENT;
+    if (n == 0) return PDBEDA_OK;
+    pdbeda_ctx *ctx = m->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return with_scratch(ctx, align_up(12 * n) + align_up(n), [&](char *base) -> int {
+        Carver cv(base);
+        int32_t *d_crs = cv.take<int32_t>(3 * n);
+        uint8_t *d_out = cv.take<uint8_t>(n);
+        HIP_TRY(ctx, hipMemcpyAsync(d_crs, crs, 12 * n, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_point_density, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->geom_dev, m->dens, d_crs, n, (double *)nullptr, d_out);
+        HIP_TRY(ctx, hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, ctx->stream));
+        return 0;
+    });
+}
+
+extern "C" int pdbeda_crs2xyz(pdbeda_map *m, const int32_t *crs, int64_t n, double *xyz) {
+    if (!m || (n > 0 && (!crs || !xyz)) || n < 0) return PDBEDA_ERR_ARGUMENT;
+    if (n == 0) return PDBEDA_OK;
+    pdbeda_ctx *ctx = m->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return with_scratch(ctx, align_up(12 * n) + align_up(24 * n), [&](char *base) -> int {
+        Carver cv(base);
+        int32_t *d_crs = cv.take<int32_t>(3 * n);
+        double *d_xyz = cv.take<double>(3 * n);
+        HIP_TRY(ctx, hipMemcpyAsync(d_crs, crs, 12 * n, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_crs2xyz, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->geom_dev, d_crs, n, d_xyz);
+        HIP_TRY(ctx, hipMemcpyAsync(xyz, d_xyz, 24 * n, hipMemcpyDeviceToHost, ctx->stream));
+        return 0;
+    });
+}
+
+extern "C" int pdbeda_xyz2crs(pdbeda_map *m, const double *xyz, int64_t n, int32_t *crs) {
+    if (!m || (n > 0 && (!crs || !xyz)) || n < 0) return PDBEDA_ERR_ARGUMENT;
+    if (n == 0) return PDBEDA_OK;
+    pdbeda_ctx *ctx = m->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return with_scratch(ctx, align_up(12 * n) + align_up(24 * n), [&](char *base) -> int {
+        Carver cv(base);
+        double *d_xyz = cv.take<double>(3 * n);
+        int32_t *d_crs = cv.take<int32_t>(3 * n);
+        HIP_TRY(ctx, hipMemcpyAsync(d_xyz, xyz, 24 * n, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_xyz2crs, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->geom_dev, d_xyz, n, d_crs);
+        HIP_TRY(ctx, hipMemcpyAsync(crs, d_crs, 12 * n, hipMemcpyDeviceToHost, ctx->stream));
+        return 0;
+    });
+}
+
+// ------------------------------------------------------------------------------------
+// Labelling jobs
+// ------------------------------------------------------------------------------------
+// Carve a job out of an arena.  max_runs / max_blobs are worst-case bounds (a run needs a
+// gap: <= bits/2 + 1 per word; a blob owns >= one 2x2x2 cell... we simply bound blobs by runs).
+static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, int64_t total_keys, int64_t max_runs,
+                        int64_t max_blobs, size_t extra_labels, int32_t **labels_out) {
+    Carver cv(base);
+    job.n_vols = n_vols;
+    job.total_words = total_words;
+    job.key_words = (total_keys + 63) / 64;
+    job.n_chunks = (int32_t)((job.key_words + KEY_CHUNK - 1) / KEY_CHUNK);
+    job.ctr = cv.take<Counters>(1);
+    job.vols = cv.take<VolDesc>(std::max(n_vols, 1));
+    job.mask = cv.take<uint64_t>(total_words);
+    job.key_bits = cv.take<uint64_t>(job.key_words);
+    job.run_base = cv.take<uint32_t>(total_words);
+    job.key_rank = cv.take<uint32_t>(job.key_words);
+    job.chunk_count = cv.take<uint32_t>(std::max(job.n_chunks, 1));
+    job.chunk_prefix = cv.take<uint32_t>(std::max(job.n_chunks, 1));
+    job.parent = cv.take<int32_t>(max_runs);
+    job.r_n = cv.take<uint32_t>(max_runs);
+    job.r_rho = cv.take<double>(max_runs);
+    job.r_rho_c = cv.take<double>(max_runs);
+    job.r_rho_r = cv.take<double>(max_runs);
+    job.r_rho_s = cv.take<double>(max_runs);
+    job.r_c = cv.take<long long>(max_runs);
+    job.r_r = cv.take<long long>(max_runs);
+    job.r_s = cv.take<long long>(max_runs);
+    job.r_key = cv.take<unsigned long long>(max_runs);
+    job.r_rank = cv.take<uint32_t>(max_runs);
+    job.b_n = cv.take<int64_t>(max_blobs);
+    job.b_key = cv.take<int64_t>(max_blobs);
+    job.b_total = cv.take<double>(max_blobs);
+    job.b_centroid = cv.take<double>(3 * max_blobs);
+    job.b_center = cv.take<double>(3 * max_blobs);
+    job.b_volume = cv.take<double>(max_blobs);
+    job.b_group = cv.take<int32_t>(max_blobs);
+    int32_t *lab = extra_labels ? cv.take<int32_t>(extra_labels) : nullptr;
+    if (labels_out) *labels_out = lab;
+    return cv.off;
+}
+
+// Enqueue the labelling engine on a job whose masks are already painted.
+static int engine_enqueue(pdbeda_ctx *ctx, pdbeda_map *m, Job &job, int64_t max_runs) {
+    hipStream_t st = ctx->stream;
+    // per-run kernels are grid-stride over the ACTUAL run count (read on the device)
+    const unsigned run_grid = grid_for(max_runs, 256, 2048);
+    if (job.total_words > 0) {
+        hipLaunchKernelGGL(k_run_index, dim3(grid_for(job.total_words, 256, 1ll << 30)), dim3(256), 0, st, job, m->dens, m->geom_dev);
+        hipLaunchKernelGGL(k_union, dim3(grid_for(job.total_words, 256, 1ll << 30)), dim3(256), 0, st, job);
+        hipLaunchKernelGGL(k_resolve, dim3(run_grid), dim3(256), 0, st, job);
+        hipLaunchKernelGGL(k_paint_keys, dim3(run_grid), dim3(256), 0, st, job);
+    }
+    if (job.n_chunks > 0) hipLaunchKernelGGL(k_key_chunks, dim3(job.n_chunks), dim3(KEY_CHUNK), 0, st, job);
+    hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, st, job);
+    if (job.total_words > 0) hipLaunchKernelGGL(k_emit, dim3(run_grid), dim3(256), 0, st, job, m->geom_dev);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+static pdbeda_bloblist *new_list(pdbeda_ctx *ctx, pdbeda_map *m) {
+    pdbeda_bloblist *bl = new pdbeda_bloblist();
+    bl->ctx = ctx;
+    bl->map = m;
+    ctx->live_handles++;
+    return bl;
+}
+
+static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool want_pos, bool want_neg, uint32_t flags,
+                           pdbeda_bloblist **out_pos, pdbeda_bloblist **out_neg) {
+    pdbeda_ctx *ctx = m->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const Geom &g = m->geom;
+    const int n_planes = (want_pos ? 1 : 0) + (want_neg ? 1 : 0);
+    const int uc = g.unique_ncrs[0], ur = g.unique_ncrs[1], us = g.unique_ncrs[2];
+    const int row_words = (uc + 63) / 64;
+    const int64_t words_pp = (int64_t)row_words * ur * us;
+    const int64_t keys_pp = (int64_t)uc * ur * us;
+    const int64_t total_words = words_pp * n_planes, total_keys = keys_pp * n_planes;
+    const int64_t max_runs = (int64_t)((uc + 1) / 2) * ur * us * n_planes + 1;
+    // 26-connectivity: all voxels of an aligned 2x2x2 cell are mutually adjacent -> <= 1 blob per cell
+    const int64_t max_blobs = (int64_t)((uc + 1) / 2) * ((ur + 1) / 2) * ((us + 1) / 2) * n_planes + 1;
+    const bool labels = (flags & PDBEDA_FLAG_LABELS) != 0;
+    const size_t lab_elems = labels ? (size_t)keys_pp * n_planes : 0;
+
+    Job job;
+    memset(&job, 0, sizeof job);
+    size_t need = job_carve(job, nullptr, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, nullptr);
+    Arena arena;
+    int rc = arena_get(ctx, need, &arena);
+    if (rc) return rc;
+    int32_t *labels_dev = nullptr;
+    job_carve(job, arena.base, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, &labels_dev);
+
+    VolDesc vd[2];
+    for (int p = 0; p < n_planes; ++p) {
+        vd[p].dim[0] = uc; vd[p].dim[1] = ur; vd[p].dim[2] = us;
+        vd[p].org[0] = vd[p].org[1] = vd[p].org[2] = 0;
+        vd[p].row_words = row_words;
+        vd[p].group = p;
+        vd[p].word_base = words_pp * p;
+        vd[p].key_base = keys_pp * p;
+    }
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(k_set_vols, dim3(1), dim3(64), 0, st, job.vols, vd[0], vd[n_planes - 1], n_planes);
+    HIP_TRY(ctx, hipMemsetAsync(job.ctr, 0, sizeof(Counters), st));
+    HIP_TRY(ctx, hipMemsetAsync(job.key_bits, 0, sizeof(uint64_t) * job.key_words, st));
+
+    uint64_t *mp = want_pos ? job.mask : nullptr;
+    uint64_t *mn = want_neg ? job.mask + (want_pos ? words_pp : 0) : nullptr;
+    rc = tile_or_stream_threshold(ctx->stream, m->dens, m->geom_dev, g, job, mp, mn, cut_pos, cut_neg, row_words, words_pp);
+    if (rc) { arena_put(ctx, arena); return fail(ctx, PDBEDA_ERR_DEVICE, "threshold launch failed"); }
+    rc = engine_enqueue(ctx, m, job, max_runs);
+    if (rc) { arena_put(ctx, arena); return rc; }
+
+    pdbeda_bloblist *first = nullptr;
+    for (int p = 0; p < n_planes; ++p) {
+        pdbeda_bloblist *bl = new_list(ctx, m);
+        bl->job = job;
+        bl->vol_lo = p;
+        bl->vol_hi = p + 1;
+        bl->whole_map = true;
+        if (p == 0) { bl->arena = arena; bl->owns_arena = true; first = bl; }
+        else { bl->owns_arena = false; bl->sibling = first; first->sibling = bl; }
+        if (labels) bl->labels_dev = labels_dev + (size_t)keys_pp * p;
+        bool is_pos = want_pos && p == 0;
+        if (is_pos) *out_pos = bl; else *out_neg = bl;
+    }
+    if (labels) {
+        // ranks of plane 1 start after plane 0's blobs: resolved on the device from chunk_prefix
+        for (int p = 0; p < n_planes; ++p)
+            hipLaunchKernelGGL(k_labels_plane, dim3(grid_for(words_pp * 64, 256, 4096)), dim3(256), 0, st, job, p,
+                               labels_dev + (size_t)keys_pp * p);
+        HIP_TRY(ctx, hipGetLastError());
+        for (int p = 0; p < n_planes; ++p) (p == 0 ? first : first->sibling)->labels_done = true;
+    }
+    return PDBEDA_OK;
+}
+
+extern "C" int pdbeda_full_blobs(pdbeda_map *m, float cutoff, uint32_t flags, pdbeda_bloblist **out) {
+    if (!m || !out) return PDBEDA_ERR_ARGUMENT;
+    *out = nullptr;
+    if (cutoff == 0.0f || cutoff != cutoff) return fail(m->ctx, PDBEDA_ERR_ARGUMENT, "cutoff must be non-zero (the reference returns None)");
+    pdbeda_bloblist *dummy = nullptr;
+    if (cutoff > 0) return full_blobs_impl(m, cutoff, 0.0f, true, false, flags, out, &dummy);
+    return full_blobs_impl(m, 0.0f, cutoff, false, true, flags, &dummy, out);
+}
+
+extern "C" int pdbeda_full_blobs_pm(pdbeda_map *m, float cutoff_pos, float cutoff_neg, uint32_t flags, pdbeda_bloblist **green,
+                                    pdbeda_bloblist **red) {
+    if (!m || !green || !red) return PDBEDA_ERR_ARGUMENT;
+    *green = *red = nullptr;
+    if (!(cutoff_pos > 0.0f) || !(cutoff_neg < 0.0f)) return fail(m->ctx, PDBEDA_ERR_ARGUMENT, "need cutoff_pos > 0 > cutoff_neg");
+    return full_blobs_impl(m, cutoff_pos, cutoff_neg, true, true, flags, green, red);
+}
+
+// ---- accessors ------------------------------------------------------------------------
+static int list_resolve_counts(pdbeda_bloblist *bl) {
+    if (bl->have_counts) return 0;
+    pdbeda_ctx *ctx = bl->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const Job &job = bl->job;
+    // rank range of this list = blobs whose key lies in [key_base(vol_lo), key_end(vol_hi-1)):
+    // chunk_prefix/key_rank give prefix counts at arbitrary key words.
+    std::vector<VolDesc> vols(job.n_vols);
+    Counters ctr;
+    HIP_TRY(ctx, hipMemcpyAsync(&ctr, job.ctr, sizeof ctr, hipMemcpyDeviceToHost, ctx->stream));
+    if (job.n_vols > 0)
+        HIP_TRY(ctx, hipMemcpyAsync(vols.data(), job.vols, sizeof(VolDesc) * job.n_vols, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    auto rank_at = [&](int64_t key, int64_t *out) -> int {
+        // number of blobs with first key < key
+        if (key <= 0) { *out = 0; return 0; }
+        int64_t total_keys = job.key_words * 64;
+        if (key >= total_keys) { *out = ctr.n_blobs; return 0; }
+        int64_t kw = key >> 6;
+        uint32_t cp = 0, kr = 0;
+        uint64_t bits = 0;
+        HIP_TRY(ctx, hipMemcpy(&cp, job.chunk_prefix + kw / KEY_CHUNK, 4, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(&kr, job.key_rank + kw, 4, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(&bits, job.key_bits + kw, 8, hipMemcpyDeviceToHost));
+        *out = (int64_t)cp + kr + popc64(bits & bits_below((int)(key & 63)));
+        return 0;
+    };
+    int64_t k_lo = 0, k_hi = 0;
+    if (job.n_vols > 0 && bl->vol_lo < job.n_vols) {
+        k_lo = vols[bl->vol_lo].key_base;
+        const VolDesc &last = vols[bl->vol_hi - 1];
+        k_hi = last.key_base + (int64_t)last.dim[0] * last.dim[1] * last.dim[2];
+    }
+    int rc = rank_at(k_lo, &bl->rank_lo);
+    if (rc) return rc;
+    rc = rank_at(k_hi, &bl->rank_hi);
+    if (rc) return rc;
+    if (bl->vol_lo == 0 && bl->vol_hi == job.n_vols) { bl->rank_lo = 0; bl->rank_hi = ctr.n_blobs; }
+    bl->have_counts = true;
+    return 0;
+}
+
+extern "C" int64_t pdbeda_bloblist_count(pdbeda_bloblist *bl) {
+    if (!bl || bl->freed) return PDBEDA_ERR_ARGUMENT;
+    int rc = list_resolve_counts(bl);
+    if (rc) return rc;
+    return bl->rank_hi - bl->rank_lo;
+}
+
+extern "C" int pdbeda_bloblist_stats(pdbeda_bloblist *bl, int64_t *n, double *total_density, double *centroid, double *coord_center,
+                                     double *volume, int64_t *first_key, int32_t *group) {
+    if (!bl || bl->freed) return PDBEDA_ERR_ARGUMENT;
+    int rc = list_resolve_counts(bl);
+    if (rc) return rc;
+    pdbeda_ctx *ctx = bl->ctx;
+    const Job &job = bl->job;
+    const int64_t lo = bl->rank_lo, cnt = bl->rank_hi - bl->rank_lo;
+    if (cnt == 0) return PDBEDA_OK;
+    hipStream_t st = ctx->stream;
+    if (n) HIP_TRY(ctx, hipMemcpyAsync(n, job.b_n + lo, 8 * cnt, hipMemcpyDeviceToHost, st));
+    if (total_density) HIP_TRY(ctx, hipMemcpyAsync(total_density, job.b_total + lo, 8 * cnt, hipMemcpyDeviceToHost, st));
+    if (centroid) HIP_TRY(ctx, hipMemcpyAsync(centroid, job.b_centroid + 3 * lo, 24 * cnt, hipMemcpyDeviceToHost, st));
+    if (coord_center) HIP_TRY(ctx, hipMemcpyAsync(coord_center, job.b_center + 3 * lo, 24 * cnt, hipMemcpyDeviceToHost, st));
+    if (volume) HIP_TRY(ctx, hipMemcpyAsync(volume, job.b_volume + lo, 8 * cnt, hipMemcpyDeviceToHost, st));
+    if (first_key) HIP_TRY(ctx, hipMemcpyAsync(first_key, job.b_key + lo, 8 * cnt, hipMemcpyDeviceToHost, st));
+    if (group) HIP_TRY(ctx, hipMemcpyAsync(group, job.b_group + lo, 4 * cnt, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return PDBEDA_OK;
+}
+
+// Voxel lists are materialised once per JOB (shared by the lists of a fused call through
+// the owning list).
+static pdbeda_bloblist *owner_of(pdbeda_bloblist *bl) { return bl->owns_arena ? bl : bl->sibling; }
+
+static int list_materialise_voxels(pdbeda_bloblist *bl) {
+    pdbeda_bloblist *ow = owner_of(bl);
+    if (ow->voxels_done) return 0;
+    pdbeda_ctx *ctx = bl->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Job &job = ow->job;
+    Counters ctr;
+    HIP_TRY(ctx, hipMemcpyAsync(&ctr, job.ctr, sizeof ctr, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t nb = ctr.n_blobs;
+    // total voxels unknown until the offsets scan; bound by key bits
+    const int64_t max_vox = job.key_words * 64;
+    size_t need = align_up(8 * (nb + 1)) + align_up(4 * std::max<int64_t>(nb, 1)) + align_up(12 * std::max<int64_t>(max_vox, 1));
+    int rc = arena_get(ctx, need, &ow->vox_arena);
+    if (rc) return rc;
+    Carver cv(ow->vox_arena.base);
+    ow->offsets_dev = cv.take<int64_t>(nb + 1);
+    ow->cursor_dev = cv.take<unsigned int>(std::max<int64_t>(nb, 1));
+    ow->crs_dev = cv.take<int32_t>(3 * std::max<int64_t>(max_vox, 1));
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemsetAsync(ow->cursor_dev, 0, 4 * std::max<int64_t>(nb, 1), st));
+    hipLaunchKernelGGL(k_blob_offsets, dim3(1), dim3(1024), 0, st, job, ow->offsets_dev);
+    if (job.total_words > 0)
+        hipLaunchKernelGGL(k_voxel_lists, dim3(grid_for(job.total_words * 64, 256, 8192)), dim3(256), 0, st, job, ow->offsets_dev,
+                           ow->cursor_dev, ow->crs_dev);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    ow->voxels_done = true;
+    return 0;
+}
+
+extern "C" int64_t pdbeda_bloblist_num_voxels(pdbeda_bloblist *bl) {
+    if (!bl || bl->freed) return PDBEDA_ERR_ARGUMENT;
+    int rc = list_resolve_counts(bl);
+    if (rc) return rc;
+    if (bl->n_voxels >= 0) return bl->n_voxels;
+    rc = list_materialise_voxels(bl);
+    if (rc) return rc;
+    pdbeda_ctx *ctx = bl->ctx;
+    pdbeda_bloblist *ow = owner_of(bl);
+    int64_t off[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpy(&off[0], ow->offsets_dev + bl->rank_lo, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(&off[1], ow->offsets_dev + bl->rank_hi, 8, hipMemcpyDeviceToHost));
+    bl->n_voxels = off[1] - off[0];
+    return bl->n_voxels;
+}
+
+extern "C" int pdbeda_bloblist_voxels(pdbeda_bloblist *bl, int32_t *crs, int64_t *blob_offsets) {
+    if (!bl || bl->freed) return PDBEDA_ERR_ARGUMENT;
+    int64_t nv = pdbeda_bloblist_num_voxels(bl);
+    if (nv < 0) return (int)nv;
+    pdbeda_ctx *ctx = bl->ctx;
+    pdbeda_bloblist *ow = owner_of(bl);
+    const int64_t cnt = bl->rank_hi - bl->rank_lo;
+    std::vector<int64_t> off(cnt + 1);
+    HIP_TRY(ctx, hipMemcpy(off.data(), ow->offsets_dev + bl->rank_lo, 8 * (cnt + 1), hipMemcpyDeviceToHost));
+    const int64_t base = off[0];
+    if (blob_offsets)
+        for (int64_t i = 0; i <= cnt; ++i) blob_offsets[i] = off[i] - base;
+    if (crs && nv > 0) HIP_TRY(ctx, hipMemcpy(crs, ow->crs_dev + 3 * base, 12 * nv, hipMemcpyDeviceToHost));
+    return PDBEDA_OK;
+}
+
+extern "C" int pdbeda_bloblist_labels(pdbeda_bloblist *bl, int32_t *labels_host) {
+    if (!bl || bl->freed || !labels_host) return PDBEDA_ERR_ARGUMENT;
+    if (!bl->whole_map) return fail(bl->ctx, PDBEDA_ERR_STATE, "dense labels exist only for whole-map blob lists");
+    pdbeda_ctx *ctx = bl->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const Geom &g = bl->map->geom;
+    const int64_t nvox = (int64_t)g.unique_ncrs[0] * g.unique_ncrs[1] * g.unique_ncrs[2];
+    if (bl->labels_dev && bl->labels_done) {
+        HIP_TRY(ctx, hipMemcpyAsync(labels_host, bl->labels_dev, 4 * nvox, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return PDBEDA_OK;
+    }
+    Arena a;
+    int rc = arena_get(ctx, 4 * nvox, &a);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_labels_plane, dim3(grid_for(nvox, 256, 4096)), dim3(256), 0, ctx->stream, bl->job, bl->vol_lo, (int32_t *)a.base);
+    hipError_t e = hipMemcpyAsync(labels_host, a.base, 4 * nvox, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    arena_put(ctx, a);
+    if (e != hipSuccess) return fail(ctx, PDBEDA_ERR_DEVICE, "labels: %s", hipGetErrorString(e));
+    return PDBEDA_OK;
+}
+
+extern "C" int pdbeda_bloblist_free(pdbeda_bloblist *bl) {
+    if (!bl) return PDBEDA_ERR_ARGUMENT;
+    if (bl->freed) return PDBEDA_ERR_STATE;
+    pdbeda_ctx *ctx = bl->ctx;
+    bl->freed = true;
+    ctx->live_handles--;
+    pdbeda_bloblist *ow = owner_of(bl);
+    pdbeda_bloblist *other = bl->sibling;
+    const bool other_alive = other && !other->freed;
+    if (!other_alive) {
+        // last list of the job: device work on the arena must be finished before reuse
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        arena_put(ctx, ow->arena);
+        arena_put(ctx, ow->vox_arena);
+        if (other) delete other;
+        delete bl;
+    }
+    return PDBEDA_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Sphere / list batches
+// ------------------------------------------------------------------------------------
+struct GroupSetup {
+    Arena in_arena;          // inputs + boxes + bounds (scratch, released after painting)
+    double *d_xyz = nullptr;
+    float *d_radii = nullptr;
+    int32_t *d_item_group = nullptr;
+    AtomBox *d_boxes = nullptr;
+    int32_t *d_crs = nullptr;
+    int32_t *g_lo = nullptr, *g_hi = nullptr;
+    VolDesc *d_vols = nullptr;
+    Counters *d_ctr = nullptr;
+    int64_t total_words = 0, total_keys = 0;
+};
+
+static int expand_groups(const int64_t *group_offsets, int64_t n_groups, int64_t n_items, std::vector<int32_t> &item_group) {
+    item_group.assign((size_t)n_items, 0);
+    if (group_offsets[0] != 0 || group_offsets[n_groups] != n_items) return -1;
+    for (int64_t g = 0; g < n_groups; ++g) {
+        if (group_offsets[g + 1] < group_offsets[g]) return -1;
+        for (int64_t i = group_offsets[g]; i < group_offsets[g + 1]; ++i) item_group[(size_t)i] = (int32_t)g;
+    }
+    return 0;
+}
+
+// Upload atoms (or explicit voxels), compute group bounding volumes on the device, read
+// the totals back (the one host round trip of a sphere / list batch).
+static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, const int32_t *crs, int64_t n_items,
+                       const int64_t *group_offsets, int64_t n_groups, GroupSetup *gs) {
+    pdbeda_ctx *ctx = m->ctx;
+    if (n_groups >= (1ll << 31) || n_items >= (1ll << 40)) return fail(ctx, PDBEDA_ERR_ARGUMENT, "batch too large");
+    std::vector<int32_t> item_group;
+    if (expand_groups(group_offsets, n_groups, n_items, item_group)) return fail(ctx, PDBEDA_ERR_ARGUMENT, "bad group_offsets");
+    const int64_t ni = std::max<int64_t>(n_items, 1), ng = std::max<int64_t>(n_groups, 1);
+    size_t need = align_up(24 * ni) + align_up(4 * ni) + align_up(4 * ni) + align_up(sizeof(AtomBox) * ni) + align_up(12 * ni) +
+                  2 * align_up(12 * ng) + align_up(sizeof(VolDesc) * ng) + align_up(sizeof(Counters));
+    int rc = arena_get(ctx, need, &gs->in_arena);
+    if (rc) return rc;
+    Carver cv(gs->in_arena.base);
+    gs->d_xyz = cv.take<double>(3 * ni);
+    gs->d_radii = cv.take<float>(ni);
+    gs->d_item_group = cv.take<int32_t>(ni);
+    gs->d_boxes = cv.take<AtomBox>(ni);
+    gs->d_crs = cv.take<int32_t>(3 * ni);
+    gs->g_lo = cv.take<int32_t>(3 * ng);
+    gs->g_hi = cv.take<int32_t>(3 * ng);
+    gs->d_vols = cv.take<VolDesc>(ng);
+    gs->d_ctr = cv.take<Counters>(1);
+    hipStream_t st = ctx->stream;
+    if (n_items > 0) {
+        if (xyz) {
+            HIP_TRY(ctx, hipMemcpyAsync(gs->d_xyz, xyz, 24 * n_items, hipMemcpyHostToDevice, st));
+            HIP_TRY(ctx, hipMemcpyAsync(gs->d_radii, radii, 4 * n_items, hipMemcpyHostToDevice, st));
+        } else {
+            HIP_TRY(ctx, hipMemcpyAsync(gs->d_crs, crs, 12 * n_items, hipMemcpyHostToDevice, st));
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(gs->d_item_group, item_group.data(), 4 * n_items, hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(ctx, hipMemsetAsync(gs->d_ctr, 0, sizeof(Counters), st));
+    hipLaunchKernelGGL(k_init_bounds, dim3(grid_for(3 * ng, 256)), dim3(256), 0, st, gs->g_lo, gs->g_hi, 3 * ng);
+    if (n_items > 0) {
+        if (xyz)
+            hipLaunchKernelGGL(k_atom_boxes, dim3(grid_for(n_items, 256)), dim3(256), 0, st, m->geom_dev, gs->d_xyz, gs->d_radii,
+                               gs->d_item_group, n_items, gs->d_boxes, gs->g_lo, gs->g_hi);
+        else
+            hipLaunchKernelGGL(k_list_boxes, dim3(grid_for(n_items, 256)), dim3(256), 0, st, gs->d_crs, gs->d_item_group, n_items,
+                               gs->g_lo, gs->g_hi);
+    }
+    hipLaunchKernelGGL(k_make_vols, dim3(1), dim3(1024), 0, st, gs->g_lo, gs->g_hi, (int)n_groups, gs->d_vols, gs->d_ctr);
+    HIP_TRY(ctx, hipGetLastError());
+    Counters ctr;
+    HIP_TRY(ctx, hipMemcpyAsync(&ctr, gs->d_ctr, sizeof ctr, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));  // item_group (host vector) is also safe to drop now
+    gs->total_words = ctr.total_words;
+    gs->total_keys = ctr.total_keys;
+    if (gs->total_words >= (1ll << 31) * 2) return fail(ctx, PDBEDA_ERR_ARGUMENT, "sphere batch too large (%lld mask words)", (long long)gs->total_words);
+    return 0;
+}
+
+static int grouped_blobs(pdbeda_map *m, const double *xyz, const float *radii, const int32_t *crs, int64_t n_items,
+                         const int64_t *group_offsets, int64_t n_groups, float cutoff, pdbeda_bloblist **out) {
+    pdbeda_ctx *ctx = m->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GroupSetup gs;
+    int rc = group_setup(m, xyz, radii, crs, n_items, group_offsets, n_groups, &gs);
+    if (rc) { arena_put(ctx, gs.in_arena); return rc; }
+    const int64_t max_runs = gs.total_keys / 2 + gs.total_words + 1;
+    Job job;
+    memset(&job, 0, sizeof job);
+    size_t need = job_carve(job, nullptr, (int)n_groups, gs.total_words, gs.total_keys, max_runs, max_runs, 0, nullptr);
+    Arena arena;
+    rc = arena_get(ctx, need, &arena);
+    if (rc) { arena_put(ctx, gs.in_arena); return rc; }
+    job_carve(job, arena.base, (int)n_groups, gs.total_words, gs.total_keys, max_runs, max_runs, 0, nullptr);
+    hipStream_t st = ctx->stream;
+    hipError_t e = hipSuccess;
+    if (n_groups > 0) e = hipMemcpyAsync(job.vols, gs.d_vols, sizeof(VolDesc) * n_groups, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(job.ctr, 0, sizeof(Counters), st);
+    if (e == hipSuccess && job.key_words > 0) e = hipMemsetAsync(job.key_bits, 0, 8 * job.key_words, st);
+    if (e == hipSuccess && job.total_words > 0) e = hipMemsetAsync(job.mask, 0, 8 * job.total_words, st);
+    if (e == hipSuccess && n_items > 0) {
+        if (xyz)
+            hipLaunchKernelGGL(k_sphere_paint, dim3((unsigned)n_items), dim3(256), 0, st, m->geom_dev, m->dens, gs.d_xyz, gs.d_radii,
+                               gs.d_item_group, gs.d_boxes, job.vols, job.mask, cutoff);
+        else
+            hipLaunchKernelGGL(k_list_paint, dim3(grid_for(n_items, 256)), dim3(256), 0, st, gs.d_crs, gs.d_item_group, n_items, job.vols, job.mask);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) rc = engine_enqueue(ctx, m, job, max_runs);
+    // inputs are consumed by the paint kernel; wait before recycling their arena
+    if (e == hipSuccess && rc == 0) e = hipStreamSynchronize(st);
+    arena_put(ctx, gs.in_arena);
+    if (e != hipSuccess || rc) {
+        arena_put(ctx, arena);
+        return rc ? rc : fail(ctx, PDBEDA_ERR_DEVICE, "grouped blobs: %s", hipGetErrorString(e));
+    }
+    pdbeda_bloblist *bl = new_list(ctx, m);
+    bl->job = job;
+    bl->arena = arena;
+    bl->vol_lo = 0;
+    bl->vol_hi = (int)n_groups;
+    *out = bl;
+    return PDBEDA_OK;
+}
+
+extern "C" int pdbeda_sphere_blobs(pdbeda_map *m, const double *xyz, const float *radii, int64_t n_atoms, const int64_t *group_offsets,
+                                   int64_t n_groups, float density_cutoff, pdbeda_bloblist **out) {
+    if (!m || !out || n_atoms < 0 || n_groups < 0 || !group_offsets || (n_atoms > 0 && (!xyz || !radii))) return PDBEDA_ERR_ARGUMENT;
+    *out = nullptr;
+    return grouped_blobs(m, xyz, radii, nullptr, n_atoms, group_offsets, n_groups, density_cutoff, out);
+}
+
+extern "C" int pdbeda_list_blobs(pdbeda_map *m, const int32_t *crs, int64_t n, const int64_t *group_offsets, int64_t n_groups,
+                                 pdbeda_bloblist **out) {
+    if (!m || !out || n < 0 || n_groups < 0 || !group_offsets || (n > 0 && !crs)) return PDBEDA_ERR_ARGUMENT;
+    *out = nullptr;
+    return grouped_blobs(m, nullptr, nullptr, crs, n, group_offsets, n_groups, 0.0f, out);
+}
+
+extern "C" int pdbeda_region_sums(pdbeda_map *m, const double *xyz, const float *radii, int64_t n_atoms, const int64_t *group_offsets,
+                                  int64_t n_groups, float cutoff, double *pos, double *neg, int64_t *n_region, uint8_t *valid) {
+    if (!m || n_atoms < 0 || n_groups < 0 || !group_offsets || (n_atoms > 0 && (!xyz || !radii))) return PDBEDA_ERR_ARGUMENT;
+    pdbeda_ctx *ctx = m->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n_groups == 0) return PDBEDA_OK;
+    GroupSetup gs;
+    int rc = group_setup(m, xyz, radii, nullptr, n_atoms, group_offsets, n_groups, &gs);
+    if (rc) { arena_put(ctx, gs.in_arena); return rc; }
+    const int64_t tw = std::max<int64_t>(gs.total_words, 1);
+    Arena a;
+    rc = arena_get(ctx, align_up(8 * tw) + 3 * align_up(8 * n_groups) + align_up(4 * n_groups), &a);
+    if (rc) { arena_put(ctx, gs.in_arena); return rc; }
+    Carver cv(a.base);
+    uint64_t *mask = cv.take<uint64_t>(tw);
+    double *d_pos = cv.take<double>(n_groups);
+    double *d_neg = cv.take<double>(n_groups);
+    unsigned long long *d_cnt = cv.take<unsigned long long>(n_groups);
+    unsigned int *d_inv = cv.take<unsigned int>(n_groups);
+    hipStream_t st = ctx->stream;
+    hipError_t e = hipMemsetAsync(a.base, 0, cv.off, st);
+    if (e == hipSuccess && n_atoms > 0) {
+        hipLaunchKernelGGL(k_sphere_paint, dim3((unsigned)n_atoms), dim3(256), 0, st, m->geom_dev, m->dens, gs.d_xyz, gs.d_radii,
+                           gs.d_item_group, gs.d_boxes, gs.d_vols, mask, 0.0f);
+        hipLaunchKernelGGL(k_region_reduce, dim3(grid_for(gs.total_words * 64, 256, 4096)), dim3(256), 0, st, m->geom_dev, m->dens, gs.d_vols,
+                           (int)n_groups, mask, gs.total_words, cutoff, d_pos, d_neg, d_cnt, d_inv);
+        e = hipGetLastError();
+    }
+    std::vector<unsigned long long> h_cnt(n_groups);
+    std::vector<unsigned int> h_inv(n_groups);
+    if (e == hipSuccess && pos) e = hipMemcpyAsync(pos, d_pos, 8 * n_groups, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && neg) e = hipMemcpyAsync(neg, d_neg, 8 * n_groups, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_cnt.data(), d_cnt, 8 * n_groups, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_inv.data(), d_inv, 4 * n_groups, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    arena_put(ctx, a);
+    arena_put(ctx, gs.in_arena);
+    if (e != hipSuccess) return fail(ctx, PDBEDA_ERR_DEVICE, "region sums: %s", hipGetErrorString(e));
+    for (int64_t g = 0; g < n_groups; ++g) {
+        if (n_region) n_region[g] = (int64_t)h_cnt[g];
+        if (valid) valid[g] = h_inv[g] ? 0 : 1;
+    }
+    return PDBEDA_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Voxel-set adjacency, symmetry atoms, nearest atom
+// ------------------------------------------------------------------------------------
+extern "C" int pdbeda_test_overlap(pdbeda_ctx *ctx, const int32_t *crs, const int64_t *set_offsets, int64_t n_sets, const int32_t *a_idx,
+                                   const int32_t *b_idx, int64_t n_pairs, uint8_t *out) {
+    if (!ctx || n_sets < 0 || n_pairs < 0 || !set_offsets || (n_pairs > 0 && (!a_idx || !b_idx || !out))) return PDBEDA_ERR_ARGUMENT;
+    if (n_pairs == 0) return PDBEDA_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t nv = set_offsets[n_sets];
+    for (int64_t p = 0; p < n_pairs; ++p)
+        if (a_idx[p] < 0 || a_idx[p] >= n_sets || b_idx[p] < 0 || b_idx[p] >= n_sets) return fail(ctx, PDBEDA_ERR_ARGUMENT, "pair index out of range");
+    std::vector<unsigned int> h_out(n_pairs);
+    int rc = with_scratch(ctx, align_up(12 * std::max<int64_t>(nv, 1)) + align_up(8 * (n_sets + 1)) + 3 * align_up(4 * n_pairs), [&](char *base) -> int {
+        Carver cv(base);
+        int32_t *d_crs = cv.take<int32_t>(3 * std::max<int64_t>(nv, 1));
+        int64_t *d_off = cv.take<int64_t>(n_sets + 1);
+        int32_t *d_a = cv.take<int32_t>(n_pairs);
+        int32_t *d_b = cv.take<int32_t>(n_pairs);
+        unsigned int *d_out = cv.take<unsigned int>(n_pairs);
+        hipStream_t st = ctx->stream;
+        if (nv > 0) HIP_TRY(ctx, hipMemcpyAsync(d_crs, crs, 12 * nv, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(d_off, set_offsets, 8 * (n_sets + 1), hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(d_a, a_idx, 4 * n_pairs, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(d_b, b_idx, 4 * n_pairs, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemsetAsync(d_out, 0, 4 * n_pairs, st));
+        hipLaunchKernelGGL(k_test_overlap, dim3((unsigned)n_pairs), dim3(256), 0, st, d_crs, d_off, d_a, d_b, d_out);
+        HIP_TRY(ctx, hipMemcpyAsync(h_out.data(), d_out, 4 * n_pairs, hipMemcpyDeviceToHost, st));
+        return 0;
+    });
+    if (rc) return rc;
+    for (int64_t p = 0; p < n_pairs; ++p) out[p] = h_out[p] ? 1 : 0;
+    return PDBEDA_OK;
+}
+
+extern "C" int pdbeda_symmetry_atoms(pdbeda_ctx *ctx, const double *xyz, int64_t n_atoms, const double *rot, int32_t n_ops,
+                                     const double ortho[9], const double bbox_lo[3], const double bbox_hi[3], int32_t *atom_index,
+                                     int32_t *symmetry, double *out_xyz, int64_t cap, int64_t *n_out) {
+    if (!ctx || n_atoms < 0 || n_ops <= 0 || !rot || !ortho || !bbox_lo || !bbox_hi || !n_out || (n_atoms > 0 && !xyz)) return PDBEDA_ERR_ARGUMENT;
+    *n_out = 0;
+    if (n_atoms == 0) return PDBEDA_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t total = 27ll * n_ops * n_atoms;
+    std::vector<double> h_xyz(3 * total);
+    std::vector<uint8_t> h_keep(total);
+    int rc = with_scratch(ctx, align_up(24 * n_atoms) + align_up(96 * n_ops) + align_up(72) + 2 * align_up(24) + align_up(24 * total) + align_up(total),
+                          [&](char *base) -> int {
+        Carver cv(base);
+        double *d_xyz = cv.take<double>(3 * n_atoms);
+        double *d_rot = cv.take<double>(12 * n_ops);
+        double *d_ortho = cv.take<double>(9);
+        double *d_lo = cv.take<double>(3);
+        double *d_hi = cv.take<double>(3);
+        double *d_out = cv.take<double>(3 * total);
+        uint8_t *d_keep = cv.take<uint8_t>(total);
+        hipStream_t st = ctx->stream;
+        HIP_TRY(ctx, hipMemcpyAsync(d_xyz, xyz, 24 * n_atoms, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(d_rot, rot, 96 * n_ops, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(d_ortho, ortho, 72, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(d_lo, bbox_lo, 24, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(d_hi, bbox_hi, 24, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_symmetry_atoms, dim3(grid_for(total, 256)), dim3(256), 0, st, d_xyz, n_atoms, d_rot, (int)n_ops, d_ortho, d_lo, d_hi, d_out, d_keep);
+        HIP_TRY(ctx, hipMemcpyAsync(h_xyz.data(), d_out, 24 * total, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(h_keep.data(), d_keep, total, hipMemcpyDeviceToHost, st));
+        return 0;
+    });
+    if (rc) return rc;
+    int64_t n = 0;
+    for (int64_t t = 0; t < total; ++t) {
+        if (!h_keep[t]) continue;
+        if (n < cap) {
+            const int64_t a = t % n_atoms, cell_op = t / n_atoms;
+            const int op = (int)(cell_op % n_ops), cell = (int)(cell_op / n_ops);
+            if (atom_index) atom_index[n] = (int32_t)a;
+            if (symmetry) { symmetry[4 * n] = cell / 9 - 1; symmetry[4 * n + 1] = (cell / 3) % 3 - 1; symmetry[4 * n + 2] = cell % 3 - 1; symmetry[4 * n + 3] = op; }
+            if (out_xyz) for (int q = 0; q < 3; ++q) out_xyz[3 * n + q] = h_xyz[3 * t + q];
+        }
+        ++n;
+    }
+    *n_out = n;
+    if (n > cap && (atom_index || symmetry || out_xyz)) return fail(ctx, PDBEDA_ERR_CAPACITY, "need capacity %lld", (long long)n);
+    return PDBEDA_OK;
+}
+
+extern "C" int pdbeda_nearest_atom(pdbeda_ctx *ctx, const double *centroids, int64_t n_centroids, const double *atom_xyz, int64_t n_atoms,
+                                   int64_t *index, double *distance) {
+    if (!ctx || n_centroids < 0 || n_atoms <= 0 || !atom_xyz || (n_centroids > 0 && (!centroids || !index || !distance))) return PDBEDA_ERR_ARGUMENT;
+    if (n_centroids == 0) return PDBEDA_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return with_scratch(ctx, align_up(24 * n_centroids) + align_up(24 * n_atoms) + 2 * align_up(8 * n_centroids), [&](char *base) -> int {
+        Carver cv(base);
+        double *d_c = cv.take<double>(3 * n_centroids);
+        double *d_a = cv.take<double>(3 * n_atoms);
+        int64_t *d_i = cv.take<int64_t>(n_centroids);
+        double *d_d = cv.take<double>(n_centroids);
+        hipStream_t st = ctx->stream;
+        HIP_TRY(ctx, hipMemcpyAsync(d_c, centroids, 24 * n_centroids, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(d_a, atom_xyz, 24 * n_atoms, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_nearest_atom, dim3((unsigned)n_centroids), dim3(256), 0, st, d_c, d_a, n_atoms, d_i, d_d);
+        HIP_TRY(ctx, hipMemcpyAsync(index, d_i, 8 * n_centroids, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(distance, d_d, 8 * n_centroids, hipMemcpyDeviceToHost, st));
+        return 0;
+    });
+}

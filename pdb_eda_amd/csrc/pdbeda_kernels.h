@@ -1,0 +1,830 @@
+// pdbeda_kernels.h -- the HIP kernels of the voxel core (gfx950 / CDNA4, wave64).
+//
+// Data model ("volume batch"): every labelling job works on a batch of bit-mask volumes.
+// A volume is a box of voxels in RAW crs coordinates (org + local); one mask bit per voxel,
+// 64 consecutive voxels along c per 64-bit word (one wave64 ballot), rows padded to whole
+// words.  The whole-map job has one volume per sign (the non-repeating box
+// header.uniqueNcrs); a findAberrantBlobs batch has one small volume per atom / residue.
+//
+// Labelling is run based: the union-find element is a *run* (maximal set of consecutive
+// set bits inside one word).  Runs of a word are found with bit tricks, indexed compactly
+// (runBase[word] + popcount), carry their own fp64 partial sums, and are united with the
+// runs of the 4 "earlier" neighbour rows + the previous word (26-connectivity,
+// non-periodic, cutils.pyx:44-70).
+#pragma once
+#include "pdbeda_device.h"
+
+namespace pdbeda {
+
+struct VolDesc {
+    int32_t dim[3];     // voxels along c, r, s
+    int32_t org[3];     // raw crs of local voxel (0,0,0)
+    int32_t row_words;  // ceil(dim[0] / 64)
+    int32_t group;      // caller-visible group id (plane for whole-map jobs)
+    int64_t word_base;  // first mask word of this volume
+    int64_t key_base;   // first key bit of this volume (key = (c*dim[1] + r)*dim[2] + s)
+};
+
+struct Counters {
+    unsigned int n_runs;
+    unsigned int n_blobs;
+    unsigned long long n_voxels;
+    long long total_words;
+    long long total_keys;
+};
+
+struct Job {
+    VolDesc *vols;
+    int32_t n_vols;
+    int64_t total_words;
+    int64_t key_words;
+    uint64_t *mask;
+    uint32_t *run_base;
+    uint64_t *key_bits;
+    uint32_t *key_rank;      // per key word: set bits before it inside its chunk
+    uint32_t *chunk_count;   // per chunk of KEY_CHUNK key words
+    uint32_t *chunk_prefix;
+    int32_t n_chunks;
+    Counters *ctr;
+    // per-run records
+    int32_t *parent;
+    uint32_t *r_n;
+    double *r_rho, *r_rho_c, *r_rho_r, *r_rho_s;
+    long long *r_c, *r_r, *r_s;
+    unsigned long long *r_key;
+    uint32_t *r_rank;
+    // blob table
+    int64_t *b_n, *b_key;
+    double *b_total, *b_centroid, *b_center, *b_volume;
+    int32_t *b_group;
+};
+
+constexpr int KEY_CHUNK = 256;  // key words per chunk (= threads per block of k_key_chunks)
+constexpr int WAVE = 64;
+
+__device__ inline int lane_id() { return threadIdx.x & 63; }
+
+__device__ inline int find_vol(const VolDesc *vols, int n, int64_t word) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (vols[mid].word_base <= word) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+__device__ inline int find_vol_by_key(const VolDesc *vols, int n, int64_t key) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (vols[mid].key_base <= key) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// ------------------------------------------------------------------------------------
+// Whole-map threshold -> bit masks (createFullCrsList, cutils.pyx:185-203; inclusive, Q2).
+// One wave per word: 64 lanes read 64 consecutive floats (256 B, coalesced), __ballot
+// gives the mask word.  Both signs come from the same read (fused green/red).
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_threshold(const float *__restrict__ dens, const Geom *__restrict__ gp,
+                                                   uint64_t *__restrict__ mask_pos, uint64_t *__restrict__ mask_neg,
+                                                   float cut_pos, float cut_neg, int row_words, int64_t words_per_plane) {
+    const int lane = lane_id();
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int nc = gp->ncrs[0], nr = gp->ncrs[1];
+    const int uc = gp->unique_ncrs[0], ur = gp->unique_ncrs[1];
+    for (int64_t w = wave; w < words_per_plane; w += n_waves) {
+        int wq = (int)(w % row_words);
+        int64_t row = w / row_words;
+        int r = (int)(row % ur);
+        int64_t s = row / ur;
+        int c = wq * 64 + lane;
+        bool in = c < uc;
+        float v = in ? dens[(s * nr + r) * nc + c] : 0.0f;
+        if (mask_pos) {
+            unsigned long long b = __ballot(in && v >= cut_pos);
+            if (lane == 0) mask_pos[w] = b;
+        }
+        if (mask_neg) {
+            unsigned long long b = __ballot(in && v <= cut_neg);
+            if (lane == 0) mask_neg[w] = b;
+        }
+    }
+}
+
+__device__ inline double wave_incl_scan(double x, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        double y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+
+// ------------------------------------------------------------------------------------
+// Run indexing + per-run statistics.  Block = 256 threads = one chunk of 256 words.
+// Phase 1 (thread per word): count runs, block scan, one atomicAdd per block -> run_base.
+// Phase 2 (wave per non-empty word, lane per voxel): wrapped density fetch
+// (getPointDensityFromCrs), two wave prefix sums (rho, rho*lane), run sums by difference
+// at the run's first lane.  fromCrsList's sums (ccp4.py:534-545) become per-run partials.
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_run_index(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp) {
+    __shared__ uint64_t s_mask[256];
+    __shared__ uint32_t s_off[256];
+    __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t chunk0 = (int64_t)blockIdx.x * 256;
+    const int64_t w = chunk0 + tid;
+    uint64_t m = (w < job.total_words) ? job.mask[w] : 0ull;
+    uint32_t cnt = (uint32_t)popc64(run_starts(m));
+    // block exclusive scan of cnt
+    uint32_t x = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) s_wsum[wv] = x;
+    s_mask[tid] = m;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t tot = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        s_base = tot ? atomicAdd(&job.ctr->n_runs, tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t wpre = 0;
+    for (int k = 0; k < wv; ++k) wpre += s_wsum[k];
+    uint32_t off = s_base + wpre + x - cnt;
+    s_off[tid] = off;
+    if (w < job.total_words) job.run_base[w] = off;
+    __syncthreads();
+
+    const Geom &g = *gp;
+    for (int j = 0; j < 64; ++j) {
+        const int slot = wv * 64 + j;
+        const uint64_t mw = s_mask[slot];
+        if (mw == 0ull) continue;
+        const int64_t word = chunk0 + slot;
+        const VolDesc vd = job.vols[find_vol(job.vols, job.n_vols, word)];
+        const int64_t rem = word - vd.word_base;
+        const int wq = (int)(rem % vd.row_words);
+        const int64_t row = rem / vd.row_words;
+        const int rl = (int)(row % vd.dim[1]);
+        const int sl = (int)(row / vd.dim[1]);
+        const int cl0 = wq * 64;
+        const int rawr = vd.org[1] + rl, raws = vd.org[2] + sl, rawc0 = vd.org[0] + cl0;
+        const bool bit = (mw >> lane) & 1ull;
+        double rho = bit ? (double)fetch_wrapped(g, dens, rawc0 + lane, rawr, raws) : 0.0;
+        double rl_ = rho * (double)lane;
+        double p1 = wave_incl_scan(rho, lane);
+        double p2 = wave_incl_scan(rl_, lane);
+        const uint64_t starts = run_starts(mw);
+        const bool is_start = (starts >> lane) & 1ull;
+        const int e = is_start ? run_end_of(mw, lane) : lane;
+        double p1e = __shfl(p1, e);
+        double p2e = __shfl(p2, e);
+        if (is_start) {
+            const int len = e - lane + 1;
+            const double s_rho = p1e - (p1 - rho);
+            const double s_rl = p2e - (p2 - rl_);
+            const uint32_t idx = s_off[slot] + (uint32_t)popc64(starts & bits_below(lane));
+            job.parent[idx] = (int32_t)idx;
+            job.r_n[idx] = (uint32_t)len;
+            job.r_rho[idx] = s_rho;
+            job.r_rho_c[idx] = (double)rawc0 * s_rho + s_rl;
+            job.r_rho_r[idx] = (double)rawr * s_rho;
+            job.r_rho_s[idx] = (double)raws * s_rho;
+            const long long a = (long long)rawc0 + lane;
+            job.r_c[idx] = (long long)len * a + (long long)len * (len - 1) / 2;
+            job.r_r[idx] = (long long)len * rawr;
+            job.r_s[idx] = (long long)len * raws;
+            job.r_key[idx] = (unsigned long long)(vd.key_base +
+                             ((int64_t)(cl0 + lane) * vd.dim[1] + rl) * vd.dim[2] + sl);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Lock-free union-find on run indices (parent[x] <= x; roots link to the smaller root).
+// atomicMin is authoritative; plain/stale reads in find() only cost a retry.
+// ------------------------------------------------------------------------------------
+__device__ inline int uf_load(const int32_t *p, int x) {
+    return __hip_atomic_load(p + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline int uf_find(const int32_t *p, int x) {
+    int q;
+    while ((q = uf_load(p, x)) != x) x = q;
+    return x;
+}
+__device__ inline void uf_unite(int32_t *p, int a, int b) {
+    while (true) {
+        a = uf_find(p, a);
+        b = uf_find(p, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; }
+        int old = atomicMin(p + a, b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+// Index of the run of word `nm` that contains set bit p.
+__device__ inline uint32_t run_of_bit(uint64_t nm, uint32_t base, int p, int *start_out) {
+    int st = run_start_of(nm, p);
+    *start_out = st;
+    return base + (uint32_t)popc64(run_starts(nm) & bits_below(st));
+}
+
+// Thread per word: unite each run with the touching runs of (a) the previous word of the
+// same row, (b) words w-1, w, w+1 of the rows (r-1,s), (r-1,s-1), (r,s-1), (r+1,s-1).
+// Two runs [a,b] and [a',b'] in adjacent rows touch iff [a-1,b+1] meets [a',b']
+// (Chebyshev distance <= 1 == cdist <= sqrt(3) on integer coordinates, cutils.pyx:43,62).
+__global__ void __launch_bounds__(256) k_union(Job job) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= job.total_words) return;
+    const uint64_t m = job.mask[w];
+    if (m == 0ull) return;
+    const VolDesc vd = job.vols[find_vol(job.vols, job.n_vols, w)];
+    const int64_t rem = w - vd.word_base;
+    const int wq = (int)(rem % vd.row_words);
+    const int64_t row = rem / vd.row_words;
+    const int rl = (int)(row % vd.dim[1]);
+    const int sl = (int)(row / vd.dim[1]);
+    const uint32_t base = job.run_base[w];
+    const uint64_t starts = run_starts(m);
+    uint64_t todo = starts;
+    uint32_t k = 0;
+    while (todo) {
+        const int a = ctz64(todo);
+        todo &= todo - 1;
+        const int b = run_end_of(m, a);
+        const int me = (int)(base + k);
+        ++k;
+        if (a == 0 && wq > 0) {
+            const uint64_t pm = job.mask[w - 1];
+            if (pm >> 63) {
+                int st;
+                uint32_t other = run_of_bit(pm, job.run_base[w - 1], 63, &st);
+                uf_unite(job.parent, me, (int)other);
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const int dr = nb == 0 ? -1 : (nb == 1 ? -1 : (nb == 2 ? 0 : 1));
+            const int ds = nb == 0 ? 0 : -1;
+            const int r2 = rl + dr, s2 = sl + ds;
+            if (r2 < 0 || r2 >= vd.dim[1] || s2 < 0) continue;
+            const int64_t rowbase = vd.word_base + ((int64_t)s2 * vd.dim[1] + r2) * vd.row_words;
+            for (int dw = -1; dw <= 1; ++dw) {
+                const int w2 = wq + dw;
+                if (w2 < 0 || w2 >= vd.row_words) continue;
+                int lo = a - 1 - 64 * dw, hi = b + 1 - 64 * dw;
+                if (hi < 0 || lo > 63) continue;
+                if (lo < 0) lo = 0;
+                if (hi > 63) hi = 63;
+                const uint64_t nm = job.mask[rowbase + w2];
+                uint64_t hit = nm & (bits_below(hi + 1) & ~bits_below(lo));
+                if (!hit) continue;
+                const uint32_t nbase = job.run_base[rowbase + w2];
+                while (hit) {
+                    const int p = ctz64(hit);
+                    int st;
+                    const uint32_t other = run_of_bit(nm, nbase, p, &st);
+                    uf_unite(job.parent, me, (int)other);
+                    const int en = run_end_of(nm, st);
+                    hit &= ~bits_below(en + 1);
+                }
+            }
+        }
+    }
+}
+
+// Thread per run: flatten, and fold non-root partial sums into the root record.
+__global__ void __launch_bounds__(256) k_resolve(Job job) {
+    const uint32_t n_runs = job.ctr->n_runs;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_runs; i += gridDim.x * blockDim.x) {
+    const int root = uf_find(job.parent, (int)i);
+    if (root == (int)i) continue;
+    job.parent[i] = root;
+    atomicAdd(&job.r_n[root], job.r_n[i]);
+    unsafeAtomicAdd(&job.r_rho[root], job.r_rho[i]);
+    unsafeAtomicAdd(&job.r_rho_c[root], job.r_rho_c[i]);
+    unsafeAtomicAdd(&job.r_rho_r[root], job.r_rho_r[i]);
+    unsafeAtomicAdd(&job.r_rho_s[root], job.r_rho_s[i]);
+    atomicAdd((unsigned long long *)&job.r_c[root], (unsigned long long)job.r_c[i]);
+    atomicAdd((unsigned long long *)&job.r_r[root], (unsigned long long)job.r_r[i]);
+    atomicAdd((unsigned long long *)&job.r_s[root], (unsigned long long)job.r_s[i]);
+    atomicMin(&job.r_key[root], job.r_key[i]);
+    }
+}
+
+// Blob order = ascending key of the blob's first voxel in the reference's c-major
+// enumeration (cutils.pyx:199 + 59-69).  Keys are unique positions, so the rank of a blob
+// is a prefix population count over a bitmap of first-voxel keys -- no sort needed.
+__global__ void __launch_bounds__(256) k_paint_keys(Job job) {
+    const uint32_t n_runs = job.ctr->n_runs;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_runs; i += gridDim.x * blockDim.x) {
+        if (job.parent[i] != (int32_t)i) continue;
+        const unsigned long long key = job.r_key[i];
+        atomicOr((unsigned long long *)&job.key_bits[key >> 6], 1ull << (key & 63));
+    }
+}
+
+__global__ void __launch_bounds__(KEY_CHUNK) k_key_chunks(Job job) {
+    __shared__ uint32_t s_wsum[KEY_CHUNK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t kw = (int64_t)blockIdx.x * KEY_CHUNK + tid;
+    uint32_t cnt = kw < job.key_words ? (uint32_t)popc64(job.key_bits[kw]) : 0u;
+    uint32_t x = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) s_wsum[wv] = x;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (int k = 0; k < wv; ++k) pre += s_wsum[k];
+    if (kw < job.key_words) job.key_rank[kw] = pre + x - cnt;
+    if (tid == KEY_CHUNK - 1) job.chunk_count[blockIdx.x] = pre + x;
+}
+
+// Single block: exclusive scan of chunk_count -> chunk_prefix, total -> n_blobs.
+__global__ void __launch_bounds__(1024) k_chunk_scan(Job job) {
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < job.n_chunks; base += 1024) {
+        const int i = base + tid;
+        uint32_t v = i < job.n_chunks ? job.chunk_count[i] : 0u;
+        uint32_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) s_w[wv] = x;
+        __syncthreads();
+        uint32_t pre = s_carry;
+        for (int k = 0; k < wv; ++k) pre += s_w[k];
+        if (i < job.n_chunks) job.chunk_prefix[i] = pre + x - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = pre + x;
+        __syncthreads();
+    }
+    if (tid == 0) job.ctr->n_blobs = s_carry;
+}
+
+// Thread per root run: rank -> blob table row (DensityBlob.fromCrsList, ccp4.py:542-545).
+__global__ void __launch_bounds__(256) k_emit(Job job, const Geom *__restrict__ gp) {
+    const uint32_t n_runs = job.ctr->n_runs;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_runs; i += gridDim.x * blockDim.x) {
+    if (job.parent[i] != (int32_t)i) continue;
+    const unsigned long long key = job.r_key[i];
+    const int64_t kw = (int64_t)(key >> 6);
+    const uint32_t rank = job.chunk_prefix[kw / KEY_CHUNK] + job.key_rank[kw] +
+                          (uint32_t)popc64(job.key_bits[kw] & bits_below((int)(key & 63)));
+    job.r_rank[i] = rank;
+    const VolDesc vd = job.vols[find_vol_by_key(job.vols, job.n_vols, (int64_t)key)];
+    const Geom &g = *gp;
+    const double n = (double)job.r_n[i];
+    const double tot = job.r_rho[i];
+    double wc[3] = {job.r_rho_c[i] / tot, job.r_rho_r[i] / tot, job.r_rho_s[i] / tot};
+    double cc[3] = {(double)job.r_c[i] / n, (double)job.r_r[i] / n, (double)job.r_s[i] / n};
+    double xyz[3];
+    crs2xyz_frac(g, wc, xyz);
+    job.b_centroid[3 * rank + 0] = xyz[0];
+    job.b_centroid[3 * rank + 1] = xyz[1];
+    job.b_centroid[3 * rank + 2] = xyz[2];
+    crs2xyz_frac(g, cc, xyz);
+    job.b_center[3 * rank + 0] = xyz[0];
+    job.b_center[3 * rank + 1] = xyz[1];
+    job.b_center[3 * rank + 2] = xyz[2];
+    job.b_n[rank] = (int64_t)job.r_n[i];
+    job.b_total[rank] = tot;
+    job.b_volume[rank] = g.unit_volume * n;
+    job.b_key[rank] = (int64_t)key - vd.key_base;
+    job.b_group[rank] = vd.group;
+    }
+}
+
+// Voxel lists grouped by blob: offsets = exclusive scan of b_n (single block), then each
+// voxel takes a slot in its blob with an atomic cursor (order inside a blob is a set).
+__global__ void __launch_bounds__(1024) k_blob_offsets(Job job, int64_t *__restrict__ offsets) {
+    __shared__ long long s_w[16];
+    __shared__ long long s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nb = (int)job.ctr->n_blobs;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        const int i = base + tid;
+        long long v = i < nb ? job.b_n[i] : 0;
+        long long x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            long long y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) s_w[wv] = x;
+        __syncthreads();
+        long long pre = s_carry;
+        for (int k = 0; k < wv; ++k) pre += s_w[k];
+        if (i < nb) offsets[i] = pre + x - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = pre + x;
+        __syncthreads();
+    }
+    if (tid == 0) { offsets[nb] = s_carry; job.ctr->n_voxels = (unsigned long long)s_carry; }
+}
+
+__global__ void __launch_bounds__(256) k_voxel_lists(Job job, const int64_t *__restrict__ offsets,
+                                                     unsigned int *__restrict__ cursor, int32_t *__restrict__ crs_out) {
+    const int lane = lane_id();
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t w = wave; w < job.total_words; w += n_waves) {
+        const uint64_t m = job.mask[w];
+        if (m == 0ull) continue;
+        if (!((m >> lane) & 1ull)) continue;
+        const VolDesc vd = job.vols[find_vol(job.vols, job.n_vols, w)];
+        const int64_t rem = w - vd.word_base;
+        const int wq = (int)(rem % vd.row_words);
+        const int64_t row = rem / vd.row_words;
+        const int st = run_start_of(m, lane);
+        const uint32_t run = job.run_base[w] + (uint32_t)popc64(run_starts(m) & bits_below(st));
+        const uint32_t root = (uint32_t)job.parent[run];
+        const uint32_t rank = job.r_rank[root];
+        const int64_t pos = offsets[rank] + atomicAdd(&cursor[rank], 1u);
+        crs_out[3 * pos + 0] = vd.org[0] + wq * 64 + lane;
+        crs_out[3 * pos + 1] = vd.org[1] + (int)(row % vd.dim[1]);
+        crs_out[3 * pos + 2] = vd.org[2] + (int)(row / vd.dim[1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Sphere batches (getSphereCrsFromXyz, cutils.pyx:220-248).
+// ------------------------------------------------------------------------------------
+struct AtomBox {
+    int32_t lo[3];
+    int32_t hi[3];  // inclusive; hi < lo => empty
+};
+
+// Thread per atom: centre C = xyz2crs(xyz), R = xyz2crs(origin + r); box [C-R-1, C+R] (Q4).
+__global__ void k_atom_boxes(const Geom *__restrict__ gp, const double *__restrict__ xyz, const float *__restrict__ radii,
+                             const int32_t *__restrict__ atom_group, int64_t n_atoms, AtomBox *__restrict__ boxes,
+                             int32_t *__restrict__ g_lo, int32_t *__restrict__ g_hi) {
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_atoms) return;
+    const Geom &g = *gp;
+    const double p[3] = {xyz[3 * a], xyz[3 * a + 1], xyz[3 * a + 2]};
+    const double rad = (double)radii[a];
+    int32_t C[3], R[3];
+    xyz2crs(g, p, C);
+    const double o[3] = {g.origin[0] + rad, g.origin[1] + rad, g.origin[2] + rad};
+    xyz2crs(g, o, R);
+    AtomBox bx;
+    bool empty = false;
+    for (int k = 0; k < 3; ++k) {
+        bx.lo[k] = C[k] - R[k] - 1;
+        bx.hi[k] = C[k] + R[k];
+        empty = empty || (bx.hi[k] < bx.lo[k]);
+    }
+    if (empty) { for (int k = 0; k < 3; ++k) { bx.lo[k] = 0; bx.hi[k] = -1; } }
+    boxes[a] = bx;
+    if (!empty) {
+        const int gidx = atom_group[a];
+        for (int k = 0; k < 3; ++k) {
+            atomicMin(&g_lo[3 * gidx + k], bx.lo[k]);
+            atomicMax(&g_hi[3 * gidx + k], bx.hi[k]);
+        }
+    }
+}
+
+// Thread per explicit voxel: group bounding boxes for list jobs.
+__global__ void k_list_boxes(const int32_t *__restrict__ crs, const int32_t *__restrict__ vox_group, int64_t n,
+                             int32_t *__restrict__ g_lo, int32_t *__restrict__ g_hi) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int gidx = vox_group[i];
+    for (int k = 0; k < 3; ++k) {
+        atomicMin(&g_lo[3 * gidx + k], crs[3 * i + k]);
+        atomicMax(&g_hi[3 * gidx + k], crs[3 * i + k]);
+    }
+}
+
+__global__ void k_init_bounds(int32_t *g_lo, int32_t *g_hi, int64_t n3) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n3) return;
+    g_lo[i] = INT32_MAX;
+    g_hi[i] = INT32_MIN;
+}
+
+// Single block: group bounding boxes -> volume descriptors with word / key offsets.
+__global__ void __launch_bounds__(1024) k_make_vols(const int32_t *__restrict__ g_lo, const int32_t *__restrict__ g_hi,
+                                                     int n_groups, VolDesc *__restrict__ vols, Counters *__restrict__ ctr) {
+    __shared__ long long s_w[16], s_k[16];
+    __shared__ long long s_cw, s_ck;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) { s_cw = 0; s_ck = 0; }
+    __syncthreads();
+    for (int base = 0; base < n_groups; base += 1024) {
+        const int i = base + tid;
+        VolDesc vd;
+        long long words = 0, keys = 0;
+        if (i < n_groups) {
+            bool empty = false;
+            for (int k = 0; k < 3; ++k) {
+                int lo = g_lo[3 * i + k], hi = g_hi[3 * i + k];
+                empty = empty || hi < lo;
+                vd.org[k] = lo;
+                vd.dim[k] = hi - lo + 1;
+            }
+            if (empty) { for (int k = 0; k < 3; ++k) { vd.org[k] = 0; vd.dim[k] = 0; } }
+            vd.row_words = (vd.dim[0] + 63) / 64;
+            vd.group = i;
+            words = (long long)vd.row_words * vd.dim[1] * vd.dim[2];
+            keys = (long long)vd.dim[0] * vd.dim[1] * vd.dim[2];
+        }
+        long long xw = words, xk = keys;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            long long yw = __shfl_up(xw, d), yk = __shfl_up(xk, d);
+            if (lane >= d) { xw += yw; xk += yk; }
+        }
+        if (lane == 63) { s_w[wv] = xw; s_k[wv] = xk; }
+        __syncthreads();
+        long long pw = s_cw, pk = s_ck;
+        for (int k = 0; k < wv; ++k) { pw += s_w[k]; pk += s_k[k]; }
+        if (i < n_groups) {
+            vd.word_base = pw + xw - words;
+            vd.key_base = pk + xk - keys;
+            vols[i] = vd;
+        }
+        __syncthreads();
+        if (tid == 1023) { s_cw = pw + xw; s_ck = pk + xk; }
+        __syncthreads();
+    }
+    if (tid == 0) { ctr->total_words = s_cw; ctr->total_keys = s_ck; }
+}
+
+// Block per atom, thread per box voxel: wrapped fetch, strict density filter (Q2), fp64
+// distance (cutils.pyx:205-218, 244-245); hits are OR-ed into the group's volume, which
+// deduplicates sphere unions on raw crs exactly like the reference's set (cutils.pyx:268-271).
+__global__ void __launch_bounds__(256) k_sphere_paint(const Geom *__restrict__ gp, const float *__restrict__ dens,
+                                                      const double *__restrict__ xyz, const float *__restrict__ radii,
+                                                      const int32_t *__restrict__ atom_group, const AtomBox *__restrict__ boxes,
+                                                      const VolDesc *__restrict__ vols, uint64_t *__restrict__ mask, float cutoff) {
+    const int64_t a = blockIdx.x;
+    const AtomBox bx = boxes[a];
+    const int dc = bx.hi[0] - bx.lo[0] + 1, dr = bx.hi[1] - bx.lo[1] + 1, dsz = bx.hi[2] - bx.lo[2] + 1;
+    if (dc <= 0 || dr <= 0 || dsz <= 0) return;
+    const Geom &g = *gp;
+    const VolDesc vd = vols[atom_group[a]];
+    const double px = xyz[3 * a], py = xyz[3 * a + 1], pz = xyz[3 * a + 2];
+    const double rad = (double)radii[a], cut = (double)cutoff;
+    const int64_t nvox = (int64_t)dc * dr * dsz;
+    for (int64_t i = threadIdx.x; i < nvox; i += blockDim.x) {
+        const int c = bx.lo[0] + (int)(i % dc);
+        const int r = bx.lo[1] + (int)((i / dc) % dr);
+        const int s = bx.lo[2] + (int)(i / ((int64_t)dc * dr));
+        const double d = (double)fetch_wrapped(g, dens, c, r, s);
+        if (!((0.0 < cut && cut < d) || (d < cut && cut < 0.0) || cut == 0.0)) continue;
+        double q[3];
+        crs2xyz(g, c, r, s, q);
+        const double dx = q[0] - px, dy = q[1] - py, dz = q[2] - pz;
+        const double dist = __dsqrt_rn((dx * dx + dy * dy) + dz * dz);
+        if (!(dist <= rad)) continue;
+        const int lc = c - vd.org[0], lr = r - vd.org[1], ls = s - vd.org[2];
+        const int64_t w = vd.word_base + ((int64_t)ls * vd.dim[1] + lr) * vd.row_words + (lc >> 6);
+        atomicOr((unsigned long long *)&mask[w], 1ull << (lc & 63));
+    }
+}
+
+__global__ void k_list_paint(const int32_t *__restrict__ crs, const int32_t *__restrict__ vox_group, int64_t n,
+                             const VolDesc *__restrict__ vols, uint64_t *__restrict__ mask) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const VolDesc vd = vols[vox_group[i]];
+    const int lc = crs[3 * i] - vd.org[0], lr = crs[3 * i + 1] - vd.org[1], ls = crs[3 * i + 2] - vd.org[2];
+    const int64_t w = vd.word_base + ((int64_t)ls * vd.dim[1] + lr) * vd.row_words + (lc >> 6);
+    atomicOr((unsigned long long *)&mask[w], 1ull << (lc & 63));
+}
+
+// Wave per word of a painted (cutoff-free) sphere-union volume: regional sums
+// (densityAnalysis.py:1183-1198) + testValidXyzList (cutils.pyx:273-313).
+__global__ void __launch_bounds__(256) k_region_reduce(const Geom *__restrict__ gp, const float *__restrict__ dens,
+                                                       const VolDesc *__restrict__ vols, int n_vols, const uint64_t *__restrict__ mask,
+                                                       int64_t total_words, float cutoff, double *__restrict__ pos,
+                                                       double *__restrict__ neg, unsigned long long *__restrict__ cnt,
+                                                       unsigned int *__restrict__ invalid) {
+    const int lane = lane_id();
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const Geom &g = *gp;
+    const double cut = (double)cutoff;
+    for (int64_t w = wave; w < total_words; w += n_waves) {
+        const uint64_t m = mask[w];
+        if (m == 0ull) continue;
+        const VolDesc vd = vols[find_vol(vols, n_vols, w)];
+        const int64_t rem = w - vd.word_base;
+        const int wq = (int)(rem % vd.row_words);
+        const int64_t row = rem / vd.row_words;
+        const bool bit = (m >> lane) & 1ull;
+        bool ok = true;
+        double d = 0.0;
+        if (bit) d = (double)fetch_wrapped(g, dens, vd.org[0] + wq * 64 + lane, vd.org[1] + (int)(row % vd.dim[1]),
+                                           vd.org[2] + (int)(row / vd.dim[1]), &ok);
+        double p = (bit && d > cut) ? d : 0.0;
+        double q = (bit && d < -cut) ? d : 0.0;
+        unsigned long long bad = __ballot(bit && !ok);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            p += __shfl_down(p, off);
+            q += __shfl_down(q, off);
+        }
+        if (lane == 0) {
+            if (p != 0.0) unsafeAtomicAdd(&pos[vd.group], p);
+            if (q != 0.0) unsafeAtomicAdd(&neg[vd.group], q);
+            atomicAdd(&cnt[vd.group], (unsigned long long)popc64(m));
+            if (bad) atomicOr(&invalid[vd.group], 1u);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Whole-map reductions.  Deterministic two-stage fp64 sums: a fixed grid writes one
+// partial per block, a single block folds the partials in index order.
+// mode 0: sum(x)   mode 1: sum((x-mean)^2)   mode 2: sum(|x|) for |x| > cutoff (strict)
+// ------------------------------------------------------------------------------------
+__device__ inline double block_sum(double v, double *s_part) {
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (lane == 0) s_part[wv] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0)
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += s_part[k];
+    return t;
+}
+
+__global__ void __launch_bounds__(256) k_reduce_partials(const float *__restrict__ x, int64_t n, int mode, const double *__restrict__ mean_p,
+                                                         double cutoff, double *__restrict__ partials) {
+    __shared__ double s_part[4];
+    const int64_t n4 = n >> 2;
+    const double mean = mode == 1 ? mean_p[0] : 0.0;
+    double acc = 0.0;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = x4[i];
+        const double e[4] = {(double)v.x, (double)v.y, (double)v.z, (double)v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (mode == 0) acc += e[k];
+            else if (mode == 1) { const double d = e[k] - mean; acc += d * d; }
+            else { const double a = fabs(e[k]); if (a > cutoff) acc += a; }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const double e = (double)x[(n4 << 2) + threadIdx.x];
+        if (mode == 0) acc += e;
+        else if (mode == 1) { const double d = e - mean; acc += d * d; }
+        else { const double a = fabs(e); if (a > cutoff) acc += a; }
+    }
+    const double t = block_sum(acc, s_part);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// Single block: out[0] = sum(partials) [/ n]  [sqrt].
+__global__ void __launch_bounds__(256) k_reduce_final(const double *__restrict__ partials, int n_part, double scale, int take_sqrt,
+                                                      double *__restrict__ out) {
+    __shared__ double s_part[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n_part; i += blockDim.x) acc += partials[i];
+    const double t = block_sum(acc, s_part);
+    if (threadIdx.x == 0) {
+        double v = t * scale;
+        out[0] = take_sqrt ? __dsqrt_rn(v) : v;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Batched point helpers.
+// ------------------------------------------------------------------------------------
+__global__ void k_point_density(const Geom *__restrict__ gp, const float *__restrict__ dens, const int32_t *__restrict__ crs, int64_t n,
+                                double *__restrict__ out, uint8_t *__restrict__ valid) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool ok;
+    const float v = fetch_wrapped(*gp, dens, crs[3 * i], crs[3 * i + 1], crs[3 * i + 2], &ok);
+    if (out) out[i] = (double)v;
+    if (valid) valid[i] = ok ? 1 : 0;
+}
+
+__global__ void k_crs2xyz(const Geom *__restrict__ gp, const int32_t *__restrict__ crs, int64_t n, double *__restrict__ xyz) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double q[3];
+    crs2xyz(*gp, crs[3 * i], crs[3 * i + 1], crs[3 * i + 2], q);
+    xyz[3 * i] = q[0]; xyz[3 * i + 1] = q[1]; xyz[3 * i + 2] = q[2];
+}
+
+__global__ void k_xyz2crs(const Geom *__restrict__ gp, const double *__restrict__ xyz, int64_t n, int32_t *__restrict__ crs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double p[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    int32_t c[3];
+    xyz2crs(*gp, p, c);
+    crs[3 * i] = c[0]; crs[3 * i + 1] = c[1]; crs[3 * i + 2] = c[2];
+}
+
+// utils.testOverlap batched (cutils.pyx:8-25): block per pair, threads over |A| x |B|.
+__global__ void __launch_bounds__(256) k_test_overlap(const int32_t *__restrict__ crs, const int64_t *__restrict__ set_off,
+                                                      const int32_t *__restrict__ a_idx, const int32_t *__restrict__ b_idx,
+                                                      unsigned int *__restrict__ out) {
+    const int p = blockIdx.x;
+    const int64_t a0 = set_off[a_idx[p]], a1 = set_off[a_idx[p] + 1];
+    const int64_t b0 = set_off[b_idx[p]], b1 = set_off[b_idx[p] + 1];
+    const int64_t na = a1 - a0, nb = b1 - b0;
+    bool hit = false;
+    for (int64_t t = threadIdx.x; t < na * nb && !hit; t += blockDim.x) {
+        const int32_t *x = crs + 3 * (a0 + t / nb);
+        const int32_t *y = crs + 3 * (b0 + t % nb);
+        const int d0 = x[0] - y[0], d1 = x[1] - y[1], d2 = x[2] - y[2];
+        hit = d0 >= -1 && d0 <= 1 && d1 >= -1 && d1 <= 1 && d2 >= -1 && d2 <= 1;
+    }
+    if (hit) atomicOr(&out[p], 1u);
+}
+
+// utils.createSymmetryAtoms (cutils.pyx:73-103): thread per (i,j,k,op,atom) candidate in
+// the reference's product order; keep flag + coordinate, compacted on the host side of the
+// C-ABI in index order.
+__global__ void k_symmetry_atoms(const double *__restrict__ xyz, int64_t n_atoms, const double *__restrict__ rot, int n_ops,
+                                 const double *__restrict__ ortho, const double *__restrict__ lo, const double *__restrict__ hi,
+                                 double *__restrict__ out_xyz, uint8_t *__restrict__ keep) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = 27ll * n_ops * n_atoms;
+    if (t >= total) return;
+    const int64_t a = t % n_atoms;
+    const int64_t cell_op = t / n_atoms;
+    const int op = (int)(cell_op % n_ops);
+    const int cell = (int)(cell_op / n_ops);
+    const int i = cell / 9 - 1, j = (cell / 3) % 3 - 1, k = cell % 3 - 1;
+    const double p[3] = {xyz[3 * a], xyz[3 * a + 1], xyz[3 * a + 2]};
+    if (i == 0 && j == 0 && k == 0 && op == 0) {
+        out_xyz[3 * t] = p[0]; out_xyz[3 * t + 1] = p[1]; out_xyz[3 * t + 2] = p[2];
+        keep[t] = 1;
+        return;
+    }
+    const double ijk[3] = {(double)i, (double)j, (double)k};
+    double ot[3];
+    matvec3(ortho, ijk, ot);
+    const double *rm = rot + 12 * op;
+    bool in = true;
+    for (int q = 0; q < 3; ++q) {
+        double v = ((rm[4 * q] * p[0] + rm[4 * q + 1] * p[1]) + rm[4 * q + 2] * p[2]);
+        v = (v + rm[4 * q + 3]) + ot[q];
+        out_xyz[3 * t + q] = v;
+        in = in && (lo[q] - 5 <= v) && (v <= hi[q] + 5);
+    }
+    keep[t] = in ? 1 : 0;
+}
+
+// Nearest atom per centroid (scipy cdist + argmin, densityAnalysis.py:934-935): block per
+// centroid, fp64 Euclidean, first index on ties.
+__global__ void __launch_bounds__(256) k_nearest_atom(const double *__restrict__ cen, const double *__restrict__ atoms, int64_t n_atoms,
+                                                      int64_t *__restrict__ index, double *__restrict__ distance) {
+    __shared__ double s_d[256];
+    __shared__ long long s_i[256];
+    const int64_t c = blockIdx.x;
+    const double cx = cen[3 * c], cy = cen[3 * c + 1], cz = cen[3 * c + 2];
+    double best = INFINITY;
+    long long bi = -1;
+    for (int64_t a = threadIdx.x; a < n_atoms; a += blockDim.x) {
+        const double dx = cx - atoms[3 * a], dy = cy - atoms[3 * a + 1], dz = cz - atoms[3 * a + 2];
+        const double d = __dsqrt_rn((dx * dx + dy * dy) + dz * dz);
+        if (d < best) { best = d; bi = a; }
+    }
+    s_d[threadIdx.x] = best;
+    s_i[threadIdx.x] = bi;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const double d2 = s_d[threadIdx.x + off];
+            const long long i2 = s_i[threadIdx.x + off];
+            if (i2 >= 0 && (d2 < s_d[threadIdx.x] || (d2 == s_d[threadIdx.x] && i2 < s_i[threadIdx.x]) || s_i[threadIdx.x] < 0)) {
+                s_d[threadIdx.x] = d2;
+                s_i[threadIdx.x] = i2;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { index[c] = s_i[0]; distance[c] = s_d[0]; }
+}
+
+}  // namespace pdbeda

@@ -1,0 +1,158 @@
+"""Seeded synthetic CCP4 maps and model structures.
+
+Real PDB entries / PDBe maps cannot be downloaded (no network), so tests, golden
+fixtures and bench.py all run on these generators.  Everything here is host-side
+input preparation; nothing is on the hot path.
+
+The CCP4 byte layout written by :func:`ccp4_bytes` is the one the reference parses in
+``pdb_eda/ccp4.py:145-150`` (56 header words + 800 label bytes, mode 2 data).
+"""
+import numpy as np
+
+__all__ = ["ccp4_bytes", "noise_grid", "MapSpec", "chain_structure", "gaussian_sum_grid", "smooth_noise"]
+
+
+class MapSpec(object):
+    """Geometry of a synthetic map: everything the CCP4 header carries."""
+
+    def __init__(self, ncrs, cell=None, angles=(90.0, 90.0, 90.0), interval=None, crs_start=(0, 0, 0),
+                 axis_order=(1, 2, 3), spacing=0.4):
+        self.ncrs = tuple(int(x) for x in ncrs)                # columns, rows, sections
+        self.axis_order = tuple(int(x) for x in axis_order)    # MAPC, MAPR, MAPS (1=X,2=Y,3=Z)
+        self.crs_start = tuple(int(x) for x in crs_start)
+        if interval is None:
+            # interval is per xyz axis; default = ncrs of the crs axis that maps onto it
+            interval = [0, 0, 0]
+            for crs_axis, xyz_axis in enumerate(self.axis_order):
+                interval[xyz_axis - 1] = self.ncrs[crs_axis]
+        self.interval = tuple(int(x) for x in interval)
+        if cell is None:
+            cell = [self.interval[i] * spacing for i in range(3)]
+        self.cell = tuple(float(np.float32(x)) for x in cell)
+        self.angles = tuple(float(np.float32(x)) for x in angles)
+
+
+def ccp4_bytes(spec, grid, big_endian=False, symmetry_bytes=b"", origin_em=(0.0, 0.0, 0.0)):
+    """Serialise ``grid`` ([ns][nr][nc] float32) with the header described by ``spec``."""
+    grid = np.ascontiguousarray(grid, dtype=np.float32)
+    nc, nr, ns = spec.ncrs
+    assert grid.shape == (ns, nr, nc), (grid.shape, spec.ncrs)
+    e = ">" if big_endian else "<"
+    words = np.zeros(56, dtype=e + "i4")
+    fl = words.view(e + "f4")
+    words[0:3] = spec.ncrs
+    words[3] = 2
+    words[4:7] = spec.crs_start
+    words[7:10] = spec.interval
+    fl[10:13] = spec.cell
+    fl[13:16] = spec.angles
+    words[16:19] = spec.axis_order
+    fl[19] = grid.min() if grid.size else 0.0
+    fl[20] = grid.max() if grid.size else 0.0
+    fl[21] = grid.mean(dtype=np.float64) if grid.size else 0.0
+    words[22] = 1
+    words[23] = len(symmetry_bytes)
+    fl[49:52] = origin_em
+    head = bytearray(words.tobytes())
+    head[208:212] = b"MAP "
+    head[212:216] = bytes([0x11, 0x11, 0, 0]) if big_endian else bytes([0x44, 0x41, 0, 0])
+    tail = np.zeros(3, dtype=e + "i4")
+    tail.view(e + "f4")[1] = grid.std(dtype=np.float64) if grid.size else 0.0
+    tail[2] = 1
+    head[216:224] = tail.tobytes()[4:12]
+    labels = b"synthetic map (pdb_eda_amd.synthetic)".ljust(800, b" ")
+    return bytes(head) + labels + bytes(symmetry_bytes) + grid.astype(e + "f4").tobytes()
+
+
+def smooth_noise(shape, seed, sigma_voxels=1.5):
+    """Gaussian-filtered white noise, periodic, float32 -- the config-2/4 map generator."""
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(seed)
+    g = rng.standard_normal(shape, dtype=np.float32)
+    if sigma_voxels > 0:
+        g = gaussian_filter(g, sigma=sigma_voxels, mode="wrap")
+    return np.ascontiguousarray(g, dtype=np.float32)
+
+
+def noise_grid(spec, seed, sigma_voxels=1.5):
+    nc, nr, ns = spec.ncrs
+    return smooth_noise((ns, nr, nc), seed, sigma_voxels)
+
+
+# ---- synthetic model: poly-ALA random-walk chain ---------------------------------------
+
+_ALA = (("N", "N", (0.0, 0.0, 0.0)), ("CA", "C", (1.458, 0.0, 0.0)), ("C", "C", (2.009, 1.420, 0.0)),
+        ("O", "O", (1.251, 2.390, 0.0)), ("CB", "C", (1.988, -0.773, -1.199)))
+
+
+def chain_structure(n_residues, seed, box_lo, box_hi, hetero_every=0, zero_occupancy_every=0, resname="ALA"):
+    """Return a :class:`pdb_eda_amd.structure.Structure` of ``n_residues`` ALA residues.
+
+    CA positions follow a 3.8 A random walk reflected inside [box_lo, box_hi]; the other
+    backbone atoms + CB are placed with a random rigid rotation of an ideal residue.
+    """
+    from .structure import Structure, Model, Chain, Residue, Atom
+    rng = np.random.default_rng(seed)
+    lo = np.asarray(box_lo, dtype=np.float64) + 3.0
+    hi = np.asarray(box_hi, dtype=np.float64) - 3.0
+    st = Structure("synth")
+    model = Model(0, st)
+    chain = Chain("A", model)
+    pos = (lo + hi) / 2 + rng.uniform(-1, 1, 3)
+    serial = 0
+    for i in range(n_residues):
+        step = rng.standard_normal(3)
+        step *= 3.8 / np.linalg.norm(step)
+        new = pos + step
+        for k in range(3):
+            if new[k] < lo[k] or new[k] > hi[k]:
+                new[k] = pos[k] - step[k]
+        pos = new
+        q = rng.standard_normal(4)
+        q /= np.linalg.norm(q)
+        w, x, y, z = q
+        rot = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                        [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                        [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        het = " " if not (hetero_every and (i + 1) % hetero_every == 0) else "H_LIG"
+        res = Residue((het, i + 1, " "), resname, chain)
+        for name, element, off in _ALA:
+            serial += 1
+            coord = (pos + rot.dot(np.asarray(off) - np.asarray(_ALA[1][2]))).astype(np.float32)
+            occ = 0.0 if (zero_occupancy_every and serial % zero_occupancy_every == 0) else 1.0
+            bfac = float(np.round(rng.uniform(8.0, 45.0), 2))
+            Atom(name, coord, occ, bfac, element, res, serial)
+    return st
+
+
+def gaussian_sum_grid(header, structure, electrons, sigma=0.55, noise=0.02, seed=0, scale=0.05):
+    """2Fo-Fc-like grid: sum over atoms of isotropic Gaussians weighted by electrons.
+
+    ``header`` is a :class:`pdb_eda_amd.ccp4.DensityHeader`; the Gaussian is evaluated on
+    the stored grid in a cubic neighbourhood of each atom (periodic in the cell).
+    ``electrons`` maps "RES_ATOM" names to electron counts (the reference's
+    ``full_atom_name_map_electrons`` table, loaded by the caller at run time).
+    """
+    nc, nr, ns = header.ncrs
+    rng = np.random.default_rng(seed)
+    grid = (rng.standard_normal((ns, nr, nc)) * noise).astype(np.float64)
+    reach = int(np.ceil(4 * sigma / min(header.gridLength))) + 1
+    off = np.arange(-reach, reach + 1)
+    oc, orr, os_ = np.meshgrid(off, off, off, indexing="ij")
+    for atom in structure.get_atoms():
+        key = atom.parent.resname.strip() + "_" + atom.name
+        w = float(electrons.get(key, 6.0)) * atom.get_occupancy()
+        if w == 0:
+            continue
+        c0, r0, s0 = header.xyz2crsCoord(atom.coord)
+        cc, rr, ss = c0 + oc, r0 + orr, s0 + os_
+        crs = np.stack([cc, rr, ss], axis=-1).reshape(-1, 3)
+        xyz = header.crs2xyz_array(crs)
+        d2 = ((xyz - atom.coord.astype(np.float64)) ** 2).sum(axis=1)
+        val = w * scale * np.exp(-d2 / (2 * sigma * sigma))
+        ci = np.mod(crs[:, 0], header.crsInterval[0])
+        ri = np.mod(crs[:, 1], header.crsInterval[1])
+        si = np.mod(crs[:, 2], header.crsInterval[2])
+        ok = (ci < nc) & (ri < nr) & (si < ns)
+        np.add.at(grid, (si[ok], ri[ok], ci[ok]), val[ok])
+    return grid.astype(np.float32)
