@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- whole-map blob labelling throughput on MI355X (BASELINE.json metric).
+
+A *step* is one pass of the hot path over one synthetic entry that is already resident in
+HBM: fused green/red blob labelling of a 256^3 map (BASELINE configs[1]) -- threshold at
++-(mean + 1.5 std), 26-neighbour connected components, per-blob fp64 statistics, blobs in
+the reference's order, and the dense int32 label volume of both signs.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU; every rank labels its own
+   entries -- the path shards over entries with no data-path collective, scaling = weak --
+   and RCCL carries only the final statistics reduction.)
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md section "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md): 8 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=256, help="grid edge (BASELINE config: 256)")
+    ap.add_argument("--nsd", type=float, default=1.5, help="cutoff = mean + nsd * std")
+    ap.add_argument("--no-labels", action="store_true", help="skip the dense label volume (not the headline configuration)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(kernel, n_vox, n_planes):
+    """Algorithmic HBM bytes of ONE launch of `kernel` ('Kernels and rooflines')."""
+    table = {
+        "k_threshold": 4 * n_vox + 8 * (n_vox // 64) * n_planes,      # read f32 grid once, write the bit masks
+        "k_tile_label": 4 * n_vox + 8 * (n_vox // 64) * n_planes,
+        "k_labels_plane": 4 * n_vox + 8 * (n_vox // 64),              # write int32 labels of one sign, read its mask
+        "k_run_index": (8 + 4) * (n_vox // 64) * n_planes,            # masks in, run_base out (+ sparse density re-read)
+        "k_union": (8 + 4) * (n_vox // 64) * n_planes,
+    }
+    return table.get(kernel)
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as entry
+    entry.build()
+    from pdb_eda_amd import _native, ccp4, synthetic
+
+    # ---- synthetic entry: smooth noise, orthogonal cell, resident in HBM ----
+    n = args.size
+    spec = synthetic.MapSpec(ncrs=(n, n, n), spacing=0.4)
+    grid = synthetic.smooth_noise((n, n, n), seed=7 + rank, sigma_voxels=1.5)
+    header = ccp4.DensityHeader.fromFileHeader(synthetic.ccp4_header_bytes(spec))
+    # torch owns the device buffer (plumbing); the library borrows the pointer (zero copy)
+    dens = torch.from_numpy(grid).to("cuda:%d" % local_rank)
+    ctx = _native.Context(local_rank)
+    dmap = _native.DeviceMap(ctx, dens, header.geometry(), device_ptr=dens.data_ptr())
+    mean, std = dmap.stats()
+    cut = mean + args.nsd * std
+    n_vox = n * n * n
+    labels = not args.no_labels
+
+    def step():
+        g, r = dmap.full_blobs_pm(cut, -cut, labels=labels)
+        return g, r
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    keep = None
+    for _ in range(args.warmup):
+        keep = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        keep = step()           # dropping the previous lists recycles their device arena (stream ordered)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    green, red = keep
+    n_green, n_red = len(green), len(red)
+    sig_vox = int(green.stats()["n"].sum() + red.stats()["n"].sum())
+
+    # final statistics reduction (the only collective of the path; KB-scale, outside the voxel work)
+    totals = torch.tensor([n_green, n_red, sig_vox], dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(totals, op=dist.ReduceOp.SUM)
+
+    # ---- per-kernel durations with HIP events on the library's stream (separate K-step pass) ----
+    ctx.profile_begin()
+    for _ in range(args.steps):
+        keep = step()
+    prof = ctx.profile_end()
+    per_kernel = {k: {"calls": c, "avg_us": 1e3 * ms / c} for k, (c, ms) in prof.items()}
+    dominant = max((k for k in prof if algorithmic_bytes(k, n_vox, 2) is not None), key=lambda k: prof[k][1])
+    dom_calls, dom_ms = prof[dominant]
+    dom_avg_s = dom_ms / dom_calls / 1e3
+    dom_bytes = algorithmic_bytes(dominant, n_vox, 2)
+    achieved = dom_bytes / dom_avg_s / 1e9
+    step_kernel_s = sum(ms for _, ms in prof.values()) / 1e3 / args.steps
+
+    value = world * n_vox * args.steps / elapsed / 1e6
+    out = {
+        "metric": "Mvoxels/s blob-labelled",
+        "value": value,
+        "unit": "Mvoxels/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "configs[1]: %d^3 synthetic CCP4 grid (gaussian-filtered noise, sigma_filter 1.5 voxels), fused green/red blob "
+                               "labelling at +-(mean+%.1f*std), per-blob fp64 stats%s, map resident in HBM" % (n, args.nsd, " + dense int32 labels of both signs" if labels else ""),
+                   "grid": [n, n, n], "cutoff_sigma": args.nsd, "labels": labels, "entries_per_rank": 1, "sharding": "one entry per rank, no data-path collective"},
+        "entries_per_min": 60.0 * world * args.steps / elapsed,
+        "blobs": {"green": n_green, "red": n_red, "significant_voxels": sig_vox, "all_ranks": [int(x) for x in totals.tolist()]},
+        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": 1e6 * dom_avg_s,
+                     "timing": "HIP events on the launch stream, separate %d-step pass" % args.steps,
+                     "pass_8B_per_voxel": {"bytes": 8 * n_vox, "kernel_sum_us": 1e6 * step_kernel_s,
+                                           "achieved": 8 * n_vox / step_kernel_s / 1e9, "frac": 8 * n_vox / step_kernel_s / 1e9 / HBM_PEAK_GBS}},
+        "kernels_us": {k: round(v["avg_us"] * v["calls"] / args.steps, 2) for k, v in sorted(per_kernel.items())},
+    }
+
+    # ---- CPU baseline: the oracle (CPU restatement, O(N) clustering) on the same entry, 1 core ----
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import oracle as ora
+        o = ora.Oracle(header, grid)
+        done, spent = 0, 0.0
+        while spent < args.cpu_seconds and done < 8:
+            t1 = time.perf_counter()
+            a = o.full_blobs(cut, labels=labels)
+            b = o.full_blobs(-cut, labels=labels)
+            spent += time.perf_counter() - t1
+            done += 1
+        assert len(a["n"]) == n_green and len(b["n"]) == n_red, "GPU / oracle blob counts differ"
+        out["cpu_baseline"] = {"value": done * n_vox / spent / 1e6, "unit": "Mvoxels/s", "cores": 1, "kind": "port",
+                               "sample": "%d x the same %d^3 entry, green+red, oracle/pdbeda_oracle.c ora_full_blobs (single thread); "
+                                         "the reference's own O(N^2) clustering cannot run this size (SURVEY.md 6)" % (done, n)}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

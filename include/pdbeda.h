@@ -70,6 +70,11 @@ int pdbeda_ctx_destroy(pdbeda_ctx *ctx);
 int pdbeda_ctx_synchronize(pdbeda_ctx *ctx);
 void *pdbeda_ctx_stream(pdbeda_ctx *ctx); /* the hipStream_t the kernels are launched on */
 const char *pdbeda_last_error(pdbeda_ctx *ctx);
+/* Per-kernel timing with HIP events recorded on the context's stream (measurement aid for
+ * bench.py; no reference counterpart).  profile_end synchronises and writes one
+ * "kernel_name calls total_ms" line per kernel into buf. */
+int pdbeda_ctx_profile_begin(pdbeda_ctx *ctx);
+int pdbeda_ctx_profile_end(pdbeda_ctx *ctx, char *buf, int64_t cap);
 
 /* ---- map residency: replaces DensityMatrix.__init__ (ccp4.py:322-341) ------------- */
 /* density: host float32 [ns][nr][nc] (c fastest); copied to HBM. */

@@ -61,6 +61,8 @@ _SIGS = {
     "pdbeda_ctx_synchronize": (C.c_int, [_p]),
     "pdbeda_ctx_stream": (_p, [_p]),
     "pdbeda_last_error": (C.c_char_p, [_p]),
+    "pdbeda_ctx_profile_begin": (C.c_int, [_p]),
+    "pdbeda_ctx_profile_end": (C.c_int, [_p, C.c_char_p, _i64]),
     "pdbeda_map_upload": (C.c_int, [_p, _p, C.POINTER(Geometry), C.POINTER(_p)]),
     "pdbeda_map_from_device": (C.c_int, [_p, _p, C.POINTER(Geometry), C.POINTER(_p)]),
     "pdbeda_map_free": (C.c_int, [_p]),
@@ -133,6 +135,19 @@ class Context(object):
     @property
     def stream(self):
         return self._lib.pdbeda_ctx_stream(self._h)
+
+    def profile_begin(self):
+        self.check(self._lib.pdbeda_ctx_profile_begin(self._h), "pdbeda_ctx_profile_begin")
+
+    def profile_end(self):
+        """{kernel: (calls, total_ms)} measured with HIP events on this context's stream."""
+        buf = C.create_string_buffer(1 << 16)
+        self.check(self._lib.pdbeda_ctx_profile_end(self._h, buf, len(buf)), "pdbeda_ctx_profile_end")
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, calls, ms = line.rsplit(" ", 2)
+            out[name] = (int(calls), float(ms))
+        return out
 
     def close(self):
         if getattr(self, "_h", None):

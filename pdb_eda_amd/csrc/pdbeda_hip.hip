@@ -35,7 +35,25 @@ struct pdbeda_ctx {
     void *pinned = nullptr;             // small pinned staging buffer
     size_t pinned_cap = 0;
     int live_handles = 0;
+    // optional per-kernel timing with HIP events on ctx->stream (bench.py's roofline leg)
+    bool profiling = false;
+    struct ProfRec { const char *name; hipEvent_t a, b; };
+    std::vector<ProfRec> prof;
 };
+
+struct ProfScope {
+    pdbeda_ctx *ctx;
+    hipEvent_t b = nullptr;
+    ProfScope(pdbeda_ctx *c, const char *name) : ctx(c) {
+        if (!ctx->profiling) return;
+        hipEvent_t a = nullptr;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { b = nullptr; return; }
+        (void)hipEventRecord(a, ctx->stream);
+        ctx->prof.push_back({name, a, b});
+    }
+    ~ProfScope() { if (b) (void)hipEventRecord(b, ctx->stream); }
+};
+#define PROF(ctx, name) ProfScope prof_scope_##__LINE__(ctx, name)
 
 struct pdbeda_map {
     pdbeda_ctx *ctx = nullptr;
@@ -201,6 +219,38 @@ extern "C" int pdbeda_ctx_destroy(pdbeda_ctx *ctx) {
 extern "C" int pdbeda_ctx_synchronize(pdbeda_ctx *ctx) {
     if (!ctx) return PDBEDA_ERR_ARGUMENT;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PDBEDA_OK;
+}
+
+extern "C" int pdbeda_ctx_profile_begin(pdbeda_ctx *ctx) {
+    if (!ctx) return PDBEDA_ERR_ARGUMENT;
+    for (auto &r : ctx->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    ctx->prof.clear();
+    ctx->profiling = true;
+    return PDBEDA_OK;
+}
+
+// Stops profiling, synchronises, and writes "name calls total_ms\n" lines into buf.
+extern "C" int pdbeda_ctx_profile_end(pdbeda_ctx *ctx, char *buf, int64_t cap) {
+    if (!ctx || !buf || cap <= 0) return PDBEDA_ERR_ARGUMENT;
+    ctx->profiling = false;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::map<std::string, std::pair<int64_t, double>> agg;
+    for (auto &r : ctx->prof) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { auto &e = agg[r.name]; e.first++; e.second += ms; }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    ctx->prof.clear();
+    std::string out;
+    char line[160];
+    for (auto &kv : agg) {
+        snprintf(line, sizeof line, "%s %lld %.6f\n", kv.first.c_str(), (long long)kv.second.first, kv.second.second);
+        out += line;
+    }
+    if ((int64_t)out.size() + 1 > cap) return fail(ctx, PDBEDA_ERR_CAPACITY, "profile buffer too small");
+    memcpy(buf, out.c_str(), out.size() + 1);
     return PDBEDA_OK;
 }
 
@@ -465,14 +515,14 @@ static int engine_enqueue(pdbeda_ctx *ctx, pdbeda_map *m, Job &job, int64_t max_
     // per-run kernels are grid-stride over the ACTUAL run count (read on the device)
     const unsigned run_grid = grid_for(max_runs, 256, 2048);
     if (job.total_words > 0) {
-        hipLaunchKernelGGL(k_run_index, dim3(grid_for(job.total_words, 256, 1ll << 30)), dim3(256), 0, st, job, m->dens, m->geom_dev);
-        hipLaunchKernelGGL(k_union, dim3(grid_for(job.total_words, 256, 1ll << 30)), dim3(256), 0, st, job);
-        hipLaunchKernelGGL(k_resolve, dim3(run_grid), dim3(256), 0, st, job);
-        hipLaunchKernelGGL(k_paint_keys, dim3(run_grid), dim3(256), 0, st, job);
+        { PROF(ctx, "k_run_index"); hipLaunchKernelGGL(k_run_index, dim3(grid_for(job.total_words, 256, 1ll << 30)), dim3(256), 0, st, job, m->dens, m->geom_dev); }
+        { PROF(ctx, "k_union"); hipLaunchKernelGGL(k_union, dim3(grid_for(job.total_words, 256, 1ll << 30)), dim3(256), 0, st, job); }
+        { PROF(ctx, "k_resolve"); hipLaunchKernelGGL(k_resolve, dim3(run_grid), dim3(256), 0, st, job); }
+        { PROF(ctx, "k_paint_keys"); hipLaunchKernelGGL(k_paint_keys, dim3(run_grid), dim3(256), 0, st, job); }
     }
-    if (job.n_chunks > 0) hipLaunchKernelGGL(k_key_chunks, dim3(job.n_chunks), dim3(KEY_CHUNK), 0, st, job);
-    hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, st, job);
-    if (job.total_words > 0) hipLaunchKernelGGL(k_emit, dim3(run_grid), dim3(256), 0, st, job, m->geom_dev);
+    if (job.n_chunks > 0) { PROF(ctx, "k_key_chunks"); hipLaunchKernelGGL(k_key_chunks, dim3(job.n_chunks), dim3(KEY_CHUNK), 0, st, job); }
+    { PROF(ctx, "k_chunk_scan"); hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, st, job); }
+    if (job.total_words > 0) { PROF(ctx, "k_emit"); hipLaunchKernelGGL(k_emit, dim3(run_grid), dim3(256), 0, st, job, m->geom_dev); }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -521,13 +571,19 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
         vd[p].key_base = keys_pp * p;
     }
     hipStream_t st = ctx->stream;
-    hipLaunchKernelGGL(k_set_vols, dim3(1), dim3(64), 0, st, job.vols, vd[0], vd[n_planes - 1], n_planes);
-    HIP_TRY(ctx, hipMemsetAsync(job.ctr, 0, sizeof(Counters), st));
-    HIP_TRY(ctx, hipMemsetAsync(job.key_bits, 0, sizeof(uint64_t) * job.key_words, st));
+    {
+        PROF(ctx, "setup(memset+vols)");
+        hipLaunchKernelGGL(k_set_vols, dim3(1), dim3(64), 0, st, job.vols, vd[0], vd[n_planes - 1], n_planes);
+        HIP_TRY(ctx, hipMemsetAsync(job.ctr, 0, sizeof(Counters), st));
+        HIP_TRY(ctx, hipMemsetAsync(job.key_bits, 0, sizeof(uint64_t) * job.key_words, st));
+    }
 
     uint64_t *mp = want_pos ? job.mask : nullptr;
     uint64_t *mn = want_neg ? job.mask + (want_pos ? words_pp : 0) : nullptr;
-    rc = tile_or_stream_threshold(ctx->stream, m->dens, m->geom_dev, g, job, mp, mn, cut_pos, cut_neg, row_words, words_pp);
+    {
+        PROF(ctx, "k_threshold");
+        rc = tile_or_stream_threshold(ctx->stream, m->dens, m->geom_dev, g, job, mp, mn, cut_pos, cut_neg, row_words, words_pp);
+    }
     if (rc) { arena_put(ctx, arena); return fail(ctx, PDBEDA_ERR_DEVICE, "threshold launch failed"); }
     rc = engine_enqueue(ctx, m, job, max_runs);
     if (rc) { arena_put(ctx, arena); return rc; }
@@ -547,9 +603,11 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
     }
     if (labels) {
         // ranks of plane 1 start after plane 0's blobs: resolved on the device from chunk_prefix
-        for (int p = 0; p < n_planes; ++p)
+        for (int p = 0; p < n_planes; ++p) {
+            PROF(ctx, "k_labels_plane");
             hipLaunchKernelGGL(k_labels_plane, dim3(grid_for(words_pp * 64, 256, 4096)), dim3(256), 0, st, job, p,
                                labels_dev + (size_t)keys_pp * p);
+        }
         HIP_TRY(ctx, hipGetLastError());
         for (int p = 0; p < n_planes; ++p) (p == 0 ? first : first->sibling)->labels_done = true;
     }
@@ -744,9 +802,8 @@ extern "C" int pdbeda_bloblist_free(pdbeda_bloblist *bl) {
     pdbeda_bloblist *other = bl->sibling;
     const bool other_alive = other && !other->freed;
     if (!other_alive) {
-        // last list of the job: device work on the arena must be finished before reuse
-        (void)hipSetDevice(ctx->device);
-        (void)hipStreamSynchronize(ctx->stream);
+        // last list of the job.  Arenas are recycled only inside this context, i.e. by work that
+        // is enqueued later on the SAME stream, so stream order protects them: no host sync.
         arena_put(ctx, ow->arena);
         arena_put(ctx, ow->vox_arena);
         if (other) delete other;

@@ -9,7 +9,7 @@ The CCP4 byte layout written by :func:`ccp4_bytes` is the one the reference pars
 """
 import numpy as np
 
-__all__ = ["ccp4_bytes", "noise_grid", "MapSpec", "chain_structure", "gaussian_sum_grid", "smooth_noise"]
+__all__ = ["ccp4_bytes", "ccp4_header_bytes", "noise_grid", "MapSpec", "chain_structure", "gaussian_sum_grid", "smooth_noise"]
 
 
 class MapSpec(object):
@@ -32,11 +32,8 @@ class MapSpec(object):
         self.angles = tuple(float(np.float32(x)) for x in angles)
 
 
-def ccp4_bytes(spec, grid, big_endian=False, symmetry_bytes=b"", origin_em=(0.0, 0.0, 0.0)):
-    """Serialise ``grid`` ([ns][nr][nc] float32) with the header described by ``spec``."""
-    grid = np.ascontiguousarray(grid, dtype=np.float32)
-    nc, nr, ns = spec.ncrs
-    assert grid.shape == (ns, nr, nc), (grid.shape, spec.ncrs)
+def ccp4_header_bytes(spec, stats=(0.0, 0.0, 0.0, 0.0), big_endian=False, n_symmetry_bytes=0, origin_em=(0.0, 0.0, 0.0)):
+    """The 1024-byte CCP4 header for ``spec``; stats = (min, max, mean, rms)."""
     e = ">" if big_endian else "<"
     words = np.zeros(56, dtype=e + "i4")
     fl = words.view(e + "f4")
@@ -47,21 +44,28 @@ def ccp4_bytes(spec, grid, big_endian=False, symmetry_bytes=b"", origin_em=(0.0,
     fl[10:13] = spec.cell
     fl[13:16] = spec.angles
     words[16:19] = spec.axis_order
-    fl[19] = grid.min() if grid.size else 0.0
-    fl[20] = grid.max() if grid.size else 0.0
-    fl[21] = grid.mean(dtype=np.float64) if grid.size else 0.0
+    fl[19], fl[20], fl[21] = stats[0], stats[1], stats[2]
     words[22] = 1
-    words[23] = len(symmetry_bytes)
+    words[23] = n_symmetry_bytes
     fl[49:52] = origin_em
+    fl[54] = stats[3]
+    words[55] = 1
     head = bytearray(words.tobytes())
     head[208:212] = b"MAP "
     head[212:216] = bytes([0x11, 0x11, 0, 0]) if big_endian else bytes([0x44, 0x41, 0, 0])
-    tail = np.zeros(3, dtype=e + "i4")
-    tail.view(e + "f4")[1] = grid.std(dtype=np.float64) if grid.size else 0.0
-    tail[2] = 1
-    head[216:224] = tail.tobytes()[4:12]
     labels = b"synthetic map (pdb_eda_amd.synthetic)".ljust(800, b" ")
-    return bytes(head) + labels + bytes(symmetry_bytes) + grid.astype(e + "f4").tobytes()
+    return bytes(head) + labels
+
+
+def ccp4_bytes(spec, grid, big_endian=False, symmetry_bytes=b"", origin_em=(0.0, 0.0, 0.0)):
+    """Serialise ``grid`` ([ns][nr][nc] float32) with the header described by ``spec``."""
+    grid = np.ascontiguousarray(grid, dtype=np.float32)
+    nc, nr, ns = spec.ncrs
+    assert grid.shape == (ns, nr, nc), (grid.shape, spec.ncrs)
+    e = ">" if big_endian else "<"
+    stats = (grid.min(), grid.max(), grid.mean(dtype=np.float64), grid.std(dtype=np.float64)) if grid.size else (0.0,) * 4
+    head = ccp4_header_bytes(spec, stats, big_endian, len(symmetry_bytes), origin_em)
+    return head + bytes(symmetry_bytes) + grid.astype(e + "f4").tobytes()
 
 
 def smooth_noise(shape, seed, sigma_voxels=1.5):
@@ -155,4 +159,11 @@ def gaussian_sum_grid(header, structure, electrons, sigma=0.55, noise=0.02, seed
         si = np.mod(crs[:, 2], header.crsInterval[2])
         ok = (ci < nc) & (ri < nr) & (si < ns)
         np.add.at(grid, (si[ok], ri[ok], ci[ok]), val[ok])
+    ic, ir, is_ = header.crsInterval
+    if nc > ic:
+        grid[:, :, ic:] = grid[:, :, :nc - ic]
+    if nr > ir:
+        grid[:, ir:, :] = grid[:, :nr - ir, :]
+    if ns > is_:
+        grid[is_:, :, :] = grid[:ns - is_, :, :]
     return grid.astype(np.float32)

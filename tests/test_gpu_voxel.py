@@ -1,0 +1,335 @@
+"""Parity tests proper: the HIP path (through the C-ABI) against the golden vectors produced
+by the reference and against the CPU oracle, on the same inputs.
+
+Bars (BASELINE.json north_star): voxel membership, counts, blob order bit exact; float
+sums within 1e-5 relative -- the assertions below hold the tighter REL = 1e-9.
+"""
+import io
+
+import numpy as np
+import pytest
+
+from conftest import VOXEL_CASES, GOLDEN, load_case, blobs_from_record, crs_set
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-9
+
+
+def device_blobs(bl):
+    st = bl.stats()
+    crs, off = bl.voxels()
+    return [{"crs": crs[off[i]:off[i + 1]], "n": int(st["n"][i]), "totalDensity": st["totalDensity"][i], "centroid": st["centroid"][i],
+             "coordCenter": st["coordCenter"][i], "volume": st["volume"][i], "firstKey": int(st["firstKey"][i]), "group": int(st["group"][i])}
+            for i in range(len(st["n"]))]
+
+
+def assert_blob_equal(g, w, rel=REL):
+    assert crs_set(g["crs"]) == crs_set(w["crs"])
+    assert g["n"] == len(w["crs"])
+    if abs(w["totalDensity"]) > 1e-9:
+        assert g["totalDensity"] == pytest.approx(w["totalDensity"], rel=rel)
+        assert np.allclose(g["centroid"], w["centroid"], rtol=rel, atol=1e-9)
+    assert np.allclose(g["coordCenter"], w["coordCenter"], rtol=rel, atol=1e-9)
+    assert g["volume"] == pytest.approx(w["volume"], rel=rel)
+
+
+@pytest.fixture(scope="module", params=VOXEL_CASES)
+def case(request, gpu_ctx):
+    from pdb_eda_amd import ccp4
+    z, header, grid = load_case(request.param)
+    dm = ccp4.parse(io.BytesIO(z["ccp4_bytes"].tobytes()), request.param, ctx=gpu_ctx)
+    return request.param, z, dm
+
+
+def test_stats_and_sum_of_abs(case):
+    _, z, dm = case
+    assert dm.meanDensity == pytest.approx(float(z["mean"]), rel=1e-12, abs=1e-15)
+    assert dm.stdDensity == pytest.approx(float(z["std"]), rel=1e-12)
+    for cut, want in zip(z["soa_cut"], z["soa"]):
+        assert dm.getTotalAbsDensity(float(cut)) == pytest.approx(want, rel=1e-12)
+
+
+def test_point_density_and_geometry(case):
+    _, z, dm = case
+    m = dm._map
+    assert np.array_equal(m.point_density(z["pt_crs"]), z["pt_density"])
+    assert np.array_equal(m.valid_crs(z["pt_crs"]).astype(np.uint8), z["pt_valid"])
+    assert np.array_equal(m.crs2xyz(z["pt_crs"]), z["pt_xyz"])                       # bit exact device geometry
+    assert np.array_equal(m.xyz2crs(z["x2c_xyz"].astype(np.float64)), z["x2c_crs"])
+    assert dm.getPointDensityFromCrs([int(x) for x in z["pt_crs"][7]]) == z["pt_density"][7]
+
+
+@pytest.mark.parametrize("tag", ["p30", "n30", "p15", "n20"])
+def test_full_map_blobs_vs_reference(case, tag):
+    _, z, dm = case
+    cut = float(z["full_%s_cut" % tag])
+    bl = dm._map.full_blobs(cut)
+    got = device_blobs(bl)
+    want = blobs_from_record(z, "full_" + tag)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):          # the reference's emission order
+        assert_blob_equal(g, w)
+    # DensityBlob surface
+    blobs = dm.createFullBlobList(cut)
+    assert [b.numVoxels for b in blobs] == [len(w["crs"]) for w in want]
+    if blobs:
+        assert blobs[0].crsList == crs_set(want[0]["crs"])
+
+
+def test_full_map_fused_and_labels(case):
+    from oracle import oracle as ora
+    name, z, dm = case
+    cp, cn = float(z["full_p30_cut"]), float(z["full_n30_cut"])
+    green, red = dm._map.full_blobs_pm(cp, cn, labels=True)
+    for bl, tag in ((green, "p30"), (red, "n30")):
+        got, want = device_blobs(bl), blobs_from_record(z, "full_" + tag)
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert_blob_equal(g, w)
+    _, header, grid = load_case(name)
+    o = ora.Oracle(header, grid)
+    for bl, cut in ((green, cp), (red, cn)):
+        lab = bl.labels(dm._map.unique_shape)
+        assert np.array_equal(lab, o.full_blobs(cut, labels=True)["labels"])
+    # lazily computed labels of a non-fused list agree too
+    single = dm._map.full_blobs(cp)
+    assert np.array_equal(single.labels(dm._map.unique_shape), green.labels(dm._map.unique_shape))
+    assert dm.createFullBlobList(0.0) is None
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2, 3])
+def test_sphere_blobs_per_atom(case, ci):
+    """findAberrantBlobs for single coordinates, batched: one group per atom."""
+    _, z, dm = case
+    cut = float(z["sph_cut"][ci])
+    n = len(z["sph_xyz"])
+    bl = dm._map.sphere_blobs(z["sph_xyz"].astype(np.float64), z["sph_radius"].astype(np.float32), np.arange(n + 1), cut)
+    got = device_blobs(bl)
+    off = z["sph%d_off" % ci]
+    boff = np.concatenate([[0], np.cumsum(z["sphb%d_nblobs" % ci])])
+    want_blobs = blobs_from_record(z, "sphb%d" % ci)
+    for a in range(n):
+        ga = [g for g in got if g["group"] == a]
+        want_set = crs_set(z["sph%d_crs" % ci][off[a]:off[a + 1]])
+        assert set().union(*[crs_set(g["crs"]) for g in ga]) == want_set if ga else want_set == set()
+        wa = want_blobs[boff[a]:boff[a + 1]]
+        assert len(ga) == len(wa)
+        for g, w in zip(ga, wa):      # single-atom lists keep the reference's emission order
+            assert_blob_equal(g, w)
+
+
+def test_sphere_unions_and_region_sums(case):
+    _, z, dm = case
+    xyz = z["sph_xyz"].astype(np.float64)
+    for tag, radii in (("s", np.full(len(xyz), 1.9, dtype=np.float32)), ("l", z["sph_radius"].astype(np.float32))):
+        goff = np.arange(0, len(xyz) + 1, 4)
+        for ci in range(3):
+            cut = float(z["sph_cut"][ci])
+            got = device_blobs(dm._map.sphere_blobs(xyz, radii, goff, cut))
+            for gi in range(6):
+                want = crs_set(z["uni_%s%d_g%d" % (tag, ci, gi)])
+                gg = [g for g in got if g["group"] == gi]
+                have = set().union(*[crs_set(g["crs"]) for g in gg]) if gg else set()
+                assert have == want
+                key = "unib_%s%d_g%d" % (tag, ci, gi)
+                if want:
+                    wb = blobs_from_record(z, key)
+                    assert len(gg) == len(wb)
+                    for g, w in zip(sorted(gg, key=lambda b: min(crs_set(b["crs"]))), wb):
+                        assert_blob_equal(g, w)
+        # regional sums: identity sum(blob.totalDensity) == masked sum over the sphere union
+        cut = float(z["sph_cut"][1])
+        pos, neg, cnt, valid = dm._map.region_sums(xyz, radii, goff, cut)
+        for gi in range(6):
+            assert cnt[gi] == len(z["uni_%s0_g%d" % (tag, gi)])
+            wp = z["unib_%s1_g%d_total" % (tag, gi)].sum() if ("unib_%s1_g%d_total" % (tag, gi)) in z.files else 0.0
+            wn = z["unib_%s2_g%d_total" % (tag, gi)].sum() if ("unib_%s2_g%d_total" % (tag, gi)) in z.files else 0.0
+            assert pos[gi] == pytest.approx(wp, rel=REL, abs=1e-12)
+            assert neg[gi] == pytest.approx(wn, rel=REL, abs=1e-12)
+            if tag == "s":
+                assert bool(valid[gi]) == bool(z["uni_valid_g%d" % gi])
+    # per-atom validity (testValidXyz)
+    n = len(xyz)
+    _, _, cnt, valid = dm._map.region_sums(xyz, z["sph_radius"].astype(np.float32), np.arange(n + 1), 0.1)
+    assert np.array_equal(valid.astype(np.uint8), z["sph_valid"])
+    off0 = z["sph0_off"]
+    assert np.array_equal(cnt, np.diff(off0))
+
+
+def test_list_blobs_merge_and_overlap(case):
+    _, z, dm = case
+    want = blobs_from_record(z, "full_p15")[:12]
+    # createBlobList on an explicit voxel list reproduces the clustering
+    allcrs = np.concatenate([w["crs"] for w in want]) if want else np.zeros((0, 3), np.int32)
+    got = device_blobs(dm._map.list_blobs(allcrs))
+    assert sorted(map(lambda g: tuple(sorted(crs_set(g["crs"]))), got)) == sorted(tuple(sorted(crs_set(w["crs"]))) for w in want)
+    if len(want) >= 2:
+        from pdb_eda_amd.ccp4 import DensityBlob
+        a = DensityBlob.fromCrsList(want[0]["crs"], dm)
+        b = DensityBlob.fromCrsList(want[1]["crs"], dm)
+        assert a.totalDensity == pytest.approx(want[0]["totalDensity"], rel=REL)
+        assert np.allclose(a.centroid, want[0]["centroid"], rtol=REL)
+        a.merge(b)
+        assert len(a.crsList) == len(want[0]["crs"]) + len(want[1]["crs"])
+        assert a.totalDensity == pytest.approx(want[0]["totalDensity"] + want[1]["totalDensity"], rel=REL)
+    blobs = want
+    sets = [w["crs"] for w in blobs]
+    off = np.concatenate([[0], np.cumsum([len(s) for s in sets])]).astype(np.int64)
+    if len(z["ovl_pairs"]):
+        res = dm._ctx.test_overlap(np.concatenate(sets), off, z["ovl_pairs"][:, 0], z["ovl_pairs"][:, 1])
+        assert np.array_equal(res.astype(np.uint8), z["ovl_res"])
+
+
+def test_symmetry_and_nearest_atom(case, gpu_ctx):
+    _, z, dm = case
+    idx, sym, xyz = gpu_ctx.symmetry_atoms(z["sph_xyz"].astype(np.float64), z["sym_rot"], np.asarray(dm.header.orthoMat, dtype=np.float64),
+                                           z["sym_box"][0], z["sym_box"][1])
+    assert np.array_equal(idx, z["sym_atom"])
+    assert np.array_equal(sym, z["sym_sym"])
+    assert np.allclose(xyz, z["sym_xyz"], rtol=0, atol=1e-12)
+    from scipy.spatial.distance import cdist
+    cen = blobs_from_record(z, "full_p15")
+    if cen:
+        c = np.array([b["centroid"] for b in cen])
+        d = cdist(c, z["sym_xyz"])
+        gi, gd = gpu_ctx.nearest_atom(c, z["sym_xyz"])
+        assert np.array_equal(gi, np.argmin(d, axis=1))
+        assert np.allclose(gd, d.min(axis=1), rtol=1e-15, atol=0)
+
+
+# ---- edge cases the reference's test design calls for (painted cubes with analytic answers) -----
+
+def _dm(grid, gpu_ctx, **kw):
+    from pdb_eda_amd import ccp4, synthetic
+    ns, nr, nc = grid.shape
+    spec = synthetic.MapSpec(ncrs=(nc, nr, ns), **kw)
+    return ccp4.parse(io.BytesIO(synthetic.ccp4_bytes(spec, grid)), "edge", ctx=gpu_ctx)
+
+
+def test_painted_cubes(gpu_ctx):
+    """The reference's own KAT idea (tests/test_ccp4.py:75-108): cubes of +-1 with analytic blobs."""
+    g = np.zeros((40, 40, 40), dtype=np.float32)
+    g[11:13, 11:13, 11:13] = 1
+    g[7:10, 11:14, 7:10] = 1
+    g[11:13, 7:9, 7:9] = -1
+    g[7:10, 7:10, 11:14] = -1
+    dm = _dm(g, gpu_ctx, spacing=0.5)
+    centre = dm.header.crs2xyzCoord([10, 10, 10])
+    green = dm.findAberrantBlobs(centre, 5, 0.5)
+    assert sorted(b.numVoxels for b in green) == [8, 27]
+    big = [b for b in green if b.numVoxels == 27][0]
+    assert np.allclose(big.centroid, dm.header.crs2xyzCoord([8, 12, 8]))
+    assert big.totalDensity == 27 and big.volume == pytest.approx(27 * dm.header.unitVolume)
+    red = dm.findAberrantBlobs(centre, 5, -0.5)
+    assert sorted(b.numVoxels for b in red) == [8, 27]
+    assert sorted(b.totalDensity for b in red) == [-27, -8]
+    full_g, full_r = dm.createFullBlobLists(0.5)
+    assert sorted(b.numVoxels for b in full_g) == [8, 27] and sorted(b.numVoxels for b in full_r) == [8, 27]
+    # merge KAT (tests/test_ccp4.py:111-131): 8 + 8 + 1 voxels touching through (10,10,10)
+    g2 = np.zeros((40, 40, 40), dtype=np.float32)
+    g2[11:13, 11:13, 11:13] = 1
+    dm2 = _dm(g2, gpu_ctx, spacing=0.5)
+    b1 = dm2.findAberrantBlobs(centre, 5, 0.5)[0]
+    g3 = np.zeros((40, 40, 40), dtype=np.float32)
+    g3[8:10, 8:10, 8:10] = 1
+    g3[10, 10, 10] = 1
+    dm3 = _dm(g3, gpu_ctx, spacing=0.5)
+    b2 = dm3.findAberrantBlobs(centre, 5, 0.5)[0]
+    assert b2.numVoxels == 9
+    assert b1.testOverlap(b2)
+
+
+def test_empty_full_and_degenerate(gpu_ctx):
+    from oracle import oracle as ora
+    g = np.zeros((5, 6, 70), dtype=np.float32)
+    dm = _dm(g, gpu_ctx)
+    assert dm.createFullBlobList(0.5) == []
+    g[:] = 1.0
+    dm = _dm(g, gpu_ctx)
+    blobs = dm.createFullBlobList(0.5)
+    assert len(blobs) == 1 and blobs[0].numVoxels == g.size
+    assert dm.createFullBlobList(1.0)[0].numVoxels == g.size      # inclusive threshold (Q2)
+    assert dm.createFullBlobList(np.nextafter(np.float32(1), np.float32(2))) == []
+    one = _dm(np.ones((1, 1, 1), dtype=np.float32), gpu_ctx)
+    b = one.createFullBlobList(0.5)
+    assert len(b) == 1 and b[0].crsList == {(0, 0, 0)}
+    # checkerboard in c (maximum number of runs per word), isolated in r/s -> every voxel its own blob
+    cb = np.zeros((9, 9, 130), dtype=np.float32)
+    cb[::2, ::2, ::2] = 1.0
+    dm = _dm(cb, gpu_ctx)
+    blobs = dm.createFullBlobList(0.5)
+    assert len(blobs) == int(cb.sum()) and all(b.numVoxels == 1 for b in blobs)
+    keys = [b.firstKey for b in blobs]
+    assert keys == sorted(keys)
+    # dense checkerboard in 3-D is ONE 26-connected blob
+    cb2 = np.zeros((8, 8, 130), dtype=np.float32)
+    idx = np.indices(cb2.shape).sum(axis=0)
+    cb2[idx % 2 == 0] = 1.0
+    dm = _dm(cb2, gpu_ctx)
+    assert [b.numVoxels for b in dm.createFullBlobList(0.5)] == [int(cb2.sum())]
+    # a long diagonal snake: deep union-find chains, runs crossing word boundaries
+    sn = np.zeros((3, 200, 200), dtype=np.float32)
+    for i in range(200):
+        sn[i % 3, i, i] = 2.0
+        sn[(i + 1) % 3, i, 199 - i] = 2.0
+    dm = _dm(sn, gpu_ctx)
+    o = ora.Oracle(dm.header, sn)
+    want = o.full_blobs(1.0, labels=True)
+    bl = dm._map.full_blobs(1.0)
+    assert np.array_equal(bl.labels(dm._map.unique_shape), want["labels"])
+    assert np.array_equal(bl.stats()["n"], want["n"])
+
+
+@pytest.mark.parametrize("shape,seed,nsd", [((128, 128, 128), 5, 1.5), ((96, 100, 200), 6, 3.0), ((61, 67, 130), 8, 1.0)])
+def test_random_maps_vs_oracle(gpu_ctx, shape, seed, nsd):
+    """Seeded smooth-noise maps at sizes the reference cannot cluster (O(N^2)) but the oracle can."""
+    from oracle import oracle as ora
+    from pdb_eda_amd import synthetic
+    g = synthetic.smooth_noise(shape, seed, 1.5)
+    dm = _dm(g, gpu_ctx)
+    o = ora.Oracle(dm.header, g)
+    mean, std = dm.meanDensity, dm.stdDensity
+    assert mean == pytest.approx(float(np.mean(g, dtype=np.float64)), rel=1e-10, abs=1e-14)
+    assert std == pytest.approx(float(np.std(g.astype(np.float64))), rel=1e-12)
+    cut = mean + nsd * std
+    green, red = dm._map.full_blobs_pm(cut, -cut, labels=True)
+    for bl, c in ((green, cut), (red, -cut)):
+        want = o.full_blobs(c, labels=True)
+        st = bl.stats()
+        assert np.array_equal(st["n"], want["n"])
+        assert np.array_equal(st["firstKey"], want["firstKey"])
+        assert np.allclose(st["totalDensity"], want["totalDensity"], rtol=REL)
+        assert np.allclose(st["centroid"], want["centroid"], rtol=REL, atol=1e-9)
+        assert np.allclose(st["coordCenter"], want["coordCenter"], rtol=REL, atol=1e-9)
+        assert np.array_equal(bl.labels(dm._map.unique_shape), want["labels"])
+        crs, off = bl.voxels()
+        assert off[-1] == st["n"].sum()
+        lab = want["labels"]
+        assert np.array_equal(lab[crs[:, 2], crs[:, 1], crs[:, 0]], np.repeat(np.arange(len(st["n"])), st["n"]))
+
+
+def test_full_size_properties(gpu_ctx):
+    """BASELINE config 2 size (256^3): size-independent properties + oracle equality."""
+    from oracle import oracle as ora
+    from pdb_eda_amd import synthetic
+    g = synthetic.smooth_noise((256, 256, 256), 7, 1.5)
+    dm = _dm(g, gpu_ctx)
+    cut = dm.meanDensity + 1.5 * dm.stdDensity
+    green, red = dm._map.full_blobs_pm(cut, -cut, labels=True)
+    for bl, sign in ((green, 1), (red, -1)):
+        st = bl.stats()
+        lab = bl.labels((256, 256, 256))
+        mask = (g >= np.float32(cut)) if sign > 0 else (g <= np.float32(-cut))
+        assert np.array_equal(lab >= 0, mask)                                 # every significant voxel labelled, nothing else
+        assert st["n"].sum() == mask.sum()
+        assert np.array_equal(np.bincount(lab[mask], minlength=len(st["n"])), st["n"])
+        assert st["totalDensity"].sum() == pytest.approx(float(g[mask].astype(np.float64).sum()), rel=1e-10)
+        assert (np.diff(st["firstKey"]) > 0).all()                            # reference emission order
+        # idempotence: labelling the label-derived mask again gives the same partition
+        again = dm._map.full_blobs(cut if sign > 0 else -cut)
+        assert np.array_equal(again.stats()["n"], st["n"])
+    o = ora.Oracle(dm.header, g)
+    want = o.full_blobs(cut, labels=True)
+    assert np.array_equal(green.labels((256, 256, 256)), want["labels"])
+    assert np.allclose(green.stats()["totalDensity"], want["totalDensity"], rtol=REL)
