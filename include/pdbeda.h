@@ -148,6 +148,10 @@ int pdbeda_bloblist_voxels(pdbeda_bloblist *bl, int32_t *crs, int64_t *blob_offs
  * -1.  Computed on first use unless PDBEDA_FLAG_LABELS was given. */
 int pdbeda_bloblist_labels(pdbeda_bloblist *bl, int32_t *labels_host);
 int pdbeda_bloblist_free(pdbeda_bloblist *bl);
+/* Diagnostic (no reference counterpart): counters of the labelling job behind a list,
+ * out[8] = runs, tile components, cross-tile pairs, blobs, tiles that fell back to the generic
+ * "unit tile" path by cause (run slots full, edge buffer full, component table full), 0. */
+int pdbeda_bloblist_counters(pdbeda_bloblist *bl, int64_t *out);
 
 /* ---- regional sums ---------------------------------------------------------------- */
 /* The voxel part of calculateRegionDiscrepancy / calculateRegionDensity

@@ -11,7 +11,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpdbeda_hip.so")
+LIB_PATH = os.environ.get("PDBEDA_LIB") or os.path.join(_HERE, "libpdbeda_hip.so")   # PDBEDA_LIB: A/B builds of the same library
 
 PDBEDA_FLAG_LABELS = 1
 
@@ -82,6 +82,7 @@ _SIGS = {
     "pdbeda_bloblist_voxels": (C.c_int, [_p, _p, _p]),
     "pdbeda_bloblist_labels": (C.c_int, [_p, _p]),
     "pdbeda_bloblist_free": (C.c_int, [_p]),
+    "pdbeda_bloblist_counters": (C.c_int, [_p, _p]),
     "pdbeda_region_sums": (C.c_int, [_p, _p, _p, _i64, _p, _i64, C.c_float, _p, _p, _p, _p]),
     "pdbeda_test_overlap": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i64, _p]),
     "pdbeda_symmetry_atoms": (C.c_int, [_p, _p, _i64, _p, C.c_int32, _p, _p, _p, _p, _p, _p, _i64, C.POINTER(_i64)]),
@@ -262,6 +263,11 @@ class BlobList(object):
         out = np.zeros(shape, dtype=np.int32)
         self._ctx.check(self._ctx._lib.pdbeda_bloblist_labels(self._h, _ptr(out)), "pdbeda_bloblist_labels")
         return out
+
+    def counters(self):
+        out = np.zeros(8, dtype=np.int64)
+        self._ctx.check(self._ctx._lib.pdbeda_bloblist_counters(self._h, _ptr(out)), "pdbeda_bloblist_counters")
+        return dict(zip(["runs", "tile_components", "cross_tile_pairs", "blobs", "unit_tiles_runs", "unit_tiles_edges", "unit_tiles_comps"], out[:7].tolist()))
 
     def free(self):
         if self._h is not None and self._ctx._h:

@@ -85,6 +85,8 @@ struct pdbeda_bloblist {
     bool voxels_done = false;
     Arena vox_arena;
     bool whole_map = false;
+    TileDims td;
+    int sign = 1;
 };
 
 static const int N_PARTIAL = 2048;
@@ -472,7 +474,7 @@ extern "C" int pdbeda_xyz2crs(pdbeda_map *m, const double *xyz, int64_t n, int32
 // Carve a job out of an arena.  max_runs / max_blobs are worst-case bounds (a run needs a
 // gap: <= bits/2 + 1 per word; a blob owns >= one 2x2x2 cell... we simply bound blobs by runs).
 static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, int64_t total_keys, int64_t max_runs,
-                        int64_t max_blobs, size_t extra_labels, int32_t **labels_out) {
+                        int64_t max_blobs, size_t extra_labels, int32_t **labels_out, int64_t n_tiles = 0) {
     Carver cv(base);
     job.n_vols = n_vols;
     job.total_words = total_words;
@@ -486,6 +488,14 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.key_rank = cv.take<uint32_t>(job.key_words);
     job.chunk_count = cv.take<uint32_t>(std::max(job.n_chunks, 1));
     job.chunk_prefix = cv.take<uint32_t>(std::max(job.n_chunks, 1));
+    job.comps_are_runs = n_tiles ? 0 : 1;
+    job.comp_of_run = n_tiles ? cv.take<uint32_t>(max_runs) : nullptr;
+    job.label_of_comp = n_tiles ? cv.take<int32_t>(max_runs) : nullptr;
+    job.tile_mode = n_tiles ? cv.take<uint8_t>(n_tiles) : nullptr;
+    job.edge_cap = n_tiles ? (std::max<int64_t>(1 << 16, 2 * total_words) + ESHARDS - 1) / ESHARDS * ESHARDS : 0;
+    job.edges = n_tiles ? cv.take<uint2>(job.edge_cap) : nullptr;
+    job.edge_fill = n_tiles ? cv.take<uint32_t>(ESHARDS) : nullptr;
+    job.vol_sign[0] = job.vol_sign[1] = 1;
     job.parent = cv.take<int32_t>(max_runs);
     job.r_n = cv.take<uint32_t>(max_runs);
     job.r_rho = cv.take<double>(max_runs);
@@ -535,6 +545,12 @@ static pdbeda_bloblist *new_list(pdbeda_ctx *ctx, pdbeda_map *m) {
     return bl;
 }
 
+template <int CW>
+static void launch_tile_label(pdbeda_ctx *ctx, unsigned n_tiles, const Job &job, const float *dens, const Geom *geom_dev, const TileDims &td) {
+    { PROF(ctx, "k_tile_label"); hipLaunchKernelGGL((k_tile_label<CW>), dim3(n_tiles), dim3(256), 0, ctx->stream, job, dens, geom_dev, td); }
+    { PROF(ctx, "k_unit_tiles"); hipLaunchKernelGGL((k_unit_tiles<CW>), dim3(n_tiles), dim3(256), 0, ctx->stream, job, dens, geom_dev, td); }
+}
+
 static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool want_pos, bool want_neg, uint32_t flags,
                            pdbeda_bloblist **out_pos, pdbeda_bloblist **out_neg) {
     pdbeda_ctx *ctx = m->ctx;
@@ -546,20 +562,37 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
     const int64_t words_pp = (int64_t)row_words * ur * us;
     const int64_t keys_pp = (int64_t)uc * ur * us;
     const int64_t total_words = words_pp * n_planes, total_keys = keys_pp * n_planes;
-    const int64_t max_runs = (int64_t)((uc + 1) / 2) * ur * us * n_planes + 1;
     // 26-connectivity: all voxels of an aligned 2x2x2 cell are mutually adjacent -> <= 1 blob per cell
     const int64_t max_blobs = (int64_t)((uc + 1) / 2) * ((ur + 1) / 2) * ((us + 1) / 2) * n_planes + 1;
     const bool labels = (flags & PDBEDA_FLAG_LABELS) != 0;
-    const size_t lab_elems = labels ? (size_t)keys_pp * n_planes : 0;
+    const size_t lab_elems = labels ? (size_t)keys_pp : 0;   // ONE signed volume, also for a fused call
+
+    TileDims td;
+    td.cw = std::min(row_words, 4);
+    td.ctiles = (row_words + td.cw - 1) / td.cw;
+    td.rtiles = (ur + TILE_R - 1) / TILE_R;
+    td.stiles = (us + TILE_S - 1) / TILE_S;
+    td.n_planes = n_planes;
+    td.cut[0] = want_pos ? cut_pos : cut_neg;
+    td.sign[0] = want_pos ? 1 : -1;
+    td.cut[1] = cut_neg;
+    td.sign[1] = -1;
+    const int64_t tiles_pp = (int64_t)td.ctiles * td.rtiles * td.stiles;
+    if (tiles_pp >= (1ll << 31)) return fail(ctx, PDBEDA_ERR_ARGUMENT, "grid too large");
+    // run / component ids: a fixed range per tile (no allocation atomics) + worst case of the unit tiles above them
+    const int64_t max_runs = tiles_pp * td.cw * 64 * 32 + (int64_t)((uc + 1) / 2) * ur * us * n_planes + 1;
+    if (max_runs >= (1ll << 31)) return fail(ctx, PDBEDA_ERR_ARGUMENT, "grid too large");
 
     Job job;
     memset(&job, 0, sizeof job);
-    size_t need = job_carve(job, nullptr, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, nullptr);
+    size_t need = job_carve(job, nullptr, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, nullptr, tiles_pp);
     Arena arena;
     int rc = arena_get(ctx, need, &arena);
     if (rc) return rc;
     int32_t *labels_dev = nullptr;
-    job_carve(job, arena.base, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, &labels_dev);
+    job_carve(job, arena.base, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, &labels_dev, tiles_pp);
+    job.vol_sign[0] = td.sign[0];
+    job.vol_sign[1] = td.sign[1];
 
     VolDesc vd[2];
     for (int p = 0; p < n_planes; ++p) {
@@ -573,43 +606,56 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
     hipStream_t st = ctx->stream;
     {
         PROF(ctx, "setup(memset+vols)");
-        hipLaunchKernelGGL(k_set_vols, dim3(1), dim3(64), 0, st, job.vols, vd[0], vd[n_planes - 1], n_planes);
         HIP_TRY(ctx, hipMemsetAsync(job.ctr, 0, sizeof(Counters), st));
+        HIP_TRY(ctx, hipMemsetAsync(job.edge_fill, 0, sizeof(uint32_t) * ESHARDS, st));
         HIP_TRY(ctx, hipMemsetAsync(job.key_bits, 0, sizeof(uint64_t) * job.key_words, st));
+        hipLaunchKernelGGL(k_set_vols, dim3(1), dim3(64), 0, st, job.vols, vd[0], vd[n_planes - 1], n_planes, job.ctr,
+                           (unsigned)(tiles_pp * td.cw * 64 * 32), (unsigned)(tiles_pp * CCAP));
     }
-
-    uint64_t *mp = want_pos ? job.mask : nullptr;
-    uint64_t *mn = want_neg ? job.mask + (want_pos ? words_pp : 0) : nullptr;
+    switch (td.cw) {
+        case 1: launch_tile_label<1>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td); break;
+        case 2: launch_tile_label<2>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td); break;
+        case 3: launch_tile_label<3>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td); break;
+        default: launch_tile_label<4>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td); break;
+    }
+    const unsigned comp_grid = grid_for(max_runs, 256, 2048);
     {
-        PROF(ctx, "k_threshold");
-        rc = tile_or_stream_threshold(ctx->stream, m->dens, m->geom_dev, g, job, mp, mn, cut_pos, cut_neg, row_words, words_pp);
+        PROF(ctx, "k_tile_edges");
+        // unit tiles are rare; if one exists its interior words need the cross pairs too, which only the all-rows layout
+        // visits -- that layout is also the general one for c-tiled (wider than 256) grids.  (A unit tile inside a narrow
+        // grid is handled by a second, all-rows launch below, gated on the device-side unit-tile counter.)
+        const int all_rows = td.ctiles > 1 ? 1 : 0;
+        hipLaunchKernelGGL(k_tile_edges, dim3(grid_for((int64_t)ur * row_words, 256, 1ll << 30), us, n_planes), dim3(256), 0, st, job, td, all_rows);
+        if (!all_rows) hipLaunchKernelGGL(k_tile_edges_unit, dim3(grid_for((int64_t)ur * row_words, 256, 1ll << 30), us, n_planes), dim3(256), 0, st, job, td);
     }
-    if (rc) { arena_put(ctx, arena); return fail(ctx, PDBEDA_ERR_DEVICE, "threshold launch failed"); }
-    rc = engine_enqueue(ctx, m, job, max_runs);
-    if (rc) { arena_put(ctx, arena); return rc; }
+    { PROF(ctx, "k_union_edges"); hipLaunchKernelGGL(k_union_edges, dim3(32, ESHARDS), dim3(256), 0, st, job); }
+    { PROF(ctx, "k_resolve"); hipLaunchKernelGGL(k_resolve, dim3(comp_grid), dim3(256), 0, st, job); }
+    { PROF(ctx, "k_paint_keys"); hipLaunchKernelGGL(k_paint_keys, dim3(comp_grid), dim3(256), 0, st, job); }
+    { PROF(ctx, "k_key_chunks"); hipLaunchKernelGGL(k_key_chunks, dim3(job.n_chunks), dim3(KEY_CHUNK), 0, st, job); }
+    { PROF(ctx, "k_chunk_scan"); hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, st, job); }
+    { PROF(ctx, "k_emit"); hipLaunchKernelGGL(k_emit, dim3(comp_grid), dim3(256), 0, st, job, m->geom_dev); }
+    if (labels) {
+        PROF(ctx, "k_labels_signed");
+        const int64_t n_seg = (int64_t)((row_words + 3) / 4) * ur * us;
+        hipLaunchKernelGGL(k_labels_signed, dim3(grid_for(n_seg * 64, 256, 8192)), dim3(256), 0, st, job, td, labels_dev);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { arena_put(ctx, arena); return fail(ctx, PDBEDA_ERR_DEVICE, "whole-map labelling launch: %s", hipGetErrorString(e)); }
 
     pdbeda_bloblist *first = nullptr;
     for (int p = 0; p < n_planes; ++p) {
         pdbeda_bloblist *bl = new_list(ctx, m);
         bl->job = job;
+        bl->td = td;
         bl->vol_lo = p;
         bl->vol_hi = p + 1;
         bl->whole_map = true;
+        bl->sign = td.sign[p];
         if (p == 0) { bl->arena = arena; bl->owns_arena = true; first = bl; }
         else { bl->owns_arena = false; bl->sibling = first; first->sibling = bl; }
-        if (labels) bl->labels_dev = labels_dev + (size_t)keys_pp * p;
-        bool is_pos = want_pos && p == 0;
-        if (is_pos) *out_pos = bl; else *out_neg = bl;
-    }
-    if (labels) {
-        // ranks of plane 1 start after plane 0's blobs: resolved on the device from chunk_prefix
-        for (int p = 0; p < n_planes; ++p) {
-            PROF(ctx, "k_labels_plane");
-            hipLaunchKernelGGL(k_labels_plane, dim3(grid_for(words_pp * 64, 256, 4096)), dim3(256), 0, st, job, p,
-                               labels_dev + (size_t)keys_pp * p);
-        }
-        HIP_TRY(ctx, hipGetLastError());
-        for (int p = 0; p < n_planes; ++p) (p == 0 ? first : first->sibling)->labels_done = true;
+        bl->labels_dev = labels_dev;
+        bl->labels_done = labels;
+        if (bl->sign > 0) *out_pos = bl; else *out_neg = bl;
     }
     return PDBEDA_OK;
 }
@@ -672,6 +718,20 @@ static int list_resolve_counts(pdbeda_bloblist *bl) {
     if (bl->vol_lo == 0 && bl->vol_hi == job.n_vols) { bl->rank_lo = 0; bl->rank_hi = ctr.n_blobs; }
     bl->have_counts = true;
     return 0;
+}
+
+// Diagnostic: device counters of the labelling job behind a list:
+// out[0..7] = runs, tile components, cross-tile pairs, blobs, unit tiles by cause (run slots, edge buffer, component table), 0.
+extern "C" int pdbeda_bloblist_counters(pdbeda_bloblist *bl, int64_t *out) {
+    if (!bl || bl->freed || !out) return PDBEDA_ERR_ARGUMENT;
+    pdbeda_ctx *ctx = bl->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Counters c;
+    HIP_TRY(ctx, hipMemcpyAsync(&c, bl->job.ctr, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    out[0] = c.n_runs; out[1] = c.n_comps; out[2] = c.n_edges; out[3] = c.n_blobs;
+    out[4] = c.unit_tiles[0]; out[5] = c.unit_tiles[1]; out[6] = c.unit_tiles[2]; out[7] = 0;
+    return PDBEDA_OK;
 }
 
 extern "C" int64_t pdbeda_bloblist_count(pdbeda_bloblist *bl) {
@@ -775,17 +835,24 @@ extern "C" int pdbeda_bloblist_labels(pdbeda_bloblist *bl, int32_t *labels_host)
     pdbeda_ctx *ctx = bl->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const Geom &g = bl->map->geom;
-    const int64_t nvox = (int64_t)g.unique_ncrs[0] * g.unique_ncrs[1] * g.unique_ncrs[2];
-    if (bl->labels_dev && bl->labels_done) {
-        HIP_TRY(ctx, hipMemcpyAsync(labels_host, bl->labels_dev, 4 * nvox, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        return PDBEDA_OK;
-    }
+    const int uc = g.unique_ncrs[0], ur = g.unique_ncrs[1], us = g.unique_ncrs[2];
+    const int64_t nvox = (int64_t)uc * ur * us;
+    // scratch: [signed volume if it was not requested at labelling time] + decoded volume
+    const bool have = bl->labels_dev && bl->labels_done;
     Arena a;
-    int rc = arena_get(ctx, 4 * nvox, &a);
+    int rc = arena_get(ctx, align_up(4 * nvox) * (have ? 1 : 2), &a);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_labels_plane, dim3(grid_for(nvox, 256, 4096)), dim3(256), 0, ctx->stream, bl->job, bl->vol_lo, (int32_t *)a.base);
-    hipError_t e = hipMemcpyAsync(labels_host, a.base, 4 * nvox, hipMemcpyDeviceToHost, ctx->stream);
+    int32_t *decoded = (int32_t *)a.base;
+    const int32_t *signed_vol = bl->labels_dev;
+    if (!have) {
+        int32_t *tmp = (int32_t *)(a.base + align_up(4 * nvox));
+        const int row_words = (uc + 63) / 64;
+        const int64_t n_seg = (int64_t)((row_words + 3) / 4) * ur * us;
+        hipLaunchKernelGGL(k_labels_signed, dim3(grid_for(n_seg * 64, 256, 8192)), dim3(256), 0, ctx->stream, bl->job, bl->td, tmp);
+        signed_vol = tmp;
+    }
+    hipLaunchKernelGGL(k_labels_decode, dim3(grid_for(nvox, 256, 4096)), dim3(256), 0, ctx->stream, signed_vol, nvox, bl->sign, decoded);
+    hipError_t e = hipMemcpyAsync(labels_host, decoded, 4 * nvox, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     arena_put(ctx, a);
     if (e != hipSuccess) return fail(ctx, PDBEDA_ERR_DEVICE, "labels: %s", hipGetErrorString(e));

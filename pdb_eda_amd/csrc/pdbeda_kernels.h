@@ -27,7 +27,10 @@ struct VolDesc {
 
 struct Counters {
     unsigned int n_runs;
+    unsigned int n_comps;
+    unsigned int n_edges;
     unsigned int n_blobs;
+    unsigned int unit_tiles[3];  // whole-map tiles that fell back to unit mode: run slots / edge buffer / component table full
     unsigned long long n_voxels;
     long long total_words;
     long long total_keys;
@@ -46,7 +49,17 @@ struct Job {
     uint32_t *chunk_prefix;
     int32_t n_chunks;
     Counters *ctr;
-    // per-run records
+    // union-find elements ("components"): tile-local components on the whole-map fast path,
+    // single runs (comp_of_run == nullptr, identity) on the generic path
+    int32_t comps_are_runs;
+    uint32_t *comp_of_run;
+    int32_t *label_of_comp;   // final signed label of every component (whole-map jobs)
+    uint8_t *tile_mode;       // per tile: 0 = united in LDS, 1 = unit tile
+    uint2 *edges;             // cross-tile run pairs parked by k_tile_edges (ESHARDS equal regions)
+    uint32_t *edge_fill;      // pairs written per region
+    int64_t edge_cap;
+    int32_t vol_sign[2];      // whole-map jobs: +1 / -1 list of volume p
+    // per-component records
     int32_t *parent;
     uint32_t *r_n;
     double *r_rho, *r_rho_c, *r_rho_r, *r_rho_s;
@@ -122,6 +135,41 @@ __device__ inline double wave_incl_scan(double x, int lane) {
     return x;
 }
 
+// One wave, one non-empty mask word `mw` (lane = voxel): wrapped density fetch
+// (getPointDensityFromCrs), two wave prefix sums (rho, rho*lane), run sums by difference at the
+// run's first lane; writes one record per run at index rec0 + (run number inside the word).
+// (cl0, rl, sl) = volume-local coordinates of lane 0, (rawc0, rawr, raws) = raw crs of lane 0.
+__device__ inline void word_run_records(const Job &job, const Geom &g, const float *__restrict__ dens, const VolDesc &vd, uint64_t mw,
+                                        int lane, int cl0, int rl, int sl, int rawc0, int rawr, int raws, uint32_t rec0) {
+    const bool bit = (mw >> lane) & 1ull;
+    const double rho = bit ? (double)fetch_wrapped(g, dens, rawc0 + lane, rawr, raws) : 0.0;
+    const double rl_ = rho * (double)lane;
+    const double p1 = wave_incl_scan(rho, lane);
+    const double p2 = wave_incl_scan(rl_, lane);
+    const uint64_t starts = run_starts(mw);
+    const bool is_start = (starts >> lane) & 1ull;
+    const int e = is_start ? run_end_of(mw, lane) : lane;
+    const double p1e = __shfl(p1, e);
+    const double p2e = __shfl(p2, e);
+    if (is_start) {
+        const int len = e - lane + 1;
+        const double s_rho = p1e - (p1 - rho);
+        const double s_rl = p2e - (p2 - rl_);
+        const uint32_t idx = rec0 + (uint32_t)popc64(starts & bits_below(lane));
+        job.parent[idx] = (int32_t)idx;
+        job.r_n[idx] = (uint32_t)len;
+        job.r_rho[idx] = s_rho;
+        job.r_rho_c[idx] = (double)rawc0 * s_rho + s_rl;
+        job.r_rho_r[idx] = (double)rawr * s_rho;
+        job.r_rho_s[idx] = (double)raws * s_rho;
+        const long long a = (long long)rawc0 + lane;
+        job.r_c[idx] = (long long)len * a + (long long)len * (len - 1) / 2;
+        job.r_r[idx] = (long long)len * rawr;
+        job.r_s[idx] = (long long)len * raws;
+        job.r_key[idx] = (unsigned long long)(vd.key_base + ((int64_t)(cl0 + lane) * vd.dim[1] + rl) * vd.dim[2] + sl);
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // Run indexing + per-run statistics.  Block = 256 threads = one chunk of 256 words.
 // Phase 1 (thread per word): count runs, block scan, one atomicAdd per block -> run_base.
@@ -173,36 +221,7 @@ __global__ void __launch_bounds__(256) k_run_index(Job job, const float *__restr
         const int64_t row = rem / vd.row_words;
         const int rl = (int)(row % vd.dim[1]);
         const int sl = (int)(row / vd.dim[1]);
-        const int cl0 = wq * 64;
-        const int rawr = vd.org[1] + rl, raws = vd.org[2] + sl, rawc0 = vd.org[0] + cl0;
-        const bool bit = (mw >> lane) & 1ull;
-        double rho = bit ? (double)fetch_wrapped(g, dens, rawc0 + lane, rawr, raws) : 0.0;
-        double rl_ = rho * (double)lane;
-        double p1 = wave_incl_scan(rho, lane);
-        double p2 = wave_incl_scan(rl_, lane);
-        const uint64_t starts = run_starts(mw);
-        const bool is_start = (starts >> lane) & 1ull;
-        const int e = is_start ? run_end_of(mw, lane) : lane;
-        double p1e = __shfl(p1, e);
-        double p2e = __shfl(p2, e);
-        if (is_start) {
-            const int len = e - lane + 1;
-            const double s_rho = p1e - (p1 - rho);
-            const double s_rl = p2e - (p2 - rl_);
-            const uint32_t idx = s_off[slot] + (uint32_t)popc64(starts & bits_below(lane));
-            job.parent[idx] = (int32_t)idx;
-            job.r_n[idx] = (uint32_t)len;
-            job.r_rho[idx] = s_rho;
-            job.r_rho_c[idx] = (double)rawc0 * s_rho + s_rl;
-            job.r_rho_r[idx] = (double)rawr * s_rho;
-            job.r_rho_s[idx] = (double)raws * s_rho;
-            const long long a = (long long)rawc0 + lane;
-            job.r_c[idx] = (long long)len * a + (long long)len * (len - 1) / 2;
-            job.r_r[idx] = (long long)len * rawr;
-            job.r_s[idx] = (long long)len * raws;
-            job.r_key[idx] = (unsigned long long)(vd.key_base +
-                             ((int64_t)(cl0 + lane) * vd.dim[1] + rl) * vd.dim[2] + sl);
-        }
+        word_run_records(job, g, dens, vd, mw, lane, wq * 64, rl, sl, vd.org[0] + wq * 64, vd.org[1] + rl, vd.org[2] + sl, s_off[slot]);
     }
 }
 
@@ -213,9 +232,14 @@ __global__ void __launch_bounds__(256) k_run_index(Job job, const float *__restr
 __device__ inline int uf_load(const int32_t *p, int x) {
     return __hip_atomic_load(p + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ inline int uf_find(const int32_t *p, int x) {
+// find with path halving by fire-and-forget atomic min (monotone: never undoes a union)
+__device__ inline int uf_find(int32_t *p, int x) {
     int q;
-    while ((q = uf_load(p, x)) != x) x = q;
+    while ((q = uf_load(p, x)) != x) {
+        const int gp = uf_load(p, q);
+        if (gp != q) atomicMin(p + x, gp);
+        x = gp;
+    }
     return x;
 }
 __device__ inline void uf_unite(int32_t *p, int a, int b) {
@@ -301,9 +325,11 @@ __global__ void __launch_bounds__(256) k_union(Job job) {
     }
 }
 
-// Thread per run: flatten, and fold non-root partial sums into the root record.
+__device__ inline uint32_t n_components(const Job &job) { return job.comps_are_runs ? job.ctr->n_runs : job.ctr->n_comps; }
+
+// Thread per component: flatten, and fold non-root partial sums into the root record.
 __global__ void __launch_bounds__(256) k_resolve(Job job) {
-    const uint32_t n_runs = job.ctr->n_runs;
+    const uint32_t n_runs = n_components(job);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_runs; i += gridDim.x * blockDim.x) {
     const int root = uf_find(job.parent, (int)i);
     if (root == (int)i) continue;
@@ -324,9 +350,9 @@ __global__ void __launch_bounds__(256) k_resolve(Job job) {
 // enumeration (cutils.pyx:199 + 59-69).  Keys are unique positions, so the rank of a blob
 // is a prefix population count over a bitmap of first-voxel keys -- no sort needed.
 __global__ void __launch_bounds__(256) k_paint_keys(Job job) {
-    const uint32_t n_runs = job.ctr->n_runs;
+    const uint32_t n_runs = n_components(job);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_runs; i += gridDim.x * blockDim.x) {
-        if (job.parent[i] != (int32_t)i) continue;
+        if (job.parent[i] != (int32_t)i || job.r_n[i] == 0u) continue;   // not a root / unused id
         const unsigned long long key = job.r_key[i];
         atomicOr((unsigned long long *)&job.key_bits[key >> 6], 1ull << (key & 63));
     }
@@ -379,36 +405,50 @@ __global__ void __launch_bounds__(1024) k_chunk_scan(Job job) {
     if (tid == 0) job.ctr->n_blobs = s_carry;
 }
 
-// Thread per root run: rank -> blob table row (DensityBlob.fromCrsList, ccp4.py:542-545).
+// Thread per component: final label of the component; roots also write their blob table row
+// (DensityBlob.fromCrsList, ccp4.py:542-545).
 __global__ void __launch_bounds__(256) k_emit(Job job, const Geom *__restrict__ gp) {
-    const uint32_t n_runs = job.ctr->n_runs;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_runs; i += gridDim.x * blockDim.x) {
-    if (job.parent[i] != (int32_t)i) continue;
-    const unsigned long long key = job.r_key[i];
-    const int64_t kw = (int64_t)(key >> 6);
-    const uint32_t rank = job.chunk_prefix[kw / KEY_CHUNK] + job.key_rank[kw] +
-                          (uint32_t)popc64(job.key_bits[kw] & bits_below((int)(key & 63)));
-    job.r_rank[i] = rank;
-    const VolDesc vd = job.vols[find_vol_by_key(job.vols, job.n_vols, (int64_t)key)];
+    const uint32_t n_comp = n_components(job);
     const Geom &g = *gp;
-    const double n = (double)job.r_n[i];
-    const double tot = job.r_rho[i];
-    double wc[3] = {job.r_rho_c[i] / tot, job.r_rho_r[i] / tot, job.r_rho_s[i] / tot};
-    double cc[3] = {(double)job.r_c[i] / n, (double)job.r_r[i] / n, (double)job.r_s[i] / n};
-    double xyz[3];
-    crs2xyz_frac(g, wc, xyz);
-    job.b_centroid[3 * rank + 0] = xyz[0];
-    job.b_centroid[3 * rank + 1] = xyz[1];
-    job.b_centroid[3 * rank + 2] = xyz[2];
-    crs2xyz_frac(g, cc, xyz);
-    job.b_center[3 * rank + 0] = xyz[0];
-    job.b_center[3 * rank + 1] = xyz[1];
-    job.b_center[3 * rank + 2] = xyz[2];
-    job.b_n[rank] = (int64_t)job.r_n[i];
-    job.b_total[rank] = tot;
-    job.b_volume[rank] = g.unit_volume * n;
-    job.b_key[rank] = (int64_t)key - vd.key_base;
-    job.b_group[rank] = vd.group;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_comp; i += gridDim.x * blockDim.x) {
+        const uint32_t root = (uint32_t)job.parent[i];
+        if (job.r_n[root] == 0u) continue;   // unused component id
+        const unsigned long long key = job.r_key[root];
+        const int64_t kw = (int64_t)(key >> 6);
+        const uint32_t rank = job.chunk_prefix[kw / KEY_CHUNK] + job.key_rank[kw] +
+                              (uint32_t)popc64(job.key_bits[kw] & bits_below((int)(key & 63)));
+        const int vi = find_vol_by_key(job.vols, job.n_vols, (int64_t)key);
+        const VolDesc vd = job.vols[vi];
+        if (job.label_of_comp) {
+            // whole-map jobs: blob index inside its own list, signed by the list
+            uint32_t below = 0;
+            if (vd.key_base > 0) {
+                const int64_t kb = vd.key_base, kbw = kb >> 6;
+                below = job.chunk_prefix[kbw / KEY_CHUNK] + job.key_rank[kbw] + (uint32_t)popc64(job.key_bits[kbw] & bits_below((int)(kb & 63)));
+            }
+            const int32_t k = (int32_t)(rank - below);
+            job.label_of_comp[i] = job.vol_sign[vi > 1 ? 1 : vi] > 0 ? 1 + k : -1 - k;
+        }
+        if (root != i) continue;
+        job.r_rank[i] = rank;
+        const double n = (double)job.r_n[i];
+        const double tot = job.r_rho[i];
+        double wc[3] = {job.r_rho_c[i] / tot, job.r_rho_r[i] / tot, job.r_rho_s[i] / tot};
+        double cc[3] = {(double)job.r_c[i] / n, (double)job.r_r[i] / n, (double)job.r_s[i] / n};
+        double xyz[3];
+        crs2xyz_frac(g, wc, xyz);
+        job.b_centroid[3 * rank + 0] = xyz[0];
+        job.b_centroid[3 * rank + 1] = xyz[1];
+        job.b_centroid[3 * rank + 2] = xyz[2];
+        crs2xyz_frac(g, cc, xyz);
+        job.b_center[3 * rank + 0] = xyz[0];
+        job.b_center[3 * rank + 1] = xyz[1];
+        job.b_center[3 * rank + 2] = xyz[2];
+        job.b_n[rank] = (int64_t)job.r_n[i];
+        job.b_total[rank] = tot;
+        job.b_volume[rank] = g.unit_volume * n;
+        job.b_key[rank] = (int64_t)key - vd.key_base;
+        job.b_group[rank] = vd.group;
     }
 }
 
@@ -457,7 +497,8 @@ __global__ void __launch_bounds__(256) k_voxel_lists(Job job, const int64_t *__r
         const int64_t row = rem / vd.row_words;
         const int st = run_start_of(m, lane);
         const uint32_t run = job.run_base[w] + (uint32_t)popc64(run_starts(m) & bits_below(st));
-        const uint32_t root = (uint32_t)job.parent[run];
+        const uint32_t comp = job.comp_of_run ? job.comp_of_run[run] : run;
+        const uint32_t root = (uint32_t)job.parent[comp];
         const uint32_t rank = job.r_rank[root];
         const int64_t pos = offsets[rank] + atomicAdd(&cursor[rank], 1u);
         crs_out[3 * pos + 0] = vd.org[0] + wq * 64 + lane;

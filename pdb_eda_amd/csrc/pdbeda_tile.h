@@ -1,18 +1,55 @@
-// pdbeda_tile.h -- whole-map specific kernels and launch helpers.
+// pdbeda_tile.h -- the whole-map fast path: one fused, LDS-tiled labelling kernel.
+//
+// k_tile_label<CW> (one 256-thread workgroup per tile of CW words x 8 rows x 8 sections,
+// i.e. up to 256 c x 8 r x 8 s = 16 Ki voxels):
+//   A  stream the tile's density once from HBM (coalesced 256-B wave loads, every value stays
+//      in a register), __ballot -> bit masks of both signs (fused green/red)
+//   B  per sign: runs of every word (bit tricks), run indexing by a block scan, 26-connected
+//      components INSIDE the tile with a lock-free union-find in LDS (ds atomic min)
+//   C  per sign: per-component fp64 sums (rho, rho*c, rho*r, rho*s), integer sums and the
+//      c-major first key accumulated with LDS atomics from the register-resident densities;
+//      one record per tile-local component is flushed to HBM.
+// Only components that touch a tile face are united globally (k_union_tiles), and only
+// non-root tile components need global atomics (k_resolve) -- two orders of magnitude fewer
+// than one per voxel / run.  A tile whose run or component count exceeds the LDS capacity
+// falls back to "unit mode" (every run its own component, united globally): slower, same result.
 #pragma once
 #include "pdbeda_kernels.h"
 
 namespace pdbeda {
 
+constexpr int TILE_R = 8, TILE_S = 8;
+constexpr int PCAP = 736;         // run slots per sign and tile handled in LDS (runs are tracked per ROW: a run crossing words is one run)
+constexpr int RCAP = 2 * PCAP;    // sign 0 uses slots [0, PCAP), sign 1 [PCAP, 2 PCAP); a wave reserves a 16-word chunk with one LDS atomic
+constexpr int CCAP = 256;   // tile-local components (both signs together) handled in LDS
+constexpr int VCAP = 3584;  // significant values per tile parked in LDS during phase A (aliases the 14 KiB scratch)
+constexpr int EQ = 12;      // touching run pairs one (row, neighbour row) task parks per batch (kept in registers)
+
+constexpr int ESHARDS = 64;  // cross-tile pair buffers (one allocation counter each: a single counter serialises at ~88 atomics/us)
+
+struct TileDims {
+    int cw;                       // words per tile along c (1..4)
+    int ctiles, rtiles, stiles;   // tile grid
+    int n_planes;
+    float cut[2];                 // threshold of plane p
+    int sign[2];                  // +1: density >= cut, -1: density <= cut
+};
+
+__host__ __device__ inline int64_t tile_index(const TileDims &td, int plane, int wq, int r, int s) {
+    return (((int64_t)plane * td.stiles + (s >> 3)) * td.rtiles + (r >> 3)) * td.ctiles + wq / td.cw;
+}
+
 // Write up to two volume descriptors passed by value (no host staging buffer, no sync).
-__global__ void k_set_vols(VolDesc *vols, VolDesc v0, VolDesc v1, int n) {
+__global__ void k_set_vols(VolDesc *vols, VolDesc v0, VolDesc v1, int n, Counters *ctr, unsigned int runs0, unsigned int comps0) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         vols[0] = v0;
         if (n > 1) vols[1] = v1;
+        ctr->n_runs = runs0;    // ids below are owned tile by tile; unit tiles allocate above them
+        ctr->n_comps = comps0;
     }
 }
 
-// Number of blobs whose first key is < key (device side twin of the host accessor).
+// Number of blobs whose first key is < key.
 __device__ inline uint32_t rank_below(const Job &job, int64_t key) {
     if (key <= 0) return 0u;
     if (key >= job.key_words * 64) return job.ctr->n_blobs;
@@ -20,43 +57,758 @@ __device__ inline uint32_t rank_below(const Job &job, int64_t key) {
     return job.chunk_prefix[kw / KEY_CHUNK] + job.key_rank[kw] + (uint32_t)popc64(job.key_bits[kw] & bits_below((int)(key & 63)));
 }
 
-// Dense labels of one plane of a whole-map job: wave per word, lane per voxel, coalesced
-// 256-B int32 stores; label = blob index inside this plane's list, or -1.
-__global__ void __launch_bounds__(256) k_labels_plane(Job job, int vol, int32_t *__restrict__ labels) {
-    const int lane = lane_id();
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const VolDesc vd = job.vols[vol];
-    const int32_t rank_offset = (int32_t)rank_below(job, vd.key_base);
-    const int64_t words = (int64_t)vd.row_words * vd.dim[1] * vd.dim[2];
-    for (int64_t lw = wave; lw < words; lw += n_waves) {
-        const int64_t w = vd.word_base + lw;
-        const uint64_t m = job.mask[w];
-        const int wq = (int)(lw % vd.row_words);
-        const int64_t row = lw / vd.row_words;
-        const int c = wq * 64 + lane;
-        int32_t lab = -1;
-        if ((m >> lane) & 1ull) {
-            const int st = run_start_of(m, lane);
-            const uint32_t run = job.run_base[w] + (uint32_t)popc64(run_starts(m) & bits_below(st));
-            lab = (int32_t)job.r_rank[job.parent[run]] - rank_offset;
-        }
-        if (c < vd.dim[0]) labels[row * vd.dim[0] + c] = lab;
+// find with path halving: every visited node is re-pointed at its grandparent with a
+// fire-and-forget atomic min (monotone, so it can never undo a concurrent union).
+__device__ inline int lds_find(uint32_t *p, int x) {
+    int q;
+    while ((q = (int)p[x]) != x) {
+        const int gp = (int)p[q];
+        if (gp != q) atomicMin(&p[x], (uint32_t)gp);
+        x = gp;
+    }
+    return x;
+}
+__device__ inline void lds_unite(uint32_t *p, int a, int b) {
+    while (true) {
+        a = lds_find(p, a);
+        b = lds_find(p, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; }
+        const int old = (int)atomicMin(&p[a], (uint32_t)b);
+        if (old == a) return;
+        a = old;
     }
 }
 
-// Threshold stage of a whole-map job.
-inline int tile_or_stream_threshold(hipStream_t st, const float *dens, const Geom *geom_dev, const Geom &g, Job &job, uint64_t *mask_pos,
-                                    uint64_t *mask_neg, float cut_pos, float cut_neg, int row_words, int64_t words_per_plane) {
-    (void)g;
-    (void)job;
-    int64_t waves = words_per_plane;
-    int64_t blocks = (waves + 3) / 4;
-    if (blocks > 8192) blocks = 8192;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_threshold, dim3((unsigned)blocks), dim3(256), 0, st, dens, geom_dev, mask_pos, mask_neg, cut_pos, cut_neg, row_words,
-                       words_per_plane);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+// number of set bits of a wave-uniform 64-bit mask at lane positions <  / <= the calling lane
+__device__ inline uint32_t mbcnt_lt(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+__device__ inline uint32_t mbcnt_le(uint64_t mask) { return mbcnt_lt(mask >> 1) + (uint32_t)(mask & 1ull); }
+
+// lane i <- lane i+1 (lane 63 <- 0): whole-wave DPP shift, no LDS traffic (GFX9 / CDNA wave_shl:1)
+__device__ inline double wave_shl1(double x) {
+    union { double d; int i[2]; } u;
+    u.d = x;
+    u.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0x130, 0xf, 0xf, true);
+    u.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0x130, 0xf, 0xf, true);
+    return u.d;
+}
+
+// Tile t owns component ids [t * CCAP, (t+1) * CCAP) and run ids [t * runs_per_tile, ...): no
+// allocation atomics on the fast path.  Unused component ids are marked empty (r_n = 0).
+__device__ inline void mark_comps_unused(const Job &job, uint32_t cb, uint32_t from, int tid) {
+    for (uint32_t i = from + tid; i < (uint32_t)CCAP; i += 256) {
+        job.parent[cb + i] = (int32_t)(cb + i);
+        job.r_n[cb + i] = 0u;
+        job.r_key[cb + i] = ~0ull;
+    }
+}
+
+template <int CW>
+__global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td) {
+    constexpr int NU = 64 * CW;   // (row, word) units of the tile = threads that own a word
+    constexpr int UPW = 16 * CW;  // units per wave (= 16 whole rows)
+    constexpr int CHU = (CW == 3) ? 12 : 16;  // units per chunk: whole rows, so a row's run slots are contiguous
+    __shared__ uint64_t s_mask[2][256];
+    __shared__ uint16_t s_first[2][256];  // LDS slot of the word's first run (may continue from the previous word)
+    __shared__ uint16_t s_next[2][256];   // LDS slot of the word's second run (the others follow)
+    __shared__ uint16_t s_gword[256];     // ordinal of the word's first word-run among the wave's word-runs
+    __shared__ uint16_t s_rowfirst[2][64];
+    __shared__ uint16_t s_rowcnt[2][64];
+    __shared__ double s_run_rho[RCAP];    // per row-run: sum(rho), sum(rho * (c - c_tile))
+    __shared__ double s_run_rhoc[RCAP];
+    __shared__ uint32_t s_parent[RCAP];
+    __shared__ uint16_t s_rse16[RCAP];    // bytes: run start / end position inside the tile row (0..255); later: component index
+    uint8_t *s_rs = reinterpret_cast<uint8_t *>(s_rse16), *s_re = s_rs + RCAP;
+    // 14 KiB scratch: per-thread edge buffers in phase B, per-component accumulators in phase C
+    __shared__ double s_scratch[(4 * CCAP * 8 + 6 * CCAP * 4) / 8];
+    double *s_rho = s_scratch, *s_rho_c = s_scratch + CCAP, *s_rho_r = s_scratch + 2 * CCAP, *s_rho_s = s_scratch + 3 * CCAP;
+    uint32_t *s_n = reinterpret_cast<uint32_t *>(s_scratch + 4 * CCAP), *s_c = s_n + CCAP, *s_r = s_n + 2 * CCAP, *s_s = s_n + 3 * CCAP,
+             *s_key = s_n + 4 * CCAP, *s_cplane = s_n + 5 * CCAP;
+    uint32_t *s_edges = reinterpret_cast<uint32_t *>(s_scratch);
+    uint16_t *s_compidx = s_rse16;        // reused after phase B
+    float *s_val = reinterpret_cast<float *>(s_scratch);  // phase A: significant values, compacted per word (4 wave regions)
+    __shared__ uint16_t s_vbase[256];
+    __shared__ uint32_t s_alloc[2];       // slots handed out per sign
+    __shared__ uint32_t s_wsx[4], s_wsy[4];
+    __shared__ uint32_t s_gcnt[4];        // word-runs per wave
+    __shared__ uint32_t s_over, s_changed, s_more, s_ncomp, s_runbase, s_compbase;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int uc = gp->unique_ncrs[0], ur = gp->unique_ncrs[1], us = gp->unique_ncrs[2];
+    const int nc = gp->ncrs[0], nr = gp->ncrs[1];
+    int t = blockIdx.x;
+    const int ct = t % td.ctiles; t /= td.ctiles;
+    const int rt = t % td.rtiles; t /= td.rtiles;
+    const int st = t;
+    const int w0 = ct * CW, r0 = rt * TILE_R, s0 = st * TILE_S;
+    const int row_words = (uc + 63) >> 6;
+    const int n_planes = td.n_planes;
+
+    if (tid == 0) { s_over = 0; s_ncomp = 0; s_alloc[0] = 0; s_alloc[1] = 0; }
+    for (int i = tid; i < RCAP; i += 256) { s_run_rho[i] = 0.0; s_run_rhoc[i] = 0.0; s_parent[i] = i; }
+    __syncthreads();
+
+    // ---- A1: stream the tile once from HBM: compare, ballot, store the masks; the significant
+    //      values of every word are compacted into LDS (lane order) with one conflict-free write.
+    {
+        uint32_t vcnt = 0;  // wave-uniform: values parked so far in this wave's region
+        const uint32_t vreg = wv * (VCAP / 4);
+        for (int chunk = 0; chunk < UPW / CHU; ++chunk) {
+            float v[CHU];
+#pragma unroll
+            for (int jj = 0; jj < CHU; ++jj) {
+                const int u = wv * UPW + chunk * CHU + jj;
+                const int wl = u % CW, rowl = u / CW;
+                const int r = r0 + (rowl & 7), s = s0 + (rowl >> 3), c = (w0 + wl) * 64 + lane;
+                const bool in = (r < ur) && (s < us) && (c < uc);
+                v[jj] = in ? dens[((int64_t)s * nr + r) * nc + c] : 0.0f;
+            }
+#pragma unroll
+            for (int jj = 0; jj < CHU; ++jj) {
+                const int u = wv * UPW + chunk * CHU + jj;
+                const int wl = u % CW, rowl = u / CW;
+                const bool in = (r0 + (rowl & 7) < ur) && (s0 + (rowl >> 3) < us) && ((w0 + wl) * 64 + lane < uc);
+                const float x = v[jj];
+                const bool hit0 = in && (td.sign[0] > 0 ? (x >= td.cut[0]) : (x <= td.cut[0]));
+                const bool hit1 = in && (n_planes > 1) && (x <= td.cut[1]);
+                const uint64_t b0 = __ballot(hit0);
+                const uint64_t b1 = (n_planes > 1) ? __ballot(hit1) : 0ull;
+                const uint64_t bb = b0 | b1;
+                if (lane == 0) { s_mask[0][u] = b0; s_mask[1][u] = b1; s_vbase[u] = (uint16_t)(vreg + vcnt); }
+                const uint32_t at = vcnt + mbcnt_lt(bb);
+                if ((hit0 || hit1) && at < (uint32_t)(VCAP / 4)) s_val[vreg + at] = x;
+                vcnt += (uint32_t)popc64(bb);
+            }
+        }
+        if (vcnt > (uint32_t)(VCAP / 4) && lane == 0) s_over = 1;
+    }
+    __syncthreads();
+#if defined(PDBEDA_STOP_AFTER) && PDBEDA_STOP_AFTER == 11
+    if (s_over == 0xffffffffu) return;
+    if (true) return;
+#endif
+
+    // ---- A2 (thread per word): run counts, row continuation, ONE block scan -> run slots ---------
+    // Runs are tracked per ROW: a run that continues from the previous word keeps that word's last
+    // slot.  Sign 0 uses slots [0, PCAP), sign 1 [PCAP, 2 PCAP); slots follow word order, so the
+    // runs of a row are contiguous and sorted by position.
+    {
+        const uint64_t a0 = (tid < NU) ? s_mask[0][tid] : 0ull, a1 = (tid < NU) ? s_mask[1][tid] : 0ull;
+        const int wl = tid % CW;
+        const bool k0 = (tid < NU) && wl > 0 && (a0 & 1ull) && (s_mask[0][tid - 1] >> 63);
+        const bool k1 = (tid < NU) && wl > 0 && (a1 & 1ull) && (s_mask[1][tid - 1] >> 63);
+        const uint32_t n0 = (uint32_t)popc64(run_starts(a0)), n1 = (uint32_t)popc64(run_starts(a1));
+        const uint32_t vx = (n0 - (k0 ? 1u : 0u)) | ((n1 - (k1 ? 1u : 0u)) << 16);  // new slots of sign 0 | sign 1
+        const uint32_t vy = n0 + n1;                                                // word-runs
+        uint32_t x = vx, y = vy;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t tx = __shfl_up(x, d), ty = __shfl_up(y, d);
+            if (lane >= d) { x += tx; y += ty; }
+        }
+        if (lane == 63) { s_wsx[wv] = x; s_wsy[wv] = y; }
+        __syncthreads();
+        uint32_t px = 0, py = 0;
+        for (int k = 0; k < wv; ++k) { px += s_wsx[k]; py += s_wsy[k]; }
+        const uint32_t ex = px + x - vx, ey = py + y - vy;
+        const uint32_t e0 = ex & 0xffffu, e1 = ex >> 16;
+        const uint32_t tx = s_wsx[0] + s_wsx[1] + s_wsx[2] + s_wsx[3];
+        const bool over_slots = (tx & 0xffffu) > (uint32_t)PCAP || (tx >> 16) > (uint32_t)PCAP;  // block-uniform
+        const uint32_t first0 = k0 ? e0 - 1u : e0, next0 = k0 ? e0 : e0 + 1u;
+        const uint32_t first1 = PCAP + (k1 ? e1 - 1u : e1), next1 = PCAP + (k1 ? e1 : e1 + 1u);
+        if (tid < NU) {
+            s_first[0][tid] = (uint16_t)(first0 | (k0 ? 0x8000u : 0u));
+            s_next[0][tid] = (uint16_t)next0;
+            s_first[1][tid] = (uint16_t)(first1 | (k1 ? 0x8000u : 0u));
+            s_next[1][tid] = (uint16_t)next1;
+            s_gword[tid] = (uint16_t)ey;
+            if (wl == 0) { s_rowfirst[0][tid / CW] = (uint16_t)e0; s_rowfirst[1][tid / CW] = (uint16_t)(PCAP + e1); }
+        }
+        if (tid == 255) {
+            s_alloc[0] = tx & 0xffffu;
+            s_alloc[1] = tx >> 16;
+            s_gcnt[0] = s_wsy[0] + s_wsy[1] + s_wsy[2] + s_wsy[3];
+            if (over_slots) s_over = 1;
+        }
+        // ---- A3 (same thread per word): exact fp64 sums of each of my runs from the parked values.
+        // Full lanes (95 % of the words of a +-1.5 sigma map are significant), sequential and
+        // deterministic inside a word; a run continuing across words is folded with an LDS atomic.
+        if (tid < NU && (a0 | a1) && !over_slots && s_over == 0) {
+            const uint64_t bb = a0 | a1;
+            const uint32_t vb = s_vbase[tid];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const uint64_t m = q ? a1 : a0;
+                if (!m) continue;
+                const bool kq = q ? k1 : k0;
+                const uint32_t fr = q ? first1 : first0, nx = q ? next1 : next0;
+                const bool next_cont = (wl < CW - 1) && (m >> 63) && (s_mask[q][tid + 1] & 1ull);
+                uint64_t todo = run_starts(m);
+                uint32_t k = 0;
+                while (todo) {
+                    const int a = ctz64(todo);
+                    todo &= todo - 1;
+                    const int e = run_end_of(m, a);
+                    const uint32_t slot = k == 0 ? fr : nx + k - 1u;
+                    ++k;
+                    const uint32_t off = vb + (uint32_t)popc64(bb & bits_below(a));
+                    double sum = 0.0, sumc = 0.0;
+                    for (int i = 0; i <= e - a; ++i) {
+                        const double val = (double)s_val[off + i];
+                        sum += val;
+                        sumc += val * (double)(wl * 64 + a + i);
+                    }
+                    unsafeAtomicAdd(&s_run_rho[slot], sum);
+                    unsafeAtomicAdd(&s_run_rhoc[slot], sumc);
+                    if (!(a == 0 && kq)) s_rs[slot] = (uint8_t)(wl * 64 + a);
+                    if (!(e == 63 && next_cont)) s_re[slot] = (uint8_t)(wl * 64 + e);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int q = tid >> 6, row = tid & 63;
+            const uint32_t end = row < 63 ? s_rowfirst[q][row + 1] : (q ? PCAP : 0) + s_alloc[q];
+            s_rowcnt[q][row] = (uint16_t)(end - s_rowfirst[q][row]);
+        }
+    }
+    __syncthreads();
+
+#if defined(PDBEDA_STOP_AFTER) && PDBEDA_STOP_AFTER == 1
+    if (s_over != 0xffffffffu) return;
+#endif
+    // my word (threads tid < NU own unit tid)
+    const int my_wl = tid % CW, my_rowl = (tid / CW) & 63;
+    const int my_rl = my_rowl & 7, my_sl = my_rowl >> 3;
+    const bool my_valid = (tid < NU) && (r0 + my_rl < ur) && (s0 + my_sl < us) && (w0 + my_wl < row_words);
+    const int64_t my_word = ((int64_t)(s0 + my_sl) * ur + (r0 + my_rl)) * row_words + (w0 + my_wl);  // inside a plane
+    const int64_t plane_words = (int64_t)row_words * ur * us;
+    const int64_t tile_id = tile_index(td, 0, w0, r0, s0);
+    const uint32_t al0 = s_alloc[0], al1 = s_alloc[1];
+    const uint32_t n_slots = al0 + al1;
+    const uint32_t n_wordruns = s_gcnt[0];
+    const uint64_t m0 = (tid < NU) ? s_mask[0][tid] : 0ull, m1 = (tid < NU) ? s_mask[1][tid] : 0ull;
+    auto slot_used = [&](uint32_t sl) -> bool { return sl < (uint32_t)PCAP ? sl < al0 : (sl - PCAP) < al1; };
+
+    if (n_slots == 0 || s_over) {
+        // nothing significant, or too many runs for LDS: publish the masks; an overflowing tile
+        // is labelled by k_unit_tiles (every run its own component)
+        if (my_valid) {
+            job.mask[my_word] = m0;
+            job.run_base[my_word] = 0u;
+            if (n_planes > 1) { job.mask[plane_words + my_word] = m1; job.run_base[plane_words + my_word] = 0u; }
+        }
+        if (tid == 0) { job.tile_mode[tile_id] = n_slots ? 1 : 0; if (n_slots) atomicAdd(&job.ctr->unit_tiles[0], 1u); }
+        mark_comps_unused(job, (uint32_t)blockIdx.x * CCAP, 0u, tid);
+        return;
+    }
+
+    // ---- B: tile-local 26-connected components ---------------------------------------------------
+    // B1: thread (row, earlier neighbour row) merges the two sorted run lists (bytes, 32-bit math)
+    //     and parks the touching pairs in a private buffer.
+    // B2: hook (fire-and-forget atomic min on the larger parent) and jump (pointer jumping) rounds
+    //     until no pair disagrees -- no returning atomic, no divergent retry loop.
+    {
+        // task of this thread: row (tid >> 2) against its earlier neighbour row number (tid & 3),
+        // for both signs (their slots never mix, so one set of rounds serves both)
+        uint32_t ia[2] = {0, 0}, ib[2] = {0, 0}, ea[2] = {0, 0}, eb[2] = {0, 0};
+        int sa[2] = {0, 0}, fa[2] = {0, 0}, sb[2] = {0, 0}, fb[2] = {0, 0};
+        bool done[2] = {true, true};
+        {
+            const int rowl = tid >> 2, nb = tid & 3;
+            const int rl = rowl & 7, sl = rowl >> 3;
+            const int dr = nb == 2 ? 0 : (nb == 3 ? 1 : -1);
+            const int ds = nb == 0 ? 0 : -1;
+            const int r2 = rl + dr, s2 = sl + ds;
+            if (r2 >= 0 && r2 < TILE_R && s2 >= 0) {
+                const int rowb = s2 * TILE_R + r2;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (q < n_planes) {
+                        ia[q] = s_rowfirst[q][rowl]; ib[q] = s_rowfirst[q][rowb];
+                        ea[q] = ia[q] + s_rowcnt[q][rowl]; eb[q] = ib[q] + s_rowcnt[q][rowb];
+                        if (ia[q] < ea[q] && ib[q] < eb[q]) {
+                            sa[q] = s_rs[ia[q]]; fa[q] = s_re[ia[q]]; sb[q] = s_rs[ib[q]]; fb[q] = s_re[ib[q]];
+                            done[q] = false;
+                        }
+                    }
+                }
+            }
+        }
+        while (true) {  // batches of at most EQ parked pairs per thread (almost always one batch)
+            if (tid == 0) s_more = 0;
+            __syncthreads();
+            uint32_t edge[EQ];
+            uint32_t n_edges = 0;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                while (!done[q] && n_edges < EQ) {
+                    if (sa[q] <= fb[q] + 1 && sb[q] <= fa[q] + 1) {
+                        const uint32_t pr = (ia[q] << 16) | ib[q];
+#pragma unroll
+                        for (int e = 0; e < EQ; ++e)
+                            if (e == (int)n_edges) edge[e] = pr;
+                        ++n_edges;
+                    }
+                    if (fa[q] < fb[q]) {
+                        if (++ia[q] >= ea[q]) { done[q] = true; break; }
+                        sa[q] = s_rs[ia[q]]; fa[q] = s_re[ia[q]];
+                    } else {
+                        if (++ib[q] >= eb[q]) { done[q] = true; break; }
+                        sb[q] = s_rs[ib[q]]; fb[q] = s_re[ib[q]];
+                    }
+                }
+            }
+            if (!done[0] || !done[1]) s_more = 1;
+            while (true) {
+#ifdef PDBEDA_COUNT_ROUNDS
+                if (tid == 0) atomicAdd(&job.ctr->unit_tiles[1], 1u);
+#endif
+                if (tid == 0) s_changed = 0;
+                __syncthreads();
+                bool ch = false;
+                uint32_t pa[EQ], pb[EQ];
+#pragma unroll
+                for (int e = 0; e < EQ; ++e) {  // independent LDS reads: one latency for all pairs
+                    if (e < (int)n_edges) { pa[e] = s_parent[edge[e] >> 16]; pb[e] = s_parent[edge[e] & 0xffffu]; }
+                }
+#pragma unroll
+                for (int e = 0; e < EQ; ++e) {
+                    if (e < (int)n_edges && pa[e] != pb[e]) {
+                        atomicMin(&s_parent[pa[e] > pb[e] ? pa[e] : pb[e]], pa[e] > pb[e] ? pb[e] : pa[e]);
+                        ch = true;
+                    }
+                }
+                // one pointer-jumping step for every used slot: P[i] = P[P[i]] -- all reads of a thread
+                // are independent (batched), no walk-to-root chains
+                uint32_t ji[6], jx[6], jy[6];
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    const uint32_t lin = tid + 256u * t;                      // 0 .. 1535: sign-0 slots first, then sign-1 slots
+                    ji[t] = lin < al0 ? lin : (lin - al0 < al1 ? PCAP + (lin - al0) : 0xffffffffu);
+                    jx[t] = ji[t] != 0xffffffffu ? s_parent[ji[t]] : 0u;
+                }
+#pragma unroll
+                for (int t = 0; t < 6; ++t) jy[t] = ji[t] != 0xffffffffu ? s_parent[jx[t]] : 0u;
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+                    if (ji[t] != 0xffffffffu && jx[t] != jy[t]) { s_parent[ji[t]] = jy[t]; ch = true; }
+                if (ch) s_changed = 1;
+                __syncthreads();
+                const bool again = s_changed != 0;
+                __syncthreads();
+                if (!again) break;
+            }
+            const bool more = s_more != 0;
+            __syncthreads();
+            if (!more) break;
+        }
+    }
+#if defined(PDBEDA_STOP_AFTER) && PDBEDA_STOP_AFTER == 2
+    if (s_over != 0xffffffffu) return;
+#endif
+    // ---- C1: number the tile-local components (s_rs / s_re are free now: reuse as u16 table) -----
+    __syncthreads();
+    for (uint32_t i = tid; i < RCAP; i += 256)
+        if (slot_used(i) && s_parent[i] == i) s_compidx[i] = (uint16_t)atomicAdd(&s_ncomp, 1u);
+    __syncthreads();
+    const uint32_t n_comp = s_ncomp;
+#if defined(PDBEDA_STOP_AFTER) && PDBEDA_STOP_AFTER == 3
+    if (s_over != 0xffffffffu) return;
+#endif
+    if (n_comp > CCAP) {  // block-uniform: too many components for LDS -> unit tile
+        if (my_valid) {
+            job.mask[my_word] = m0;
+            job.run_base[my_word] = 0u;
+            if (n_planes > 1) { job.mask[plane_words + my_word] = m1; job.run_base[plane_words + my_word] = 0u; }
+        }
+        if (tid == 0) { job.tile_mode[tile_id] = 1; atomicAdd(&job.ctr->unit_tiles[2], 1u); }
+        mark_comps_unused(job, (uint32_t)blockIdx.x * CCAP, 0u, tid);
+        return;
+    }
+    if (tid == 0) {
+        s_runbase = (uint32_t)blockIdx.x * (uint32_t)(NU * 32);
+        s_compbase = (uint32_t)blockIdx.x * CCAP;
+    }
+    for (uint32_t i = tid; i < n_comp; i += 256) {
+        s_rho[i] = 0.0; s_rho_c[i] = 0.0; s_rho_r[i] = 0.0; s_rho_s[i] = 0.0;
+        s_n[i] = 0u; s_c[i] = 0u; s_r[i] = 0u; s_s[i] = 0u; s_key[i] = 0xffffffffu; s_cplane[i] = 0u;
+    }
+    __syncthreads();
+    // ---- C2 + flush (thread per word): fold run pieces into component sums; publish run -> comp ----
+    const uint32_t cb = s_compbase, rb = s_runbase;
+    const uint32_t my_g = rb + ((tid < NU) ? s_gword[tid] : 0u);
+    if (tid < NU && (m0 | m1)) {
+        const int r = r0 + my_rl, s = s0 + my_sl, cword = (w0 + my_wl) * 64, ctile = w0 * 64;
+        uint32_t g = my_g;
+        for (int q = 0; q < n_planes; ++q) {
+            const uint64_t m = q ? m1 : m0;
+            uint64_t todo = run_starts(m);
+            const uint32_t first = s_first[q][tid], next = s_next[q][tid];
+            uint32_t k = 0;
+            while (todo) {
+                const int a = ctz64(todo);
+                todo &= todo - 1;
+                const int len = run_end_of(m, a) - a + 1;
+                const uint32_t slot = k == 0 ? (first & 0x7fffu) : next + k - 1u;
+                ++k;
+                const uint32_t comp = s_compidx[s_parent[slot]];
+                job.comp_of_run[g++] = cb + comp;
+                const bool owner = !(a == 0 && my_wl > 0 && (s_mask[q][tid - 1] >> 63));  // piece that starts the row-run
+                if (owner) {
+                    const double rho = s_run_rho[slot];
+                    unsafeAtomicAdd(&s_rho[comp], rho);
+                    unsafeAtomicAdd(&s_rho_c[comp], (double)ctile * rho + s_run_rhoc[slot]);
+                    unsafeAtomicAdd(&s_rho_r[comp], (double)r * rho);
+                    unsafeAtomicAdd(&s_rho_s[comp], (double)s * rho);
+                    atomicMin(&s_key[comp], (uint32_t)(((int64_t)(cword + a) * ur + r) * us + s));
+                    if (q) s_cplane[comp] = 1u;
+                }
+                atomicAdd(&s_n[comp], (uint32_t)len);
+                atomicAdd(&s_c[comp], (uint32_t)(len * (cword + a) + len * (len - 1) / 2));
+                atomicAdd(&s_r[comp], (uint32_t)(len * r));
+                atomicAdd(&s_s[comp], (uint32_t)(len * s));
+            }
+        }
+    }
+    if (my_valid) {
+        job.mask[my_word] = m0;
+        job.run_base[my_word] = my_g;
+        if (n_planes > 1) { job.mask[plane_words + my_word] = m1; job.run_base[plane_words + my_word] = my_g + (uint32_t)popc64(run_starts(m0)); }
+    }
+    if (tid == 0) job.tile_mode[tile_id] = 0;
+    __syncthreads();
+    const int64_t keys_pp = (int64_t)uc * ur * us;
+    for (uint32_t i = tid; i < n_comp; i += 256) {
+        const uint32_t g = cb + i;
+        job.parent[g] = (int32_t)g;
+        job.r_n[g] = s_n[i];
+        job.r_rho[g] = s_rho[i];
+        job.r_rho_c[g] = s_rho_c[i];
+        job.r_rho_r[g] = s_rho_r[i];
+        job.r_rho_s[g] = s_rho_s[i];
+        job.r_c[g] = (long long)s_c[i];
+        job.r_r[g] = (long long)s_r[i];
+        job.r_s[g] = (long long)s_s[i];
+        job.r_key[g] = (unsigned long long)(s_cplane[i] ? keys_pp : 0) + s_key[i];
+    }
+    mark_comps_unused(job, cb, n_comp, tid);
+    (void)n_wordruns;
+}
+
+// Generic labelling of the tiles k_tile_label could not hold in LDS ("unit tiles"): every run
+// is its own component with its own record (wave prefix sums per word, as k_run_index);
+// k_union_tiles then unites ALL touching pairs of such a tile globally.  Block per tile.
+template <int CW>
+__global__ void __launch_bounds__(256) k_unit_tiles(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td) {
+    constexpr int NU = 64 * CW;
+    constexpr int UPW = 16 * CW;
+    __shared__ uint64_t s_m[256];
+    __shared__ uint32_t s_off[256];
+    __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_rb, s_cb;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int t = blockIdx.x;
+    const int ct = t % td.ctiles; t /= td.ctiles;
+    const int rt = t % td.rtiles; t /= td.rtiles;
+    const int st = t;
+    const int w0 = ct * CW, r0 = rt * TILE_R, s0 = st * TILE_S;
+    if (job.tile_mode[tile_index(td, 0, w0, r0, s0)] == 0) return;
+    const Geom &g = *gp;
+    const int ur = g.unique_ncrs[1], us = g.unique_ncrs[2];
+    const int row_words = (g.unique_ncrs[0] + 63) >> 6;
+    const int my_wl = tid % CW, my_rowl = (tid / CW) & 63;
+    const int my_rl = my_rowl & 7, my_sl = my_rowl >> 3;
+    const bool my_valid = (tid < NU) && (r0 + my_rl < ur) && (s0 + my_sl < us) && (w0 + my_wl < row_words);
+    for (int q = 0; q < td.n_planes; ++q) {
+        const VolDesc vd = job.vols[q];
+        const int64_t my_word = vd.word_base + ((int64_t)(s0 + my_sl) * ur + (r0 + my_rl)) * row_words + (w0 + my_wl);
+        const uint64_t m = my_valid ? job.mask[my_word] : 0ull;
+        const uint32_t cnt = (uint32_t)popc64(run_starts(m));
+        uint32_t x = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) s_wsum[wv] = x;
+        s_m[tid] = m;
+        __syncthreads();
+        uint32_t pre = 0;
+        for (int k = 0; k < wv; ++k) pre += s_wsum[k];
+        if (tid == 255) {
+            const uint32_t tot = pre + x;
+            s_rb = tot ? atomicAdd(&job.ctr->n_runs, tot) : 0u;
+            s_cb = tot ? atomicAdd(&job.ctr->n_comps, tot) : 0u;
+        }
+        __syncthreads();
+        const uint32_t off = pre + x - cnt;
+        s_off[tid] = off;
+        if (my_valid) job.run_base[my_word] = s_rb + off;
+        __syncthreads();
+        for (int j = 0; j < UPW; ++j) {
+            const int u = wv * UPW + j;
+            const uint64_t mw = s_m[u];
+            if (mw == 0ull) continue;
+            const int wl = u % CW, rowl = u / CW;
+            const int r = r0 + (rowl & 7), s = s0 + (rowl >> 3), c0 = (w0 + wl) * 64;
+            const uint32_t run0 = s_rb + s_off[u], comp0 = s_cb + s_off[u];
+            word_run_records(job, g, dens, vd, mw, lane, c0, r, s, c0, r, s, comp0);
+            const uint64_t starts = run_starts(mw);
+            if ((starts >> lane) & 1ull) {
+                const uint32_t k = (uint32_t)popc64(starts & bits_below(lane));
+                job.comp_of_run[run0 + k] = comp0 + k;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Cross-tile pairs of one mask word.  All global loads (the 13 neighbour masks and run bases)
+// are issued up front and unconditionally -- one memory latency instead of one per neighbour --
+// then the touching RUN pairs are enumerated from registers.  Pairs inside one normally
+// processed tile were already united in LDS and are skipped (their neighbour mask is zeroed).
+// emit(runA, runB) with global run ids; k_union_edges maps them to components.
+struct NbWords {
+    uint64_t m[13];     // [0] = previous word of my row; [1 + nb*3 + (dw+1)] = neighbour rows
+    uint32_t base[13];
+};
+
+__device__ inline bool load_cross_tile(const Job &job, const TileDims &td, int64_t w, uint64_t m, NbWords &nw, uint32_t &my_base) {
+    const int plane = (job.n_vols > 1 && w >= job.vols[1].word_base) ? 1 : 0;
+    const VolDesc vd = job.vols[plane];
+    const int64_t rem = w - vd.word_base;
+    const int wq = (int)(rem % vd.row_words);
+    const int64_t row = rem / vd.row_words;
+    const int rl = (int)(row % vd.dim[1]);
+    const int sl = (int)(row / vd.dim[1]);
+    const bool my_unit = job.tile_mode[tile_index(td, 0, wq, rl, sl)] != 0;
+    // does any of the 13 earlier neighbours live in ANOTHER tile?
+    const bool edge = ((rl & 7) == 0 && rl > 0) || ((sl & 7) == 0 && sl > 0) || ((rl & 7) == 7 && rl + 1 < vd.dim[1] && sl > 0) ||
+                      (wq % td.cw == 0 && wq > 0) || (wq % td.cw == td.cw - 1 && wq + 1 < vd.row_words && (rl > 0 || sl > 0));
+    if (!edge && !my_unit) return false;
+    bool want[13];
+    int64_t at[13];
+    want[0] = (m & 1ull) && wq > 0 && (my_unit || (wq % td.cw == 0));
+    at[0] = w - 1;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int dr = nb == 2 ? 0 : (nb == 3 ? 1 : -1);
+        const int ds = nb == 0 ? 0 : -1;
+        const int r2 = rl + dr, s2 = sl + ds;
+        const bool row_ok = r2 >= 0 && r2 < vd.dim[1] && s2 >= 0;
+        const bool row_same_tile = ((r2 >> 3) == (rl >> 3)) && ((s2 >> 3) == (sl >> 3));
+        const int64_t rowbase = vd.word_base + ((int64_t)s2 * vd.dim[1] + r2) * vd.row_words;
+#pragma unroll
+        for (int dw = -1; dw <= 1; ++dw) {
+            const int w2 = wq + dw;
+            const int i = 1 + nb * 3 + (dw + 1);
+            bool ok = row_ok && w2 >= 0 && w2 < vd.row_words;
+            if (ok && !my_unit && row_same_tile && (w2 / td.cw == wq / td.cw)) ok = false;  // united in LDS
+            if (dw < 0 && !(m & 1ull)) ok = false;
+            if (dw > 0 && !(m >> 63)) ok = false;
+            want[i] = ok;
+            at[i] = rowbase + w2;
+        }
+    }
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        const int64_t a = want[i] ? at[i] : w;  // unconditional load (own word when unwanted)
+        nw.m[i] = job.mask[a];
+        nw.base[i] = job.run_base[a];
+    }
+    my_base = job.run_base[w];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        if (!want[i]) nw.m[i] = 0ull;
+        any = any || nw.m[i] != 0ull;
+    }
+    return any;
+}
+
+template <typename F>
+__device__ inline void cross_tile_pairs(uint64_t m, uint32_t my_base, const NbWords &nw, F &&emit) {
+    const uint64_t mstarts = run_starts(m);
+    const uint64_t dil = m | (m << 1) | (m >> 1);
+    if (nw.m[0] >> 63) {
+        const uint64_t pm = nw.m[0];
+        emit(my_base, nw.base[0] + (uint32_t)popc64(run_starts(pm) & bits_below(run_start_of(pm, 63))));
+    }
+#pragma unroll
+    for (int i = 1; i < 13; ++i) {
+        const int dw = (i - 1) % 3 - 1;
+        const uint64_t nm = nw.m[i];
+        uint64_t hit = dw == 0 ? (nm & dil) : dw < 0 ? (nm & (1ull << 63)) : (nm & 1ull);
+        while (hit) {
+            const int qb = ctz64(hit);
+            const int stb = run_start_of(nm, qb);
+            const int enb = run_end_of(nm, stb);
+            hit &= ~bits_below(enb + 1);
+            const uint32_t other = nw.base[i] + (uint32_t)popc64(run_starts(nm) & bits_below(stb));
+            int lo = stb - 1 + 64 * dw, hi = enb + 1 + 64 * dw;
+            if (lo < 0) lo = 0;
+            if (hi > 63) hi = 63;
+            uint64_t mine = m & (bits_below(hi + 1) & ~bits_below(lo));
+            while (mine) {
+                const int pa = ctz64(mine);
+                const int sta = run_start_of(m, pa);
+                mine &= ~bits_below(run_end_of(m, sta) + 1);
+                emit(my_base + (uint32_t)popc64(mstarts & bits_below(sta)), other);
+            }
+        }
+    }
+}
+
+// Thread per word: count the cross-tile run pairs; the block reserves space with ONE atomic on
+// its shard's counter (64 shards -> the allocation never serialises), then the pairs are written.
+// (If a shard is full its pairs are united on the spot -- slower, same result.)
+// Threads are laid out over the CANDIDATE rows only (grid.y = section, grid.z = sign): all rows of
+// a section that starts a tile layer, else the rows r % 8 in {0, 7} -- so every wave is dense with
+// tile-edge words.  Grids wider than 4 words (c tiles) and unit tiles need every row: `all_rows`.
+__global__ void __launch_bounds__(256) k_tile_edges(Job job, TileDims td, int all_rows) {
+    __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const VolDesc v0 = job.vols[0];
+    const int sl = blockIdx.y, plane = blockIdx.z;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + tid;   // candidate word inside this section
+    const int rw = v0.row_words;
+    const int64_t jr = j / rw;
+    int r;
+    if (all_rows || ((sl & 7) == 0 && sl > 0)) r = (int)jr;
+    else r = (int)(jr >> 1) * 8 + ((jr & 1) ? 7 : 0);
+    const bool inside = r < v0.dim[1];
+    const int64_t w = (int64_t)plane * rw * v0.dim[1] * v0.dim[2] + ((int64_t)sl * v0.dim[1] + (inside ? r : 0)) * rw + (j % rw);
+    const uint64_t m = inside ? job.mask[w] : 0ull;
+    NbWords nw;
+    uint32_t my_base = 0;
+    bool act = false;
+    if (m != 0ull) act = load_cross_tile(job, td, w, m, nw, my_base);
+    uint32_t n = 0;
+    if (act) cross_tile_pairs(m, my_base, nw, [&](uint32_t, uint32_t) { ++n; });
+    uint32_t x = n;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) s_wsum[wv] = x;
+    __syncthreads();
+    const uint32_t tot = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    if (tot == 0) return;  // block-uniform
+    const int shard = (blockIdx.x + 7 * blockIdx.y + 3 * blockIdx.z) % ESHARDS;
+    const uint32_t shard_cap = (uint32_t)(job.edge_cap / ESHARDS);
+    if (tid == 0) s_base = atomicAdd(&job.edge_fill[shard], tot);
+    __syncthreads();
+    uint32_t pre = 0;
+    for (int k = 0; k < wv; ++k) pre += s_wsum[k];
+    uint32_t i = s_base + pre + x - n;
+    if (!act || n == 0) return;
+    if (s_base + tot <= shard_cap) {
+        uint2 *dst = job.edges + (size_t)shard * shard_cap;
+        cross_tile_pairs(m, my_base, nw, [&](uint32_t a, uint32_t b) { dst[i++] = make_uint2(a, b); });
+    } else {
+        cross_tile_pairs(m, my_base, nw, [&](uint32_t a, uint32_t b) { uf_unite(job.parent, (int)job.comp_of_run[a], (int)job.comp_of_run[b]); });
+    }
+}
+
+// Companion launch for narrow grids: visits every row, but only when some tile fell back to unit
+// mode (device-side counter), and then only does work for words of unit tiles.
+__global__ void __launch_bounds__(256) k_tile_edges_unit(Job job, TileDims td) {
+    if (job.ctr->unit_tiles[0] + job.ctr->unit_tiles[2] == 0) return;
+    const VolDesc v0 = job.vols[0];
+    const int sl = blockIdx.y, plane = blockIdx.z, rw = v0.row_words;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = (int)(j / rw);
+    if (r >= v0.dim[1]) return;
+    const int wq = (int)(j % rw);
+    if (job.tile_mode[tile_index(td, 0, wq, r, sl)] == 0) return;
+    // rows the candidate layout already visited are skipped here
+    if (((sl & 7) == 0 && sl > 0) || (r & 7) == 0 || (r & 7) == 7) return;
+    const int64_t w = (int64_t)plane * rw * v0.dim[1] * v0.dim[2] + ((int64_t)sl * v0.dim[1] + r) * rw + wq;
+    const uint64_t m = job.mask[w];
+    if (m == 0ull) return;
+    NbWords nw;
+    uint32_t my_base;
+    if (!load_cross_tile(job, td, w, m, nw, my_base)) return;
+    cross_tile_pairs(m, my_base, nw, [&](uint32_t a, uint32_t b) { uf_unite(job.parent, (int)job.comp_of_run[a], (int)job.comp_of_run[b]); });
+}
+
+// Thread per parked run pair: map to tile components, global union-find with device-scope atomics.
+__global__ void __launch_bounds__(256) k_union_edges(Job job) {
+    const uint32_t shard_cap = (uint32_t)(job.edge_cap / ESHARDS);
+    for (int sh = blockIdx.y; sh < ESHARDS; sh += gridDim.y) {
+        const uint32_t fill = job.edge_fill[sh];
+        const uint32_t n = fill < shard_cap ? fill : shard_cap;
+        const uint2 *src = job.edges + (size_t)sh * shard_cap;
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+            const uint2 e = src[i];
+            const int a = (int)job.comp_of_run[e.x], b = (int)job.comp_of_run[e.y];
+            if (a != b) uf_unite(job.parent, a, b);
+        }
+    }
+}
+
+// Signed dense labels of a whole-map job in ONE pass: 0 background, +1+k for blob k of the
+// ">= cutoff" list, -1-k for blob k of the "<= cutoff" list (4 B/voxel written once, also
+// for a fused green/red call).  Wave per 256-voxel row segment, 4 voxels per lane, 16-B stores.
+__global__ void __launch_bounds__(256) k_labels_signed(Job job, TileDims td, int32_t *__restrict__ labels) {
+    const int lane = lane_id();
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const VolDesc v0 = job.vols[0];
+    const int uc = v0.dim[0], row_words = v0.row_words;
+    const int segs_per_row = (row_words + 3) >> 2;
+    const int64_t rows = (int64_t)v0.dim[1] * v0.dim[2];
+    const int64_t n_seg = rows * segs_per_row;
+    const int64_t plane_words = (int64_t)row_words * rows;
+    for (int64_t sg = wave; sg < n_seg; sg += n_waves) {
+        const int64_t row = sg / segs_per_row;
+        const int seg = (int)(sg % segs_per_row);
+        const int wq = seg * 4 + (lane >> 4);
+        const int bit0 = (lane & 15) * 4;
+        int32_t out[4] = {0, 0, 0, 0};
+        if (wq < row_words) {
+            const int64_t w = row * row_words + wq;
+            for (int p = 0; p < td.n_planes; ++p) {
+                const uint64_t m = job.mask[w + p * plane_words];
+                const unsigned nib = (unsigned)((m >> bit0) & 0xfull);
+                if (!nib) continue;
+                const uint32_t base = job.run_base[w + p * plane_words];
+                const uint64_t starts = run_starts(m);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if ((nib >> q) & 1u) {
+                        const int stb = run_start_of(m, bit0 + q);
+                        const uint32_t run = base + (uint32_t)popc64(starts & bits_below(stb));
+                        out[q] = job.label_of_comp[job.comp_of_run ? job.comp_of_run[run] : run];
+                    }
+                }
+            }
+        }
+        const int c = wq * 64 + bit0;
+        int32_t *dst = labels + row * uc + c;
+        if (wq < row_words) {
+            if (c + 3 < uc && ((uc & 3) == 0)) {
+                *reinterpret_cast<int4 *>(dst) = make_int4(out[0], out[1], out[2], out[3]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (c + q < uc) dst[q] = out[q];
+            }
+        }
+    }
+}
+
+// Decode the signed volume for one list: -1 background / other sign, else 0-based blob index.
+__global__ void k_labels_decode(const int32_t *__restrict__ signed_labels, int64_t n, int sign, int32_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t v = signed_labels[i];
+        out[i] = sign > 0 ? (v > 0 ? v - 1 : -1) : (v < 0 ? -v - 1 : -1);
+    }
 }
 
 }  // namespace pdbeda
