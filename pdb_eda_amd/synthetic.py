@@ -9,7 +9,7 @@ The CCP4 byte layout written by :func:`ccp4_bytes` is the one the reference pars
 """
 import numpy as np
 
-__all__ = ["ccp4_bytes", "ccp4_header_bytes", "noise_grid", "MapSpec", "chain_structure", "gaussian_sum_grid", "smooth_noise"]
+__all__ = ["ccp4_bytes", "ccp4_header_bytes", "synthetic_params", "noise_grid", "MapSpec", "chain_structure", "gaussian_sum_grid", "smooth_noise"]
 
 
 class MapSpec(object):
@@ -167,3 +167,19 @@ def gaussian_sum_grid(header, structure, electrons, sigma=0.55, noise=0.02, seed
     if ns > is_:
         grid[is_:, :, :] = grid[:ns - is_, :, :]
     return grid.astype(np.float32)
+
+
+def synthetic_params():
+    """A small, made-up analysis parameter table (same schema as the reference's
+    ``conf/optimized_params.json``: radii, slopes, electrons, atom types, bonded atoms) covering the
+    poly-ALA model of :func:`chain_structure`.  The values are NOT the reference's."""
+    types = {"ALA_N": "N.syn.amide", "ALA_CA": "C.syn.alpha", "ALA_C": "C.syn.carbonyl", "ALA_O": "O.syn.carbonyl", "ALA_CB": "C.syn.methyl"}
+    return {
+        "radii": {"N.syn.amide": 0.78, "C.syn.alpha": 0.81, "C.syn.carbonyl": 0.74, "O.syn.carbonyl": 0.86, "C.syn.methyl": 0.9},
+        "slopes": {"N.syn.amide": -0.52, "C.syn.alpha": -0.61, "C.syn.carbonyl": -0.55, "O.syn.carbonyl": -0.48, "C.syn.methyl": -0.7},
+        "full_atom_name_map_atom_type": types,
+        "full_atom_name_map_electrons": {"ALA_N": 8.0, "ALA_CA": 7.0, "ALA_C": 6.0, "ALA_O": 8.0, "ALA_CB": 9.0},
+        "bonded_atoms": {"ALA_N": ["ALA_CA"], "ALA_CA": ["ALA_N", "ALA_C", "ALA_CB"], "ALA_C": ["ALA_CA", "ALA_O", "ALA_OXT"],
+                         "ALA_O": ["ALA_C"], "ALA_CB": ["ALA_CA"]},
+        "leaving_atoms": [],
+    }

@@ -41,3 +41,27 @@ def blobs_from_record(z, prefix):
 
 def crs_set(a):
     return {tuple(int(x) for x in v) for v in np.asarray(a).reshape(-1, 3)}
+
+
+ANALYSIS_CASES = ["orth", "hex"]
+
+
+def load_analysis_case(name):
+    """Analysis golden fixture -> (npz, MapSpec, Structure, PDBEntry, params)."""
+    import json
+    from pdb_eda_amd import synthetic, structure
+    z = np.load(os.path.join(GOLDEN, "analysis_%s.npz" % name))
+    spec = synthetic.MapSpec(**json.loads(str(z["spec"])))
+    st = structure.Structure("synth")
+    model = structure.Model(0, st)
+    chain = structure.Chain("A", model)
+    res = None
+    last = None
+    for i in range(len(z["atom_name"])):
+        key = (str(z["atom_het"][i]), int(z["atom_resnum"][i]))
+        if key != last:
+            res = structure.Residue((key[0], key[1], " "), str(z["atom_resname"][i]), chain)
+            last = key
+        structure.Atom(str(z["atom_name"][i]), z["atom_coord"][i], float(z["atom_occ"][i]), float(z["atom_b"][i]), str(z["atom_element"][i]), res, i + 1)
+    pdb = structure.PDBEntry(structure.PDBHeader(pdbid=name, resolution=2.0, spaceGroup="P_1", rotationMats=[m for m in z["rot"]]))
+    return z, spec, st, pdb, synthetic.synthetic_params()
