@@ -1,0 +1,115 @@
+"""Multiple-structure mode on MI355X: entries are independent, so they are sharded over ranks
+(one process per GPU) and, inside a rank, over a small pool of HIP streams.
+
+Replaces the *dispatch* of ``pdb_eda/multipleStructures.py`` -- ``multiprocessing.Pool().map(
+processFunction, pdbids, chunksize=1)`` (multipleStructures.py:167-168) and the temp-JSON hand-off
+(fileUtils.py:12-28) -- and reproduces the per-entry record of ``analyzePDBID``
+(multipleStructures.py:320-356).  HIP contexts do not survive ``fork`` (what ``Pool`` does), so the
+pool here is threads: one ``pdbeda_ctx`` (= one stream) per worker thread; ctypes releases the GIL
+inside every C-ABI call, so streams overlap.  Filters, reload, CSV writers: out of scope.
+"""
+import collections
+import io
+import queue
+import threading
+import time
+
+import numpy as np
+
+from . import _native, ccp4, densityAnalysis
+
+statsHeaders = ['density_electron_ratio', 'voxel_volume', 'f000', 'num_voxels_aggregated', 'total_aggregated_electrons', 'density_mean',
+                'diff_density_mean', 'resolution', 'space_group', 'num_atoms_analyzed', 'num_residue_clouds_analyzed',
+                'num_domain_clouds_analyzed', 'atom_overlap_completeness']
+
+
+class Entry(object):
+    """One PDB entry: a loader returning (2Fo-Fc CCP4 bytes, Fo-Fc CCP4 bytes, structure, pdbObj)."""
+
+    def __init__(self, pdbid, loader, cost_hint=0.0):
+        self.pdbid = pdbid
+        self.loader = loader
+        self.cost_hint = cost_hint      # e.g. last iteration's execution_time (optimizeParams.py:392-393)
+
+
+def shard(entries, rank, world_size):
+    """Longest-first (the reference's heuristic, optimizeParams.py:392-393), then dealt round-robin."""
+    order = sorted(range(len(entries)), key=lambda i: -entries[i].cost_hint)
+    return [entries[i] for i in order[rank::world_size]]
+
+
+def analyzeEntry(entry, ctx=None):
+    """ref multipleStructures.py:320-356: one entry -> result record, or 0 when the entry fails
+    (load error, or no density-electron ratio: Q7).  A failed entry never poisons the pool."""
+    startTime = time.process_time()
+    try:
+        dens_bytes, diff_bytes, biopdbObj, pdbObj = entry.loader()
+        densityObj = ccp4.parse(io.BytesIO(dens_bytes), entry.pdbid, ctx=ctx)
+        diffDensityObj = ccp4.parse(io.BytesIO(diff_bytes), entry.pdbid, ctx=ctx)
+        densityAnalysis._attachCutoffs(densityObj, diffDensityObj)
+        analyzer = densityAnalysis.DensityAnalysis(entry.pdbid, densityObj, diffDensityObj, biopdbObj, pdbObj)
+    except Exception:
+        return 0
+    if not analyzer.densityElectronRatio:
+        return 0
+    ratio = analyzer.densityElectronRatio
+    corrected = analyzer.medians['corrected_density_electron_ratio']
+    diffs = {atomType: ((corrected[atomType] - ratio) / ratio) if atomType in corrected else 0 for atomType in sorted(densityAnalysis.paramsGlobal["radii"])}
+    complete = sum(analyzer.atomTypeOverlapCompleteness.values())
+    incomplete = sum(analyzer.atomTypeOverlapIncompleteness.values())
+    if complete > 0 or incomplete > 0:
+        complete = complete / (complete + incomplete)
+    stats = {'density_electron_ratio': ratio, 'voxel_volume': densityObj.header.unitVolume, 'f000': None,
+             'num_voxels_aggregated': analyzer.numVoxelsAggregated, 'total_aggregated_electrons': analyzer.totalAggregatedElectrons,
+             'density_mean': densityObj.header.densityMean, 'diff_density_mean': diffDensityObj.header.densityMean,
+             'resolution': pdbObj.header.resolution, 'space_group': pdbObj.header.spaceGroup,
+             'num_atoms_analyzed': len(analyzer.atomCloudDescriptions), 'num_residue_clouds_analyzed': len(analyzer.residueCloudDescriptions),
+             'num_domain_clouds_analyzed': len(analyzer.domainCloudDescriptions), 'atom_overlap_completeness': complete}
+    properties = {'residue_counts': dict(collections.Counter(residue.resname for residue in biopdbObj.get_residues())),
+                  'element_counts': dict(collections.Counter(atom.element for atom in biopdbObj.get_atoms()))}
+    slopes = {t: float(v) for t, v in analyzer.medians['slopes'].items() if not np.isnan(v)}
+    return {"pdbid": entry.pdbid, "diffs": {k: float(v) for k, v in diffs.items()}, "stats": stats, "slopes": slopes,
+            "atomtype_overlap_completeness": dict(analyzer.atomTypeOverlapCompleteness),
+            "atomtype_overlap_incompleteness": dict(analyzer.atomTypeOverlapIncompleteness),
+            "execution_time": time.process_time() - startTime, "properties": properties}
+
+
+class StreamPool(object):
+    """N worker threads on one GPU, each with its own context (HIP stream + device arena cache)."""
+
+    def __init__(self, device=0, n_streams=4):
+        self.device = device
+        self.n_streams = max(1, int(n_streams))
+
+    def map(self, fn, entries):
+        todo = queue.Queue()
+        for i, e in enumerate(entries):
+            todo.put((i, e))
+        results = [0] * len(entries)
+
+        def work():
+            ctx = _native.Context(self.device)
+            try:
+                while True:
+                    try:
+                        i, e = todo.get_nowait()
+                    except queue.Empty:
+                        return
+                    try:
+                        results[i] = fn(e, ctx)
+                    except Exception:
+                        results[i] = 0          # per-entry failure is dropped, like multipleStructures.py:297-304
+            finally:
+                ctx.synchronize()
+        threads = [threading.Thread(target=work) for _ in range(min(self.n_streams, max(1, len(entries))))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        return results
+
+
+def processEntries(entries, device=0, n_streams=4):
+    """The per-GPU part of ``pdb_eda multiple``: {pdbid: record} for the entries that succeed."""
+    records = StreamPool(device, n_streams).map(analyzeEntry, entries)
+    return {r["pdbid"]: r for r in records if r}

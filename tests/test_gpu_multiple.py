@@ -1,0 +1,48 @@
+"""Multiple-structure mode on one GPU: entries dealt to a pool of HIP streams (one context per
+worker thread) give the same records as sequential processing, failed entries are dropped without
+poisoning the pool, and the record matches the reference-derived goldens."""
+import numpy as np
+import pytest
+
+from conftest import load_analysis_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _entries(n_copies=3):
+    from pdb_eda_amd import synthetic, multipleStructures
+    out = []
+    for k in range(n_copies):
+        for name in ("orth", "hex"):
+            z, spec, st, pdb, params = load_analysis_case(name)
+            dens, diff = synthetic.ccp4_bytes(spec, z["dens"]), synthetic.ccp4_bytes(spec, z["diff"])
+            out.append(multipleStructures.Entry("%s%d" % (name, k), (lambda d=dens, f=diff, s=st, p=pdb: (d, f, s, p)), cost_hint=len(dens)))
+    out.append(multipleStructures.Entry("broken", lambda: (b"not a map", b"", None, None)))
+    return out
+
+
+def test_stream_pool_matches_sequential(gpu_ctx):
+    from pdb_eda_amd import synthetic, densityAnalysis, multipleStructures
+    densityAnalysis.setGlobals(synthetic.synthetic_params())
+    entries = _entries()
+    seq = {e.pdbid: multipleStructures.analyzeEntry(e, gpu_ctx) for e in entries}
+    par = multipleStructures.processEntries(entries, device=0, n_streams=3)
+    assert "broken" not in par and seq["broken"] == 0
+    assert set(par) == {k for k, v in seq.items() if v}
+    for k, rec in par.items():
+        want = seq[k]
+        for key in ("density_electron_ratio", "num_voxels_aggregated", "total_aggregated_electrons", "num_atoms_analyzed",
+                    "num_residue_clouds_analyzed", "num_domain_clouds_analyzed", "atom_overlap_completeness"):
+            assert rec["stats"][key] == pytest.approx(want["stats"][key], rel=1e-12), key
+        assert rec["diffs"].keys() == want["diffs"].keys()
+        for t in rec["diffs"]:
+            assert rec["diffs"][t] == pytest.approx(want["diffs"][t], rel=1e-9, abs=1e-12)
+        z = load_analysis_case(k[:-1])[0]
+        assert rec["stats"]["density_electron_ratio"] == pytest.approx(float(z["ratio"]), rel=1e-8)
+        assert rec["stats"]["num_voxels_aggregated"] == int(z["num_voxels"])
+    # the reduction of optimise mode over these records (single rank here; 2 ranks in the gloo test)
+    from pdb_eda_amd import optimizeStats
+    med = optimizeStats.calculateMedianDiffsSlopes(list(par.values()), densityAnalysis.paramsGlobal)[0]
+    assert set(med) == set(densityAnalysis.paramsGlobal["radii"])
+    order = multipleStructures.shard(entries, 0, 2)
+    assert order[0].cost_hint >= order[-1].cost_hint
