@@ -43,12 +43,12 @@ def parse_args():
 
 def algorithmic_bytes(kernel, n_vox, n_planes):
     """Algorithmic HBM bytes of ONE launch of `kernel` ('Kernels and rooflines')."""
+    words = (n_vox // 64) * n_planes
     table = {
-        "k_threshold": 4 * n_vox + 8 * (n_vox // 64) * n_planes,      # read f32 grid once, write the bit masks
-        "k_tile_label": 4 * n_vox + 8 * (n_vox // 64) * n_planes,
-        "k_labels_plane": 4 * n_vox + 8 * (n_vox // 64),              # write int32 labels of one sign, read its mask
-        "k_run_index": (8 + 4) * (n_vox // 64) * n_planes,            # masks in, run_base out (+ sparse density re-read)
-        "k_union": (8 + 4) * (n_vox // 64) * n_planes,
+        "k_tile_label": 4 * n_vox + (8 + 4) * words,      # read the f32 grid once; write bit masks + run bases
+        "k_labels_signed": 4 * n_vox + (8 + 4) * words,   # write ONE signed int32 label volume; read masks + run bases
+        "k_tile_edges": (8 + 4) * words,                  # masks + run bases in
+        "k_union_edges": 0,                                # sparse (pairs << voxels): no per-voxel bytes
     }
     return table.get(kernel)
 
@@ -124,12 +124,28 @@ def main():
         keep = step()
     prof = ctx.profile_end()
     per_kernel = {k: {"calls": c, "avg_us": 1e3 * ms / c} for k, (c, ms) in prof.items()}
-    dominant = max((k for k in prof if algorithmic_bytes(k, n_vox, 2) is not None), key=lambda k: prof[k][1])
+    dominant = max((k for k in prof if algorithmic_bytes(k, n_vox, 2)), key=lambda k: prof[k][1])
     dom_calls, dom_ms = prof[dominant]
     dom_avg_s = dom_ms / dom_calls / 1e3
     dom_bytes = algorithmic_bytes(dominant, n_vox, 2)
     achieved = dom_bytes / dom_avg_s / 1e9
     step_kernel_s = sum(ms for _, ms in prof.values()) / 1e3 / args.steps
+
+    # measured HBM traffic of the dominant kernel (rocprofv3 PMC passes, committed under profiles/; gfx950 corrections applied there)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            pmc = json.load(fh)["kernels"]
+        if dominant in pmc and n == 256 and labels and args.nsd == 1.5:
+            traffic = pmc[dominant]["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        traffic = None
+
+    # host -> HBM upload of one entry (the boundary hands over a host buffer); never part of `value`
+    t1 = time.perf_counter()
+    tmp = _native.DeviceMap(ctx, grid, header.geometry())
+    h2d_s = time.perf_counter() - t1
+    tmp.free()
 
     value = world * n_vox * args.steps / elapsed / 1e6
     out = {
@@ -151,11 +167,14 @@ def main():
         "entries_per_min": 60.0 * world * args.steps / elapsed,
         "blobs": {"green": n_green, "red": n_red, "significant_voxels": sig_vox, "all_ranks": [int(x) for x in totals.tolist()]},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": 1e6 * dom_avg_s,
+                     "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": 1e6 * dom_avg_s,
                      "timing": "HIP events on the launch stream, separate %d-step pass" % args.steps,
                      "pass_8B_per_voxel": {"bytes": 8 * n_vox, "kernel_sum_us": 1e6 * step_kernel_s,
                                            "achieved": 8 * n_vox / step_kernel_s / 1e9, "frac": 8 * n_vox / step_kernel_s / 1e9 / HBM_PEAK_GBS}},
         "kernels_us": {k: round(v["avg_us"] * v["calls"] / args.steps, 2) for k, v in sorted(per_kernel.items())},
+        "h2d": {"upload_ms": 1e3 * h2d_s, "pcie_inclusive_Mvoxels_per_s": n_vox / (h2d_s + elapsed / args.steps) / 1e6,
+                "note": "pageable host buffer -> HBM through pdbeda_map_upload; reported for information, never part of value"},
+        "fallback_tiles": green.counters(),
     }
 
     # ---- CPU baseline: the oracle (CPU restatement, O(N) clustering) on the same entry, 1 core ----

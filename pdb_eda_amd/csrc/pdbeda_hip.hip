@@ -605,12 +605,9 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
     }
     hipStream_t st = ctx->stream;
     {
-        PROF(ctx, "setup(memset+vols)");
-        HIP_TRY(ctx, hipMemsetAsync(job.ctr, 0, sizeof(Counters), st));
-        HIP_TRY(ctx, hipMemsetAsync(job.edge_fill, 0, sizeof(uint32_t) * ESHARDS, st));
-        HIP_TRY(ctx, hipMemsetAsync(job.key_bits, 0, sizeof(uint64_t) * job.key_words, st));
+        PROF(ctx, "setup");
         hipLaunchKernelGGL(k_set_vols, dim3(1), dim3(64), 0, st, job.vols, vd[0], vd[n_planes - 1], n_planes, job.ctr,
-                           (unsigned)(tiles_pp * td.cw * 64 * 32), (unsigned)(tiles_pp * CCAP));
+                           (unsigned)(tiles_pp * td.cw * 64 * 32), (unsigned)(tiles_pp * CCAP), job.edge_fill);
     }
     switch (td.cw) {
         case 1: launch_tile_label<1>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td); break;

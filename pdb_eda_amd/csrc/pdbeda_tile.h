@@ -40,12 +40,17 @@ __host__ __device__ inline int64_t tile_index(const TileDims &td, int plane, int
 }
 
 // Write up to two volume descriptors passed by value (no host staging buffer, no sync).
-__global__ void k_set_vols(VolDesc *vols, VolDesc v0, VolDesc v1, int n, Counters *ctr, unsigned int runs0, unsigned int comps0) {
+__global__ void k_set_vols(VolDesc *vols, VolDesc v0, VolDesc v1, int n, Counters *ctr, unsigned int runs0, unsigned int comps0,
+                           uint32_t *edge_fill) {
+    if (threadIdx.x < ESHARDS) edge_fill[threadIdx.x] = 0u;
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         vols[0] = v0;
         if (n > 1) vols[1] = v1;
-        ctr->n_runs = runs0;    // ids below are owned tile by tile; unit tiles allocate above them
-        ctr->n_comps = comps0;
+        Counters c;
+        memset(&c, 0, sizeof c);
+        c.n_runs = runs0;    // ids below are owned tile by tile; unit tiles allocate above them
+        c.n_comps = comps0;
+        *ctr = c;
     }
 }
 
@@ -147,6 +152,11 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
     const int n_planes = td.n_planes;
 
     if (tid == 0) { s_over = 0; s_ncomp = 0; s_alloc[0] = 0; s_alloc[1] = 0; }
+    {   // every tile clears its slice of the first-key bitmap (saves a memset launch; it is painted two kernels later)
+        const int64_t per = (job.key_words + gridDim.x - 1) / gridDim.x;
+        const int64_t lo = per * blockIdx.x, hi = lo + per < job.key_words ? lo + per : job.key_words;
+        for (int64_t i = lo + tid; i < hi; i += 256) job.key_bits[i] = 0ull;
+    }
     for (int i = tid; i < RCAP; i += 256) { s_run_rho[i] = 0.0; s_run_rhoc[i] = 0.0; s_parent[i] = i; }
     __syncthreads();
 
