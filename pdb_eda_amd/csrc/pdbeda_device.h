@@ -154,6 +154,20 @@ __host__ __device__ inline int run_start_of(uint64_t m, int p) {
     uint64_t z = ~m & bits_below(p);
     return z ? 64 - clz64(z) : 0;
 }
+// ordinal (0-based, inside the word) of the run that contains set bit p: the run's own start and the
+// starts of all earlier runs are exactly the starts at positions <= p.  32-bit halves only.
+__host__ __device__ inline uint32_t run_ordinal(uint64_t starts, int p) {
+    const uint32_t lo = (uint32_t)starts, hi = (uint32_t)(starts >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t ml = p >= 31 ? 0xffffffffu : ((2u << p) - 1u);
+    const uint32_t mh = p < 32 ? 0u : (p >= 63 ? 0xffffffffu : ((2u << (p - 32)) - 1u));
+    return (uint32_t)__popc(lo & ml) + (uint32_t)__popc(hi & mh) - 1u;
+#else
+    const uint32_t ml = p >= 31 ? 0xffffffffu : ((2u << p) - 1u);
+    const uint32_t mh = p < 32 ? 0u : (p >= 63 ? 0xffffffffu : ((2u << (p - 32)) - 1u));
+    return (uint32_t)__builtin_popcount(lo & ml) + (uint32_t)__builtin_popcount(hi & mh) - 1u;
+#endif
+}
 // last bit of the run (within this word) that starts at bit a
 __host__ __device__ inline int run_end_of(uint64_t m, int a) {
     uint64_t inv = ~(m >> a);

@@ -492,6 +492,9 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.comp_of_run = n_tiles ? cv.take<uint32_t>(max_runs) : nullptr;
     job.label_of_comp = n_tiles ? cv.take<int32_t>(max_runs) : nullptr;
     job.tile_mode = n_tiles ? cv.take<uint8_t>(n_tiles) : nullptr;
+    job.tile_runs = n_tiles ? cv.take<uint32_t>(n_tiles) : nullptr;
+    job.stamps = n_tiles ? cv.take<unsigned long long>(16 * n_tiles) : nullptr;
+    job.run_sums = n_tiles ? cv.take<double2>((size_t)n_tiles * RCAP) : nullptr;
     job.edge_cap = n_tiles ? (std::max<int64_t>(1 << 16, 2 * total_words) + ESHARDS - 1) / ESHARDS * ESHARDS : 0;
     job.edges = n_tiles ? cv.take<uint2>(job.edge_cap) : nullptr;
     job.edge_fill = n_tiles ? cv.take<uint32_t>(ESHARDS) : nullptr;
@@ -548,7 +551,17 @@ static pdbeda_bloblist *new_list(pdbeda_ctx *ctx, pdbeda_map *m) {
 template <int CW>
 static void launch_tile_label(pdbeda_ctx *ctx, unsigned n_tiles, const Job &job, const float *dens, const Geom *geom_dev, const TileDims &td) {
     { PROF(ctx, "k_tile_label"); hipLaunchKernelGGL((k_tile_label<CW>), dim3(n_tiles), dim3(256), 0, ctx->stream, job, dens, geom_dev, td); }
-    { PROF(ctx, "k_unit_tiles"); hipLaunchKernelGGL((k_unit_tiles<CW>), dim3(n_tiles), dim3(256), 0, ctx->stream, job, dens, geom_dev, td); }
+    { PROF(ctx, "k_unit_tiles"); hipLaunchKernelGGL((k_unit_tiles<CW>), dim3(n_tiles * 4), dim3(256), 0, ctx->stream, job, dens, geom_dev, td); }
+}
+
+static void launch_labels(pdbeda_ctx *ctx, const Job &job, const TileDims &td, int32_t *labels_dev) {
+    const unsigned n_tiles = (unsigned)(td.ctiles * td.rtiles * td.stiles);
+    switch (td.cw) {
+        case 1: hipLaunchKernelGGL((k_labels_tiles<1>), dim3(n_tiles), dim3(256), 0, ctx->stream, job, td, labels_dev); break;
+        case 2: hipLaunchKernelGGL((k_labels_tiles<2>), dim3(n_tiles), dim3(256), 0, ctx->stream, job, td, labels_dev); break;
+        case 3: hipLaunchKernelGGL((k_labels_tiles<3>), dim3(n_tiles), dim3(256), 0, ctx->stream, job, td, labels_dev); break;
+        default: hipLaunchKernelGGL((k_labels_tiles<4>), dim3(n_tiles), dim3(256), 0, ctx->stream, job, td, labels_dev); break;
+    }
 }
 
 static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool want_pos, bool want_neg, uint32_t flags,
@@ -632,9 +645,8 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
     { PROF(ctx, "k_chunk_scan"); hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, st, job); }
     { PROF(ctx, "k_emit"); hipLaunchKernelGGL(k_emit, dim3(comp_grid), dim3(256), 0, st, job, m->geom_dev); }
     if (labels) {
-        PROF(ctx, "k_labels_signed");
-        const int64_t n_seg = (int64_t)((row_words + 3) / 4) * ur * us;
-        hipLaunchKernelGGL(k_labels_signed, dim3(grid_for(n_seg * 64, 256, 8192)), dim3(256), 0, st, job, td, labels_dev);
+        PROF(ctx, "k_labels_tiles");
+        launch_labels(ctx, job, td, labels_dev);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { arena_put(ctx, arena); return fail(ctx, PDBEDA_ERR_DEVICE, "whole-map labelling launch: %s", hipGetErrorString(e)); }
@@ -728,6 +740,15 @@ extern "C" int pdbeda_bloblist_counters(pdbeda_bloblist *bl, int64_t *out) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     out[0] = c.n_runs; out[1] = c.n_comps; out[2] = c.n_edges; out[3] = c.n_blobs;
     out[4] = c.unit_tiles[0]; out[5] = c.unit_tiles[1]; out[6] = c.unit_tiles[2]; out[7] = 0;
+    return PDBEDA_OK;
+}
+
+// Diagnostic builds only (-DPDBEDA_STAMPS): 8 s_memtime stamps per tile of the whole-map tile kernel.
+extern "C" int pdbeda_bloblist_stamps(pdbeda_bloblist *bl, unsigned long long *out, int64_t n_tiles) {
+    if (!bl || bl->freed || !out || !bl->job.stamps) return PDBEDA_ERR_ARGUMENT;
+    pdbeda_ctx *ctx = bl->ctx;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, bl->job.stamps, 128 * n_tiles, hipMemcpyDeviceToHost));
     return PDBEDA_OK;
 }
 
@@ -843,9 +864,7 @@ extern "C" int pdbeda_bloblist_labels(pdbeda_bloblist *bl, int32_t *labels_host)
     const int32_t *signed_vol = bl->labels_dev;
     if (!have) {
         int32_t *tmp = (int32_t *)(a.base + align_up(4 * nvox));
-        const int row_words = (uc + 63) / 64;
-        const int64_t n_seg = (int64_t)((row_words + 3) / 4) * ur * us;
-        hipLaunchKernelGGL(k_labels_signed, dim3(grid_for(n_seg * 64, 256, 8192)), dim3(256), 0, ctx->stream, bl->job, bl->td, tmp);
+        launch_labels(ctx, bl->job, bl->td, tmp);
         signed_vol = tmp;
     }
     hipLaunchKernelGGL(k_labels_decode, dim3(grid_for(nvox, 256, 4096)), dim3(256), 0, ctx->stream, signed_vol, nvox, bl->sign, decoded);

@@ -55,6 +55,9 @@ struct Job {
     uint32_t *comp_of_run;
     int32_t *label_of_comp;   // final signed label of every component (whole-map jobs)
     uint8_t *tile_mode;       // per tile: 0 = united in LDS, 1 = unit tile
+    uint32_t *tile_runs;      // per tile: number of word-runs (ids tile * runs_per_tile ...)
+    double2 *run_sums;        // whole-map tiles: per run slot (sum rho, sum rho*(c - c_tile)), RCAP per tile
+    unsigned long long *stamps;   // diagnostic builds (-DPDBEDA_STAMPS): 8 s_memtime stamps per tile
     uint2 *edges;             // cross-tile run pairs parked by k_tile_edges (ESHARDS equal regions)
     uint32_t *edge_fill;      // pairs written per region
     int64_t edge_cap;
@@ -495,8 +498,7 @@ __global__ void __launch_bounds__(256) k_voxel_lists(Job job, const int64_t *__r
         const int64_t rem = w - vd.word_base;
         const int wq = (int)(rem % vd.row_words);
         const int64_t row = rem / vd.row_words;
-        const int st = run_start_of(m, lane);
-        const uint32_t run = job.run_base[w] + (uint32_t)popc64(run_starts(m) & bits_below(st));
+        const uint32_t run = job.run_base[w] + run_ordinal(run_starts(m), lane);
         const uint32_t comp = job.comp_of_run ? job.comp_of_run[run] : run;
         const uint32_t root = (uint32_t)job.parent[comp];
         const uint32_t rank = job.r_rank[root];

@@ -19,12 +19,16 @@
 namespace pdbeda {
 
 constexpr int TILE_R = 8, TILE_S = 8;
-constexpr int PCAP = 736;         // run slots per sign and tile handled in LDS (runs are tracked per ROW: a run crossing words is one run)
+constexpr int PCAP = 704;         // run slots per sign and tile handled in LDS (runs are tracked per ROW: a run crossing words is one run)
 constexpr int RCAP = 2 * PCAP;    // sign 0 uses slots [0, PCAP), sign 1 [PCAP, 2 PCAP); a wave reserves a 16-word chunk with one LDS atomic
 constexpr int CCAP = 256;   // tile-local components (both signs together) handled in LDS
 constexpr int VCAP = 3584;  // significant values per tile parked in LDS during phase A (aliases the 14 KiB scratch)
-constexpr int EQ = 12;      // touching run pairs one (row, neighbour row) task parks per batch (kept in registers)
+constexpr int VREG = 768;   // of the VCAP parked values: a private region per wave (no atomics) ...
+constexpr int VPOOL = VCAP - 4 * VREG;   // ... and a shared pool a wave spills into with one LDS atomic (rare)
+constexpr int EQ = 11;      // touching run pairs one (row, neighbour row) task parks per batch: EQ * 256 * 4 B + the 16-bit
+                            // proposal table (RCAP * 2 B) share the 14 KiB scratch during phase B
 
+constexpr int EDGE_Q = 8;    // cross-tile pairs one word stages in LDS (single enumeration pass)
 constexpr int ESHARDS = 64;  // cross-tile pair buffers (one allocation counter each: a single counter serialises at ~88 atomics/us)
 
 struct TileDims {
@@ -110,6 +114,12 @@ __device__ inline void mark_comps_unused(const Job &job, uint32_t cb, uint32_t f
     }
 }
 
+#ifdef PDBEDA_STAMPS
+#define STAMP(k) do { if (threadIdx.x == 0) job.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 template <int CW>
 __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td) {
     constexpr int NU = 64 * CW;   // (row, word) units of the tile = threads that own a word
@@ -117,28 +127,32 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
     constexpr int CHU = (CW == 3) ? 12 : 16;  // units per chunk: whole rows, so a row's run slots are contiguous
     __shared__ uint64_t s_mask[2][256];
     __shared__ uint16_t s_first[2][256];  // LDS slot of the word's first run (may continue from the previous word)
-    __shared__ uint16_t s_next[2][256];   // LDS slot of the word's second run (the others follow)
+    // (the word's second run has slot (first & 0x7fff) + 1, the others follow)
     __shared__ uint16_t s_gword[256];     // ordinal of the word's first word-run among the wave's word-runs
     __shared__ uint16_t s_rowfirst[2][64];
     __shared__ uint16_t s_rowcnt[2][64];
-    __shared__ double s_run_rho[RCAP];    // per row-run: sum(rho), sum(rho * (c - c_tile))
-    __shared__ double s_run_rhoc[RCAP];
-    __shared__ uint32_t s_parent[RCAP];
+    // per row-run sums sum(rho), sum(rho * (c - c_tile)) live in HBM/L2 (job.run_sums, 2 doubles per slot of this
+    // tile): written in A3 and read back in C2 by the SAME thread, so they cost no LDS (occupancy) and no atomics
+    double2 *g_run = job.run_sums + (size_t)blockIdx.x * RCAP;
+    __shared__ uint16_t s_parent[RCAP];   // hook-and-jump parents (plain stores only, so 16 bits suffice)
     __shared__ uint16_t s_rse16[RCAP];    // bytes: run start / end position inside the tile row (0..255); later: component index
     uint8_t *s_rs = reinterpret_cast<uint8_t *>(s_rse16), *s_re = s_rs + RCAP;
+    __shared__ uint8_t s_rowof[RCAP];     // tile row (0..63) of every run slot
     // 14 KiB scratch: per-thread edge buffers in phase B, per-component accumulators in phase C
     __shared__ double s_scratch[(4 * CCAP * 8 + 6 * CCAP * 4) / 8];
     double *s_rho = s_scratch, *s_rho_c = s_scratch + CCAP, *s_rho_r = s_scratch + 2 * CCAP, *s_rho_s = s_scratch + 3 * CCAP;
     uint32_t *s_n = reinterpret_cast<uint32_t *>(s_scratch + 4 * CCAP), *s_c = s_n + CCAP, *s_r = s_n + 2 * CCAP, *s_s = s_n + 3 * CCAP,
              *s_key = s_n + 4 * CCAP, *s_cplane = s_n + 5 * CCAP;
     uint32_t *s_edges = reinterpret_cast<uint32_t *>(s_scratch);
+    uint16_t *s_cand = reinterpret_cast<uint16_t *>(s_edges + EQ * 256);   // phase B: hook proposals (0xffff = none)
+    static_assert(EQ * 256 * 4 + RCAP * 2 <= (4 * CCAP * 8 + 6 * CCAP * 4), "phase-B tables must fit the scratch");
     uint16_t *s_compidx = s_rse16;        // reused after phase B
     float *s_val = reinterpret_cast<float *>(s_scratch);  // phase A: significant values, compacted per word (4 wave regions)
     __shared__ uint16_t s_vbase[256];
     __shared__ uint32_t s_alloc[2];       // slots handed out per sign
     __shared__ uint32_t s_wsx[4], s_wsy[4];
     __shared__ uint32_t s_gcnt[4];        // word-runs per wave
-    __shared__ uint32_t s_over, s_changed, s_more, s_ncomp, s_runbase, s_compbase;
+    __shared__ uint32_t s_over, s_changed, s_more, s_ncomp, s_runbase, s_compbase, s_vpool;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int uc = gp->unique_ncrs[0], ur = gp->unique_ncrs[1], us = gp->unique_ncrs[2];
@@ -151,20 +165,21 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
     const int row_words = (uc + 63) >> 6;
     const int n_planes = td.n_planes;
 
-    if (tid == 0) { s_over = 0; s_ncomp = 0; s_alloc[0] = 0; s_alloc[1] = 0; }
+    STAMP(0);
+    if (tid == 0) { s_over = 0; s_ncomp = 0; s_alloc[0] = 0; s_alloc[1] = 0; s_vpool = 0; }
     {   // every tile clears its slice of the first-key bitmap (saves a memset launch; it is painted two kernels later)
         const int64_t per = (job.key_words + gridDim.x - 1) / gridDim.x;
         const int64_t lo = per * blockIdx.x, hi = lo + per < job.key_words ? lo + per : job.key_words;
         for (int64_t i = lo + tid; i < hi; i += 256) job.key_bits[i] = 0ull;
     }
-    for (int i = tid; i < RCAP; i += 256) { s_run_rho[i] = 0.0; s_run_rhoc[i] = 0.0; s_parent[i] = i; }
+    for (int i = tid; i < RCAP; i += 256) s_parent[i] = (uint16_t)i;
     __syncthreads();
 
     // ---- A1: stream the tile once from HBM: compare, ballot, store the masks; the significant
     //      values of every word are compacted into LDS (lane order) with one conflict-free write.
     {
         uint32_t vcnt = 0;  // wave-uniform: values parked so far in this wave's region
-        const uint32_t vreg = wv * (VCAP / 4);
+        const uint32_t vreg = wv * VREG;
         for (int chunk = 0; chunk < UPW / CHU; ++chunk) {
             float v[CHU];
 #pragma unroll
@@ -186,15 +201,23 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
                 const uint64_t b0 = __ballot(hit0);
                 const uint64_t b1 = (n_planes > 1) ? __ballot(hit1) : 0ull;
                 const uint64_t bb = b0 | b1;
-                if (lane == 0) { s_mask[0][u] = b0; s_mask[1][u] = b1; s_vbase[u] = (uint16_t)(vreg + vcnt); }
-                const uint32_t at = vcnt + mbcnt_lt(bb);
-                if ((hit0 || hit1) && at < (uint32_t)(VCAP / 4)) s_val[vreg + at] = x;
-                vcnt += (uint32_t)popc64(bb);
+                const uint32_t nv = (uint32_t)popc64(bb);
+                uint32_t base = vreg + vcnt;
+                if (vcnt + nv <= (uint32_t)VREG) {   // wave-uniform: the common case costs no LDS round trip
+                    vcnt += nv;
+                } else {
+                    uint32_t got = 0;
+                    if (lane == 0) got = atomicAdd(&s_vpool, nv);
+                    base = 4 * VREG + (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+                    if (base + nv > (uint32_t)VCAP) { base = 0; if (lane == 0) s_over = 1; }   // tile too dense for LDS -> unit tile
+                }
+                if (lane == 0) { s_mask[0][u] = b0; s_mask[1][u] = b1; s_vbase[u] = (uint16_t)base; }
+                if (hit0 || hit1) s_val[base + mbcnt_lt(bb)] = x;
             }
         }
-        if (vcnt > (uint32_t)(VCAP / 4) && lane == 0) s_over = 1;
     }
     __syncthreads();
+    STAMP(1);
 #if defined(PDBEDA_STOP_AFTER) && PDBEDA_STOP_AFTER == 11
     if (s_over == 0xffffffffu) return;
     if (true) return;
@@ -230,9 +253,7 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
         const uint32_t first1 = PCAP + (k1 ? e1 - 1u : e1), next1 = PCAP + (k1 ? e1 : e1 + 1u);
         if (tid < NU) {
             s_first[0][tid] = (uint16_t)(first0 | (k0 ? 0x8000u : 0u));
-            s_next[0][tid] = (uint16_t)next0;
             s_first[1][tid] = (uint16_t)(first1 | (k1 ? 0x8000u : 0u));
-            s_next[1][tid] = (uint16_t)next1;
             s_gword[tid] = (uint16_t)ey;
             if (wl == 0) { s_rowfirst[0][tid / CW] = (uint16_t)e0; s_rowfirst[1][tid / CW] = (uint16_t)(PCAP + e1); }
         }
@@ -242,38 +263,44 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
             s_gcnt[0] = s_wsy[0] + s_wsy[1] + s_wsy[2] + s_wsy[3];
             if (over_slots) s_over = 1;
         }
-        // ---- A3 (same thread per word): exact fp64 sums of each of my runs from the parked values.
-        // Full lanes (95 % of the words of a +-1.5 sigma map are significant), sequential and
-        // deterministic inside a word; a run continuing across words is folded with an LDS atomic.
+        // ---- A3 (same thread per word): exact fp64 sums of each run that STARTS in my word, from the parked
+        // values; a run that continues into the following word(s) of the row is followed by its owner, so every
+        // run has one writer: no atomics, sequential and deterministic.  Full lanes (95 % of the words of a
+        // +-1.5 sigma map are significant).
         if (tid < NU && (a0 | a1) && !over_slots && s_over == 0) {
-            const uint64_t bb = a0 | a1;
-            const uint32_t vb = s_vbase[tid];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const uint64_t m = q ? a1 : a0;
                 if (!m) continue;
                 const bool kq = q ? k1 : k0;
                 const uint32_t fr = q ? first1 : first0, nx = q ? next1 : next0;
-                const bool next_cont = (wl < CW - 1) && (m >> 63) && (s_mask[q][tid + 1] & 1ull);
                 uint64_t todo = run_starts(m);
                 uint32_t k = 0;
                 while (todo) {
                     const int a = ctz64(todo);
                     todo &= todo - 1;
-                    const int e = run_end_of(m, a);
                     const uint32_t slot = k == 0 ? fr : nx + k - 1u;
                     ++k;
-                    const uint32_t off = vb + (uint32_t)popc64(bb & bits_below(a));
+                    if (a == 0 && kq) continue;   // continues a run of the previous word: its owner handles it
                     double sum = 0.0, sumc = 0.0;
-                    for (int i = 0; i <= e - a; ++i) {
-                        const double val = (double)s_val[off + i];
-                        sum += val;
-                        sumc += val * (double)(wl * 64 + a + i);
+                    int cur = tid, ca = a, wlc = wl, last_end = 0;
+                    while (true) {   // the piece in word `cur` starts at bit ca
+                        const uint64_t mc = s_mask[q][cur];
+                        const uint64_t bbc = s_mask[0][cur] | s_mask[1][cur];
+                        const int e = run_end_of(mc, ca);
+                        const uint32_t off = s_vbase[cur] + (uint32_t)popc64(bbc & bits_below(ca));
+                        for (int i = 0; i <= e - ca; ++i) {
+                            const double val = (double)s_val[off + i];
+                            sum += val;
+                            sumc += val * (double)(wlc * 64 + ca + i);
+                        }
+                        last_end = wlc * 64 + e;
+                        if (e == 63 && wlc < CW - 1 && (s_mask[q][cur + 1] & 1ull)) { ++cur; ++wlc; ca = 0; } else break;
                     }
-                    unsafeAtomicAdd(&s_run_rho[slot], sum);
-                    unsafeAtomicAdd(&s_run_rhoc[slot], sumc);
-                    if (!(a == 0 && kq)) s_rs[slot] = (uint8_t)(wl * 64 + a);
-                    if (!(e == 63 && next_cont)) s_re[slot] = (uint8_t)(wl * 64 + e);
+                    g_run[slot] = make_double2(sum, sumc);
+                    s_rs[slot] = (uint8_t)(wl * 64 + a);
+                    s_re[slot] = (uint8_t)last_end;
+                    s_rowof[slot] = (uint8_t)(tid / CW);
                 }
             }
         }
@@ -286,6 +313,7 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
     }
     __syncthreads();
 
+    STAMP(2);
 #if defined(PDBEDA_STOP_AFTER) && PDBEDA_STOP_AFTER == 1
     if (s_over != 0xffffffffu) return;
 #endif
@@ -321,92 +349,107 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
     // B2: hook (fire-and-forget atomic min on the larger parent) and jump (pointer jumping) rounds
     //     until no pair disagrees -- no returning atomic, no divergent retry loop.
     {
-        // task of this thread: row (tid >> 2) against its earlier neighbour row number (tid & 3),
-        // for both signs (their slots never mix, so one set of rounds serves both)
-        uint32_t ia[2] = {0, 0}, ib[2] = {0, 0}, ea[2] = {0, 0}, eb[2] = {0, 0};
-        int sa[2] = {0, 0}, fa[2] = {0, 0}, sb[2] = {0, 0}, fb[2] = {0, 0};
-        bool done[2] = {true, true};
-        {
-            const int rowl = tid >> 2, nb = tid & 3;
-            const int rl = rowl & 7, sl = rowl >> 3;
-            const int dr = nb == 2 ? 0 : (nb == 3 ? 1 : -1);
-            const int ds = nb == 0 ? 0 : -1;
-            const int r2 = rl + dr, s2 = sl + ds;
-            if (r2 >= 0 && r2 < TILE_R && s2 >= 0) {
-                const int rowb = s2 * TILE_R + r2;
+        // B1 tasks: (run slot, earlier neighbour row).  A thread owns the slots tid, tid+256, ... (sign-0 slots
+        // first, then sign-1); for each it binary-searches the neighbour row's sorted run list for the first run
+        // that can touch and walks the (1-2) touching runs.  Balanced: no wave waits for one long row.
+        uint32_t ji[6];
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    if (q < n_planes) {
-                        ia[q] = s_rowfirst[q][rowl]; ib[q] = s_rowfirst[q][rowb];
-                        ea[q] = ia[q] + s_rowcnt[q][rowl]; eb[q] = ib[q] + s_rowcnt[q][rowb];
-                        if (ia[q] < ea[q] && ib[q] < eb[q]) {
-                            sa[q] = s_rs[ia[q]]; fa[q] = s_re[ia[q]]; sb[q] = s_rs[ib[q]]; fb[q] = s_re[ib[q]];
-                            done[q] = false;
+        for (int t = 0; t < 6; ++t) {
+            const uint32_t lin = tid + 256u * t;
+            ji[t] = lin < al0 ? lin : (lin - al0 < al1 ? PCAP + (lin - al0) : 0xffffffffu);
+            if (ji[t] != 0xffffffffu) s_cand[ji[t]] = 0xffffu;
+        }
+        int task = 0;            // next (slot index t, neighbour nb) = task / 4, task % 4
+        uint32_t resume_j = 0xffffffffu;
+        while (true) {  // batches of at most EQ parked pairs per thread (almost always one batch)
+            STAMP(8);
+            if (tid == 0) s_more = 0;
+            __syncthreads();
+            STAMP(9);
+            uint32_t n_edges = 0;
+            while (task < 24 && n_edges < EQ) {
+                const uint32_t i = ji[task >> 2 == 0 ? 0 : task >> 2 == 1 ? 1 : task >> 2 == 2 ? 2 : task >> 2 == 3 ? 3 : task >> 2 == 4 ? 4 : 5];
+                if (i == 0xffffffffu) { task = (task | 3) + 1; continue; }
+                const int nb = task & 3;
+                const int q = i >= (uint32_t)PCAP ? 1 : 0;
+                const int rowl = s_rowof[i];
+                const int r2 = (rowl & 7) + (nb == 2 ? 0 : (nb == 3 ? 1 : -1)), s2 = (rowl >> 3) + (nb == 0 ? 0 : -1);
+                if (r2 < 0 || r2 >= TILE_R || s2 < 0) { ++task; resume_j = 0xffffffffu; continue; }
+                const int rowb = s2 * TILE_R + r2;
+                const uint32_t jb = s_rowfirst[q][rowb], je = jb + s_rowcnt[q][rowb];
+                const int a0 = s_rs[i], a1 = s_re[i];
+                uint32_t j = resume_j;
+                if (j == 0xffffffffu) {   // first run of the neighbour row whose end reaches a0 - 1
+                    uint32_t lo = jb, hi = je;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if ((int)s_re[mid] + 1 < a0) lo = mid + 1; else hi = mid;
+                    }
+                    j = lo;
+                }
+                while (j < je && (int)s_rs[j] <= a1 + 1 && n_edges < EQ) {
+                    s_edges[n_edges * 256 + tid] = (i << 16) | j;
+                    ++n_edges;
+                    ++j;
+                }
+                if (j < je && (int)s_rs[j] <= a1 + 1) { resume_j = j; break; }   // buffer full: resume here next batch
+                resume_j = 0xffffffffu;
+                ++task;
+            }
+            if (task < 24) s_more = 1;
+            STAMP(3);
+            uint32_t wmax = n_edges;   // wave maximum of the pair counts
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(wmax, d); wmax = o > wmax ? o : wmax; }
+            wmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wmax);
+            while (true) {
+                if (tid == 0) s_changed = 0;
+                __syncthreads();
+                // hook: a pair whose two roots differ proposes "larger root -> smaller root".  ANY proposal that
+                // reaches the table is good enough (hook-and-jump needs a smaller neighbour, not the smallest), so
+                // a plain racy 16-bit store replaces the same-address atomic that serialised this phase.
+                bool ch = false;
+                for (uint32_t e0 = 0; e0 < wmax; e0 += 4) {   // wave-uniform bound; 4 independent pairs per trip
+                    uint32_t pa[4], pb[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const uint32_t pr = e0 + t < n_edges ? s_edges[(e0 + t) * 256 + tid] : 0u;
+                        pa[t] = s_parent[pr >> 16];
+                        pb[t] = s_parent[pr & 0xffffu];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (pa[t] != pb[t]) {
+                            s_cand[pa[t] > pb[t] ? pa[t] : pb[t]] = (uint16_t)(pa[t] > pb[t] ? pb[t] : pa[t]);
+                            ch = true;
                         }
                     }
                 }
-            }
-        }
-        while (true) {  // batches of at most EQ parked pairs per thread (almost always one batch)
-            if (tid == 0) s_more = 0;
-            __syncthreads();
-            uint32_t edge[EQ];
-            uint32_t n_edges = 0;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                while (!done[q] && n_edges < EQ) {
-                    if (sa[q] <= fb[q] + 1 && sb[q] <= fa[q] + 1) {
-                        const uint32_t pr = (ia[q] << 16) | ib[q];
-#pragma unroll
-                        for (int e = 0; e < EQ; ++e)
-                            if (e == (int)n_edges) edge[e] = pr;
-                        ++n_edges;
-                    }
-                    if (fa[q] < fb[q]) {
-                        if (++ia[q] >= ea[q]) { done[q] = true; break; }
-                        sa[q] = s_rs[ia[q]]; fa[q] = s_re[ia[q]];
-                    } else {
-                        if (++ib[q] >= eb[q]) { done[q] = true; break; }
-                        sb[q] = s_rs[ib[q]]; fb[q] = s_re[ib[q]];
-                    }
-                }
-            }
-            if (!done[0] || !done[1]) s_more = 1;
-            while (true) {
-#ifdef PDBEDA_COUNT_ROUNDS
-                if (tid == 0) atomicAdd(&job.ctr->unit_tiles[1], 1u);
-#endif
-                if (tid == 0) s_changed = 0;
-                __syncthreads();
-                bool ch = false;
-                uint32_t pa[EQ], pb[EQ];
-#pragma unroll
-                for (int e = 0; e < EQ; ++e) {  // independent LDS reads: one latency for all pairs
-                    if (e < (int)n_edges) { pa[e] = s_parent[edge[e] >> 16]; pb[e] = s_parent[edge[e] & 0xffffu]; }
-                }
-#pragma unroll
-                for (int e = 0; e < EQ; ++e) {
-                    if (e < (int)n_edges && pa[e] != pb[e]) {
-                        atomicMin(&s_parent[pa[e] > pb[e] ? pa[e] : pb[e]], pa[e] > pb[e] ? pb[e] : pa[e]);
-                        ch = true;
-                    }
-                }
-                // one pointer-jumping step for every used slot: P[i] = P[P[i]] -- all reads of a thread
-                // are independent (batched), no walk-to-root chains
-                uint32_t ji[6], jx[6], jy[6];
-#pragma unroll
-                for (int t = 0; t < 6; ++t) {
-                    const uint32_t lin = tid + 256u * t;                      // 0 .. 1535: sign-0 slots first, then sign-1 slots
-                    ji[t] = lin < al0 ? lin : (lin - al0 < al1 ? PCAP + (lin - al0) : 0xffffffffu);
-                    jx[t] = ji[t] != 0xffffffffu ? s_parent[ji[t]] : 0u;
-                }
-#pragma unroll
-                for (int t = 0; t < 6; ++t) jy[t] = ji[t] != 0xffffffffu ? s_parent[jx[t]] : 0u;
-#pragma unroll
-                for (int t = 0; t < 6; ++t)
-                    if (ji[t] != 0xffffffffu && jx[t] != jy[t]) { s_parent[ji[t]] = jy[t]; ch = true; }
                 if (ch) s_changed = 1;
                 __syncthreads();
+                // apply: the owner of a slot attaches it (roots only) to its proposal
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    if (ji[t] != 0xffffffffu) {
+                        const uint32_t c = s_cand[ji[t]];
+                        if (c != 0xffffu) {
+                            if (s_parent[ji[t]] == ji[t]) s_parent[ji[t]] = (uint16_t)c;
+                            s_cand[ji[t]] = 0xffffu;
+                        }
+                    }
+                }
+                __syncthreads();
+                // flatten: every used slot points at its root again (chains are as long as the hooks of this round)
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    if (ji[t] != 0xffffffffu) {
+                        uint32_t x = s_parent[ji[t]], y = s_parent[x];
+                        if (x != y) {
+                            while (x != y) { x = y; y = s_parent[x]; }
+                            s_parent[ji[t]] = (uint16_t)x;
+                        }
+                    }
+                }
                 const bool again = s_changed != 0;
                 __syncthreads();
                 if (!again) break;
@@ -416,6 +459,7 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
             if (!more) break;
         }
     }
+    STAMP(4);
 #if defined(PDBEDA_STOP_AFTER) && PDBEDA_STOP_AFTER == 2
     if (s_over != 0xffffffffu) return;
 #endif
@@ -425,6 +469,7 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
         if (slot_used(i) && s_parent[i] == i) s_compidx[i] = (uint16_t)atomicAdd(&s_ncomp, 1u);
     __syncthreads();
     const uint32_t n_comp = s_ncomp;
+    STAMP(5);
 #if defined(PDBEDA_STOP_AFTER) && PDBEDA_STOP_AFTER == 3
     if (s_over != 0xffffffffu) return;
 #endif
@@ -456,7 +501,7 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
         for (int q = 0; q < n_planes; ++q) {
             const uint64_t m = q ? m1 : m0;
             uint64_t todo = run_starts(m);
-            const uint32_t first = s_first[q][tid], next = s_next[q][tid];
+            const uint32_t first = s_first[q][tid], next = (first & 0x7fffu) + 1u;
             uint32_t k = 0;
             while (todo) {
                 const int a = ctz64(todo);
@@ -468,9 +513,10 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
                 job.comp_of_run[g++] = cb + comp;
                 const bool owner = !(a == 0 && my_wl > 0 && (s_mask[q][tid - 1] >> 63));  // piece that starts the row-run
                 if (owner) {
-                    const double rho = s_run_rho[slot];
+                    const double2 rs2 = g_run[slot];
+                    const double rho = rs2.x;
                     unsafeAtomicAdd(&s_rho[comp], rho);
-                    unsafeAtomicAdd(&s_rho_c[comp], (double)ctile * rho + s_run_rhoc[slot]);
+                    unsafeAtomicAdd(&s_rho_c[comp], (double)ctile * rho + rs2.y);
                     unsafeAtomicAdd(&s_rho_r[comp], (double)r * rho);
                     unsafeAtomicAdd(&s_rho_s[comp], (double)s * rho);
                     atomicMin(&s_key[comp], (uint32_t)(((int64_t)(cword + a) * ur + r) * us + s));
@@ -490,6 +536,7 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
     }
     if (tid == 0) job.tile_mode[tile_id] = 0;
     __syncthreads();
+    STAMP(6);
     const int64_t keys_pp = (int64_t)uc * ur * us;
     for (uint32_t i = tid; i < n_comp; i += 256) {
         const uint32_t g = cb + i;
@@ -505,22 +552,24 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
         job.r_key[g] = (unsigned long long)(s_cplane[i] ? keys_pp : 0) + s_key[i];
     }
     mark_comps_unused(job, cb, n_comp, tid);
-    (void)n_wordruns;
+    if (tid == 0) job.tile_runs[blockIdx.x] = n_wordruns;
+    STAMP(7);
 }
 
 // Generic labelling of the tiles k_tile_label could not hold in LDS ("unit tiles"): every run
 // is its own component with its own record (wave prefix sums per word, as k_run_index);
-// k_union_tiles then unites ALL touching pairs of such a tile globally.  Block per tile.
+// the cross-tile kernels then unite ALL touching pairs of such a tile globally.  One workgroup per
+// QUARTER tile (16 rows: 4x the parallelism of the rare slow path); run / component ids come from the
+// global counters, above the per-tile ranges.
 template <int CW>
 __global__ void __launch_bounds__(256) k_unit_tiles(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td) {
-    constexpr int NU = 64 * CW;
-    constexpr int UPW = 16 * CW;
-    __shared__ uint64_t s_m[256];
-    __shared__ uint32_t s_off[256];
-    __shared__ uint32_t s_wsum[4];
+    constexpr int QU = 16 * CW;   // units of a quarter tile
+    __shared__ uint64_t s_m[64];
+    __shared__ uint32_t s_off[64];
     __shared__ uint32_t s_rb, s_cb;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int t = blockIdx.x;
+    int t = blockIdx.x >> 2;
+    const int quarter = blockIdx.x & 3;
     const int ct = t % td.ctiles; t /= td.ctiles;
     const int rt = t % td.rtiles; t /= td.rtiles;
     const int st = t;
@@ -529,42 +578,36 @@ __global__ void __launch_bounds__(256) k_unit_tiles(Job job, const float *__rest
     const Geom &g = *gp;
     const int ur = g.unique_ncrs[1], us = g.unique_ncrs[2];
     const int row_words = (g.unique_ncrs[0] + 63) >> 6;
-    const int my_wl = tid % CW, my_rowl = (tid / CW) & 63;
-    const int my_rl = my_rowl & 7, my_sl = my_rowl >> 3;
-    const bool my_valid = (tid < NU) && (r0 + my_rl < ur) && (s0 + my_sl < us) && (w0 + my_wl < row_words);
     for (int q = 0; q < td.n_planes; ++q) {
         const VolDesc vd = job.vols[q];
+        // thread tid < QU owns unit quarter*QU + tid
+        const int u = quarter * QU + tid;
+        const int my_wl = u % CW, my_rowl = (u / CW) & 63;
+        const int my_rl = my_rowl & 7, my_sl = my_rowl >> 3;
+        const bool my_valid = (tid < QU) && (r0 + my_rl < ur) && (s0 + my_sl < us) && (w0 + my_wl < row_words);
         const int64_t my_word = vd.word_base + ((int64_t)(s0 + my_sl) * ur + (r0 + my_rl)) * row_words + (w0 + my_wl);
         const uint64_t m = my_valid ? job.mask[my_word] : 0ull;
         const uint32_t cnt = (uint32_t)popc64(run_starts(m));
-        uint32_t x = cnt;
+        uint32_t x = (wv == 0) ? cnt : 0u;   // QU <= 64: all owners sit in wave 0
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t y = __shfl_up(x, d);
             if (lane >= d) x += y;
         }
-        if (lane == 63) s_wsum[wv] = x;
-        s_m[tid] = m;
-        __syncthreads();
-        uint32_t pre = 0;
-        for (int k = 0; k < wv; ++k) pre += s_wsum[k];
-        if (tid == 255) {
-            const uint32_t tot = pre + x;
-            s_rb = tot ? atomicAdd(&job.ctr->n_runs, tot) : 0u;
-            s_cb = tot ? atomicAdd(&job.ctr->n_comps, tot) : 0u;
+        if (tid < 64) { s_m[tid] = (tid < QU) ? m : 0ull; s_off[tid] = x - cnt; }
+        if (tid == 63) {
+            s_rb = x ? atomicAdd(&job.ctr->n_runs, x) : 0u;
+            s_cb = x ? atomicAdd(&job.ctr->n_comps, x) : 0u;
         }
         __syncthreads();
-        const uint32_t off = pre + x - cnt;
-        s_off[tid] = off;
-        if (my_valid) job.run_base[my_word] = s_rb + off;
-        __syncthreads();
-        for (int j = 0; j < UPW; ++j) {
-            const int u = wv * UPW + j;
-            const uint64_t mw = s_m[u];
+        if (my_valid) job.run_base[my_word] = s_rb + s_off[tid];
+        for (int j = wv; j < QU; j += 4) {   // a wave per unit: 4 units in flight per workgroup
+            const uint64_t mw = s_m[j];
             if (mw == 0ull) continue;
-            const int wl = u % CW, rowl = u / CW;
+            const int uu = quarter * QU + j;
+            const int wl = uu % CW, rowl = (uu / CW) & 63;
             const int r = r0 + (rowl & 7), s = s0 + (rowl >> 3), c0 = (w0 + wl) * 64;
-            const uint32_t run0 = s_rb + s_off[u], comp0 = s_cb + s_off[u];
+            const uint32_t run0 = s_rb + s_off[j], comp0 = s_cb + s_off[j];
             word_run_records(job, g, dens, vd, mw, lane, c0, r, s, c0, r, s, comp0);
             const uint64_t starts = run_starts(mw);
             if ((starts >> lane) & 1ull) {
@@ -697,8 +740,12 @@ __global__ void __launch_bounds__(256) k_tile_edges(Job job, TileDims td, int al
     uint32_t my_base = 0;
     bool act = false;
     if (m != 0ull) act = load_cross_tile(job, td, w, m, nw, my_base);
+    __shared__ uint2 s_stage[256 * EDGE_Q];   // pairs of the block, EDGE_Q per thread; a thread with more re-enumerates (rare)
     uint32_t n = 0;
-    if (act) cross_tile_pairs(m, my_base, nw, [&](uint32_t, uint32_t) { ++n; });
+    if (act) cross_tile_pairs(m, my_base, nw, [&](uint32_t a, uint32_t b) {
+        if (n < (uint32_t)EDGE_Q) s_stage[n * 256 + tid] = make_uint2(a, b);
+        ++n;
+    });
     uint32_t x = n;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -719,7 +766,11 @@ __global__ void __launch_bounds__(256) k_tile_edges(Job job, TileDims td, int al
     if (!act || n == 0) return;
     if (s_base + tot <= shard_cap) {
         uint2 *dst = job.edges + (size_t)shard * shard_cap;
-        cross_tile_pairs(m, my_base, nw, [&](uint32_t a, uint32_t b) { dst[i++] = make_uint2(a, b); });
+        if (n <= (uint32_t)EDGE_Q) {
+            for (uint32_t e = 0; e < n; ++e) dst[i + e] = s_stage[e * 256 + tid];
+        } else {
+            cross_tile_pairs(m, my_base, nw, [&](uint32_t a, uint32_t b) { dst[i++] = make_uint2(a, b); });
+        }
     } else {
         cross_tile_pairs(m, my_base, nw, [&](uint32_t a, uint32_t b) { uf_unite(job.parent, (int)job.comp_of_run[a], (int)job.comp_of_run[b]); });
     }
@@ -748,16 +799,27 @@ __global__ void __launch_bounds__(256) k_tile_edges_unit(Job job, TileDims td) {
 }
 
 // Thread per parked run pair: map to tile components, global union-find with device-scope atomics.
+// Consecutive pairs of a word mostly name the same two components: a lane whose pair equals its
+// left neighbour's is dropped (wave shuffle), as are pairs already inside one component.
 __global__ void __launch_bounds__(256) k_union_edges(Job job) {
     const uint32_t shard_cap = (uint32_t)(job.edge_cap / ESHARDS);
+    const int lane = lane_id();
     for (int sh = blockIdx.y; sh < ESHARDS; sh += gridDim.y) {
         const uint32_t fill = job.edge_fill[sh];
         const uint32_t n = fill < shard_cap ? fill : shard_cap;
         const uint2 *src = job.edges + (size_t)sh * shard_cap;
-        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-            const uint2 e = src[i];
-            const int a = (int)job.comp_of_run[e.x], b = (int)job.comp_of_run[e.y];
-            if (a != b) uf_unite(job.parent, a, b);
+        const uint32_t stride = gridDim.x * blockDim.x;
+        for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n; i0 += stride) {   // block-uniform trip count: shuffles are safe
+            const uint32_t i = i0 + threadIdx.x;
+            int a = -1, b = -1;
+            if (i < n) {
+                const uint2 e = src[i];
+                a = (int)job.comp_of_run[e.x];
+                b = (int)job.comp_of_run[e.y];
+            }
+            const int pa = __shfl_up(a, 1), pb = __shfl_up(b, 1);
+            const bool dup = lane > 0 && pa == a && pb == b;
+            if (i < n && a != b && !dup) uf_unite(job.parent, a, b);
         }
     }
 }
@@ -809,6 +871,90 @@ __global__ void __launch_bounds__(256) k_labels_signed(Job job, TileDims td, int
                 for (int q = 0; q < 4; ++q)
                     if (c + q < uc) dst[q] = out[q];
             }
+        }
+    }
+}
+
+// Signed labels, one workgroup per tile, all look-ups in LDS: the tile's label-of-component table
+// (<= CCAP ints), its run -> local component table (bytes) and its mask / run-base words; the 64 KiB
+// of labels of a 256 x 8 x 8 tile are then streamed out with 16-B stores (1 KiB per wave and row).
+// Unit tiles / tiles with too many runs take the global look-up path (same result).
+constexpr int LCAP = 4096;  // word-runs of a tile whose run -> component bytes fit the LDS table
+template <int CW>
+__global__ void __launch_bounds__(256) k_labels_tiles(Job job, TileDims td, int32_t *__restrict__ labels) {
+    constexpr int NU = 64 * CW;
+    __shared__ int32_t s_lab[CCAP];
+    __shared__ uint8_t s_comp8[LCAP];
+    __shared__ uint64_t s_m[2][256];
+    __shared__ uint32_t s_rb[2][256];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const VolDesc v0 = job.vols[0];
+    const int uc = v0.dim[0], ur = v0.dim[1], us = v0.dim[2], row_words = v0.row_words;
+    int t = blockIdx.x;
+    const int ct = t % td.ctiles; t /= td.ctiles;
+    const int rt = t % td.rtiles; t /= td.rtiles;
+    const int st = t;
+    const int w0 = ct * CW, r0 = rt * TILE_R, s0 = st * TILE_S;
+    const int64_t plane_words = (int64_t)row_words * ur * us;
+    const uint32_t rb = (uint32_t)blockIdx.x * (uint32_t)(NU * 32), cb = (uint32_t)blockIdx.x * CCAP;
+    const bool unit = job.tile_mode[tile_index(td, 0, w0, r0, s0)] != 0;
+    const uint32_t n_runs = unit ? 0u : job.tile_runs[blockIdx.x];
+    const bool fast = !unit && n_runs <= (uint32_t)LCAP;   // block-uniform
+    {
+        const int wl = tid % CW, rowl = (tid / CW) & 63;
+        const int r = r0 + (rowl & 7), s = s0 + (rowl >> 3);
+        const bool valid = tid < NU && r < ur && s < us && w0 + wl < row_words;
+        const int64_t w = ((int64_t)s * ur + r) * row_words + (w0 + wl);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const bool has = valid && p < td.n_planes;
+            s_m[p][tid] = has ? job.mask[w + p * plane_words] : 0ull;
+            s_rb[p][tid] = has ? job.run_base[w + p * plane_words] : 0u;
+        }
+        if (fast) {
+            if (tid < CCAP) s_lab[tid] = job.label_of_comp[cb + tid];
+            for (uint32_t i = tid; i < n_runs; i += 256) s_comp8[i] = (uint8_t)(job.comp_of_run[rb + i] - cb);
+        }
+    }
+    __syncthreads();
+    // wave wv writes rows wv*16 .. wv*16+15 of the tile; a lane owns 4 consecutive voxels of a 256-voxel row
+    for (int rr = 0; rr < 16; ++rr) {
+        const int rowl = wv * 16 + rr;
+        const int r = r0 + (rowl & 7), s = s0 + (rowl >> 3);
+        if (r >= ur || s >= us) continue;   // wave-uniform
+        const int wl = lane >> 4, bit0 = (lane & 15) * 4;
+        const int c = (w0 + wl) * 64 + bit0;
+        if (wl >= CW || c >= uc) continue;
+        const int u = rowl * CW + wl;
+        int32_t out[4] = {0, 0, 0, 0};
+        const int sh = bit0 & 31;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const uint64_t m = s_m[p][u];
+            const uint32_t half = bit0 >= 32 ? (uint32_t)(m >> 32) : (uint32_t)m;   // my 4 voxels live in one 32-bit half
+            const unsigned nib = (half >> sh) & 0xfu;
+            if (!nib) continue;
+            const uint64_t starts = run_starts(m);
+            const uint32_t base = s_rb[p][u];
+            // starts below my nibble (32-bit halves), then the nibble's own starts bit by bit
+            const uint32_t slo = (uint32_t)starts, shi = (uint32_t)(starts >> 32);
+            const uint32_t below = bit0 >= 32 ? (uint32_t)__popc(slo) + (uint32_t)__popc(shi & ((1u << sh) - 1u)) : (uint32_t)__popc(slo & ((1u << sh) - 1u));
+            const unsigned snib = ((bit0 >= 32 ? shi : slo) >> sh) & 0xfu;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if ((nib >> q) & 1u) {
+                    const uint32_t run = base + below + (uint32_t)__popc(snib & ((2u << q) - 1u)) - 1u;
+                    out[q] = fast ? s_lab[s_comp8[run - rb]] : job.label_of_comp[job.comp_of_run[run]];
+                }
+            }
+        }
+        int32_t *dst = labels + ((int64_t)s * ur + r) * uc + c;
+        if (c + 3 < uc && ((uc & 3) == 0)) {
+            *reinterpret_cast<int4 *>(dst) = make_int4(out[0], out[1], out[2], out[3]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (c + q < uc) dst[q] = out[q];
         }
     }
 }

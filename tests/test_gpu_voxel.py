@@ -281,7 +281,9 @@ def test_empty_full_and_degenerate(gpu_ctx):
     assert np.array_equal(bl.stats()["n"], want["n"])
 
 
-@pytest.mark.parametrize("shape,seed,nsd", [((128, 128, 128), 5, 1.5), ((96, 100, 200), 6, 3.0), ((61, 67, 130), 8, 1.0)])
+@pytest.mark.parametrize("shape,seed,nsd", [((128, 128, 128), 5, 1.5), ((96, 100, 200), 6, 3.0), ((61, 67, 130), 8, 1.0),
+                                            ((40, 48, 256), 9, 0.3),     # dense: most tiles overflow LDS -> unit-tile fallback
+                                            ((24, 40, 600), 10, 0.8)])   # rows wider than one tile (c tiles) + dense
 def test_random_maps_vs_oracle(gpu_ctx, shape, seed, nsd):
     """Seeded smooth-noise maps at sizes the reference cannot cluster (O(N^2)) but the oracle can."""
     from oracle import oracle as ora
