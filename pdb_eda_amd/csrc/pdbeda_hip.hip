@@ -39,6 +39,11 @@ struct pdbeda_ctx {
     bool profiling = false;
     struct ProfRec { const char *name; hipEvent_t a, b; };
     std::vector<ProfRec> prof;
+    // test hooks (environment, read once at creation): PDBEDA_DEBUG_POISON=1 fills every arena with 0xFF bytes when it
+    // is handed out (a kernel that trusts recycled memory shows up at once); PDBEDA_DEBUG_EDGE_CAP=n shrinks the
+    // cross-tile pair buffer so the shard-overflow path runs on small inputs.
+    bool debug_poison = false;
+    int64_t debug_edge_cap = 0;
 };
 
 struct ProfScope {
@@ -110,7 +115,15 @@ static int fail(pdbeda_ctx *ctx, int code, const char *fmt, ...) {
 
 static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+static int arena_get_raw(pdbeda_ctx *ctx, size_t bytes, Arena *out);
+
 static int arena_get(pdbeda_ctx *ctx, size_t bytes, Arena *out) {
+    int rc = arena_get_raw(ctx, bytes, out);
+    if (rc == 0 && ctx->debug_poison) HIP_TRY(ctx, hipMemsetAsync(out->base, 0xFF, out->cap, ctx->stream));
+    return rc;
+}
+
+static int arena_get_raw(pdbeda_ctx *ctx, size_t bytes, Arena *out) {
     bytes = align_up(std::max<size_t>(bytes, 256));
     auto it = ctx->pool.lower_bound(bytes);
     if (it != ctx->pool.end() && it->first <= bytes * 2 + (1u << 20)) {
@@ -199,6 +212,8 @@ extern "C" int pdbeda_ctx_create_on_stream(int device_id, void *hip_stream, pdbe
         delete ctx;
         return PDBEDA_ERR_MEMORY;
     }
+    if (const char *v = getenv("PDBEDA_DEBUG_POISON")) ctx->debug_poison = v[0] && v[0] != '0';
+    if (const char *v = getenv("PDBEDA_DEBUG_EDGE_CAP")) ctx->debug_edge_cap = atoll(v);
     *out = ctx;
     return PDBEDA_OK;
 }
@@ -474,7 +489,7 @@ extern "C" int pdbeda_xyz2crs(pdbeda_map *m, const double *xyz, int64_t n, int32
 // Carve a job out of an arena.  max_runs / max_blobs are worst-case bounds (a run needs a
 // gap: <= bits/2 + 1 per word; a blob owns >= one 2x2x2 cell... we simply bound blobs by runs).
 static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, int64_t total_keys, int64_t max_runs,
-                        int64_t max_blobs, size_t extra_labels, int32_t **labels_out, int64_t n_tiles = 0) {
+                        int64_t max_blobs, size_t extra_labels, int32_t **labels_out, int64_t n_tiles = 0, int64_t edge_cap_override = 0) {
     Carver cv(base);
     job.n_vols = n_vols;
     job.total_words = total_words;
@@ -495,7 +510,8 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.tile_runs = n_tiles ? cv.take<uint32_t>(n_tiles) : nullptr;
     job.stamps = n_tiles ? cv.take<unsigned long long>(16 * n_tiles) : nullptr;
     job.run_sums = n_tiles ? cv.take<double2>((size_t)n_tiles * RCAP) : nullptr;
-    job.edge_cap = n_tiles ? (std::max<int64_t>(1 << 16, 2 * total_words) + ESHARDS - 1) / ESHARDS * ESHARDS : 0;
+    job.edge_cap = n_tiles ? (std::max<int64_t>(1 << 18, 2 * total_words) + ESHARDS - 1) / ESHARDS * ESHARDS : 0;
+    if (n_tiles && edge_cap_override > 0) job.edge_cap = (edge_cap_override + ESHARDS - 1) / ESHARDS * ESHARDS;
     job.edges = n_tiles ? cv.take<uint2>(job.edge_cap) : nullptr;
     job.edge_fill = n_tiles ? cv.take<uint32_t>(ESHARDS) : nullptr;
     job.vol_sign[0] = job.vol_sign[1] = 1;
@@ -598,12 +614,12 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
 
     Job job;
     memset(&job, 0, sizeof job);
-    size_t need = job_carve(job, nullptr, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, nullptr, tiles_pp);
+    size_t need = job_carve(job, nullptr, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, nullptr, tiles_pp, ctx->debug_edge_cap);
     Arena arena;
     int rc = arena_get(ctx, need, &arena);
     if (rc) return rc;
     int32_t *labels_dev = nullptr;
-    job_carve(job, arena.base, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, &labels_dev, tiles_pp);
+    job_carve(job, arena.base, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, &labels_dev, tiles_pp, ctx->debug_edge_cap);
     job.vol_sign[0] = td.sign[0];
     job.vol_sign[1] = td.sign[1];
 

@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
             job.run_base[my_word] = 0u;
             if (n_planes > 1) { job.mask[plane_words + my_word] = m1; job.run_base[plane_words + my_word] = 0u; }
         }
-        if (tid == 0) { job.tile_mode[tile_id] = n_slots ? 1 : 0; if (n_slots) atomicAdd(&job.ctr->unit_tiles[0], 1u); }
+        if (tid == 0) { job.tile_mode[tile_id] = n_slots ? 1 : 0; job.tile_runs[blockIdx.x] = 0u; if (n_slots) atomicAdd(&job.ctr->unit_tiles[0], 1u); }
         mark_comps_unused(job, (uint32_t)blockIdx.x * CCAP, 0u, tid);
         return;
     }
@@ -479,7 +479,7 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
             job.run_base[my_word] = 0u;
             if (n_planes > 1) { job.mask[plane_words + my_word] = m1; job.run_base[plane_words + my_word] = 0u; }
         }
-        if (tid == 0) { job.tile_mode[tile_id] = 1; atomicAdd(&job.ctr->unit_tiles[2], 1u); }
+        if (tid == 0) { job.tile_mode[tile_id] = 1; job.tile_runs[blockIdx.x] = 0u; atomicAdd(&job.ctr->unit_tiles[2], 1u); }
         mark_comps_unused(job, (uint32_t)blockIdx.x * CCAP, 0u, tid);
         return;
     }
@@ -764,15 +764,21 @@ __global__ void __launch_bounds__(256) k_tile_edges(Job job, TileDims td, int al
     for (int k = 0; k < wv; ++k) pre += s_wsum[k];
     uint32_t i = s_base + pre + x - n;
     if (!act || n == 0) return;
+    uint2 *dst = job.edges + (size_t)shard * shard_cap;
     if (s_base + tot <= shard_cap) {
-        uint2 *dst = job.edges + (size_t)shard * shard_cap;
         if (n <= (uint32_t)EDGE_Q) {
             for (uint32_t e = 0; e < n; ++e) dst[i + e] = s_stage[e * 256 + tid];
         } else {
             cross_tile_pairs(m, my_base, nw, [&](uint32_t a, uint32_t b) { dst[i++] = make_uint2(a, b); });
         }
     } else {
-        cross_tile_pairs(m, my_base, nw, [&](uint32_t a, uint32_t b) { uf_unite(job.parent, (int)job.comp_of_run[a], (int)job.comp_of_run[b]); });
+        // shard full: the block's range [s_base, s_base + tot) is written up to the capacity (k_union_edges reads
+        // min(fill, capacity) entries, so no slot below it may stay unwritten); the rest is united on the spot
+        cross_tile_pairs(m, my_base, nw, [&](uint32_t a, uint32_t b) {
+            if (i < shard_cap) dst[i] = make_uint2(a, b);
+            else uf_unite(job.parent, (int)job.comp_of_run[a], (int)job.comp_of_run[b]);
+            ++i;
+        });
     }
 }
 

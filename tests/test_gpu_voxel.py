@@ -311,6 +311,39 @@ def test_random_maps_vs_oracle(gpu_ctx, shape, seed, nsd):
         assert np.array_equal(lab[crs[:, 2], crs[:, 1], crs[:, 0]], np.repeat(np.arange(len(st["n"])), st["n"]))
 
 
+def test_recycled_arenas_and_edge_overflow(monkeypatch):
+    """Every device arena poisoned with 0xFF when handed out (a kernel that trusts recycled memory to be zero
+    shows up at once) and a cross-tile pair buffer far too small (shards overflow: their tail is united on the
+    spot) -- same answers, including the dense fallbacks and the grids wider than one tile."""
+    from oracle import oracle as ora
+    from pdb_eda_amd import _native, synthetic
+    monkeypatch.setenv("PDBEDA_DEBUG_POISON", "1")
+    monkeypatch.setenv("PDBEDA_DEBUG_EDGE_CAP", "4096")
+    ctx = _native.Context(0)
+    for shape, seed, nsd in (((24, 40, 600), 10, 0.8), ((40, 48, 256), 9, 1.5), ((17, 23, 70), 3, 1.0), ((24, 40, 600), 11, 2.0)):
+        g = synthetic.smooth_noise(shape, seed, 1.5)
+        dm = _dm(g, ctx)
+        o = ora.Oracle(dm.header, g)
+        cut = dm.meanDensity + nsd * dm.stdDensity
+        for rep in range(2):   # the second pass runs in the arena the first one gave back
+            green, red = dm._map.full_blobs_pm(cut, -cut, labels=True)
+            for bl, c in ((green, cut), (red, -cut)):
+                want = o.full_blobs(c, labels=True)
+                st = bl.stats()
+                assert np.array_equal(st["n"], want["n"])
+                assert np.array_equal(st["firstKey"], want["firstKey"])
+                assert np.allclose(st["totalDensity"], want["totalDensity"], rtol=REL)
+                assert np.array_equal(bl.labels(dm._map.unique_shape), want["labels"])
+            green.free(); red.free()
+        # the grouped (sphere / list) engine on poisoned arenas
+        xyz = np.array([[3.0, 4.0, 5.0], [6.5, 7.25, 3.0]])
+        got = dm._map.sphere_blobs(xyz, np.array([1.5, 2.0]), np.array([0, 1, 2]), cut)
+        st = got.stats()
+        for k in range(2):
+            assert int(st["n"][st["group"] == k].sum()) == len(o.sphere_crs(xyz[k], [1.5, 2.0][k], cut))
+        got.free()
+
+
 def test_full_size_properties(gpu_ctx):
     """BASELINE config 2 size (256^3): size-independent properties + oracle equality."""
     from oracle import oracle as ora
