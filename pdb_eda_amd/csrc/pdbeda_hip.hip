@@ -564,9 +564,12 @@ static pdbeda_bloblist *new_list(pdbeda_ctx *ctx, pdbeda_map *m) {
     return bl;
 }
 
+#ifndef PDBEDA_TILE_NT
+#define PDBEDA_TILE_NT 512   // threads per tile workgroup (256 or 512; see k_tile_label)
+#endif
 template <int CW>
 static void launch_tile_label(pdbeda_ctx *ctx, unsigned n_tiles, const Job &job, const float *dens, const Geom *geom_dev, const TileDims &td) {
-    { PROF(ctx, "k_tile_label"); hipLaunchKernelGGL((k_tile_label<CW>), dim3(n_tiles), dim3(256), 0, ctx->stream, job, dens, geom_dev, td); }
+    { PROF(ctx, "k_tile_label"); hipLaunchKernelGGL((k_tile_label<CW, PDBEDA_TILE_NT>), dim3(n_tiles), dim3(PDBEDA_TILE_NT), 0, ctx->stream, job, dens, geom_dev, td); }
     { PROF(ctx, "k_unit_tiles"); hipLaunchKernelGGL((k_unit_tiles<CW>), dim3(n_tiles * 4), dim3(256), 0, ctx->stream, job, dens, geom_dev, td); }
 }
 

@@ -23,12 +23,16 @@ constexpr int PCAP = 704;         // run slots per sign and tile handled in LDS 
 constexpr int RCAP = 2 * PCAP;    // sign 0 uses slots [0, PCAP), sign 1 [PCAP, 2 PCAP); a wave reserves a 16-word chunk with one LDS atomic
 constexpr int CCAP = 256;   // tile-local components (both signs together) handled in LDS
 constexpr int VCAP = 3584;  // significant values per tile parked in LDS during phase A (aliases the 14 KiB scratch)
-constexpr int VREG = 768;   // of the VCAP parked values: a private region per wave (no atomics) ...
-constexpr int VPOOL = VCAP - 4 * VREG;   // ... and a shared pool a wave spills into with one LDS atomic (rare)
-constexpr int EQ = 11;      // touching run pairs one (row, neighbour row) task parks per batch: EQ * 256 * 4 B + the 16-bit
-                            // proposal table (RCAP * 2 B) share the 14 KiB scratch during phase B
+constexpr int VMAIN = 3072; // of the VCAP parked values: split into one private region per wave (no atomics) ...
+constexpr int VPOOL = VCAP - VMAIN;      // ... and a shared pool a wave spills into with one LDS atomic (rare)
+// touching run pairs a thread parks per batch: EQ * NT * 4 B + the 16-bit proposal table (RCAP * 2 B) share the scratch
+// during phase B (the 512-thread kernel spends 5 KiB more LDS on it: 4 workgroups = 32 waves per CU either way)
+constexpr int tile_eq(int nt) { return nt == 512 ? 8 : 11; }
+constexpr int tile_scratch_bytes(int nt) {
+    return tile_eq(nt) * nt * 4 + RCAP * 2 > 4 * CCAP * 8 + 6 * CCAP * 4 ? tile_eq(nt) * nt * 4 + RCAP * 2 : 4 * CCAP * 8 + 6 * CCAP * 4;
+}
 
-constexpr int EDGE_Q = 8;    // cross-tile pairs one word stages in LDS (single enumeration pass)
+constexpr int EDGE_Q = 16;   // cross-tile pairs one word stages in LDS (single enumeration pass; words of a tile-layer section have 9 neighbour words)
 constexpr int ESHARDS = 64;  // cross-tile pair buffers (one allocation counter each: a single counter serialises at ~88 atomics/us)
 
 struct TileDims {
@@ -106,8 +110,8 @@ __device__ inline double wave_shl1(double x) {
 
 // Tile t owns component ids [t * CCAP, (t+1) * CCAP) and run ids [t * runs_per_tile, ...): no
 // allocation atomics on the fast path.  Unused component ids are marked empty (r_n = 0).
-__device__ inline void mark_comps_unused(const Job &job, uint32_t cb, uint32_t from, int tid) {
-    for (uint32_t i = from + tid; i < (uint32_t)CCAP; i += 256) {
+__device__ inline void mark_comps_unused(const Job &job, uint32_t cb, uint32_t from, int tid, int nt) {
+    for (uint32_t i = from + tid; i < (uint32_t)CCAP; i += nt) {
         job.parent[cb + i] = (int32_t)(cb + i);
         job.r_n[cb + i] = 0u;
         job.r_key[cb + i] = ~0ull;
@@ -120,11 +124,19 @@ __device__ inline void mark_comps_unused(const Job &job, uint32_t cb, uint32_t f
 #define STAMP(k) do { } while (0)
 #endif
 
-template <int CW>
-__global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td) {
+// NT = 512 threads: the same tile with twice the waves -- the kernel is one round of co-resident workgroups (1024
+// tiles at 256^3, 4 per CU), so its duration is the critical path of ONE tile; 8 waves halve the serial word loop of
+// A1, split A3 / C2 by sign (threads 256.. own the "<= cutoff" plane) and halve the pair tasks per thread.
+template <int CW, int NT>
+__global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td) {
+    constexpr int NW = NT / 64;   // waves
     constexpr int NU = 64 * CW;   // (row, word) units of the tile = threads that own a word
-    constexpr int UPW = 16 * CW;  // units per wave (= 16 whole rows)
-    constexpr int CHU = (CW == 3) ? 12 : 16;  // units per chunk: whole rows, so a row's run slots are contiguous
+    constexpr int UPW = NU / NW;  // units per wave (whole rows)
+    constexpr int CHU = UPW < 16 ? UPW : ((CW == 3) ? 12 : 16);  // units per chunk: whole rows
+    constexpr int VREG = VMAIN / NW;
+    constexpr int EQ = tile_eq(NT);
+    constexpr int SLOTS = (RCAP + NT - 1) / NT;   // run slots a thread owns in phase B
+    static_assert(UPW % CHU == 0 && CHU % CW == 0, "chunks are whole rows");
     __shared__ uint64_t s_mask[2][256];
     __shared__ uint16_t s_first[2][256];  // LDS slot of the word's first run (may continue from the previous word)
     // (the word's second run has slot (first & 0x7fff) + 1, the others follow)
@@ -139,22 +151,24 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
     uint8_t *s_rs = reinterpret_cast<uint8_t *>(s_rse16), *s_re = s_rs + RCAP;
     __shared__ uint8_t s_rowof[RCAP];     // tile row (0..63) of every run slot
     // 14 KiB scratch: per-thread edge buffers in phase B, per-component accumulators in phase C
-    __shared__ double s_scratch[(4 * CCAP * 8 + 6 * CCAP * 4) / 8];
+    __shared__ double s_scratch[tile_scratch_bytes(NT) / 8];
     double *s_rho = s_scratch, *s_rho_c = s_scratch + CCAP, *s_rho_r = s_scratch + 2 * CCAP, *s_rho_s = s_scratch + 3 * CCAP;
     uint32_t *s_n = reinterpret_cast<uint32_t *>(s_scratch + 4 * CCAP), *s_c = s_n + CCAP, *s_r = s_n + 2 * CCAP, *s_s = s_n + 3 * CCAP,
              *s_key = s_n + 4 * CCAP, *s_cplane = s_n + 5 * CCAP;
     uint32_t *s_edges = reinterpret_cast<uint32_t *>(s_scratch);
-    uint16_t *s_cand = reinterpret_cast<uint16_t *>(s_edges + EQ * 256);   // phase B: hook proposals (0xffff = none)
-    static_assert(EQ * 256 * 4 + RCAP * 2 <= (4 * CCAP * 8 + 6 * CCAP * 4), "phase-B tables must fit the scratch");
+    uint16_t *s_cand = reinterpret_cast<uint16_t *>(s_edges + EQ * NT);   // phase B: hook proposals (0xffff = none)
+    static_assert(EQ * NT * 4 + RCAP * 2 <= tile_scratch_bytes(NT) && VCAP * 4 <= tile_scratch_bytes(NT), "phase-A/B tables must fit the scratch");
     uint16_t *s_compidx = s_rse16;        // reused after phase B
     float *s_val = reinterpret_cast<float *>(s_scratch);  // phase A: significant values, compacted per word (4 wave regions)
     __shared__ uint16_t s_vbase[256];
     __shared__ uint32_t s_alloc[2];       // slots handed out per sign
-    __shared__ uint32_t s_wsx[4], s_wsy[4];
+    __shared__ uint32_t s_wsx[4], s_wsy[4];   // the word-owning threads are the first 256 (= 4 waves) also when NT = 512
     __shared__ uint32_t s_gcnt[4];        // word-runs per wave
     __shared__ uint32_t s_over, s_changed, s_more, s_ncomp, s_runbase, s_compbase, s_vpool;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wt = tid & 255;     // the word this thread owns in the thread-per-word phases ...
+    const int half = tid >> 8;    // ... and (NT = 512) the sign plane it works on there; threads 256.. mirror 0..255 in A2
     const int uc = gp->unique_ncrs[0], ur = gp->unique_ncrs[1], us = gp->unique_ncrs[2];
     const int nc = gp->ncrs[0], nr = gp->ncrs[1];
     int t = blockIdx.x;
@@ -170,9 +184,9 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
     {   // every tile clears its slice of the first-key bitmap (saves a memset launch; it is painted two kernels later)
         const int64_t per = (job.key_words + gridDim.x - 1) / gridDim.x;
         const int64_t lo = per * blockIdx.x, hi = lo + per < job.key_words ? lo + per : job.key_words;
-        for (int64_t i = lo + tid; i < hi; i += 256) job.key_bits[i] = 0ull;
+        for (int64_t i = lo + tid; i < hi; i += NT) job.key_bits[i] = 0ull;
     }
-    for (int i = tid; i < RCAP; i += 256) s_parent[i] = (uint16_t)i;
+    for (int i = tid; i < RCAP; i += NT) s_parent[i] = (uint16_t)i;
     __syncthreads();
 
     // ---- A1: stream the tile once from HBM: compare, ballot, store the masks; the significant
@@ -208,7 +222,7 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
                 } else {
                     uint32_t got = 0;
                     if (lane == 0) got = atomicAdd(&s_vpool, nv);
-                    base = 4 * VREG + (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+                    base = VMAIN + (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
                     if (base + nv > (uint32_t)VCAP) { base = 0; if (lane == 0) s_over = 1; }   // tile too dense for LDS -> unit tile
                 }
                 if (lane == 0) { s_mask[0][u] = b0; s_mask[1][u] = b1; s_vbase[u] = (uint16_t)base; }
@@ -228,10 +242,10 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
     // slot.  Sign 0 uses slots [0, PCAP), sign 1 [PCAP, 2 PCAP); slots follow word order, so the
     // runs of a row are contiguous and sorted by position.
     {
-        const uint64_t a0 = (tid < NU) ? s_mask[0][tid] : 0ull, a1 = (tid < NU) ? s_mask[1][tid] : 0ull;
-        const int wl = tid % CW;
-        const bool k0 = (tid < NU) && wl > 0 && (a0 & 1ull) && (s_mask[0][tid - 1] >> 63);
-        const bool k1 = (tid < NU) && wl > 0 && (a1 & 1ull) && (s_mask[1][tid - 1] >> 63);
+        const uint64_t a0 = (wt < NU) ? s_mask[0][wt] : 0ull, a1 = (wt < NU) ? s_mask[1][wt] : 0ull;
+        const int wl = wt % CW;
+        const bool k0 = (wt < NU) && wl > 0 && (a0 & 1ull) && (s_mask[0][wt - 1] >> 63);
+        const bool k1 = (wt < NU) && wl > 0 && (a1 & 1ull) && (s_mask[1][wt - 1] >> 63);
         const uint32_t n0 = (uint32_t)popc64(run_starts(a0)), n1 = (uint32_t)popc64(run_starts(a1));
         const uint32_t vx = (n0 - (k0 ? 1u : 0u)) | ((n1 - (k1 ? 1u : 0u)) << 16);  // new slots of sign 0 | sign 1
         const uint32_t vy = n0 + n1;                                                // word-runs
@@ -241,10 +255,10 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
             const uint32_t tx = __shfl_up(x, d), ty = __shfl_up(y, d);
             if (lane >= d) { x += tx; y += ty; }
         }
-        if (lane == 63) { s_wsx[wv] = x; s_wsy[wv] = y; }
+        if (lane == 63) { s_wsx[wv & 3] = x; s_wsy[wv & 3] = y; }   // (mirror waves store the same numbers)
         __syncthreads();
         uint32_t px = 0, py = 0;
-        for (int k = 0; k < wv; ++k) { px += s_wsx[k]; py += s_wsy[k]; }
+        for (int k = 0; k < (wv & 3); ++k) { px += s_wsx[k]; py += s_wsy[k]; }
         const uint32_t ex = px + x - vx, ey = py + y - vy;
         const uint32_t e0 = ex & 0xffffu, e1 = ex >> 16;
         const uint32_t tx = s_wsx[0] + s_wsx[1] + s_wsx[2] + s_wsx[3];
@@ -267,11 +281,11 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
         // values; a run that continues into the following word(s) of the row is followed by its owner, so every
         // run has one writer: no atomics, sequential and deterministic.  Full lanes (95 % of the words of a
         // +-1.5 sigma map are significant).
-        if (tid < NU && (a0 | a1) && !over_slots && s_over == 0) {
+        if (wt < NU && (a0 | a1) && !over_slots && s_over == 0) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const uint64_t m = q ? a1 : a0;
-                if (!m) continue;
+                if (!m || (NT == 512 && q != half)) continue;
                 const bool kq = q ? k1 : k0;
                 const uint32_t fr = q ? first1 : first0, nx = q ? next1 : next0;
                 uint64_t todo = run_starts(m);
@@ -283,7 +297,7 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
                     ++k;
                     if (a == 0 && kq) continue;   // continues a run of the previous word: its owner handles it
                     double sum = 0.0, sumc = 0.0;
-                    int cur = tid, ca = a, wlc = wl, last_end = 0;
+                    int cur = wt, ca = a, wlc = wl, last_end = 0;
                     while (true) {   // the piece in word `cur` starts at bit ca
                         const uint64_t mc = s_mask[q][cur];
                         const uint64_t bbc = s_mask[0][cur] | s_mask[1][cur];
@@ -300,7 +314,7 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
                     g_run[slot] = make_double2(sum, sumc);
                     s_rs[slot] = (uint8_t)(wl * 64 + a);
                     s_re[slot] = (uint8_t)last_end;
-                    s_rowof[slot] = (uint8_t)(tid / CW);
+                    s_rowof[slot] = (uint8_t)(wt / CW);
                 }
             }
         }
@@ -318,7 +332,7 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
     if (s_over != 0xffffffffu) return;
 #endif
     // my word (threads tid < NU own unit tid)
-    const int my_wl = tid % CW, my_rowl = (tid / CW) & 63;
+    const int my_wl = wt % CW, my_rowl = (wt / CW) & 63;
     const int my_rl = my_rowl & 7, my_sl = my_rowl >> 3;
     const bool my_valid = (tid < NU) && (r0 + my_rl < ur) && (s0 + my_sl < us) && (w0 + my_wl < row_words);
     const int64_t my_word = ((int64_t)(s0 + my_sl) * ur + (r0 + my_rl)) * row_words + (w0 + my_wl);  // inside a plane
@@ -327,7 +341,7 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
     const uint32_t al0 = s_alloc[0], al1 = s_alloc[1];
     const uint32_t n_slots = al0 + al1;
     const uint32_t n_wordruns = s_gcnt[0];
-    const uint64_t m0 = (tid < NU) ? s_mask[0][tid] : 0ull, m1 = (tid < NU) ? s_mask[1][tid] : 0ull;
+    const uint64_t m0 = (wt < NU) ? s_mask[0][wt] : 0ull, m1 = (wt < NU) ? s_mask[1][wt] : 0ull;
     auto slot_used = [&](uint32_t sl) -> bool { return sl < (uint32_t)PCAP ? sl < al0 : (sl - PCAP) < al1; };
 
     if (n_slots == 0 || s_over) {
@@ -339,7 +353,7 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
             if (n_planes > 1) { job.mask[plane_words + my_word] = m1; job.run_base[plane_words + my_word] = 0u; }
         }
         if (tid == 0) { job.tile_mode[tile_id] = n_slots ? 1 : 0; job.tile_runs[blockIdx.x] = 0u; if (n_slots) atomicAdd(&job.ctr->unit_tiles[0], 1u); }
-        mark_comps_unused(job, (uint32_t)blockIdx.x * CCAP, 0u, tid);
+        mark_comps_unused(job, (uint32_t)blockIdx.x * CCAP, 0u, tid, NT);
         return;
     }
 
@@ -352,10 +366,10 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
         // B1 tasks: (run slot, earlier neighbour row).  A thread owns the slots tid, tid+256, ... (sign-0 slots
         // first, then sign-1); for each it binary-searches the neighbour row's sorted run list for the first run
         // that can touch and walks the (1-2) touching runs.  Balanced: no wave waits for one long row.
-        uint32_t ji[6];
+        uint32_t ji[SLOTS];
 #pragma unroll
-        for (int t = 0; t < 6; ++t) {
-            const uint32_t lin = tid + 256u * t;
+        for (int t = 0; t < SLOTS; ++t) {
+            const uint32_t lin = tid + (uint32_t)NT * t;
             ji[t] = lin < al0 ? lin : (lin - al0 < al1 ? PCAP + (lin - al0) : 0xffffffffu);
             if (ji[t] != 0xffffffffu) s_cand[ji[t]] = 0xffffu;
         }
@@ -367,8 +381,10 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
             __syncthreads();
             STAMP(9);
             uint32_t n_edges = 0;
-            while (task < 24 && n_edges < EQ) {
-                const uint32_t i = ji[task >> 2 == 0 ? 0 : task >> 2 == 1 ? 1 : task >> 2 == 2 ? 2 : task >> 2 == 3 ? 3 : task >> 2 == 4 ? 4 : 5];
+            while (task < 4 * SLOTS && n_edges < EQ) {
+                uint32_t i = ji[0];
+#pragma unroll
+                for (int t = 1; t < SLOTS; ++t) i = (task >> 2) == t ? ji[t] : i;
                 if (i == 0xffffffffu) { task = (task | 3) + 1; continue; }
                 const int nb = task & 3;
                 const int q = i >= (uint32_t)PCAP ? 1 : 0;
@@ -388,7 +404,7 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
                     j = lo;
                 }
                 while (j < je && (int)s_rs[j] <= a1 + 1 && n_edges < EQ) {
-                    s_edges[n_edges * 256 + tid] = (i << 16) | j;
+                    s_edges[n_edges * NT + tid] = (i << 16) | j;
                     ++n_edges;
                     ++j;
                 }
@@ -396,14 +412,20 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
                 resume_j = 0xffffffffu;
                 ++task;
             }
-            if (task < 24) s_more = 1;
+            if (task < 4 * SLOTS) s_more = 1;
             STAMP(3);
             uint32_t wmax = n_edges;   // wave maximum of the pair counts
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(wmax, d); wmax = o > wmax ? o : wmax; }
             wmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wmax);
+#ifdef PDBEDA_COUNT_ROUNDS
+            if (n_edges) atomicAdd(&job.ctr->unit_tiles[1], n_edges);
+#endif
             while (true) {
                 if (tid == 0) s_changed = 0;
+#ifdef PDBEDA_COUNT_ROUNDS
+                if (tid == 0) atomicAdd(&job.ctr->n_edges, 1u);
+#endif
                 __syncthreads();
                 // hook: a pair whose two roots differ proposes "larger root -> smaller root".  ANY proposal that
                 // reaches the table is good enough (hook-and-jump needs a smaller neighbour, not the smallest), so
@@ -413,7 +435,7 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
                     uint32_t pa[4], pb[4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const uint32_t pr = e0 + t < n_edges ? s_edges[(e0 + t) * 256 + tid] : 0u;
+                        const uint32_t pr = e0 + t < n_edges ? s_edges[(e0 + t) * NT + tid] : 0u;
                         pa[t] = s_parent[pr >> 16];
                         pb[t] = s_parent[pr & 0xffffu];
                     }
@@ -429,7 +451,7 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
                 __syncthreads();
                 // apply: the owner of a slot attaches it (roots only) to its proposal
 #pragma unroll
-                for (int t = 0; t < 6; ++t) {
+                for (int t = 0; t < SLOTS; ++t) {
                     if (ji[t] != 0xffffffffu) {
                         const uint32_t c = s_cand[ji[t]];
                         if (c != 0xffffu) {
@@ -441,7 +463,7 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
                 __syncthreads();
                 // flatten: every used slot points at its root again (chains are as long as the hooks of this round)
 #pragma unroll
-                for (int t = 0; t < 6; ++t) {
+                for (int t = 0; t < SLOTS; ++t) {
                     if (ji[t] != 0xffffffffu) {
                         uint32_t x = s_parent[ji[t]], y = s_parent[x];
                         if (x != y) {
@@ -465,7 +487,7 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
 #endif
     // ---- C1: number the tile-local components (s_rs / s_re are free now: reuse as u16 table) -----
     __syncthreads();
-    for (uint32_t i = tid; i < RCAP; i += 256)
+    for (uint32_t i = tid; i < RCAP; i += NT)
         if (slot_used(i) && s_parent[i] == i) s_compidx[i] = (uint16_t)atomicAdd(&s_ncomp, 1u);
     __syncthreads();
     const uint32_t n_comp = s_ncomp;
@@ -480,28 +502,29 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
             if (n_planes > 1) { job.mask[plane_words + my_word] = m1; job.run_base[plane_words + my_word] = 0u; }
         }
         if (tid == 0) { job.tile_mode[tile_id] = 1; job.tile_runs[blockIdx.x] = 0u; atomicAdd(&job.ctr->unit_tiles[2], 1u); }
-        mark_comps_unused(job, (uint32_t)blockIdx.x * CCAP, 0u, tid);
+        mark_comps_unused(job, (uint32_t)blockIdx.x * CCAP, 0u, tid, NT);
         return;
     }
     if (tid == 0) {
         s_runbase = (uint32_t)blockIdx.x * (uint32_t)(NU * 32);
         s_compbase = (uint32_t)blockIdx.x * CCAP;
     }
-    for (uint32_t i = tid; i < n_comp; i += 256) {
+    for (uint32_t i = tid; i < n_comp; i += NT) {
         s_rho[i] = 0.0; s_rho_c[i] = 0.0; s_rho_r[i] = 0.0; s_rho_s[i] = 0.0;
         s_n[i] = 0u; s_c[i] = 0u; s_r[i] = 0u; s_s[i] = 0u; s_key[i] = 0xffffffffu; s_cplane[i] = 0u;
     }
     __syncthreads();
     // ---- C2 + flush (thread per word): fold run pieces into component sums; publish run -> comp ----
     const uint32_t cb = s_compbase, rb = s_runbase;
-    const uint32_t my_g = rb + ((tid < NU) ? s_gword[tid] : 0u);
-    if (tid < NU && (m0 | m1)) {
+    const uint32_t my_g = rb + ((wt < NU) ? s_gword[wt] : 0u);
+    if (wt < NU && (m0 | m1)) {
         const int r = r0 + my_rl, s = s0 + my_sl, cword = (w0 + my_wl) * 64, ctile = w0 * 64;
-        uint32_t g = my_g;
         for (int q = 0; q < n_planes; ++q) {
+            if (NT == 512 && q != half) continue;
             const uint64_t m = q ? m1 : m0;
+            uint32_t g = my_g + (q ? (uint32_t)popc64(run_starts(m0)) : 0u);
             uint64_t todo = run_starts(m);
-            const uint32_t first = s_first[q][tid], next = (first & 0x7fffu) + 1u;
+            const uint32_t first = s_first[q][wt], next = (first & 0x7fffu) + 1u;
             uint32_t k = 0;
             while (todo) {
                 const int a = ctz64(todo);
@@ -511,7 +534,7 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
                 ++k;
                 const uint32_t comp = s_compidx[s_parent[slot]];
                 job.comp_of_run[g++] = cb + comp;
-                const bool owner = !(a == 0 && my_wl > 0 && (s_mask[q][tid - 1] >> 63));  // piece that starts the row-run
+                const bool owner = !(a == 0 && my_wl > 0 && (s_mask[q][wt - 1] >> 63));  // piece that starts the row-run
                 if (owner) {
                     const double2 rs2 = g_run[slot];
                     const double rho = rs2.x;
@@ -538,7 +561,7 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
     __syncthreads();
     STAMP(6);
     const int64_t keys_pp = (int64_t)uc * ur * us;
-    for (uint32_t i = tid; i < n_comp; i += 256) {
+    for (uint32_t i = tid; i < n_comp; i += NT) {
         const uint32_t g = cb + i;
         job.parent[g] = (int32_t)g;
         job.r_n[g] = s_n[i];
@@ -551,7 +574,7 @@ __global__ void __launch_bounds__(256) k_tile_label(Job job, const float *__rest
         job.r_s[g] = (long long)s_s[i];
         job.r_key[g] = (unsigned long long)(s_cplane[i] ? keys_pp : 0) + s_key[i];
     }
-    mark_comps_unused(job, cb, n_comp, tid);
+    mark_comps_unused(job, cb, n_comp, tid, NT);
     if (tid == 0) job.tile_runs[blockIdx.x] = n_wordruns;
     STAMP(7);
 }
