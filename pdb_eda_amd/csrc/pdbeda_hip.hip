@@ -44,6 +44,7 @@ struct pdbeda_ctx {
     // cross-tile pair buffer so the shard-overflow path runs on small inputs.
     bool debug_poison = false;
     int64_t debug_edge_cap = 0;
+    uint32_t next_epoch = 1;            // whole-map job numbers (Job::epoch)
 };
 
 struct ProfScope {
@@ -506,6 +507,7 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.comps_are_runs = n_tiles ? 0 : 1;
     job.comp_of_run = n_tiles ? cv.take<uint32_t>(max_runs) : nullptr;
     job.label_of_comp = n_tiles ? cv.take<int32_t>(max_runs) : nullptr;
+    job.unit_flag = n_tiles ? cv.take<uint32_t>(1) : nullptr;
     job.tile_mode = n_tiles ? cv.take<uint8_t>(n_tiles) : nullptr;
     job.tile_runs = n_tiles ? cv.take<uint32_t>(n_tiles) : nullptr;
     job.stamps = n_tiles ? cv.take<unsigned long long>(16 * n_tiles) : nullptr;
@@ -568,8 +570,9 @@ static pdbeda_bloblist *new_list(pdbeda_ctx *ctx, pdbeda_map *m) {
 #define PDBEDA_TILE_NT 512   // threads per tile workgroup (256 or 512; see k_tile_label)
 #endif
 template <int CW>
-static void launch_tile_label(pdbeda_ctx *ctx, unsigned n_tiles, const Job &job, const float *dens, const Geom *geom_dev, const TileDims &td) {
-    { PROF(ctx, "k_tile_label"); hipLaunchKernelGGL((k_tile_label<CW, PDBEDA_TILE_NT>), dim3(n_tiles), dim3(PDBEDA_TILE_NT), 0, ctx->stream, job, dens, geom_dev, td); }
+static void launch_tile_label(pdbeda_ctx *ctx, unsigned n_tiles, const Job &job, const float *dens, const Geom *geom_dev, const TileDims &td,
+                              const JobInit &init) {
+    { PROF(ctx, "k_tile_label"); hipLaunchKernelGGL((k_tile_label<CW, PDBEDA_TILE_NT>), dim3(n_tiles), dim3(PDBEDA_TILE_NT), 0, ctx->stream, job, dens, geom_dev, td, init); }
     { PROF(ctx, "k_unit_tiles"); hipLaunchKernelGGL((k_unit_tiles<CW>), dim3(n_tiles * 4), dim3(256), 0, ctx->stream, job, dens, geom_dev, td); }
 }
 
@@ -625,27 +628,28 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
     job_carve(job, arena.base, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, &labels_dev, tiles_pp, ctx->debug_edge_cap);
     job.vol_sign[0] = td.sign[0];
     job.vol_sign[1] = td.sign[1];
+    job.epoch = ctx->next_epoch++;
+    if (ctx->next_epoch == 0xffffffffu) ctx->next_epoch = 1;   // never 0 / the poison pattern
 
-    VolDesc vd[2];
+    JobInit init;
+    memset(&init, 0, sizeof init);
     for (int p = 0; p < n_planes; ++p) {
-        vd[p].dim[0] = uc; vd[p].dim[1] = ur; vd[p].dim[2] = us;
-        vd[p].org[0] = vd[p].org[1] = vd[p].org[2] = 0;
-        vd[p].row_words = row_words;
-        vd[p].group = p;
-        vd[p].word_base = words_pp * p;
-        vd[p].key_base = keys_pp * p;
+        VolDesc &v = init.v[p];
+        v.dim[0] = uc; v.dim[1] = ur; v.dim[2] = us;
+        v.org[0] = v.org[1] = v.org[2] = 0;
+        v.row_words = row_words;
+        v.group = p;
+        v.word_base = words_pp * p;
+        v.key_base = keys_pp * p;
     }
+    init.runs0 = (unsigned)(tiles_pp * td.cw * 64 * 32);
+    init.comps0 = (unsigned)(tiles_pp * CCAP);
     hipStream_t st = ctx->stream;
-    {
-        PROF(ctx, "setup");
-        hipLaunchKernelGGL(k_set_vols, dim3(1), dim3(64), 0, st, job.vols, vd[0], vd[n_planes - 1], n_planes, job.ctr,
-                           (unsigned)(tiles_pp * td.cw * 64 * 32), (unsigned)(tiles_pp * CCAP), job.edge_fill);
-    }
     switch (td.cw) {
-        case 1: launch_tile_label<1>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td); break;
-        case 2: launch_tile_label<2>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td); break;
-        case 3: launch_tile_label<3>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td); break;
-        default: launch_tile_label<4>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td); break;
+        case 1: launch_tile_label<1>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init); break;
+        case 2: launch_tile_label<2>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init); break;
+        case 3: launch_tile_label<3>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init); break;
+        default: launch_tile_label<4>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init); break;
     }
     const unsigned comp_grid = grid_for(max_runs, 256, 2048);
     {
@@ -654,8 +658,9 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
         // visits -- that layout is also the general one for c-tiled (wider than 256) grids.  (A unit tile inside a narrow
         // grid is handled by a second, all-rows launch below, gated on the device-side unit-tile counter.)
         const int all_rows = td.ctiles > 1 ? 1 : 0;
-        hipLaunchKernelGGL(k_tile_edges, dim3(grid_for((int64_t)ur * row_words, 256, 1ll << 30), us, n_planes), dim3(256), 0, st, job, td, all_rows);
-        if (!all_rows) hipLaunchKernelGGL(k_tile_edges_unit, dim3(grid_for((int64_t)ur * row_words, 256, 1ll << 30), us, n_planes), dim3(256), 0, st, job, td);
+        const unsigned gx = grid_for((int64_t)ur * row_words, 256, 1ll << 30);
+        hipLaunchKernelGGL(k_tile_edges, dim3(gx, us, n_planes), dim3(256), 0, st, job, td, all_rows);
+        if (!all_rows) hipLaunchKernelGGL(k_tile_edges_unit, dim3(gx, us, n_planes), dim3(256), 0, st, job, td);
     }
     { PROF(ctx, "k_union_edges"); hipLaunchKernelGGL(k_union_edges, dim3(32, ESHARDS), dim3(256), 0, st, job); }
     { PROF(ctx, "k_resolve"); hipLaunchKernelGGL(k_resolve, dim3(comp_grid), dim3(256), 0, st, job); }
@@ -758,7 +763,14 @@ extern "C" int pdbeda_bloblist_counters(pdbeda_bloblist *bl, int64_t *out) {
     HIP_TRY(ctx, hipMemcpyAsync(&c, bl->job.ctr, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     out[0] = c.n_runs; out[1] = c.n_comps; out[2] = c.n_edges; out[3] = c.n_blobs;
-    out[4] = c.unit_tiles[0]; out[5] = c.unit_tiles[1]; out[6] = c.unit_tiles[2]; out[7] = 0;
+    out[4] = out[5] = out[6] = out[7] = 0;
+    if (bl->whole_map && bl->job.tile_mode) {   // unit tiles by cause: tile_mode 1 = run slots / values, 3 = component table
+        const int64_t n_tiles = (int64_t)bl->td.ctiles * bl->td.rtiles * bl->td.stiles;
+        std::vector<uint8_t> mode(n_tiles);
+        HIP_TRY(ctx, hipMemcpyAsync(mode.data(), bl->job.tile_mode, n_tiles, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint8_t v : mode) { if (v == 1) ++out[4]; else if (v == 3) ++out[6]; }
+    }
     return PDBEDA_OK;
 }
 

@@ -47,20 +47,13 @@ __host__ __device__ inline int64_t tile_index(const TileDims &td, int plane, int
     return (((int64_t)plane * td.stiles + (s >> 3)) * td.rtiles + (r >> 3)) * td.ctiles + wq / td.cw;
 }
 
-// Write up to two volume descriptors passed by value (no host staging buffer, no sync).
-__global__ void k_set_vols(VolDesc *vols, VolDesc v0, VolDesc v1, int n, Counters *ctr, unsigned int runs0, unsigned int comps0,
-                           uint32_t *edge_fill) {
-    if (threadIdx.x < ESHARDS) edge_fill[threadIdx.x] = 0u;
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        vols[0] = v0;
-        if (n > 1) vols[1] = v1;
-        Counters c;
-        memset(&c, 0, sizeof c);
-        c.n_runs = runs0;    // ids below are owned tile by tile; unit tiles allocate above them
-        c.n_comps = comps0;
-        *ctr = c;
-    }
-}
+// What workgroup 0 of k_tile_label publishes for the later kernels of the job (descriptors by value: no host
+// staging buffer, no memset / init launch, no sync): the volume descriptors and the id counters.  Run / component
+// ids below runs0 / comps0 are owned tile by tile; k_unit_tiles allocates above them.
+struct JobInit {
+    VolDesc v[2];
+    unsigned int runs0, comps0;
+};
 
 // Number of blobs whose first key is < key.
 __device__ inline uint32_t rank_below(const Job &job, int64_t key) {
@@ -128,7 +121,8 @@ __device__ inline void mark_comps_unused(const Job &job, uint32_t cb, uint32_t f
 // tiles at 256^3, 4 per CU), so its duration is the critical path of ONE tile; 8 waves halve the serial word loop of
 // A1, split A3 / C2 by sign (threads 256.. own the "<= cutoff" plane) and halve the pair tasks per thread.
 template <int CW, int NT>
-__global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td) {
+__global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td,
+                                                                       JobInit init) {
     constexpr int NW = NT / 64;   // waves
     constexpr int NU = 64 * CW;   // (row, word) units of the tile = threads that own a word
     constexpr int UPW = NU / NW;  // units per wave (whole rows)
@@ -181,6 +175,16 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
 
     STAMP(0);
     if (tid == 0) { s_over = 0; s_ncomp = 0; s_alloc[0] = 0; s_alloc[1] = 0; s_vpool = 0; }
+    if (blockIdx.x == 0 && tid < ESHARDS) job.edge_fill[tid] = 0u;
+    if (blockIdx.x == 0 && tid == 0) {   // read by the kernels that follow; nothing in this kernel touches them
+        job.vols[0] = init.v[0];
+        if (td.n_planes > 1) job.vols[1] = init.v[1];
+        Counters c;
+        memset(&c, 0, sizeof c);
+        c.n_runs = init.runs0;
+        c.n_comps = init.comps0;
+        *job.ctr = c;
+    }
     {   // every tile clears its slice of the first-key bitmap (saves a memset launch; it is painted two kernels later)
         const int64_t per = (job.key_words + gridDim.x - 1) / gridDim.x;
         const int64_t lo = per * blockIdx.x, hi = lo + per < job.key_words ? lo + per : job.key_words;
@@ -352,7 +356,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
             job.run_base[my_word] = 0u;
             if (n_planes > 1) { job.mask[plane_words + my_word] = m1; job.run_base[plane_words + my_word] = 0u; }
         }
-        if (tid == 0) { job.tile_mode[tile_id] = n_slots ? 1 : 0; job.tile_runs[blockIdx.x] = 0u; if (n_slots) atomicAdd(&job.ctr->unit_tiles[0], 1u); }
+        if (tid == 0) { job.tile_mode[tile_id] = n_slots ? 1 : 0; job.tile_runs[blockIdx.x] = 0u; if (n_slots) *job.unit_flag = job.epoch; }   // mode 1: run slots / values overflowed
         mark_comps_unused(job, (uint32_t)blockIdx.x * CCAP, 0u, tid, NT);
         return;
     }
@@ -418,14 +422,8 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(wmax, d); wmax = o > wmax ? o : wmax; }
             wmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wmax);
-#ifdef PDBEDA_COUNT_ROUNDS
-            if (n_edges) atomicAdd(&job.ctr->unit_tiles[1], n_edges);
-#endif
             while (true) {
                 if (tid == 0) s_changed = 0;
-#ifdef PDBEDA_COUNT_ROUNDS
-                if (tid == 0) atomicAdd(&job.ctr->n_edges, 1u);
-#endif
                 __syncthreads();
                 // hook: a pair whose two roots differ proposes "larger root -> smaller root".  ANY proposal that
                 // reaches the table is good enough (hook-and-jump needs a smaller neighbour, not the smallest), so
@@ -501,7 +499,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
             job.run_base[my_word] = 0u;
             if (n_planes > 1) { job.mask[plane_words + my_word] = m1; job.run_base[plane_words + my_word] = 0u; }
         }
-        if (tid == 0) { job.tile_mode[tile_id] = 1; job.tile_runs[blockIdx.x] = 0u; atomicAdd(&job.ctr->unit_tiles[2], 1u); }
+        if (tid == 0) { job.tile_mode[tile_id] = 3; job.tile_runs[blockIdx.x] = 0u; *job.unit_flag = job.epoch; }   // mode 3: component table overflowed
         mark_comps_unused(job, (uint32_t)blockIdx.x * CCAP, 0u, tid, NT);
         return;
     }
@@ -597,6 +595,7 @@ __global__ void __launch_bounds__(256) k_unit_tiles(Job job, const float *__rest
     const int rt = t % td.rtiles; t /= td.rtiles;
     const int st = t;
     const int w0 = ct * CW, r0 = rt * TILE_R, s0 = st * TILE_S;
+    if (*job.unit_flag != job.epoch) return;   // no unit tile in this job
     if (job.tile_mode[tile_index(td, 0, w0, r0, s0)] == 0) return;
     const Geom &g = *gp;
     const int ur = g.unique_ncrs[1], us = g.unique_ncrs[2];
@@ -805,10 +804,10 @@ __global__ void __launch_bounds__(256) k_tile_edges(Job job, TileDims td, int al
     }
 }
 
-// Companion launch for narrow grids: visits every row, but only when some tile fell back to unit
-// mode (device-side counter), and then only does work for words of unit tiles.
+// Companion launch of k_tile_edges for narrow grids: visits every row, but only does work for words of unit tiles
+// (rare), whose interior pairs no tile kernel united; rows the candidate layout already visited are skipped.
 __global__ void __launch_bounds__(256) k_tile_edges_unit(Job job, TileDims td) {
-    if (job.ctr->unit_tiles[0] + job.ctr->unit_tiles[2] == 0) return;
+    if (*job.unit_flag != job.epoch) return;   // no unit tile in this job (uniform: one scalar load)
     const VolDesc v0 = job.vols[0];
     const int sl = blockIdx.y, plane = blockIdx.z, rw = v0.row_words;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -816,7 +815,6 @@ __global__ void __launch_bounds__(256) k_tile_edges_unit(Job job, TileDims td) {
     if (r >= v0.dim[1]) return;
     const int wq = (int)(j % rw);
     if (job.tile_mode[tile_index(td, 0, wq, r, sl)] == 0) return;
-    // rows the candidate layout already visited are skipped here
     if (((sl & 7) == 0 && sl > 0) || (r & 7) == 0 || (r & 7) == 7) return;
     const int64_t w = (int64_t)plane * rw * v0.dim[1] * v0.dim[2] + ((int64_t)sl * v0.dim[1] + r) * rw + wq;
     const uint64_t m = job.mask[w];
