@@ -659,7 +659,8 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
         // grid is handled by a second, all-rows launch below, gated on the device-side unit-tile counter.)
         const int all_rows = td.ctiles > 1 ? 1 : 0;
         const unsigned gx = grid_for((int64_t)ur * row_words, 256, 1ll << 30);
-        hipLaunchKernelGGL(k_tile_edges, dim3(gx, us, n_planes), dim3(256), 0, st, job, td, all_rows);
+        const unsigned gx1 = all_rows ? gx : grid_for((int64_t)((ur + 7) / 8) * 2 * row_words, 256, 1ll << 30);
+        hipLaunchKernelGGL(k_tile_edges, dim3((unsigned)((us + 7) / 8) * (gx + 7 * gx1), 1, n_planes), dim3(256), 0, st, job, td, all_rows);
         if (!all_rows) hipLaunchKernelGGL(k_tile_edges_unit, dim3(gx, us, n_planes), dim3(256), 0, st, job, td);
     }
     { PROF(ctx, "k_union_edges"); hipLaunchKernelGGL(k_union_edges, dim3(32, ESHARDS), dim3(256), 0, st, job); }

@@ -748,12 +748,19 @@ __global__ void __launch_bounds__(256) k_tile_edges(Job job, TileDims td, int al
     __shared__ uint32_t s_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const VolDesc v0 = job.vols[0];
-    const int sl = blockIdx.y, plane = blockIdx.z;
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + tid;   // candidate word inside this section
-    const int rw = v0.row_words;
+    // compact grid (no empty workgroups): per group of 8 sections, nb8 workgroups for the section that starts a tile
+    // layer (all rows) followed by nb1 workgroups for each of the other 7 (candidate rows only); all_rows: nb1 == nb8
+    const int plane = blockIdx.z, rw = v0.row_words;
+    const int nb8 = (int)(((int64_t)v0.dim[1] * rw + 255) / 256);
+    const int nb1 = all_rows ? nb8 : (int)(((int64_t)((v0.dim[1] + 7) / 8) * 2 * rw + 255) / 256);
+    const int grp = (int)blockIdx.x / (nb8 + 7 * nb1), off = (int)blockIdx.x % (nb8 + 7 * nb1);
+    const int sl = grp * 8 + (off < nb8 ? 0 : 1 + (off - nb8) / nb1);
+    const int bx = off < nb8 ? off : (off - nb8) % nb1;
+    if (sl >= v0.dim[2]) return;   // block-uniform
+    const int64_t j = (int64_t)bx * blockDim.x + tid;   // candidate word inside this section
     const int64_t jr = j / rw;
     int r;
-    if (all_rows || ((sl & 7) == 0 && sl > 0)) r = (int)jr;
+    if (all_rows || (sl & 7) == 0) r = (int)jr;
     else r = (int)(jr >> 1) * 8 + ((jr & 1) ? 7 : 0);
     const bool inside = r < v0.dim[1];
     const int64_t w = (int64_t)plane * rw * v0.dim[1] * v0.dim[2] + ((int64_t)sl * v0.dim[1] + (inside ? r : 0)) * rw + (j % rw);
@@ -778,7 +785,7 @@ __global__ void __launch_bounds__(256) k_tile_edges(Job job, TileDims td, int al
     __syncthreads();
     const uint32_t tot = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
     if (tot == 0) return;  // block-uniform
-    const int shard = (blockIdx.x + 7 * blockIdx.y + 3 * blockIdx.z) % ESHARDS;
+    const int shard = (blockIdx.x + 29 * blockIdx.z) % ESHARDS;
     const uint32_t shard_cap = (uint32_t)(job.edge_cap / ESHARDS);
     if (tid == 0) s_base = atomicAdd(&job.edge_fill[shard], tot);
     __syncthreads();
