@@ -232,10 +232,18 @@ __global__ void __launch_bounds__(256) k_run_index(Job job, const float *__restr
 
 // ------------------------------------------------------------------------------------
 // Lock-free union-find on run indices (parent[x] <= x; roots link to the smaller root).
-// atomicMin is authoritative; plain/stale reads in find() only cost a retry.
+// atomicMin is authoritative; stale reads in find() only cost a retry: every value a load can return was the node's
+// parent at some time, i.e. a smaller-or-equal id of the SAME set, so walking it, halving with it (atomic min) and
+// comparing roots stay valid, and a unite only ends on the memory-side return value of its atomic min.  That is why
+// find() may use cached (workgroup-scope) loads: an L2 hit instead of a trip to the memory side on this multi-XCD part
+// (k_union_edges 40 -> 35 us).
 // ------------------------------------------------------------------------------------
 __device__ inline int uf_load(const int32_t *p, int x) {
+#ifndef PDBEDA_UF_AGENT_LOADS
+    return __hip_atomic_load(p + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
     return __hip_atomic_load(p + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 // find with path halving by fire-and-forget atomic min (monotone: never undoes a union)
 __device__ inline int uf_find(int32_t *p, int x) {

@@ -15,6 +15,7 @@
 // falls back to "unit mode" (every run its own component, united globally): slower, same result.
 #pragma once
 #include "pdbeda_kernels.h"
+#include <type_traits>
 
 namespace pdbeda {
 
@@ -25,11 +26,11 @@ constexpr int CCAP = 256;   // tile-local components (both signs together) handl
 constexpr int VCAP = 3584;  // significant values per tile parked in LDS during phase A (aliases the 14 KiB scratch)
 constexpr int VMAIN = 3072; // of the VCAP parked values: split into one private region per wave (no atomics) ...
 constexpr int VPOOL = VCAP - VMAIN;      // ... and a shared pool a wave spills into with one LDS atomic (rare)
-// touching run pairs a thread parks per batch: EQ * NT * 4 B + the 16-bit proposal table (RCAP * 2 B) share the scratch
-// during phase B (the 512-thread kernel spends 5 KiB more LDS on it: 4 workgroups = 32 waves per CU either way)
-constexpr int tile_eq(int nt) { return nt == 512 ? 8 : 11; }
+// touching run pairs a (row, neighbour row) task parks per batch, 16 bits each (both run numbers relative to their
+// rows): EQ * NT * 2 B + the 16-bit proposal table (RCAP * 2 B) share the scratch during phase B
+constexpr int tile_eq(int) { return 16; }
 constexpr int tile_scratch_bytes(int nt) {
-    return tile_eq(nt) * nt * 4 + RCAP * 2 > 4 * CCAP * 8 + 6 * CCAP * 4 ? tile_eq(nt) * nt * 4 + RCAP * 2 : 4 * CCAP * 8 + 6 * CCAP * 4;
+    return tile_eq(nt) * nt * 2 + RCAP * 2 > 4 * CCAP * 8 + 6 * CCAP * 4 ? tile_eq(nt) * nt * 2 + RCAP * 2 : 4 * CCAP * 8 + 6 * CCAP * 4;
 }
 
 constexpr int EDGE_Q = 16;   // cross-tile pairs one word stages in LDS (single enumeration pass; words of a tile-layer section have 9 neighbour words)
@@ -92,6 +93,14 @@ __device__ inline uint32_t mbcnt_lt(uint64_t mask) {
 }
 __device__ inline uint32_t mbcnt_le(uint64_t mask) { return mbcnt_lt(mask >> 1) + (uint32_t)(mask & 1ull); }
 
+// lane `sel` of `old` <- the wave-uniform value `sval` (v_writelane_b32; this clang has no builtin for it).
+// A select on `lane == sel` would do, but its 64-bit masks are loop invariant: hoisted, 16 of them spill the SGPRs.
+// (`sel` must fold to a constant 0..63 -- an inline constant: a second SGPR would break the constant-bus limit.)
+__device__ __forceinline__ uint32_t wave_writelane(uint32_t old, uint32_t sval, int sel) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(__builtin_amdgcn_readfirstlane((int)sval)), "n"(sel));
+    return old;
+}
+
 // lane i <- lane i+1 (lane 63 <- 0): whole-wave DPP shift, no LDS traffic (GFX9 / CDNA wave_shl:1)
 __device__ inline double wave_shl1(double x) {
     union { double d; int i[2]; } u;
@@ -131,6 +140,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
     constexpr int EQ = tile_eq(NT);
     constexpr int SLOTS = (RCAP + NT - 1) / NT;   // run slots a thread owns in phase B
     static_assert(UPW % CHU == 0 && CHU % CW == 0, "chunks are whole rows");
+    static_assert(NT == 512, "phase B maps one (sign, row, neighbour row) merge task to each of 2 x 64 x 4 threads");
     __shared__ uint64_t s_mask[2][256];
     __shared__ uint16_t s_first[2][256];  // LDS slot of the word's first run (may continue from the previous word)
     // (the word's second run has slot (first & 0x7fff) + 1, the others follow)
@@ -149,9 +159,9 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
     double *s_rho = s_scratch, *s_rho_c = s_scratch + CCAP, *s_rho_r = s_scratch + 2 * CCAP, *s_rho_s = s_scratch + 3 * CCAP;
     uint32_t *s_n = reinterpret_cast<uint32_t *>(s_scratch + 4 * CCAP), *s_c = s_n + CCAP, *s_r = s_n + 2 * CCAP, *s_s = s_n + 3 * CCAP,
              *s_key = s_n + 4 * CCAP, *s_cplane = s_n + 5 * CCAP;
-    uint32_t *s_edges = reinterpret_cast<uint32_t *>(s_scratch);
-    uint16_t *s_cand = reinterpret_cast<uint16_t *>(s_edges + EQ * NT);   // phase B: hook proposals (0xffff = none)
-    static_assert(EQ * NT * 4 + RCAP * 2 <= tile_scratch_bytes(NT) && VCAP * 4 <= tile_scratch_bytes(NT), "phase-A/B tables must fit the scratch");
+    uint16_t *s_edges = reinterpret_cast<uint16_t *>(s_scratch);
+    uint16_t *s_cand = s_edges + EQ * NT;   // phase B: hook proposals (0xffff = none)
+    static_assert(EQ * NT * 2 + RCAP * 2 <= tile_scratch_bytes(NT) && VCAP * 4 <= tile_scratch_bytes(NT), "phase-A/B tables must fit the scratch");
     uint16_t *s_compidx = s_rse16;        // reused after phase B
     float *s_val = reinterpret_cast<float *>(s_scratch);  // phase A: significant values, compacted per word (4 wave regions)
     __shared__ uint16_t s_vbase[256];
@@ -195,44 +205,78 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
 
     // ---- A1: stream the tile once from HBM: compare, ballot, store the masks; the significant
     //      values of every word are compacted into LDS (lane order) with one conflict-free write.
+    //      A tile that lies wholly inside the grid (all but the last ones along each axis) takes the
+    //      unguarded path: scalar row bases + immediate offsets, no per-load address arithmetic or
+    //      exec juggling (this phase is scalar-/vector-issue bound next to the HBM stream).
     {
+        const int wvs = __builtin_amdgcn_readfirstlane(wv);
+        const bool interior = (r0 + TILE_R <= ur) && (s0 + TILE_S <= us) && ((w0 + CW) * 64 <= uc);   // block-uniform
         uint32_t vcnt = 0;  // wave-uniform: values parked so far in this wave's region
-        const uint32_t vreg = wv * VREG;
-        for (int chunk = 0; chunk < UPW / CHU; ++chunk) {
-            float v[CHU];
+        const uint32_t vreg = (uint32_t)wvs * VREG;
+        auto stream = [&](auto interior_tag) {
+            constexpr bool INTERIOR = decltype(interior_tag)::value;
+#pragma unroll 1
+            for (int chunk = 0; chunk < UPW / CHU; ++chunk) {
+                const int u0 = wvs * UPW + chunk * CHU;   // first unit of the chunk (scalar; a multiple of CW)
+                const int rowl0 = u0 / CW;                // its CHU / CW rows lie in one section
+                const float *cbase = dens + ((int64_t)(s0 + (rowl0 >> 3)) * nr + (r0 + (rowl0 & 7))) * nc + w0 * 64 + lane;
+                float v[CHU];
 #pragma unroll
-            for (int jj = 0; jj < CHU; ++jj) {
-                const int u = wv * UPW + chunk * CHU + jj;
-                const int wl = u % CW, rowl = u / CW;
-                const int r = r0 + (rowl & 7), s = s0 + (rowl >> 3), c = (w0 + wl) * 64 + lane;
-                const bool in = (r < ur) && (s < us) && (c < uc);
-                v[jj] = in ? dens[((int64_t)s * nr + r) * nc + c] : 0.0f;
-            }
-#pragma unroll
-            for (int jj = 0; jj < CHU; ++jj) {
-                const int u = wv * UPW + chunk * CHU + jj;
-                const int wl = u % CW, rowl = u / CW;
-                const bool in = (r0 + (rowl & 7) < ur) && (s0 + (rowl >> 3) < us) && ((w0 + wl) * 64 + lane < uc);
-                const float x = v[jj];
-                const bool hit0 = in && (td.sign[0] > 0 ? (x >= td.cut[0]) : (x <= td.cut[0]));
-                const bool hit1 = in && (n_planes > 1) && (x <= td.cut[1]);
-                const uint64_t b0 = __ballot(hit0);
-                const uint64_t b1 = (n_planes > 1) ? __ballot(hit1) : 0ull;
-                const uint64_t bb = b0 | b1;
-                const uint32_t nv = (uint32_t)popc64(bb);
-                uint32_t base = vreg + vcnt;
-                if (vcnt + nv <= (uint32_t)VREG) {   // wave-uniform: the common case costs no LDS round trip
-                    vcnt += nv;
-                } else {
-                    uint32_t got = 0;
-                    if (lane == 0) got = atomicAdd(&s_vpool, nv);
-                    base = VMAIN + (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-                    if (base + nv > (uint32_t)VCAP) { base = 0; if (lane == 0) s_over = 1; }   // tile too dense for LDS -> unit tile
+                for (int jj = 0; jj < CHU; ++jj) {
+                    const float *ptr = cbase + (int64_t)(jj / CW) * nc + (jj % CW) * 64;
+                    if (INTERIOR) {
+                        v[jj] = *ptr;
+                    } else {
+                        const int rowl = rowl0 + jj / CW;
+                        const bool in = (r0 + (rowl & 7) < ur) && (s0 + (rowl >> 3) < us) && ((w0 + jj % CW) * 64 + lane < uc);
+                        v[jj] = in ? *ptr : 0.0f;
+                    }
                 }
-                if (lane == 0) { s_mask[0][u] = b0; s_mask[1][u] = b1; s_vbase[u] = (uint16_t)base; }
-                if (hit0 || hit1) s_val[base + mbcnt_lt(bb)] = x;
+                // lane jj of the chunk collects the masks / value base of unit jj (v_writelane from the scalar
+                // ballots); one 16-lane LDS write per array and chunk instead of three lane-0 writes per unit
+                uint32_t k0lo = 0, k0hi = 0, k1lo = 0, k1hi = 0, kvb = 0;
+#pragma unroll
+                for (int jj = 0; jj < CHU; ++jj) {
+                    const int u = u0 + jj;
+                    const int wl = u % CW, rowl = u / CW;
+                    const float x = v[jj];
+                    bool hit0 = td.sign[0] > 0 ? (x >= td.cut[0]) : (x <= td.cut[0]);
+                    bool hit1 = (n_planes > 1) && (x <= td.cut[1]);
+                    if (!INTERIOR) {
+                        const bool in = (r0 + (rowl & 7) < ur) && (s0 + (rowl >> 3) < us) && ((w0 + wl) * 64 + lane < uc);
+                        hit0 = hit0 && in;
+                        hit1 = hit1 && in;
+                    }
+                    const uint64_t b0 = __ballot(hit0);
+                    const uint64_t b1 = (n_planes > 1) ? __ballot(hit1) : 0ull;
+                    const uint64_t bb = b0 | b1;
+                    const uint32_t nv = (uint32_t)popc64(bb);
+                    uint32_t base = vreg + vcnt;
+                    if (vcnt + nv <= (uint32_t)VREG) {   // wave-uniform: the common case costs no LDS round trip
+                        vcnt += nv;
+                    } else {
+                        uint32_t got = 0;
+                        if (lane == 0) got = atomicAdd(&s_vpool, nv);
+                        base = VMAIN + (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+                        if (base + nv > (uint32_t)VCAP) { base = 0; if (lane == 0) s_over = 1; }   // tile too dense for LDS -> unit tile
+                    }
+                    k0lo = wave_writelane(k0lo, (uint32_t)b0, jj);
+                    k0hi = wave_writelane(k0hi, (uint32_t)(b0 >> 32), jj);
+                    if (n_planes > 1) {
+                        k1lo = wave_writelane(k1lo, (uint32_t)b1, jj);
+                        k1hi = wave_writelane(k1hi, (uint32_t)(b1 >> 32), jj);
+                    }
+                    kvb = wave_writelane(kvb, base, jj);
+                    if (hit0 || hit1) s_val[base + mbcnt_lt(bb)] = x;
+                }
+                if (lane < CHU) {
+                    s_mask[0][u0 + lane] = ((uint64_t)k0hi << 32) | k0lo;
+                    s_mask[1][u0 + lane] = ((uint64_t)k1hi << 32) | k1lo;
+                    s_vbase[u0 + lane] = (uint16_t)kvb;
+                }
             }
-        }
+        };
+        if (interior) stream(std::true_type{}); else stream(std::false_type{});
     }
     __syncthreads();
     STAMP(1);
@@ -367,9 +411,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
     // B2: hook (fire-and-forget atomic min on the larger parent) and jump (pointer jumping) rounds
     //     until no pair disagrees -- no returning atomic, no divergent retry loop.
     {
-        // B1 tasks: (run slot, earlier neighbour row).  A thread owns the slots tid, tid+256, ... (sign-0 slots
-        // first, then sign-1); for each it binary-searches the neighbour row's sorted run list for the first run
-        // that can touch and walks the (1-2) touching runs.  Balanced: no wave waits for one long row.
+        // Slot ownership for the apply / flatten passes: a thread owns the slots tid, tid + NT, ... (sign-0 first).
         uint32_t ji[SLOTS];
 #pragma unroll
         for (int t = 0; t < SLOTS; ++t) {
@@ -377,76 +419,96 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
             ji[t] = lin < al0 ? lin : (lin - al0 < al1 ? PCAP + (lin - al0) : 0xffffffffu);
             if (ji[t] != 0xffffffffu) s_cand[ji[t]] = 0xffffu;
         }
-        int task = 0;            // next (slot index t, neighbour nb) = task / 4, task % 4
-        uint32_t resume_j = 0xffffffffu;
+        // B1 task of this thread: (sign q, row A, earlier neighbour row B) -- 2 x 64 x 4 = NT tasks.  The runs of a
+        // row are contiguous slots sorted by position, so the touching pairs of two rows come out of ONE two-pointer
+        // merge of two short byte lists (~6 runs each): no searching, a dozen instructions per step.  A pair is
+        // parked as (run number in A) << 8 | (run number in B): 16 bits.
+        const int tq = tid >> 8, trow = (tid >> 2) & 63, tnb = tid & 3;
+        const int tr2 = (trow & 7) + (tnb == 2 ? 0 : (tnb == 3 ? 1 : -1)), ts2 = (trow >> 3) + (tnb == 0 ? 0 : -1);
+        const bool ttask = tr2 >= 0 && tr2 < TILE_R && ts2 >= 0 && (tq == 0 || n_planes > 1);
+        const int trowb = ttask ? ts2 * TILE_R + tr2 : 0;
+        const uint32_t a_first = s_rowfirst[tq][trow], b_first = s_rowfirst[tq][trowb];
+        const uint32_t na = ttask ? s_rowcnt[tq][trow] : 0u, nb = ttask ? s_rowcnt[tq][trowb] : 0u;
+        uint32_t mi = 0, mj = 0;   // merge state (kept across batches)
+        bool first_batch = true;   // parents are still the identity: B1 itself is the first hook pass
         while (true) {  // batches of at most EQ parked pairs per thread (almost always one batch)
             STAMP(8);
             if (tid == 0) s_more = 0;
             __syncthreads();
             STAMP(9);
             uint32_t n_edges = 0;
-            while (task < 4 * SLOTS && n_edges < EQ) {
-                uint32_t i = ji[0];
-#pragma unroll
-                for (int t = 1; t < SLOTS; ++t) i = (task >> 2) == t ? ji[t] : i;
-                if (i == 0xffffffffu) { task = (task | 3) + 1; continue; }
-                const int nb = task & 3;
-                const int q = i >= (uint32_t)PCAP ? 1 : 0;
-                const int rowl = s_rowof[i];
-                const int r2 = (rowl & 7) + (nb == 2 ? 0 : (nb == 3 ? 1 : -1)), s2 = (rowl >> 3) + (nb == 0 ? 0 : -1);
-                if (r2 < 0 || r2 >= TILE_R || s2 < 0) { ++task; resume_j = 0xffffffffu; continue; }
-                const int rowb = s2 * TILE_R + r2;
-                const uint32_t jb = s_rowfirst[q][rowb], je = jb + s_rowcnt[q][rowb];
-                const int a0 = s_rs[i], a1 = s_re[i];
-                uint32_t j = resume_j;
-                if (j == 0xffffffffu) {   // first run of the neighbour row whose end reaches a0 - 1
-                    uint32_t lo = jb, hi = je;
-                    while (lo < hi) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if ((int)s_re[mid] + 1 < a0) lo = mid + 1; else hi = mid;
+            if (mi < na && mj < nb) {
+                int as = s_rs[a_first + mi], ae = s_re[a_first + mi], bs = s_rs[b_first + mj], be = s_re[b_first + mj];
+                while (true) {
+                    bool adv_a;
+                    if (be + 1 < as) adv_a = false;        // B run entirely before the A run
+                    else if (ae + 1 < bs) adv_a = true;    // A run entirely before the B run
+                    else {                                  // they touch (Chebyshev distance <= 1 along c)
+                        if (n_edges == (uint32_t)EQ) break;           // buffer full: resume here in the next batch
+                        s_edges[n_edges * NT + tid] = (uint16_t)((mi << 8) | mj);
+                        const uint32_t i = a_first + mi, j = b_first + mj;
+                        if (first_batch) s_cand[i > j ? i : j] = (uint16_t)(i > j ? j : i);
+                        ++n_edges;
+                        adv_a = ae < be;                    // the run that ends first cannot touch anything further
                     }
-                    j = lo;
+                    if (adv_a) {
+                        if (++mi == na) break;
+                        as = s_rs[a_first + mi]; ae = s_re[a_first + mi];
+                    } else {
+                        if (++mj == nb) break;
+                        bs = s_rs[b_first + mj]; be = s_re[b_first + mj];
+                    }
                 }
-                while (j < je && (int)s_rs[j] <= a1 + 1 && n_edges < EQ) {
-                    s_edges[n_edges * NT + tid] = (i << 16) | j;
-                    ++n_edges;
-                    ++j;
-                }
-                if (j < je && (int)s_rs[j] <= a1 + 1) { resume_j = j; break; }   // buffer full: resume here next batch
-                resume_j = 0xffffffffu;
-                ++task;
             }
-            if (task < 4 * SLOTS) s_more = 1;
+            if (mi < na && mj < nb) s_more = 1;
             STAMP(3);
             uint32_t wmax = n_edges;   // wave maximum of the pair counts
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(wmax, d); wmax = o > wmax ? o : wmax; }
             wmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wmax);
+            bool hooked = first_batch;   // the proposals of this round are already in the table
+            first_batch = false;
             while (true) {
                 if (tid == 0) s_changed = 0;
                 __syncthreads();
                 // hook: a pair whose two roots differ proposes "larger root -> smaller root".  ANY proposal that
                 // reaches the table is good enough (hook-and-jump needs a smaller neighbour, not the smallest), so
                 // a plain racy 16-bit store replaces the same-address atomic that serialised this phase.
+                // A pair whose ends share a root stays satisfied for ever: it is dropped from the thread's list.
                 bool ch = false;
-                for (uint32_t e0 = 0; e0 < wmax; e0 += 4) {   // wave-uniform bound; 4 independent pairs per trip
-                    uint32_t pa[4], pb[4];
+                if (hooked) {
+                    ch = n_edges != 0;
+                    hooked = false;
+                } else {
+                    uint32_t keep = 0;
+                    for (uint32_t e0 = 0; e0 < wmax; e0 += 4) {   // wave-uniform bound; 4 independent pairs per trip
+                        uint32_t pr[4], pa[4], pb[4];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const uint32_t pr = e0 + t < n_edges ? s_edges[(e0 + t) * NT + tid] : 0u;
-                        pa[t] = s_parent[pr >> 16];
-                        pb[t] = s_parent[pr & 0xffffu];
-                    }
+                        for (int t = 0; t < 4; ++t) {
+                            const bool valid = e0 + t < n_edges;
+                            pr[t] = valid ? s_edges[(e0 + t) * NT + tid] : 0u;
+                            pa[t] = valid ? s_parent[a_first + (pr[t] >> 8)] : 0u;
+                            pb[t] = valid ? s_parent[b_first + (pr[t] & 0xffu)] : 0u;
+                        }
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        if (pa[t] != pb[t]) {
-                            s_cand[pa[t] > pb[t] ? pa[t] : pb[t]] = (uint16_t)(pa[t] > pb[t] ? pb[t] : pa[t]);
-                            ch = true;
+                        for (int t = 0; t < 4; ++t) {
+                            if (pa[t] != pb[t]) {
+                                s_cand[pa[t] > pb[t] ? pa[t] : pb[t]] = (uint16_t)(pa[t] > pb[t] ? pb[t] : pa[t]);
+                                s_edges[keep * NT + tid] = (uint16_t)pr[t];   // keep <= e0 + t: never ahead of the reads
+                                ++keep;
+                            }
                         }
                     }
+                    ch = keep != 0;
+                    n_edges = keep;
+                    wmax = keep;
+#pragma unroll
+                    for (int d = 32; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(wmax, d); wmax = o > wmax ? o : wmax; }
+                    wmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wmax);
                 }
                 if (ch) s_changed = 1;
                 __syncthreads();
+                if (s_changed == 0) break;   // block-uniform: every pair is satisfied (no proposal was made)
                 // apply: the owner of a slot attaches it (roots only) to its proposal
 #pragma unroll
                 for (int t = 0; t < SLOTS; ++t) {
@@ -470,9 +532,8 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
                         }
                     }
                 }
-                const bool again = s_changed != 0;
-                __syncthreads();
-                if (!again) break;
+                // (the barrier at the top of the loop orders these writes before the next round's reads, and the
+                //  s_changed reset after everybody's read above)
             }
             const bool more = s_more != 0;
             __syncthreads();
