@@ -38,6 +38,7 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=3, help="extra leg: entries in flight per GPU, one HIP stream + host thread each (multiple-structure mode); 1 = skip")
     ap.add_argument("--no-labels", action="store_true", help="skip the dense label volume (not the headline configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-analysis", action="store_true", help="skip the informational densityAnalysis leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -52,6 +53,56 @@ def algorithmic_bytes(kernel, n_vox, n_planes):
         "k_union_edges": 0,                                # sparse (pairs << voxels): no per-voxel bytes
     }
     return table.get(kernel)
+
+
+def analysis_leg(ctx, n_res=400, edge=128, reps=5):
+    """Whole per-entry pipeline on a synthetic entry: parse + upload of both maps, aggregateCloud, atom and residue region
+    discrepancies, green/red blob statistics (the record `pdb_eda multiple` keeps per entry)."""
+    import io
+    from pdb_eda_amd import ccp4, synthetic, structure, densityAnalysis as da
+    spec = synthetic.MapSpec(ncrs=(edge, edge, edge), spacing=0.5)
+    header = ccp4.DensityHeader.fromFileHeader(synthetic.ccp4_header_bytes(spec))
+    lo, hi = np.array(header.crs2xyzCoord([6, 6, 6])), np.array(header.crs2xyzCoord([edge - 7] * 3))
+    st = synthetic.chain_structure(n_res, 5, lo, hi, hetero_every=9, zero_occupancy_every=37)
+    params = synthetic.synthetic_params()
+    da.setGlobals(params)
+    dens = synthetic.gaussian_sum_grid(header, st, params["full_atom_name_map_electrons"], sigma=0.55, noise=0.02, seed=5)
+    diff = (synthetic.noise_grid(spec, 105, 1.2) * 0.12).astype(np.float32)
+    files = synthetic.ccp4_bytes(spec, dens), synthetic.ccp4_bytes(spec, diff)
+    rot = [np.hstack([np.eye(3), np.zeros((3, 1))]), np.array([[-1.0, 0, 0, 0.5 * header.xlength], [0, -1.0, 0, 0], [0, 0, 1.0, 0.5 * header.zlength]])]
+    pdbObj = structure.PDBEntry(structure.PDBHeader(pdbid="synth", resolution=2.0, spaceGroup="P_1", rotationMats=rot))
+
+    def once():
+        t = {}
+        t0 = time.perf_counter()
+        densityObj = ccp4.parse(io.BytesIO(files[0]), "synth", ctx=ctx)
+        diffObj = ccp4.parse(io.BytesIO(files[1]), "synth", ctx=ctx)
+        da._attachCutoffs(densityObj, diffObj)
+        an = da.DensityAnalysis("synth", densityObj, diffObj, st, pdbObj)
+        t["parse_upload"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        an.aggregateCloud()
+        t["aggregateCloud"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        an.calculateAtomRegionDiscrepancies(3.5, 3.0, "")
+        an.calculateResidueRegionDiscrepancies(3.5, 3.0, "")
+        t["region_discrepancies"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        an.calculateAtomSpecificBlobStatistics(an.greenBlobList + an.redBlobList)
+        t["blob_statistics"] = time.perf_counter() - t0
+        return an, t
+    once()
+    best = None
+    for _ in range(reps):
+        an, t = once()
+        if best is None or sum(t.values()) < sum(best.values()):
+            best = t
+    total = sum(best.values())
+    return {"workload": "synthetic ~2 A entry: %d^3 grid at 0.5 A, %d atoms (%d with clouds), 2Fo-Fc + Fo-Fc maps parsed from CCP4 bytes" %
+                        (edge, len(list(st.get_atoms())), len(an.atomCloudDescriptions)),
+            "ms": {k: round(1e3 * v, 2) for k, v in best.items()}, "ms_per_entry": 1e3 * total, "entries_per_min": 60.0 / total,
+            "density_electron_ratio": an.densityElectronRatio,
+            "note": "single host thread + one stream; the reference measured in the build container (SURVEY 6): calculateAtomRegionDiscrepancies ~33 ms per ATOM"}
 
 
 def main():
@@ -185,6 +236,26 @@ def main():
     except Exception:
         traffic = None
 
+    # on-box device-to-device copy ceiling (report the roofline against the datasheet peak AND a measured ceiling)
+    src_t = torch.empty(64 << 20, dtype=torch.float32, device="cuda")   # 256 MiB
+    dst_t = torch.empty_like(src_t)
+    dst_t.copy_(src_t)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(10):
+        dst_t.copy_(src_t)
+    ev1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 10 * 2 * src_t.numel() * 4 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9   # read + write bytes
+    del src_t, dst_t
+
+    # densityAnalysis leg (informational): a "~2 A entry" (SURVEY 8d config 3 stand-in) through aggregateCloud + atom / residue
+    # region discrepancies + blob statistics, maps uploaded from host buffers -> entries/min of the whole per-entry pipeline
+    analysis = None
+    if rank == 0 and not args.no_analysis:
+        analysis = analysis_leg(ctx)
+
     # host -> HBM upload of one entry (the boundary hands over a host buffer); never part of `value`
     t1 = time.perf_counter()
     tmp = _native.DeviceMap(ctx, grid, header.geometry())
@@ -212,6 +283,7 @@ def main():
         "blobs": {"green": n_green, "red": n_red, "significant_voxels": sig_vox, "all_ranks": [int(x) for x in totals.tolist()]},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": 1e6 * dom_avg_s,
+                     "d2d_copy_ceiling_GBs": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs,
                      "timing": "HIP events on the launch stream, separate %d-step pass" % args.steps,
                      "pass_8B_per_voxel": {"bytes": 8 * n_vox, "kernel_sum_us": 1e6 * step_kernel_s,
                                            "achieved": 8 * n_vox / step_kernel_s / 1e9, "frac": 8 * n_vox / step_kernel_s / 1e9 / HBM_PEAK_GBS}},
@@ -222,6 +294,8 @@ def main():
     }
     if multi:
         out["multi_stream"] = multi
+    if analysis:
+        out["analysis_entry"] = analysis
 
     # ---- CPU baseline: the oracle (CPU restatement, O(N) clustering) on the same entry, 1 core ----
     if rank == 0 and not args.no_cpu_baseline:
