@@ -177,6 +177,7 @@ class DensityAnalysis(object):
         self._totalAggregatedDensity = None
         self._atomTypeOverlapCompleteness = None
         self._atomTypeOverlapIncompleteness = None
+        self._fc = None
 
     # ---- lazy properties (ref densityAnalysis.py:326-565) ------------------------------------
     def _lazy(name, trigger):
@@ -523,6 +524,127 @@ class DensityAnalysis(object):
             blobStats.append([d, sign, abs(blob.totalDensity / ratio), blob.numVoxels, blob.volume, atom.parent.parent.id, atom.parent.id[1], atom.parent.resname,
                               atom.name, atom.symmetry, atom.coord, blob.centroid])
         return blobStats
+
+    # ---- Fo / Fc maps, RSCC / RSR (ref densityAnalysis.py:426-446, 783-882) -------------------
+    @property
+    def fo(self):
+        """ref densityAnalysis.py:438-446: the Fo map is the 2Fo-Fc map."""
+        return self.densityObj
+
+    @property
+    def fc(self):
+        """ref densityAnalysis.py:426-435: Fc = 2Fo-Fc - 2 (Fo-Fc), as a DensityMatrix.
+
+        Reference behaviour kept on purpose: the reference makes a ``deepcopy`` of the 2Fo-Fc object and replaces only
+        ``.density`` -- ``densityArray`` and the cached ``meanDensity`` / ``stdDensity`` / ``getTotalAbsDensity`` stay those
+        of the Fo map (golden ``fc_mean_std``).  The device copy of the grid is float32 (the reference's is float64):
+        the metrics below therefore take Fc voxel values as ``fo - 2 * diff`` in float64 from the two gathered float32
+        values, which is exact."""
+        if self._fc is None:
+            d = self.densityObj
+            grid = d.density.astype(np.float64) - self.diffDensityObj.density.astype(np.float64) * 2
+            fc = ccp4.DensityMatrix(d.header, d.origin, grid.astype(np.float32), d.pdbid, ctx=d._ctx)
+            fc.densityArray = d.densityArray
+            fc._meanDensity, fc._stdDensity = d.meanDensity, d.stdDensity
+            fc._totalAbsDensity = d._totalAbsDensity
+            self._fc = fc
+        return self._fc
+
+    def medianAbsFoFc(self):
+        """ref densityAnalysis.py:783-801: medians of |Fo| and |Fc| over the voxels of the unique box whose |Fo| and |Fc| are
+        both below mean + 1 sigma.  A whole-map order statistic of a diagnostic call: host numpy, like the reference's tail."""
+        fo, fc = self.fo, self.fc
+        foCut = fo.meanDensity + 1.0 * fo.stdDensity
+        fcCut = fc.meanDensity + 1.0 * fc.stdDensity
+        uc, ur, us = fo.header.uniqueNcrs
+        a = fo.density[:us, :ur, :uc].astype(np.float64)
+        b = a - self.diffDensityObj.density[:us, :ur, :uc].astype(np.float64) * 2
+        keep = (np.abs(a) < foCut) & (np.abs(b) < fcCut)
+        return (np.median(np.abs(a[keep])), np.median(np.abs(b[keep])))
+
+    residueMetricsHeaderList = ['chain', 'residue_number', 'residue_name', "rscc", "rsr", "mean_occupancy", "occupancy_weighted_mean_bfactor"]
+    atomMetricsHeaderList = ['chain', 'residue_number', 'residue_name', "atom_name", "symmetry", "xyz", "rscc", "rsr", "occupancy", "bfactor"]
+
+    def _metricsRadius(self):
+        """ref densityAnalysis.py:813-818 / 850-855."""
+        resolution = self.biopdbObj.header['resolution']
+        radius = 0.7
+        if 0.6 <= resolution <= 3:
+            radius = (resolution - 0.6) / 3 + 0.7
+        elif resolution > 3:
+            radius = resolution * 0.5
+        return radius
+
+    def _rsccRsr(self, groups, radius):
+        """RSCC and RSR of every group of coordinates: ONE sphere batch (all voxels of the sphere union, de-duplicated on the
+        raw crs like the reference's set), two gathers (2Fo-Fc and Fo-Fc values under the wrap contract), then segmented
+        float64 sums.  Pearson r as scipy.stats.pearsonr computes it (centre, normalise, dot, clip)."""
+        xyz = np.array([c for g in groups for c in g], dtype=np.float64).reshape(-1, 3)
+        off = np.concatenate([[0], np.cumsum([len(g) for g in groups])]).astype(np.int64)
+        bl = self.densityObj._map.sphere_blobs(xyz, np.full(len(xyz), radius, dtype=np.float32), off, 0.0)
+        st = bl.stats()
+        crs, voff = bl.voxels()
+        vgroup = np.repeat(st["group"].astype(np.int64), np.diff(voff))
+        order = np.argsort(vgroup, kind="stable")
+        crs, vgroup = crs[order], vgroup[order]
+        fo = self.densityObj._map.point_density(crs)
+        fc = fo - self.diffDensityObj._map.point_density(crs) * 2
+        n_groups = len(groups)
+        cnt = np.bincount(vgroup, minlength=n_groups).astype(np.int64)
+        start = np.concatenate([[0], np.cumsum(cnt)])[:-1]
+        rscc = np.full(n_groups, np.nan)
+        rsr = np.full(n_groups, np.nan)
+        has = cnt > 0
+        if has.any():
+            seg = start[has]
+            mean_fo = np.add.reduceat(fo, seg) / cnt[has]
+            mean_fc = np.add.reduceat(fc, seg) / cnt[has]
+            idx = np.cumsum(has) - 1                       # group -> row of the non-empty tables
+            xm = fo - mean_fo[idx[vgroup]]
+            ym = fc - mean_fc[idx[vgroup]]
+            nx = np.sqrt(np.add.reduceat(xm * xm, seg))
+            ny = np.sqrt(np.add.reduceat(ym * ym, seg))
+            with np.errstate(invalid="ignore", divide="ignore"):
+                r = np.add.reduceat((xm / nx[idx[vgroup]]) * (ym / ny[idx[vgroup]]), seg)
+                rscc[has] = np.clip(r, -1.0, 1.0)
+                rsr[has] = np.add.reduceat(np.abs(fo - fc), seg) / np.add.reduceat(np.abs(fo + fc), seg)
+            rscc[cnt < 2] = np.nan                          # scipy raises for fewer than two points
+        return rscc, rsr
+
+    def calculateRsccRsrMetrics(self, crsList):
+        """ref densityAnalysis.py:864-882 for one explicit voxel set."""
+        crs = np.asarray(sorted(set(map(tuple, crsList))), dtype=np.int32).reshape(-1, 3)
+        fo = self.densityObj._map.point_density(crs)
+        fc = fo - self.diffDensityObj._map.point_density(crs) * 2
+        xm, ym = fo - fo.mean(), fc - fc.mean()
+        rscc = float(np.clip(np.dot(xm / np.linalg.norm(xm), ym / np.linalg.norm(ym)), -1.0, 1.0)) if len(crs) > 1 else float("nan")
+        rsr = float(np.abs(fo - fc).sum() / np.abs(fo + fc).sum())
+        return (rscc, rsr)
+
+    def residueMetrics(self, residueList=None):
+        """ref densityAnalysis.py:803-838: [chain, resnum, resname, rscc, rsr, mean occupancy, occupancy-weighted mean B]."""
+        radius = self._metricsRadius()
+        if residueList is None:
+            residueList = list(self.biopdbObj.get_residues())
+        rscc, rsr = self._rsccRsr([[atom.coord for atom in residue.child_list] for residue in residueList], radius)
+        results = []
+        for residue, cc, rr in zip(residueList, rscc, rsr):
+            bfactorWeightedSum = occupancySum = 0.0
+            for atom in residue.child_list:
+                bfactorWeightedSum += atom.get_bfactor() * atom.get_occupancy()
+                occupancySum += atom.get_occupancy()
+            results.append([residue.parent.id, residue.id[1], residue.resname, float(cc), float(rr), occupancySum / len(residue.child_list),
+                            bfactorWeightedSum / occupancySum])
+        return results
+
+    def atomMetrics(self, atomList=None):
+        """ref densityAnalysis.py:840-862: [chain, resnum, resname, atom, symmetry, xyz, rscc, rsr, occupancy, bfactor]."""
+        radius = self._metricsRadius()
+        if atomList is None:
+            atomList = self.asymmetryAtoms
+        rscc, rsr = self._rsccRsr([[atom.coord] for atom in atomList], radius)
+        return [[atom.parent.parent.id, atom.parent.id[1], atom.parent.resname, atom.name, atom.symmetry, atom.coord, float(cc), float(rr),
+                 atom.get_occupancy(), atom.get_bfactor()] for atom, cc, rr in zip(atomList, rscc, rsr)]
 
     # ---- region density / discrepancy (ref densityAnalysis.py:948-1211), batched ---------------
     def _regionBatch(self, dm, groups, radii, cutoff):

@@ -103,6 +103,20 @@ def main(ccp4, da):
             out["blob_%s_sign" % tag] = np.array([s[1] for s in stats])
             out["blob_%s_atom" % tag] = np.array(["%s|%s|%s|%s" % (s[6], s[7], s[8], tuple(int(v) for v in s[9])) for s in stats])
             out["blob_%s_centroid" % tag] = np.array([list(s[11]) for s in stats], dtype=np.float64).reshape(-1, 3)
+        # RSCC / RSR metrics (densityAnalysis.py:803-882) at the entry's resolution, and the Fo / Fc scale check (783-801)
+        st.header = {"resolution": 2.0}
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")      # scipy.stats.stats deprecation in the reference's pearsonr call
+            rm = an.residueMetrics()
+            am = an.atomMetrics()
+            out["residue_metrics"] = np.array([[r[3], r[4], r[5], r[6]] for r in rm], dtype=np.float64)
+            out["residue_metrics_id"] = np.array(["%s|%s|%s" % (r[0], r[1], r[2]) for r in rm])
+            out["atom_metrics"] = np.array([[r[6], r[7], r[8], r[9]] for r in am], dtype=np.float64)
+            out["atom_metrics_id"] = np.array(["%s|%s|%s|%s" % (r[0], r[1], r[2], r[3]) for r in am])
+            out["median_abs_fo_fc"] = np.array(an.medianAbsFoFc(), dtype=np.float64)
+            fc = an.fc
+            out["fc_mean_std"] = np.array([fc.meanDensity, fc.stdDensity], dtype=np.float64)
         path = os.path.join(HERE, "analysis_%s.npz" % name)
         np.savez_compressed(path, **out)
         print("wrote", path, os.path.getsize(path) // 1024, "KiB")

@@ -110,6 +110,26 @@ def test_blob_statistics(analysis):
         assert np.allclose(np.array([list(s[11]) for s in stats]).reshape(-1, 3), z["blob_%s_centroid" % tag], rtol=1e-7, atol=1e-9)
 
 
+def test_rscc_rsr_metrics(analysis):
+    """RSCC / RSR per residue and per atom, the Fo / Fc scale check and the Fc map quirk (densityAnalysis.py:426-435, 783-882)."""
+    z, an = analysis
+    an.biopdbObj.header = {"resolution": 2.0}
+    rm = an.residueMetrics()
+    assert ["%s|%s|%s" % (r[0], r[1], r[2]) for r in rm] == list(z["residue_metrics_id"])
+    assert np.allclose(np.array([[r[3], r[4], r[5], r[6]] for r in rm]), z["residue_metrics"], rtol=1e-7, atol=1e-12)
+    am = an.atomMetrics()
+    assert ["%s|%s|%s|%s" % (r[0], r[1], r[2], r[3]) for r in am] == list(z["atom_metrics_id"])
+    assert np.allclose(np.array([[r[6], r[7], r[8], r[9]] for r in am]), z["atom_metrics"], rtol=1e-7, atol=1e-12)
+    assert np.allclose(an.medianAbsFoFc(), z["median_abs_fo_fc"], rtol=1e-9)
+    fc = an.fc
+    assert np.allclose([fc.meanDensity, fc.stdDensity], z["fc_mean_std"], rtol=1e-9)    # the reference's Fc keeps the Fo statistics
+    # one explicit voxel set through the single-set entry point == the batched path
+    atom = an.asymmetryAtoms[3]
+    crs = an.densityObj.getSphereCrsFromXyz(atom.coord, an._metricsRadius(), 0.0)
+    one = an.calculateRsccRsrMetrics(crs)
+    assert one[0] == pytest.approx(am[3][6], rel=1e-9) and one[1] == pytest.approx(am[3][7], rel=1e-9)
+
+
 def test_silent_failure_contract(gpu_ctx):
     """Q7: below the electrons minimum everything stays None and users of the ratio raise."""
     from pdb_eda_amd import ccp4, synthetic, densityAnalysis
