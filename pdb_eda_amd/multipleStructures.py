@@ -6,10 +6,14 @@ processFunction, pdbids, chunksize=1)`` (multipleStructures.py:167-168) and the 
 (fileUtils.py:12-28) -- and reproduces the per-entry record of ``analyzePDBID``
 (multipleStructures.py:320-356).  HIP contexts do not survive ``fork`` (what ``Pool`` does), so the
 pool here is threads: one ``pdbeda_ctx`` (= one stream) per worker thread; ctypes releases the GIL
-inside every C-ABI call, so streams overlap.  Filters, reload, CSV writers: out of scope.
+inside every C-ABI call, so streams overlap.  ``writeResults`` emits the reference's JSON / CSV (182-194).
+Filters and reload: out of scope.
 """
 import collections
+import csv
 import io
+import json
+import sys
 import queue
 import threading
 import time
@@ -113,3 +117,26 @@ def processEntries(entries, device=0, n_streams=4):
     """The per-GPU part of ``pdb_eda multiple``: {pdbid: record} for the entries that succeed."""
     records = StreamPool(device, n_streams).map(analyzeEntry, entries)
     return {r["pdbid"]: r for r in records if r}
+
+
+def writeResults(fullResults, outFile="-", outFormat="json"):
+    """ref multipleStructures.py:182-194: the merged per-entry records as JSON (indent 2, sorted keys) or as the CSV table
+    pdbid + statsHeaders + one diff column per atom type (sorted)."""
+    if outFormat in ('csv', 'txt'):
+        atomTypes = sorted(densityAnalysis.paramsGlobal["radii"])
+        fh = open(outFile, "w", newline='') if outFile != "-" else sys.stdout
+        try:
+            writer = csv.writer(fh)
+            writer.writerow(['pdbid'] + statsHeaders + atomTypes)
+            for result in fullResults.values():
+                writer.writerow([result['pdbid']] + [result["stats"][h] for h in statsHeaders] + [result["diffs"][t] for t in atomTypes])
+        finally:
+            if fh is not sys.stdout:
+                fh.close()
+    else:
+        text = json.dumps(fullResults, indent=2, sort_keys=True) + "\n"
+        if outFile == "-":
+            sys.stdout.write(text)
+        else:
+            with open(outFile, "w") as fh:
+                fh.write(text)
