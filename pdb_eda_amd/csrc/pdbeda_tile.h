@@ -20,8 +20,8 @@
 namespace pdbeda {
 
 constexpr int TILE_R = 8, TILE_S = 8;
-constexpr int PCAP = 704;         // run slots per sign and tile handled in LDS (runs are tracked per ROW: a run crossing words is one run)
-constexpr int RCAP = 2 * PCAP;    // sign 0 uses slots [0, PCAP), sign 1 [PCAP, 2 PCAP); a wave reserves a 16-word chunk with one LDS atomic
+constexpr int RCAP = 1408;        // run slots per tile handled in LDS (runs are tracked per ROW: a run crossing words is one run);
+                                  // sign 0 fills them from the bottom, sign 1 ends at the top: [RCAP - n1, RCAP) -- a one-sign job has them all
 constexpr int CCAP = 256;   // tile-local components (both signs together) handled in LDS
 constexpr int VCAP = 3584;  // significant values per tile parked in LDS during phase A (aliases the 14 KiB scratch)
 constexpr int VMAIN = 3072; // of the VCAP parked values: split into one private region per wave (no atomics) ...
@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
     __shared__ uint32_t s_alloc[2];       // slots handed out per sign
     __shared__ uint32_t s_wsx[4], s_wsy[4];   // the word-owning threads are the first 256 (= 4 waves) also when NT = 512
     __shared__ uint32_t s_gcnt[4];        // word-runs per wave
-    __shared__ uint32_t s_over, s_changed, s_more, s_ncomp, s_runbase, s_compbase, s_vpool;
+    __shared__ uint32_t s_over, s_vover, s_changed, s_more, s_ncomp, s_runbase, s_compbase, s_vpool;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wt = tid & 255;     // the word this thread owns in the thread-per-word phases ...
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
     const int n_planes = td.n_planes;
 
     STAMP(0);
-    if (tid == 0) { s_over = 0; s_ncomp = 0; s_alloc[0] = 0; s_alloc[1] = 0; s_vpool = 0; }
+    if (tid == 0) { s_over = 0; s_vover = 0; s_ncomp = 0; s_alloc[0] = 0; s_alloc[1] = 0; s_vpool = 0; }
     if (blockIdx.x == 0 && tid < ESHARDS) job.edge_fill[tid] = 0u;
     if (blockIdx.x == 0 && tid == 0) {   // read by the kernels that follow; nothing in this kernel touches them
         job.vols[0] = init.v[0];
@@ -258,8 +258,8 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
                         uint32_t got = 0;
                         if (lane == 0) got = atomicAdd(&s_vpool, nv);
                         base = VMAIN + (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-                        if (base + nv > (uint32_t)VCAP) { base = 0; if (lane == 0) s_over = 1; }   // tile too dense for LDS -> unit tile
-                    }
+                        if (base + nv > (uint32_t)VCAP) { base = 0xffffu; if (lane == 0) s_vover = 1; }   // tile too dense to park its values:
+                    }                                                                                      // A3 re-reads them from global memory (L2)
                     k0lo = wave_writelane(k0lo, (uint32_t)b0, jj);
                     k0hi = wave_writelane(k0hi, (uint32_t)(b0 >> 32), jj);
                     if (n_planes > 1) {
@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
                         k1hi = wave_writelane(k1hi, (uint32_t)(b1 >> 32), jj);
                     }
                     kvb = wave_writelane(kvb, base, jj);
-                    if (hit0 || hit1) s_val[base + mbcnt_lt(bb)] = x;
+                    if ((hit0 || hit1) && base != 0xffffu) s_val[base + mbcnt_lt(bb)] = x;
                 }
                 if (lane < CHU) {
                     s_mask[0][u0 + lane] = ((uint64_t)k0hi << 32) | k0lo;
@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
 
     // ---- A2 (thread per word): run counts, row continuation, ONE block scan -> run slots ---------
     // Runs are tracked per ROW: a run that continues from the previous word keeps that word's last
-    // slot.  Sign 0 uses slots [0, PCAP), sign 1 [PCAP, 2 PCAP); slots follow word order, so the
+    // slot.  Sign 0 uses slots [0, n0), sign 1 [RCAP - n1, RCAP); slots follow word order, so the
     // runs of a row are contiguous and sorted by position.
     {
         const uint64_t a0 = (wt < NU) ? s_mask[0][wt] : 0ull, a1 = (wt < NU) ? s_mask[1][wt] : 0ull;
@@ -310,14 +310,15 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
         const uint32_t ex = px + x - vx, ey = py + y - vy;
         const uint32_t e0 = ex & 0xffffu, e1 = ex >> 16;
         const uint32_t tx = s_wsx[0] + s_wsx[1] + s_wsx[2] + s_wsx[3];
-        const bool over_slots = (tx & 0xffffu) > (uint32_t)PCAP || (tx >> 16) > (uint32_t)PCAP;  // block-uniform
+        const bool over_slots = (tx & 0xffffu) + (tx >> 16) > (uint32_t)RCAP;  // block-uniform
+        const uint32_t base1 = (uint32_t)RCAP - (tx >> 16);                    // first slot of sign 1
         const uint32_t first0 = k0 ? e0 - 1u : e0, next0 = k0 ? e0 : e0 + 1u;
-        const uint32_t first1 = PCAP + (k1 ? e1 - 1u : e1), next1 = PCAP + (k1 ? e1 : e1 + 1u);
+        const uint32_t first1 = base1 + (k1 ? e1 - 1u : e1), next1 = base1 + (k1 ? e1 : e1 + 1u);
         if (tid < NU) {
             s_first[0][tid] = (uint16_t)(first0 | (k0 ? 0x8000u : 0u));
             s_first[1][tid] = (uint16_t)(first1 | (k1 ? 0x8000u : 0u));
             s_gword[tid] = (uint16_t)ey;
-            if (wl == 0) { s_rowfirst[0][tid / CW] = (uint16_t)e0; s_rowfirst[1][tid / CW] = (uint16_t)(PCAP + e1); }
+            if (wl == 0) { s_rowfirst[0][tid / CW] = (uint16_t)e0; s_rowfirst[1][tid / CW] = (uint16_t)(base1 + e1); }
         }
         if (tid == 255) {
             s_alloc[0] = tx & 0xffffu;
@@ -329,6 +330,8 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
         // values; a run that continues into the following word(s) of the row is followed by its owner, so every
         // run has one writer: no atomics, sequential and deterministic.  Full lanes (95 % of the words of a
         // +-1.5 sigma map are significant).
+        const bool from_global = s_vover != 0;   // block-uniform (set before the barrier that ended A1)
+        const float *rowptr = dens + ((int64_t)(s0 + ((wt / CW) >> 3)) * nr + (r0 + ((wt / CW) & 7))) * nc + w0 * 64;   // my row inside the tile
         if (wt < NU && (a0 | a1) && !over_slots && s_over == 0) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -350,11 +353,28 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
                         const uint64_t mc = s_mask[q][cur];
                         const uint64_t bbc = s_mask[0][cur] | s_mask[1][cur];
                         const int e = run_end_of(mc, ca);
-                        const uint32_t off = s_vbase[cur] + (uint32_t)popc64(bbc & bits_below(ca));
-                        for (int i = 0; i <= e - ca; ++i) {
-                            const double val = (double)s_val[off + i];
-                            sum += val;
-                            sumc += val * (double)(wlc * 64 + ca + i);
+                        if (!from_global) {
+                            const uint32_t off = s_vbase[cur] + (uint32_t)popc64(bbc & bits_below(ca));
+                            for (int i = 0; i <= e - ca; ++i) {
+                                const double val = (double)s_val[off + i];
+                                sum += val;
+                                sumc += val * (double)(wlc * 64 + ca + i);
+                            }
+                        } else {   // dense tile: the values were not parked; 4 loads in flight per trip (clamped inside the run)
+                            const int p0 = wlc * 64 + ca, p1 = wlc * 64 + e;
+                            for (int pp = p0; pp <= p1; pp += 4) {
+                                float v4[4];
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) v4[t] = rowptr[pp + t <= p1 ? pp + t : p1];
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) {
+                                    if (pp + t <= p1) {
+                                        const double val = (double)v4[t];
+                                        sum += val;
+                                        sumc += val * (double)(pp + t);
+                                    }
+                                }
+                            }
                         }
                         last_end = wlc * 64 + e;
                         if (e == 63 && wlc < CW - 1 && (s_mask[q][cur + 1] & 1ull)) { ++cur; ++wlc; ca = 0; } else break;
@@ -369,7 +389,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
         __syncthreads();
         if (tid < 128) {
             const int q = tid >> 6, row = tid & 63;
-            const uint32_t end = row < 63 ? s_rowfirst[q][row + 1] : (q ? PCAP : 0) + s_alloc[q];
+            const uint32_t end = row < 63 ? s_rowfirst[q][row + 1] : (q ? (uint32_t)RCAP : s_alloc[0]);
             s_rowcnt[q][row] = (uint16_t)(end - s_rowfirst[q][row]);
         }
     }
@@ -390,7 +410,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
     const uint32_t n_slots = al0 + al1;
     const uint32_t n_wordruns = s_gcnt[0];
     const uint64_t m0 = (wt < NU) ? s_mask[0][wt] : 0ull, m1 = (wt < NU) ? s_mask[1][wt] : 0ull;
-    auto slot_used = [&](uint32_t sl) -> bool { return sl < (uint32_t)PCAP ? sl < al0 : (sl - PCAP) < al1; };
+    auto slot_used = [&](uint32_t sl) -> bool { return sl < al0 || sl >= (uint32_t)RCAP - al1; };
 
     if (n_slots == 0 || s_over) {
         // nothing significant, or too many runs for LDS: publish the masks; an overflowing tile
@@ -416,7 +436,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
 #pragma unroll
         for (int t = 0; t < SLOTS; ++t) {
             const uint32_t lin = tid + (uint32_t)NT * t;
-            ji[t] = lin < al0 ? lin : (lin - al0 < al1 ? PCAP + (lin - al0) : 0xffffffffu);
+            ji[t] = lin < al0 ? lin : (lin - al0 < al1 ? (uint32_t)RCAP - al1 + (lin - al0) : 0xffffffffu);
             if (ji[t] != 0xffffffffu) s_cand[ji[t]] = 0xffffu;
         }
         // B1 task of this thread: (sign q, row A, earlier neighbour row B) -- 2 x 64 x 4 = NT tasks.  The runs of a
