@@ -664,7 +664,7 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
         if (!all_rows) hipLaunchKernelGGL(k_tile_edges_unit, dim3(gx, us, n_planes), dim3(256), 0, st, job, td);
     }
     { PROF(ctx, "k_union_edges"); hipLaunchKernelGGL(k_union_edges, dim3(32, ESHARDS), dim3(256), 0, st, job); }
-    { PROF(ctx, "k_resolve"); hipLaunchKernelGGL(k_resolve, dim3(comp_grid), dim3(256), 0, st, job); }
+    { PROF(ctx, "k_resolve"); hipLaunchKernelGGL(k_resolve_tiles, dim3((unsigned)tiles_pp + 64u), dim3(256), 0, st, job, (int)tiles_pp); }
     { PROF(ctx, "k_paint_keys"); hipLaunchKernelGGL(k_paint_keys, dim3(comp_grid), dim3(256), 0, st, job); }
     { PROF(ctx, "k_key_chunks"); hipLaunchKernelGGL(k_key_chunks, dim3(job.n_chunks), dim3(KEY_CHUNK), 0, st, job); }
     { PROF(ctx, "k_chunk_scan"); hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, st, job); }
@@ -765,6 +765,13 @@ extern "C" int pdbeda_bloblist_counters(pdbeda_bloblist *bl, int64_t *out) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     out[0] = c.n_runs; out[1] = c.n_comps; out[2] = c.n_edges; out[3] = c.n_blobs;
     out[4] = out[5] = out[6] = out[7] = 0;
+    if (bl->whole_map && bl->job.edge_fill) {   // cross-tile pairs parked in the shard buffers (demand, also when a shard overflowed)
+        uint32_t fill[ESHARDS];
+        HIP_TRY(ctx, hipMemcpyAsync(fill, bl->job.edge_fill, sizeof fill, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        out[2] = 0;
+        for (uint32_t v : fill) out[2] += v;
+    }
     if (bl->whole_map && bl->job.tile_mode) {   // unit tiles by cause: tile_mode 1 = run slots / values, 3 = component table
         const int64_t n_tiles = (int64_t)bl->td.ctiles * bl->td.rtiles * bl->td.stiles;
         std::vector<uint8_t> mode(n_tiles);
@@ -774,6 +781,22 @@ extern "C" int pdbeda_bloblist_counters(pdbeda_bloblist *bl, int64_t *out) {
     }
     return PDBEDA_OK;
 }
+
+#ifdef PDBEDA_COUNT_FIND
+extern "C" int pdbeda_debug_find_counters(unsigned long long *out, int reset) {
+    unsigned long long z = 0;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(&out[0], HIP_SYMBOL(pdbeda::g_find_calls), 8);
+    (void)hipMemcpyFromSymbol(&out[1], HIP_SYMBOL(pdbeda::g_find_steps), 8);
+    (void)hipMemcpyFromSymbol(&out[2], HIP_SYMBOL(pdbeda::g_unite_retries), 8);
+    (void)hipMemcpyFromSymbol(&out[3], HIP_SYMBOL(pdbeda::g_unite_ticks_max), 8);
+    (void)hipMemcpyFromSymbol(&out[4], HIP_SYMBOL(pdbeda::g_unite_ticks_sum), 8);
+    (void)hipMemcpyFromSymbol(&out[5], HIP_SYMBOL(pdbeda::g_unite_n), 8);
+    if (reset) { (void)hipMemcpyToSymbol(HIP_SYMBOL(pdbeda::g_unite_ticks_max), &z, 8); (void)hipMemcpyToSymbol(HIP_SYMBOL(pdbeda::g_unite_ticks_sum), &z, 8); (void)hipMemcpyToSymbol(HIP_SYMBOL(pdbeda::g_unite_n), &z, 8); }
+    if (reset) { (void)hipMemcpyToSymbol(HIP_SYMBOL(pdbeda::g_find_calls), &z, 8); (void)hipMemcpyToSymbol(HIP_SYMBOL(pdbeda::g_find_steps), &z, 8); (void)hipMemcpyToSymbol(HIP_SYMBOL(pdbeda::g_unite_retries), &z, 8); }
+    return 0;
+}
+#endif
 
 // Diagnostic builds only (-DPDBEDA_STAMPS): 8 s_memtime stamps per tile of the whole-map tile kernel.
 extern "C" int pdbeda_bloblist_stamps(pdbeda_bloblist *bl, unsigned long long *out, int64_t n_tiles) {

@@ -246,9 +246,18 @@ __device__ inline int uf_load(const int32_t *p, int x) {
 #endif
 }
 // find with path halving by fire-and-forget atomic min (monotone: never undoes a union)
+#ifdef PDBEDA_COUNT_FIND
+__device__ unsigned long long g_find_steps, g_find_calls, g_unite_retries, g_unite_ticks_max, g_unite_ticks_sum, g_unite_n;
+#endif
 __device__ inline int uf_find(int32_t *p, int x) {
     int q;
+#ifdef PDBEDA_COUNT_FIND
+    atomicAdd(&g_find_calls, 1ull);
+#endif
     while ((q = uf_load(p, x)) != x) {
+#ifdef PDBEDA_COUNT_FIND
+        atomicAdd(&g_find_steps, 1ull);
+#endif
         const int gp = uf_load(p, q);
         if (gp != q) atomicMin(p + x, gp);
         x = gp;
@@ -256,6 +265,9 @@ __device__ inline int uf_find(int32_t *p, int x) {
     return x;
 }
 __device__ inline void uf_unite(int32_t *p, int a, int b) {
+#ifdef PDBEDA_COUNT_FIND
+    unsigned long long my_retries = 0;
+#endif
     while (true) {
         a = uf_find(p, a);
         b = uf_find(p, b);
@@ -263,6 +275,10 @@ __device__ inline void uf_unite(int32_t *p, int a, int b) {
         if (a < b) { int t = a; a = b; b = t; }
         int old = atomicMin(p + a, b);
         if (old == a) return;
+#ifdef PDBEDA_COUNT_FIND
+        atomicAdd(&g_unite_retries, 1ull);
+        atomicMax(&g_find_calls, (++my_retries) << 40);   // max retries of one unite in the top bits
+#endif
         a = old;
     }
 }

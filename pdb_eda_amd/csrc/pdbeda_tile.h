@@ -934,9 +934,85 @@ __global__ void __launch_bounds__(256) k_union_edges(Job job) {
             }
             const int pa = __shfl_up(a, 1), pb = __shfl_up(b, 1);
             const bool dup = lane > 0 && pa == a && pb == b;
+#ifdef PDBEDA_COUNT_FIND
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
             if (i < n && a != b && !dup) uf_unite(job.parent, a, b);
+            const unsigned long long dt = __builtin_amdgcn_s_memtime() - t0;
+            if (i < n && a != b && !dup) { atomicMax(&g_unite_ticks_max, dt); atomicAdd(&g_unite_ticks_sum, dt); atomicAdd(&g_unite_n, 1ull); }
+#else
+            if (i < n && a != b && !dup) uf_unite(job.parent, a, b);
+#endif
         }
     }
+}
+
+// Whole-map k_resolve: one workgroup per tile (its CCAP component ids).  Every component finds its root; the
+// non-root components of a tile that share a root are first summed in LDS (leader = lowest such thread), then ONE
+// set of global atomics per (tile, root) folds them into the root record.  A blob that spans the map (the chain of a
+// protein at 1.5 sigma: tens of thousands of tile components) would otherwise pile 9 same-address atomics per
+// component on one record.  Workgroups beyond the tiles handle the components of unit tiles one by one.
+__global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
+    static_assert(CCAP == 256, "one thread per component id of a tile");
+    const int tid = threadIdx.x;
+    auto fold = [&](uint32_t root, uint32_t n, double rho, double rc, double rr, double rs, unsigned long long c, unsigned long long r,
+                    unsigned long long s, unsigned long long key) {
+        atomicAdd(&job.r_n[root], n);
+        unsafeAtomicAdd(&job.r_rho[root], rho);
+        unsafeAtomicAdd(&job.r_rho_c[root], rc);
+        unsafeAtomicAdd(&job.r_rho_r[root], rr);
+        unsafeAtomicAdd(&job.r_rho_s[root], rs);
+        atomicAdd((unsigned long long *)&job.r_c[root], c);
+        atomicAdd((unsigned long long *)&job.r_r[root], r);
+        atomicAdd((unsigned long long *)&job.r_s[root], s);
+        atomicMin(&job.r_key[root], key);
+    };
+    if ((int)blockIdx.x >= n_tiles) {
+        const uint32_t n_comp = n_components(job);
+        for (uint32_t i = (uint32_t)n_tiles * CCAP + (blockIdx.x - n_tiles) * 256u + tid; i < n_comp; i += (gridDim.x - n_tiles) * 256u) {
+            const int root = uf_find(job.parent, (int)i);
+            if (root == (int)i) continue;
+            job.parent[i] = root;
+            fold((uint32_t)root, job.r_n[i], job.r_rho[i], job.r_rho_c[i], job.r_rho_r[i], job.r_rho_s[i], (unsigned long long)job.r_c[i],
+                 (unsigned long long)job.r_r[i], (unsigned long long)job.r_s[i], job.r_key[i]);
+        }
+        return;
+    }
+    __shared__ int s_root[256];
+    __shared__ double s_f[4][256];
+    __shared__ unsigned long long s_i[3][256], s_key[256];
+    __shared__ uint32_t s_cnt[256];
+    const uint32_t i = (uint32_t)blockIdx.x * CCAP + tid;
+    const uint32_t n_i = job.r_n[i];
+    int root = -1 - tid;   // unused ids and roots: a value no other thread holds
+    bool member = false;   // non-root component with voxels
+    if (n_i > 0u) {
+        const int r = uf_find(job.parent, (int)i);
+        if (r != (int)i) { root = r; member = true; job.parent[i] = r; }
+    }
+    s_root[tid] = root;
+    s_f[0][tid] = 0.0; s_f[1][tid] = 0.0; s_f[2][tid] = 0.0; s_f[3][tid] = 0.0;
+    s_i[0][tid] = 0ull; s_i[1][tid] = 0ull; s_i[2][tid] = 0ull; s_key[tid] = ~0ull; s_cnt[tid] = 0u;
+    __syncthreads();
+    if (__syncthreads_or(member ? 1 : 0) == 0) return;   // nothing to fold in this tile
+    int leader = tid;
+    for (int j = 0; j < 256; ++j) {   // uniform loop, broadcast reads: the lowest thread that holds my root
+        const int rj = s_root[j];
+        if (rj == root && j < leader) leader = j;
+    }
+    if (member) {
+        atomicAdd(&s_cnt[leader], n_i);
+        unsafeAtomicAdd(&s_f[0][leader], job.r_rho[i]);
+        unsafeAtomicAdd(&s_f[1][leader], job.r_rho_c[i]);
+        unsafeAtomicAdd(&s_f[2][leader], job.r_rho_r[i]);
+        unsafeAtomicAdd(&s_f[3][leader], job.r_rho_s[i]);
+        atomicAdd(&s_i[0][leader], (unsigned long long)job.r_c[i]);
+        atomicAdd(&s_i[1][leader], (unsigned long long)job.r_r[i]);
+        atomicAdd(&s_i[2][leader], (unsigned long long)job.r_s[i]);
+        atomicMin(&s_key[leader], job.r_key[i]);
+    }
+    __syncthreads();
+    if (member && leader == tid)
+        fold((uint32_t)root, s_cnt[tid], s_f[0][tid], s_f[1][tid], s_f[2][tid], s_f[3][tid], s_i[0][tid], s_i[1][tid], s_i[2][tid], s_key[tid]);
 }
 
 // Signed dense labels of a whole-map job in ONE pass: 0 background, +1+k for blob k of the

@@ -28,4 +28,4 @@ for nsd in (1.5, 1.0, 0.5, 3.0):
     st_ = k.stats()
     tot = sum(ms / c for c, ms in prof.values())
     print("nsd %.1f blobs %d biggest %d sig %.2f%% total %.0f us" % (nsd, len(st_["n"]), st_["n"].max(), 100.0 * st_["n"].sum() / dens.size, tot * 1e3),
-          {a: round(ms / c * 1e3, 1) for a, (c, ms) in sorted(prof.items())}, k.counters()["unit_tiles_runs"], k.counters()["unit_tiles_comps"], flush=True)
+          {a: round(ms / c * 1e3, 1) for a, (c, ms) in sorted(prof.items())}, k.counters(), flush=True)
