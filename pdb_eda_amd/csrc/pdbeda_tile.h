@@ -916,6 +916,9 @@ __global__ void __launch_bounds__(256) k_tile_edges_unit(Job job, TileDims td) {
 // Thread per parked run pair: map to tile components, global union-find with device-scope atomics.
 // Consecutive pairs of a word mostly name the same two components: a lane whose pair equals its
 // left neighbour's is dropped (wave shuffle), as are pairs already inside one component.
+#ifndef PDBEDA_DEDUP_WINDOW
+#define PDBEDA_DEDUP_WINDOW 16
+#endif
 __global__ void __launch_bounds__(256) k_union_edges(Job job) {
     const uint32_t shard_cap = (uint32_t)(job.edge_cap / ESHARDS);
     const int lane = lane_id();
@@ -932,8 +935,13 @@ __global__ void __launch_bounds__(256) k_union_edges(Job job) {
                 a = (int)job.comp_of_run[e.x];
                 b = (int)job.comp_of_run[e.y];
             }
-            const int pa = __shfl_up(a, 1), pb = __shfl_up(b, 1);
-            const bool dup = lane > 0 && pa == a && pb == b;
+            if (a > b) { const int t = a; a = b; b = t; }   // unordered pair
+            bool dup = false;
+#pragma unroll
+            for (int d = 1; d <= PDBEDA_DEDUP_WINDOW; ++d) {   // the same two components a few lanes back (pairs of one tile face interleave)
+                const int pa = __shfl_up(a, d), pb = __shfl_up(b, d);
+                dup = dup || (lane >= d && pa == a && pb == b);
+            }
 #ifdef PDBEDA_COUNT_FIND
             const unsigned long long t0 = __builtin_amdgcn_s_memtime();
             if (i < n && a != b && !dup) uf_unite(job.parent, a, b);
