@@ -507,6 +507,8 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.comps_are_runs = n_tiles ? 0 : 1;
     job.comp_of_run = n_tiles ? cv.take<uint32_t>(max_runs) : nullptr;
     job.label_of_comp = n_tiles ? cv.take<int32_t>(max_runs) : nullptr;
+    job.pair_filter_mask = n_tiles ? (1u << 18) - 1u : 0u;
+    job.pair_filter = n_tiles ? cv.take<unsigned long long>((size_t)job.pair_filter_mask + 1) : nullptr;
     job.unit_flag = n_tiles ? cv.take<uint32_t>(1) : nullptr;
     job.tile_mode = n_tiles ? cv.take<uint8_t>(n_tiles) : nullptr;
     job.tile_runs = n_tiles ? cv.take<uint32_t>(n_tiles) : nullptr;

@@ -54,6 +54,8 @@ struct Job {
     int32_t comps_are_runs;
     uint32_t *comp_of_run;
     int32_t *label_of_comp;   // final signed label of every component (whole-map jobs)
+    unsigned long long *pair_filter;   // lossy set of the component pairs already handed to the global union-find (0 = empty slot)
+    uint32_t pair_filter_mask;         // slots - 1 (a power of two)
     uint32_t *unit_flag;      // == epoch iff some tile of THIS job fell back to unit mode (stale values of a recycled arena never match)
     uint32_t epoch;           // job number of the context (never 0)
     uint8_t *tile_mode;       // per tile: 0 = united in LDS, 1 = unit tile

@@ -199,6 +199,9 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
         const int64_t per = (job.key_words + gridDim.x - 1) / gridDim.x;
         const int64_t lo = per * blockIdx.x, hi = lo + per < job.key_words ? lo + per : job.key_words;
         for (int64_t i = lo + tid; i < hi; i += NT) job.key_bits[i] = 0ull;
+        const int64_t nf = (int64_t)job.pair_filter_mask + 1, perf = (nf + gridDim.x - 1) / gridDim.x;   // and of the pair filter
+        const int64_t flo = perf * blockIdx.x, fhi = flo + perf < nf ? flo + perf : nf;
+        for (int64_t i = flo + tid; i < fhi; i += NT) job.pair_filter[i] = 0ull;
     }
     for (int i = tid; i < RCAP; i += NT) s_parent[i] = (uint16_t)i;
     __syncthreads();
@@ -948,7 +951,16 @@ __global__ void __launch_bounds__(256) k_union_edges(Job job) {
             const unsigned long long dt = __builtin_amdgcn_s_memtime() - t0;
             if (i < n && a != b && !dup) { atomicMax(&g_unite_ticks_max, dt); atomicAdd(&g_unite_ticks_sum, dt); atomicAdd(&g_unite_n, 1ull); }
 #else
-            if (i < n && a != b && !dup) uf_unite(job.parent, a, b);
+            if (i < n && a != b && !dup) {
+#ifndef PDBEDA_NO_PAIR_FILTER
+                // the same two components meet on many rows / sections of a tile face, in other workgroups: a lossy global
+                // set (one CAS) keeps all but the first of them away from the union-find, where repeats only contend
+                const unsigned long long key = ((unsigned long long)(uint32_t)a << 32) | (uint32_t)b;
+                const uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & job.pair_filter_mask;
+                if (atomicCAS(&job.pair_filter[h], 0ull, key) != key)
+#endif
+                    uf_unite(job.parent, a, b);
+            }
 #endif
         }
     }
