@@ -344,6 +344,38 @@ def test_recycled_arenas_and_edge_overflow(monkeypatch):
         got.free()
 
 
+@pytest.mark.parametrize("nsd", [1.5, 0.5, 3.0])
+def test_protein_like_map_vs_oracle(gpu_ctx, nsd):
+    """A chain of Gaussian atoms: ONE blob spans the map at 1.5 sigma (hot roots in the global union-find and in the
+    record fold), its interior tiles are too dense to park their values in LDS (re-read path) and a one-sign job uses
+    the run slots of both signs."""
+    from oracle import oracle as ora
+    from pdb_eda_amd import ccp4, synthetic
+    spec = synthetic.MapSpec(ncrs=(256, 72, 64), spacing=0.5)
+    header = ccp4.DensityHeader.fromFileHeader(synthetic.ccp4_header_bytes(spec))
+    lo, hi = np.array(header.crs2xyzCoord([6, 6, 6])), np.array(header.crs2xyzCoord([249, 65, 57]))
+    st = synthetic.chain_structure(700, 3, lo, hi)
+    g = synthetic.gaussian_sum_grid(header, st, synthetic.synthetic_params()["full_atom_name_map_electrons"], sigma=0.55, noise=0.02, seed=3)
+    dm = _dm(g, gpu_ctx, spacing=0.5)
+    o = ora.Oracle(dm.header, g)
+    cut = dm.meanDensity + nsd * dm.stdDensity
+    want = o.full_blobs(cut, labels=True)
+    assert want["n"].max() > 10000                     # the chain is one big blob
+    for rep in range(2):
+        bl = dm._map.full_blobs(cut, labels=True)
+        st_ = bl.stats()
+        assert np.array_equal(st_["n"], want["n"])
+        assert np.array_equal(st_["firstKey"], want["firstKey"])
+        assert np.allclose(st_["totalDensity"], want["totalDensity"], rtol=REL)
+        assert np.allclose(st_["centroid"], want["centroid"], rtol=REL, atol=1e-9)
+        assert np.array_equal(bl.labels(dm._map.unique_shape), want["labels"])
+        assert bl.counters()["unit_tiles_runs"] == 0 and bl.counters()["unit_tiles_comps"] == 0   # stays on the LDS path
+    green, red = dm._map.full_blobs_pm(cut, -cut, labels=True)
+    assert np.array_equal(green.stats()["n"], want["n"])
+    wr = o.full_blobs(-cut)
+    assert np.array_equal(red.stats()["n"], wr["n"])
+
+
 def test_full_size_properties(gpu_ctx):
     """BASELINE config 2 size (256^3): size-independent properties + oracle equality."""
     from oracle import oracle as ora
