@@ -129,13 +129,16 @@ __device__ inline void mark_comps_unused(const Job &job, uint32_t cb, uint32_t f
 // NT = 512 threads: the same tile with twice the waves -- the kernel is one round of co-resident workgroups (1024
 // tiles at 256^3, 4 per CU), so its duration is the critical path of ONE tile; 8 waves halve the serial word loop of
 // A1, split A3 / C2 by sign (threads 256.. own the "<= cutoff" plane) and halve the pair tasks per thread.
+#ifndef PDBEDA_CHU_ALL
+#define PDBEDA_CHU_ALL 0
+#endif
 template <int CW, int NT>
 __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td,
                                                                        JobInit init) {
     constexpr int NW = NT / 64;   // waves
     constexpr int NU = 64 * CW;   // (row, word) units of the tile = threads that own a word
     constexpr int UPW = NU / NW;  // units per wave (whole rows)
-    constexpr int CHU = UPW < 16 ? UPW : ((CW == 3) ? 12 : 16);  // units per chunk: whole rows
+    constexpr int CHU = PDBEDA_CHU_ALL ? UPW : (UPW < 16 ? UPW : ((CW == 3) ? 12 : 16));  // units per chunk: whole rows
     constexpr int VREG = VMAIN / NW;
     constexpr int EQ = tile_eq(NT);
     constexpr int SLOTS = (RCAP + NT - 1) / NT;   // run slots a thread owns in phase B
@@ -1014,10 +1017,13 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
     s_i[0][tid] = 0ull; s_i[1][tid] = 0ull; s_i[2][tid] = 0ull; s_key[tid] = ~0ull; s_cnt[tid] = 0u;
     __syncthreads();
     if (__syncthreads_or(member ? 1 : 0) == 0) return;   // nothing to fold in this tile
+    const int used = __syncthreads_count(n_i > 0u);       // a tile's components are the ids [0, used)
     int leader = tid;
-    for (int j = 0; j < 256; ++j) {   // uniform loop, broadcast reads: the lowest thread that holds my root
-        const int rj = s_root[j];
-        if (rj == root && j < leader) leader = j;
+    if (__ballot(member) != 0ull) {   // wave-uniform: only waves with something to fold look for leaders
+        for (int j = 0; j < used; ++j) {   // uniform loop, broadcast reads: the lowest thread that holds my root
+            const int rj = s_root[j];
+            if (rj == root && j < leader) leader = j;
+        }
     }
     if (member) {
         atomicAdd(&s_cnt[leader], n_i);
@@ -1161,7 +1167,12 @@ __global__ void __launch_bounds__(256) k_labels_tiles(Job job, TileDims td, int3
         }
         int32_t *dst = labels + ((int64_t)s * ur + r) * uc + c;
         if (c + 3 < uc && ((uc & 3) == 0)) {
+#ifdef PDBEDA_LABELS_NT
+            __builtin_nontemporal_store(out[0], dst); __builtin_nontemporal_store(out[1], dst + 1);
+            __builtin_nontemporal_store(out[2], dst + 2); __builtin_nontemporal_store(out[3], dst + 3);
+#else
             *reinterpret_cast<int4 *>(dst) = make_int4(out[0], out[1], out[2], out[3]);
+#endif
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
