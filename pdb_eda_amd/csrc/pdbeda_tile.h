@@ -219,6 +219,10 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
         const bool interior = (r0 + TILE_R <= ur) && (s0 + TILE_S <= us) && ((w0 + CW) * 64 <= uc);   // block-uniform
         uint32_t vcnt = 0;  // wave-uniform: values parked so far in this wave's region
         const uint32_t vreg = (uint32_t)wvs * VREG;
+        // plane 0 is ">= cut" or "<= cut": x * sg >= cut * sg with sg = +-1 (exact) is one multiply + one compare whose
+        // mask IS the ballot; plane 1 ("<= cut[1]") is masked off as a whole for one-plane jobs
+        const float sg0 = td.sign[0] > 0 ? 1.0f : -1.0f, cs0 = td.cut[0] * sg0, c1 = td.cut[1];
+        const uint64_t pm1 = n_planes > 1 ? ~0ull : 0ull;
         auto stream = [&](auto interior_tag) {
             constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll 1
@@ -246,15 +250,15 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
                     const int u = u0 + jj;
                     const int wl = u % CW, rowl = u / CW;
                     const float x = v[jj];
-                    bool hit0 = td.sign[0] > 0 ? (x >= td.cut[0]) : (x <= td.cut[0]);
-                    bool hit1 = (n_planes > 1) && (x <= td.cut[1]);
+                    bool hit0 = x * sg0 >= cs0;
+                    bool hit1 = x <= c1;
                     if (!INTERIOR) {
                         const bool in = (r0 + (rowl & 7) < ur) && (s0 + (rowl >> 3) < us) && ((w0 + wl) * 64 + lane < uc);
                         hit0 = hit0 && in;
                         hit1 = hit1 && in;
                     }
                     const uint64_t b0 = __ballot(hit0);
-                    const uint64_t b1 = (n_planes > 1) ? __ballot(hit1) : 0ull;
+                    const uint64_t b1 = __ballot(hit1) & pm1;
                     const uint64_t bb = b0 | b1;
                     const uint32_t nv = (uint32_t)popc64(bb);
                     uint32_t base = vreg + vcnt;
@@ -268,12 +272,10 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
                     }                                                                                      // A3 re-reads them from global memory (L2)
                     k0lo = wave_writelane(k0lo, (uint32_t)b0, jj);
                     k0hi = wave_writelane(k0hi, (uint32_t)(b0 >> 32), jj);
-                    if (n_planes > 1) {
-                        k1lo = wave_writelane(k1lo, (uint32_t)b1, jj);
-                        k1hi = wave_writelane(k1hi, (uint32_t)(b1 >> 32), jj);
-                    }
+                    k1lo = wave_writelane(k1lo, (uint32_t)b1, jj);
+                    k1hi = wave_writelane(k1hi, (uint32_t)(b1 >> 32), jj);
                     kvb = wave_writelane(kvb, base, jj);
-                    if ((hit0 || hit1) && base != 0xffffu) s_val[base + mbcnt_lt(bb)] = x;
+                    if (((bb >> lane) & 1ull) && base != 0xffffu) s_val[base + mbcnt_lt(bb)] = x;
                 }
                 if (lane < CHU) {
                     s_mask[0][u0 + lane] = ((uint64_t)k0hi << 32) | k0lo;
