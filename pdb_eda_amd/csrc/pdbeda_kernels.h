@@ -101,37 +101,6 @@ __device__ inline int find_vol_by_key(const VolDesc *vols, int n, int64_t key) {
     return lo;
 }
 
-// ------------------------------------------------------------------------------------
-// Whole-map threshold -> bit masks (createFullCrsList, cutils.pyx:185-203; inclusive, Q2).
-// One wave per word: 64 lanes read 64 consecutive floats (256 B, coalesced), __ballot
-// gives the mask word.  Both signs come from the same read (fused green/red).
-// ------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_threshold(const float *__restrict__ dens, const Geom *__restrict__ gp,
-                                                   uint64_t *__restrict__ mask_pos, uint64_t *__restrict__ mask_neg,
-                                                   float cut_pos, float cut_neg, int row_words, int64_t words_per_plane) {
-    const int lane = lane_id();
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int nc = gp->ncrs[0], nr = gp->ncrs[1];
-    const int uc = gp->unique_ncrs[0], ur = gp->unique_ncrs[1];
-    for (int64_t w = wave; w < words_per_plane; w += n_waves) {
-        int wq = (int)(w % row_words);
-        int64_t row = w / row_words;
-        int r = (int)(row % ur);
-        int64_t s = row / ur;
-        int c = wq * 64 + lane;
-        bool in = c < uc;
-        float v = in ? dens[(s * nr + r) * nc + c] : 0.0f;
-        if (mask_pos) {
-            unsigned long long b = __ballot(in && v >= cut_pos);
-            if (lane == 0) mask_pos[w] = b;
-        }
-        if (mask_neg) {
-            unsigned long long b = __ballot(in && v <= cut_neg);
-            if (lane == 0) mask_neg[w] = b;
-        }
-    }
-}
 
 __device__ inline double wave_incl_scan(double x, int lane) {
 #pragma unroll

@@ -1,18 +1,20 @@
-// pdbeda_tile.h -- the whole-map fast path: one fused, LDS-tiled labelling kernel.
+// pdbeda_tile.h -- the whole-map fast path (pdbeda_full_blobs / pdbeda_full_blobs_pm).
 //
-// k_tile_label<CW> (one 256-thread workgroup per tile of CW words x 8 rows x 8 sections,
+// k_tile_label<CW, 512> (one 512-thread workgroup per tile of CW words x 8 rows x 8 sections,
 // i.e. up to 256 c x 8 r x 8 s = 16 Ki voxels):
-//   A  stream the tile's density once from HBM (coalesced 256-B wave loads, every value stays
-//      in a register), __ballot -> bit masks of both signs (fused green/red)
-//   B  per sign: runs of every word (bit tricks), run indexing by a block scan, 26-connected
-//      components INSIDE the tile with a lock-free union-find in LDS (ds atomic min)
-//   C  per sign: per-component fp64 sums (rho, rho*c, rho*r, rho*s), integer sums and the
-//      c-major first key accumulated with LDS atomics from the register-resident densities;
-//      one record per tile-local component is flushed to HBM.
-// Only components that touch a tile face are united globally (k_union_tiles), and only
-// non-root tile components need global atomics (k_resolve) -- two orders of magnitude fewer
-// than one per voxel / run.  A tile whose run or component count exceeds the LDS capacity
-// falls back to "unit mode" (every run its own component, united globally): slower, same result.
+//   A1 stream the tile's density once from HBM (coalesced 256-B wave loads), compare -> the compare
+//      masks ARE the wave ballots -> bit masks of both signs (fused green/red); the significant values
+//      are compacted into LDS
+//   A2 runs of every word (bit tricks), one block scan -> per-row run slots
+//   A3 exact fp64 (sum rho, sum rho*c) of every run, sequentially by the thread that owns its first word
+//   B  26-connected components INSIDE the tile: one two-pointer merge per (sign, row, earlier neighbour
+//      row) lists the touching run pairs; hook-and-jump rounds in LDS unite them (no returning atomics)
+//   C  per-component fp64 / integer sums and the c-major first key; one record per tile component is
+//      flushed to HBM, run -> component ids are published for the label writer.
+// Only component pairs that touch across a tile face are united globally (k_tile_edges ->
+// k_union_edges), and only non-root tile components cost global atomics (k_resolve_tiles, after an
+// LDS pre-reduction per tile).  A tile whose run or component count exceeds the LDS capacity falls
+// back to "unit mode" (k_unit_tiles: every run its own component, united globally): slower, same result.
 #pragma once
 #include "pdbeda_kernels.h"
 #include <type_traits>
@@ -64,34 +66,10 @@ __device__ inline uint32_t rank_below(const Job &job, int64_t key) {
     return job.chunk_prefix[kw / KEY_CHUNK] + job.key_rank[kw] + (uint32_t)popc64(job.key_bits[kw] & bits_below((int)(key & 63)));
 }
 
-// find with path halving: every visited node is re-pointed at its grandparent with a
-// fire-and-forget atomic min (monotone, so it can never undo a concurrent union).
-__device__ inline int lds_find(uint32_t *p, int x) {
-    int q;
-    while ((q = (int)p[x]) != x) {
-        const int gp = (int)p[q];
-        if (gp != q) atomicMin(&p[x], (uint32_t)gp);
-        x = gp;
-    }
-    return x;
-}
-__device__ inline void lds_unite(uint32_t *p, int a, int b) {
-    while (true) {
-        a = lds_find(p, a);
-        b = lds_find(p, b);
-        if (a == b) return;
-        if (a < b) { int t = a; a = b; b = t; }
-        const int old = (int)atomicMin(&p[a], (uint32_t)b);
-        if (old == a) return;
-        a = old;
-    }
-}
-
-// number of set bits of a wave-uniform 64-bit mask at lane positions <  / <= the calling lane
+// number of set bits of a wave-uniform 64-bit mask at lane positions < the calling lane
 __device__ inline uint32_t mbcnt_lt(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
-__device__ inline uint32_t mbcnt_le(uint64_t mask) { return mbcnt_lt(mask >> 1) + (uint32_t)(mask & 1ull); }
 
 // lane `sel` of `old` <- the wave-uniform value `sval` (v_writelane_b32; this clang has no builtin for it).
 // A select on `lane == sel` would do, but its 64-bit masks are loop invariant: hoisted, 16 of them spill the SGPRs.
@@ -99,15 +77,6 @@ __device__ inline uint32_t mbcnt_le(uint64_t mask) { return mbcnt_lt(mask >> 1) 
 __device__ __forceinline__ uint32_t wave_writelane(uint32_t old, uint32_t sval, int sel) {
     asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(__builtin_amdgcn_readfirstlane((int)sval)), "n"(sel));
     return old;
-}
-
-// lane i <- lane i+1 (lane 63 <- 0): whole-wave DPP shift, no LDS traffic (GFX9 / CDNA wave_shl:1)
-__device__ inline double wave_shl1(double x) {
-    union { double d; int i[2]; } u;
-    u.d = x;
-    u.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0x130, 0xf, 0xf, true);
-    u.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0x130, 0xf, 0xf, true);
-    return u.d;
 }
 
 // Tile t owns component ids [t * CCAP, (t+1) * CCAP) and run ids [t * runs_per_tile, ...): no
@@ -1041,57 +1010,6 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
     __syncthreads();
     if (member && leader == tid)
         fold((uint32_t)root, s_cnt[tid], s_f[0][tid], s_f[1][tid], s_f[2][tid], s_f[3][tid], s_i[0][tid], s_i[1][tid], s_i[2][tid], s_key[tid]);
-}
-
-// Signed dense labels of a whole-map job in ONE pass: 0 background, +1+k for blob k of the
-// ">= cutoff" list, -1-k for blob k of the "<= cutoff" list (4 B/voxel written once, also
-// for a fused green/red call).  Wave per 256-voxel row segment, 4 voxels per lane, 16-B stores.
-__global__ void __launch_bounds__(256) k_labels_signed(Job job, TileDims td, int32_t *__restrict__ labels) {
-    const int lane = lane_id();
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const VolDesc v0 = job.vols[0];
-    const int uc = v0.dim[0], row_words = v0.row_words;
-    const int segs_per_row = (row_words + 3) >> 2;
-    const int64_t rows = (int64_t)v0.dim[1] * v0.dim[2];
-    const int64_t n_seg = rows * segs_per_row;
-    const int64_t plane_words = (int64_t)row_words * rows;
-    for (int64_t sg = wave; sg < n_seg; sg += n_waves) {
-        const int64_t row = sg / segs_per_row;
-        const int seg = (int)(sg % segs_per_row);
-        const int wq = seg * 4 + (lane >> 4);
-        const int bit0 = (lane & 15) * 4;
-        int32_t out[4] = {0, 0, 0, 0};
-        if (wq < row_words) {
-            const int64_t w = row * row_words + wq;
-            for (int p = 0; p < td.n_planes; ++p) {
-                const uint64_t m = job.mask[w + p * plane_words];
-                const unsigned nib = (unsigned)((m >> bit0) & 0xfull);
-                if (!nib) continue;
-                const uint32_t base = job.run_base[w + p * plane_words];
-                const uint64_t starts = run_starts(m);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if ((nib >> q) & 1u) {
-                        const int stb = run_start_of(m, bit0 + q);
-                        const uint32_t run = base + (uint32_t)popc64(starts & bits_below(stb));
-                        out[q] = job.label_of_comp[job.comp_of_run ? job.comp_of_run[run] : run];
-                    }
-                }
-            }
-        }
-        const int c = wq * 64 + bit0;
-        int32_t *dst = labels + row * uc + c;
-        if (wq < row_words) {
-            if (c + 3 < uc && ((uc & 3) == 0)) {
-                *reinterpret_cast<int4 *>(dst) = make_int4(out[0], out[1], out[2], out[3]);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (c + q < uc) dst[q] = out[q];
-            }
-        }
-    }
 }
 
 // Signed labels, one workgroup per tile, all look-ups in LDS: the tile's label-of-component table
