@@ -490,7 +490,7 @@ extern "C" int pdbeda_xyz2crs(pdbeda_map *m, const double *xyz, int64_t n, int32
 // Carve a job out of an arena.  max_runs / max_blobs are worst-case bounds (a run needs a
 // gap: <= bits/2 + 1 per word; a blob owns >= one 2x2x2 cell... we simply bound blobs by runs).
 static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, int64_t total_keys, int64_t max_runs,
-                        int64_t max_blobs, size_t extra_labels, int32_t **labels_out, int64_t n_tiles = 0, int64_t edge_cap_override = 0) {
+                        int64_t max_blobs, size_t extra_labels, int32_t **labels_out, int64_t n_tiles = 0, int64_t edge_cap_override = 0, bool faces = false) {
     Carver cv(base);
     job.n_vols = n_vols;
     job.total_words = total_words;
@@ -509,6 +509,9 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.label_of_comp = n_tiles ? cv.take<int32_t>(max_runs) : nullptr;
     job.pair_filter_mask = n_tiles ? (1u << 18) - 1u : 0u;
     job.pair_filter = n_tiles ? cv.take<unsigned long long>((size_t)job.pair_filter_mask + 1) : nullptr;
+    job.face_runs = (n_tiles && faces) ? cv.take<uint32_t>((size_t)n_tiles * RCAP) : nullptr;
+    job.face_rows = (n_tiles && faces) ? cv.take<uint32_t>((size_t)n_tiles * 128) : nullptr;
+    job.edges_hold_comps = (n_tiles && faces) ? 1 : 0;
     job.unit_flag = n_tiles ? cv.take<uint32_t>(1) : nullptr;
     job.tile_mode = n_tiles ? cv.take<uint8_t>(n_tiles) : nullptr;
     job.tile_runs = n_tiles ? cv.take<uint32_t>(n_tiles) : nullptr;
@@ -620,14 +623,15 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
     const int64_t max_runs = tiles_pp * td.cw * 64 * 32 + (int64_t)((uc + 1) / 2) * ur * us * n_planes + 1;
     if (max_runs >= (1ll << 31)) return fail(ctx, PDBEDA_ERR_ARGUMENT, "grid too large");
 
+    const bool faces = td.ctiles == 1;   // rows fit one tile: cross-tile unions from the tiles' exported run lists
     Job job;
     memset(&job, 0, sizeof job);
-    size_t need = job_carve(job, nullptr, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, nullptr, tiles_pp, ctx->debug_edge_cap);
+    size_t need = job_carve(job, nullptr, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, nullptr, tiles_pp, ctx->debug_edge_cap, faces);
     Arena arena;
     int rc = arena_get(ctx, need, &arena);
     if (rc) return rc;
     int32_t *labels_dev = nullptr;
-    job_carve(job, arena.base, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, &labels_dev, tiles_pp, ctx->debug_edge_cap);
+    job_carve(job, arena.base, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, &labels_dev, tiles_pp, ctx->debug_edge_cap, faces);
     job.vol_sign[0] = td.sign[0];
     job.vol_sign[1] = td.sign[1];
     job.epoch = ctx->next_epoch++;
@@ -659,11 +663,14 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
         // unit tiles are rare; if one exists its interior words need the cross pairs too, which only the all-rows layout
         // visits -- that layout is also the general one for c-tiled (wider than 256) grids.  (A unit tile inside a narrow
         // grid is handled by a second, all-rows launch below, gated on the device-side unit-tile counter.)
-        const int all_rows = td.ctiles > 1 ? 1 : 0;
         const unsigned gx = grid_for((int64_t)ur * row_words, 256, 1ll << 30);
-        const unsigned gx1 = all_rows ? gx : grid_for((int64_t)((ur + 7) / 8) * 2 * row_words, 256, 1ll << 30);
-        hipLaunchKernelGGL(k_tile_edges, dim3((unsigned)((us + 7) / 8) * (gx + 7 * gx1), 1, n_planes), dim3(256), 0, st, job, td, all_rows);
-        if (!all_rows) hipLaunchKernelGGL(k_tile_edges_unit, dim3(gx, us, n_planes), dim3(256), 0, st, job, td);
+        if (faces) {
+            hipLaunchKernelGGL(k_face_merge, dim3((unsigned)tiles_pp), dim3(128), 0, st, job, td);
+            hipLaunchKernelGGL(k_tile_edges_unit, dim3(gx, us, n_planes), dim3(256), 0, st, job, td, 1);
+        } else {
+            // grids wider than one tile: the word-by-word enumeration over every row (it also covers unit tiles)
+            hipLaunchKernelGGL(k_tile_edges, dim3((unsigned)((us + 7) / 8) * (gx + 7 * gx), 1, n_planes), dim3(256), 0, st, job, td, 1);
+        }
     }
     { PROF(ctx, "k_union_edges"); hipLaunchKernelGGL(k_union_edges, dim3(32, ESHARDS), dim3(256), 0, st, job); }
     { PROF(ctx, "k_resolve"); hipLaunchKernelGGL(k_resolve_tiles, dim3((unsigned)tiles_pp + 64u), dim3(256), 0, st, job, (int)tiles_pp); }

@@ -54,6 +54,11 @@ struct Job {
     int32_t comps_are_runs;
     uint32_t *comp_of_run;
     int32_t *label_of_comp;   // final signed label of every component (whole-map jobs)
+    // tiles export their runs (start | end << 8 | tile component << 16, slot order = row order) and, per sign and row,
+    // first slot | count << 16: k_face_merge unites across tile faces by merging two such lists (grids <= 256 wide)
+    uint32_t *face_runs;               // [tile][RCAP]
+    uint32_t *face_rows;               // [tile][2][64]
+    int edges_hold_comps;              // the parked pairs are component ids (k_face_merge) / run ids (k_tile_edges)
     unsigned long long *pair_filter;   // lossy set of the component pairs already handed to the global union-find (0 = empty slot)
     uint32_t pair_filter_mask;         // slots - 1 (a power of two)
     uint32_t *unit_flag;      // == epoch iff some tile of THIS job fell back to unit mode (stale values of a recycled arena never match)
