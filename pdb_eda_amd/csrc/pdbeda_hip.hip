@@ -576,9 +576,12 @@ static pdbeda_bloblist *new_list(pdbeda_ctx *ctx, pdbeda_map *m) {
 #endif
 template <int CW>
 static void launch_tile_label(pdbeda_ctx *ctx, unsigned n_tiles, const Job &job, const float *dens, const Geom *geom_dev, const TileDims &td,
-                              const JobInit &init) {
+                              const JobInit &init, bool faces) {
     { PROF(ctx, "k_tile_label"); hipLaunchKernelGGL((k_tile_label<CW, PDBEDA_TILE_NT>), dim3(n_tiles), dim3(PDBEDA_TILE_NT), 0, ctx->stream, job, dens, geom_dev, td, init); }
-    { PROF(ctx, "k_unit_tiles"); hipLaunchKernelGGL((k_unit_tiles<CW>), dim3(n_tiles * 4), dim3(256), 0, ctx->stream, job, dens, geom_dev, td); }
+    // tiles that overflowed LDS (rare): with k_face_merge both unit-tile steps sit behind one launch, else the labelling step
+    // runs here and k_tile_edges (every row) unites their pairs
+    if (faces) { PROF(ctx, "k_unit_fallback"); hipLaunchKernelGGL((k_unit_fallback<CW>), dim3(512), dim3(256), 0, ctx->stream, job, dens, geom_dev, td); }
+    else { PROF(ctx, "k_unit_tiles"); hipLaunchKernelGGL((k_unit_tiles<CW>), dim3(n_tiles * 4), dim3(256), 0, ctx->stream, job, dens, geom_dev, td); }
 }
 
 static void launch_labels(pdbeda_ctx *ctx, const Job &job, const TileDims &td, int32_t *labels_dev) {
@@ -652,25 +655,18 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
     init.comps0 = (unsigned)(tiles_pp * CCAP);
     hipStream_t st = ctx->stream;
     switch (td.cw) {
-        case 1: launch_tile_label<1>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init); break;
-        case 2: launch_tile_label<2>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init); break;
-        case 3: launch_tile_label<3>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init); break;
-        default: launch_tile_label<4>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init); break;
+        case 1: launch_tile_label<1>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init, faces); break;
+        case 2: launch_tile_label<2>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init, faces); break;
+        case 3: launch_tile_label<3>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init, faces); break;
+        default: launch_tile_label<4>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init, faces); break;
     }
     const unsigned comp_grid = grid_for(max_runs, 256, 2048);
-    {
+    if (faces) {
+        PROF(ctx, "k_face_merge");
+        hipLaunchKernelGGL(k_face_merge, dim3((unsigned)tiles_pp), dim3(128), 0, st, job, td);
+    } else {
         PROF(ctx, "k_tile_edges");
-        // unit tiles are rare; if one exists its interior words need the cross pairs too, which only the all-rows layout
-        // visits -- that layout is also the general one for c-tiled (wider than 256) grids.  (A unit tile inside a narrow
-        // grid is handled by a second, all-rows launch below, gated on the device-side unit-tile counter.)
-        const unsigned gx = grid_for((int64_t)ur * row_words, 256, 1ll << 30);
-        if (faces) {
-            hipLaunchKernelGGL(k_face_merge, dim3((unsigned)tiles_pp), dim3(128), 0, st, job, td);
-            hipLaunchKernelGGL(k_tile_edges_unit, dim3(gx, us, n_planes), dim3(256), 0, st, job, td, 1);
-        } else {
-            // grids wider than one tile: the word-by-word enumeration over every row (it also covers unit tiles)
-            hipLaunchKernelGGL(k_tile_edges, dim3((unsigned)((us + 7) / 8) * (gx + 7 * gx), 1, n_planes), dim3(256), 0, st, job, td, 1);
-        }
+        hipLaunchKernelGGL(k_tile_edges, dim3(grid_for((int64_t)ur * row_words, 256, 1ll << 30), us, n_planes), dim3(256), 0, st, job, td);
     }
     { PROF(ctx, "k_union_edges"); hipLaunchKernelGGL(k_union_edges, dim3(32, ESHARDS), dim3(256), 0, st, job); }
     { PROF(ctx, "k_resolve"); hipLaunchKernelGGL(k_resolve_tiles, dim3((unsigned)tiles_pp + 64u), dim3(256), 0, st, job, (int)tiles_pp); }

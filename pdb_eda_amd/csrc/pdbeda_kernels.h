@@ -30,6 +30,7 @@ struct Counters {
     unsigned int n_comps;
     unsigned int n_edges;
     unsigned int n_blobs;
+    unsigned int barrier;        // arrivals at the grid barrier of k_unit_fallback
     unsigned int unit_tiles[3];  // whole-map tiles that fell back to unit mode: run slots / edge buffer / component table full
     unsigned long long n_voxels;
     long long total_words;

@@ -658,20 +658,19 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
 // QUARTER tile (16 rows: 4x the parallelism of the rare slow path); run / component ids come from the
 // global counters, above the per-tile ranges.
 template <int CW>
-__global__ void __launch_bounds__(256) k_unit_tiles(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td) {
+__device__ void unit_quarter_tile(const Job &job, const float *__restrict__ dens, const Geom *__restrict__ gp, const TileDims &td, int qt) {
     constexpr int QU = 16 * CW;   // units of a quarter tile
     __shared__ uint64_t s_m[64];
     __shared__ uint32_t s_off[64];
     __shared__ uint32_t s_rb, s_cb;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int t = blockIdx.x >> 2;
-    const int quarter = blockIdx.x & 3;
+    int t = qt >> 2;
+    const int quarter = qt & 3;
     const int ct = t % td.ctiles; t /= td.ctiles;
     const int rt = t % td.rtiles; t /= td.rtiles;
     const int st = t;
     const int w0 = ct * CW, r0 = rt * TILE_R, s0 = st * TILE_S;
-    if (*job.unit_flag != job.epoch) return;   // no unit tile in this job
-    if (job.tile_mode[tile_index(td, 0, w0, r0, s0)] == 0) return;
+    if (job.tile_mode[tile_index(td, 0, w0, r0, s0)] == 0) return;   // block-uniform
     const Geom &g = *gp;
     const int ur = g.unique_ncrs[1], us = g.unique_ncrs[2];
     const int row_words = (g.unique_ncrs[0] + 63) >> 6;
@@ -714,6 +713,12 @@ __global__ void __launch_bounds__(256) k_unit_tiles(Job job, const float *__rest
         }
         __syncthreads();
     }
+}
+
+template <int CW>
+__global__ void __launch_bounds__(256) k_unit_tiles(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td) {
+    if (*job.unit_flag != job.epoch) return;   // no unit tile in this job
+    unit_quarter_tile<CW>(job, dens, gp, td, (int)blockIdx.x);
 }
 
 // Cross-tile pairs of one mask word.  All global loads (the 13 neighbour masks and run bases)
@@ -816,31 +821,19 @@ __device__ inline void cross_tile_pairs(uint64_t m, uint32_t my_base, const NbWo
     }
 }
 
-// Thread per word: count the cross-tile run pairs; the block reserves space with ONE atomic on
-// its shard's counter (64 shards -> the allocation never serialises), then the pairs are written.
-// (If a shard is full its pairs are united on the spot -- slower, same result.)
-// Threads are laid out over the CANDIDATE rows only (grid.y = section, grid.z = sign): all rows of
-// a section that starts a tile layer, else the rows r % 8 in {0, 7} -- so every wave is dense with
-// tile-edge words.  Grids wider than 4 words (c tiles) and unit tiles need every row: `all_rows`.
-__global__ void __launch_bounds__(256) k_tile_edges(Job job, TileDims td, int all_rows) {
+// Grids wider than one tile (rows of more than 256 voxels): thread per mask word, every row (grid.y = section,
+// grid.z = sign).  The touching run pairs that cross a tile face -- and every pair of a unit tile -- are staged in
+// LDS; the block reserves space with ONE atomic on its shard's counter (64 shards: the allocation never serialises),
+// then the pairs are written for k_union_edges.  (If a shard is full its pairs are united on the spot.)
+// Narrower grids take k_face_merge instead.
+__global__ void __launch_bounds__(256) k_tile_edges(Job job, TileDims td) {
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const VolDesc v0 = job.vols[0];
-    // compact grid (no empty workgroups): per group of 8 sections, nb8 workgroups for the section that starts a tile
-    // layer (all rows) followed by nb1 workgroups for each of the other 7 (candidate rows only); all_rows: nb1 == nb8
-    const int plane = blockIdx.z, rw = v0.row_words;
-    const int nb8 = (int)(((int64_t)v0.dim[1] * rw + 255) / 256);
-    const int nb1 = all_rows ? nb8 : (int)(((int64_t)((v0.dim[1] + 7) / 8) * 2 * rw + 255) / 256);
-    const int grp = (int)blockIdx.x / (nb8 + 7 * nb1), off = (int)blockIdx.x % (nb8 + 7 * nb1);
-    const int sl = grp * 8 + (off < nb8 ? 0 : 1 + (off - nb8) / nb1);
-    const int bx = off < nb8 ? off : (off - nb8) % nb1;
-    if (sl >= v0.dim[2]) return;   // block-uniform
-    const int64_t j = (int64_t)bx * blockDim.x + tid;   // candidate word inside this section
-    const int64_t jr = j / rw;
-    int r;
-    if (all_rows || (sl & 7) == 0) r = (int)jr;
-    else r = (int)(jr >> 1) * 8 + ((jr & 1) ? 7 : 0);
+    const int plane = blockIdx.z, sl = blockIdx.y, rw = v0.row_words;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + tid;   // word inside this section
+    const int r = (int)(j / rw);
     const bool inside = r < v0.dim[1];
     const int64_t w = (int64_t)plane * rw * v0.dim[1] * v0.dim[2] + ((int64_t)sl * v0.dim[1] + (inside ? r : 0)) * rw + (j % rw);
     const uint64_t m = inside ? job.mask[w] : 0ull;
@@ -864,7 +857,7 @@ __global__ void __launch_bounds__(256) k_tile_edges(Job job, TileDims td, int al
     __syncthreads();
     const uint32_t tot = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
     if (tot == 0) return;  // block-uniform
-    const int shard = (blockIdx.x + 29 * blockIdx.z) % ESHARDS;
+    const int shard = (blockIdx.x + 7 * blockIdx.y + 29 * blockIdx.z) % ESHARDS;
     const uint32_t shard_cap = (uint32_t)(job.edge_cap / ESHARDS);
     if (tid == 0) s_base = atomicAdd(&job.edge_fill[shard], tot);
     __syncthreads();
@@ -980,28 +973,48 @@ __global__ void __launch_bounds__(128) k_face_merge(Job job, TileDims td) {
     }
 }
 
-// Companion launch of k_tile_edges for narrow grids: visits every row, but only does work for words of unit tiles
-// (rare), whose interior pairs no tile kernel united; rows the candidate layout already visited are skipped.
-// With k_face_merge (`faces` != 0) it owns EVERY pair that has a unit tile on either side, on all rows.
-__global__ void __launch_bounds__(256) k_tile_edges_unit(Job job, TileDims td, int faces) {
-    if (*job.unit_flag != job.epoch) return;   // no unit tile in this job (uniform: one scalar load)
-    const VolDesc v0 = job.vols[0];
-    const int sl = blockIdx.y, plane = blockIdx.z, rw = v0.row_words;
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = (int)(j / rw);
-    if (r >= v0.dim[1]) return;
-    const int wq = (int)(j % rw);
-    if (!faces) {
-        if (job.tile_mode[tile_index(td, 0, wq, r, sl)] == 0) return;
-        if (((sl & 7) == 0 && sl > 0) || (r & 7) == 0 || (r & 7) == 7) return;   // k_tile_edges' candidate rows
-    }
+// One mask word of the unit-tile companion of k_face_merge: it owns EVERY pair that has a unit tile on either side
+// (all rows), and unites on the spot.
+__device__ void unit_edges_word(const Job &job, const TileDims &td, const VolDesc &v0, int plane, int sl, int r, int wq) {
+    const int rw = v0.row_words;
     const int64_t w = (int64_t)plane * rw * v0.dim[1] * v0.dim[2] + ((int64_t)sl * v0.dim[1] + r) * rw + wq;
     const uint64_t m = job.mask[w];
     if (m == 0ull) return;
     NbWords nw;
     uint32_t my_base;
-    if (!load_cross_tile(job, td, w, m, nw, my_base, faces != 0)) return;
+    if (!load_cross_tile(job, td, w, m, nw, my_base, true)) return;
     cross_tile_pairs(m, my_base, nw, [&](uint32_t a, uint32_t b) { uf_unite(job.parent, (int)job.comp_of_run[a], (int)job.comp_of_run[b]); });
+}
+
+// The two unit-tile kernels behind ONE launch (the k_face_merge path): normally no tile overflowed and the kernel
+// exits on the epoch flag -- one launch floor instead of two.  Otherwise: label the unit tiles, grid barrier (the grid
+// is small enough to be co-resident on any occupancy: 512 workgroups), then unite every pair that has a unit tile on
+// either side.
+template <int CW>
+__global__ void __launch_bounds__(256) k_unit_fallback(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td) {
+    if (*job.unit_flag != job.epoch) return;
+    const int n_qt = td.ctiles * td.rtiles * td.stiles * 4;
+    for (int qt = blockIdx.x; qt < n_qt; qt += gridDim.x) {   // block-uniform trip count
+        unit_quarter_tile<CW>(job, dens, gp, td, qt);
+        __syncthreads();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();   // publish run bases / records / run -> component ids
+        atomicAdd(&job.ctr->barrier, 1u);
+        while (__hip_atomic_load(&job.ctr->barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) __builtin_amdgcn_s_sleep(8);
+        __threadfence();
+    }
+    __syncthreads();
+    const VolDesc v0 = job.vols[0];
+    const int64_t per_plane = (int64_t)v0.row_words * v0.dim[1] * v0.dim[2], total = per_plane * td.n_planes;
+    for (int64_t L = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; L < total; L += (int64_t)gridDim.x * blockDim.x) {
+        const int plane = (int)(L / per_plane);
+        const int64_t rem = L % per_plane;
+        const int wq = (int)(rem % v0.row_words);
+        const int64_t row = rem / v0.row_words;
+        unit_edges_word(job, td, v0, plane, (int)(row / v0.dim[1]), (int)(row % v0.dim[1]), wq);
+    }
 }
 
 // Thread per parked run pair: map to tile components, global union-find with device-scope atomics.
