@@ -49,7 +49,6 @@ def algorithmic_bytes(kernel, n_vox, n_planes):
     table = {
         "k_tile_label": 4 * n_vox + (8 + 4) * words,      # read the f32 grid once; write bit masks + run bases
         "k_labels_tiles": 4 * n_vox + (8 + 4) * words,    # write ONE signed int32 label volume; read masks + run bases
-        "k_tile_edges": (8 + 4) * words,                  # masks + run bases in (grids wider than one tile)
         "k_face_merge": 0,                                 # run lists of the rows on tile faces: KB per tile
         "k_union_edges": 0,                                # sparse (pairs << voxels): no per-voxel bytes
     }

@@ -576,12 +576,10 @@ static pdbeda_bloblist *new_list(pdbeda_ctx *ctx, pdbeda_map *m) {
 #endif
 template <int CW>
 static void launch_tile_label(pdbeda_ctx *ctx, unsigned n_tiles, const Job &job, const float *dens, const Geom *geom_dev, const TileDims &td,
-                              const JobInit &init, bool faces) {
+                              const JobInit &init) {
     { PROF(ctx, "k_tile_label"); hipLaunchKernelGGL((k_tile_label<CW, PDBEDA_TILE_NT>), dim3(n_tiles), dim3(PDBEDA_TILE_NT), 0, ctx->stream, job, dens, geom_dev, td, init); }
-    // tiles that overflowed LDS (rare): with k_face_merge both unit-tile steps sit behind one launch, else the labelling step
-    // runs here and k_tile_edges (every row) unites their pairs
-    if (faces) { PROF(ctx, "k_unit_fallback"); hipLaunchKernelGGL((k_unit_fallback<CW>), dim3(512), dim3(256), 0, ctx->stream, job, dens, geom_dev, td); }
-    else { PROF(ctx, "k_unit_tiles"); hipLaunchKernelGGL((k_unit_tiles<CW>), dim3(n_tiles * 4), dim3(256), 0, ctx->stream, job, dens, geom_dev, td); }
+    // tiles that overflowed LDS (rare): their labelling and their pairs sit behind one launch that normally exits at once
+    { PROF(ctx, "k_unit_fallback"); hipLaunchKernelGGL((k_unit_fallback<CW>), dim3(512), dim3(256), 0, ctx->stream, job, dens, geom_dev, td); }
 }
 
 static void launch_labels(pdbeda_ctx *ctx, const Job &job, const TileDims &td, int32_t *labels_dev) {
@@ -611,8 +609,8 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
     const size_t lab_elems = labels ? (size_t)keys_pp : 0;   // ONE signed volume, also for a fused call
 
     TileDims td;
-    td.cw = std::min(row_words, 4);
-    td.ctiles = (row_words + td.cw - 1) / td.cw;
+    td.ctiles = (row_words + 3) / 4;                      // tiles of at most 4 mask words (256 voxels) along c ...
+    td.cw = (row_words + td.ctiles - 1) / td.ctiles;      // ... of equal width: 5 words are 3 + 2, not 4 + 1
     td.rtiles = (ur + TILE_R - 1) / TILE_R;
     td.stiles = (us + TILE_S - 1) / TILE_S;
     td.n_planes = n_planes;
@@ -626,7 +624,7 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
     const int64_t max_runs = tiles_pp * td.cw * 64 * 32 + (int64_t)((uc + 1) / 2) * ur * us * n_planes + 1;
     if (max_runs >= (1ll << 31)) return fail(ctx, PDBEDA_ERR_ARGUMENT, "grid too large");
 
-    const bool faces = td.ctiles == 1;   // rows fit one tile: cross-tile unions from the tiles' exported run lists
+    const bool faces = true;   // cross-tile unions from the tiles' exported run lists (k_face_merge)
     Job job;
     memset(&job, 0, sizeof job);
     size_t need = job_carve(job, nullptr, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, nullptr, tiles_pp, ctx->debug_edge_cap, faces);
@@ -655,19 +653,13 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
     init.comps0 = (unsigned)(tiles_pp * CCAP);
     hipStream_t st = ctx->stream;
     switch (td.cw) {
-        case 1: launch_tile_label<1>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init, faces); break;
-        case 2: launch_tile_label<2>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init, faces); break;
-        case 3: launch_tile_label<3>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init, faces); break;
-        default: launch_tile_label<4>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init, faces); break;
+        case 1: launch_tile_label<1>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init); break;
+        case 2: launch_tile_label<2>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init); break;
+        case 3: launch_tile_label<3>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init); break;
+        default: launch_tile_label<4>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init); break;
     }
     const unsigned comp_grid = grid_for(max_runs, 256, 2048);
-    if (faces) {
-        PROF(ctx, "k_face_merge");
-        hipLaunchKernelGGL(k_face_merge, dim3((unsigned)tiles_pp), dim3(128), 0, st, job, td);
-    } else {
-        PROF(ctx, "k_tile_edges");
-        hipLaunchKernelGGL(k_tile_edges, dim3(grid_for((int64_t)ur * row_words, 256, 1ll << 30), us, n_planes), dim3(256), 0, st, job, td);
-    }
+    { PROF(ctx, "k_face_merge"); hipLaunchKernelGGL(k_face_merge, dim3((unsigned)tiles_pp), dim3(128), 0, st, job, td); }
     { PROF(ctx, "k_union_edges"); hipLaunchKernelGGL(k_union_edges, dim3(32, ESHARDS), dim3(256), 0, st, job); }
     { PROF(ctx, "k_resolve"); hipLaunchKernelGGL(k_resolve_tiles, dim3((unsigned)tiles_pp + 64u), dim3(256), 0, st, job, (int)tiles_pp); }
     { PROF(ctx, "k_paint_keys"); hipLaunchKernelGGL(k_paint_keys, dim3(comp_grid), dim3(256), 0, st, job); }

@@ -59,7 +59,7 @@ struct Job {
     // first slot | count << 16: k_face_merge unites across tile faces by merging two such lists (grids <= 256 wide)
     uint32_t *face_runs;               // [tile][RCAP]
     uint32_t *face_rows;               // [tile][2][64]
-    int edges_hold_comps;              // the parked pairs are component ids (k_face_merge) / run ids (k_tile_edges)
+    int edges_hold_comps;              // the parked pairs are component ids (k_face_merge), not run ids
     unsigned long long *pair_filter;   // lossy set of the component pairs already handed to the global union-find (0 = empty slot)
     uint32_t pair_filter_mask;         // slots - 1 (a power of two)
     uint32_t *unit_flag;      // == epoch iff some tile of THIS job fell back to unit mode (stale values of a recycled arena never match)
@@ -68,7 +68,7 @@ struct Job {
     uint32_t *tile_runs;      // per tile: number of word-runs (ids tile * runs_per_tile ...)
     double2 *run_sums;        // whole-map tiles: per run slot (sum rho, sum rho*(c - c_tile)), RCAP per tile
     unsigned long long *stamps;   // diagnostic builds (-DPDBEDA_STAMPS): 8 s_memtime stamps per tile
-    uint2 *edges;             // cross-tile run pairs parked by k_tile_edges (ESHARDS equal regions)
+    uint2 *edges;             // cross-tile component pairs parked by k_face_merge (ESHARDS equal regions)
     uint32_t *edge_fill;      // pairs written per region
     int64_t edge_cap;
     int32_t vol_sign[2];      // whole-map jobs: +1 / -1 list of volume p

@@ -11,10 +11,10 @@
 //      row) lists the touching run pairs; hook-and-jump rounds in LDS unite them (no returning atomics)
 //   C  per-component fp64 / integer sums and the c-major first key; one record per tile component is
 //      flushed to HBM, run -> component ids are published for the label writer.
-// Only component pairs that touch across a tile face are united globally (k_tile_edges ->
+// Only component pairs that touch across a tile face are united globally (k_face_merge ->
 // k_union_edges), and only non-root tile components cost global atomics (k_resolve_tiles, after an
 // LDS pre-reduction per tile).  A tile whose run or component count exceeds the LDS capacity falls
-// back to "unit mode" (k_unit_tiles: every run its own component, united globally): slower, same result.
+// back to "unit mode" (k_unit_fallback: every run its own component, united globally): slower, same result.
 #pragma once
 #include "pdbeda_kernels.h"
 #include <type_traits>
@@ -35,7 +35,7 @@ constexpr int tile_scratch_bytes(int nt) {
     return tile_eq(nt) * nt * 2 + RCAP * 2 > 4 * CCAP * 8 + 6 * CCAP * 4 ? tile_eq(nt) * nt * 2 + RCAP * 2 : 4 * CCAP * 8 + 6 * CCAP * 4;
 }
 
-constexpr int EDGE_Q = 16;   // cross-tile pairs one word stages in LDS (single enumeration pass; words of a tile-layer section have 9 neighbour words)
+constexpr int EDGE_Q = 16;   // cross-tile component pairs one k_face_merge thread stages in LDS (more are united on the spot)
 constexpr int ESHARDS = 64;  // cross-tile pair buffers (one allocation counter each: a single counter serialises at ~88 atomics/us)
 
 struct TileDims {
@@ -52,7 +52,7 @@ __host__ __device__ inline int64_t tile_index(const TileDims &td, int plane, int
 
 // What workgroup 0 of k_tile_label publishes for the later kernels of the job (descriptors by value: no host
 // staging buffer, no memset / init launch, no sync): the volume descriptors and the id counters.  Run / component
-// ids below runs0 / comps0 are owned tile by tile; k_unit_tiles allocates above them.
+// ids below runs0 / comps0 are owned tile by tile; k_unit_fallback allocates above them.
 struct JobInit {
     VolDesc v[2];
     unsigned int runs0, comps0;
@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
 
     if (n_slots == 0 || s_over) {
         // nothing significant, or too many runs for LDS: publish the masks; an overflowing tile
-        // is labelled by k_unit_tiles (every run its own component)
+        // is labelled by k_unit_fallback (every run its own component)
         if (my_valid) {
             job.mask[my_word] = m0;
             job.run_base[my_word] = 0u;
@@ -715,11 +715,6 @@ __device__ void unit_quarter_tile(const Job &job, const float *__restrict__ dens
     }
 }
 
-template <int CW>
-__global__ void __launch_bounds__(256) k_unit_tiles(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td) {
-    if (*job.unit_flag != job.epoch) return;   // no unit tile in this job
-    unit_quarter_tile<CW>(job, dens, gp, td, (int)blockIdx.x);
-}
 
 // Cross-tile pairs of one mask word.  All global loads (the 13 neighbour masks and run bases)
 // are issued up front and unconditionally -- one memory latency instead of one per neighbour --
@@ -821,74 +816,13 @@ __device__ inline void cross_tile_pairs(uint64_t m, uint32_t my_base, const NbWo
     }
 }
 
-// Grids wider than one tile (rows of more than 256 voxels): thread per mask word, every row (grid.y = section,
-// grid.z = sign).  The touching run pairs that cross a tile face -- and every pair of a unit tile -- are staged in
-// LDS; the block reserves space with ONE atomic on its shard's counter (64 shards: the allocation never serialises),
-// then the pairs are written for k_union_edges.  (If a shard is full its pairs are united on the spot.)
-// Narrower grids take k_face_merge instead.
-__global__ void __launch_bounds__(256) k_tile_edges(Job job, TileDims td) {
-    __shared__ uint32_t s_wsum[4];
-    __shared__ uint32_t s_base;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const VolDesc v0 = job.vols[0];
-    const int plane = blockIdx.z, sl = blockIdx.y, rw = v0.row_words;
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + tid;   // word inside this section
-    const int r = (int)(j / rw);
-    const bool inside = r < v0.dim[1];
-    const int64_t w = (int64_t)plane * rw * v0.dim[1] * v0.dim[2] + ((int64_t)sl * v0.dim[1] + (inside ? r : 0)) * rw + (j % rw);
-    const uint64_t m = inside ? job.mask[w] : 0ull;
-    NbWords nw;
-    uint32_t my_base = 0;
-    bool act = false;
-    if (m != 0ull) act = load_cross_tile(job, td, w, m, nw, my_base);
-    __shared__ uint2 s_stage[256 * EDGE_Q];   // pairs of the block, EDGE_Q per thread; a thread with more re-enumerates (rare)
-    uint32_t n = 0;
-    if (act) cross_tile_pairs(m, my_base, nw, [&](uint32_t a, uint32_t b) {
-        if (n < (uint32_t)EDGE_Q) s_stage[n * 256 + tid] = make_uint2(a, b);
-        ++n;
-    });
-    uint32_t x = n;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d);
-        if (lane >= d) x += y;
-    }
-    if (lane == 63) s_wsum[wv] = x;
-    __syncthreads();
-    const uint32_t tot = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-    if (tot == 0) return;  // block-uniform
-    const int shard = (blockIdx.x + 7 * blockIdx.y + 29 * blockIdx.z) % ESHARDS;
-    const uint32_t shard_cap = (uint32_t)(job.edge_cap / ESHARDS);
-    if (tid == 0) s_base = atomicAdd(&job.edge_fill[shard], tot);
-    __syncthreads();
-    uint32_t pre = 0;
-    for (int k = 0; k < wv; ++k) pre += s_wsum[k];
-    uint32_t i = s_base + pre + x - n;
-    if (!act || n == 0) return;
-    uint2 *dst = job.edges + (size_t)shard * shard_cap;
-    if (s_base + tot <= shard_cap) {
-        if (n <= (uint32_t)EDGE_Q) {
-            for (uint32_t e = 0; e < n; ++e) dst[i + e] = s_stage[e * 256 + tid];
-        } else {
-            cross_tile_pairs(m, my_base, nw, [&](uint32_t a, uint32_t b) { dst[i++] = make_uint2(a, b); });
-        }
-    } else {
-        // shard full: the block's range [s_base, s_base + tot) is written up to the capacity (k_union_edges reads
-        // min(fill, capacity) entries, so no slot below it may stay unwritten); the rest is united on the spot
-        cross_tile_pairs(m, my_base, nw, [&](uint32_t a, uint32_t b) {
-            if (i < shard_cap) dst[i] = make_uint2(a, b);
-            else uf_unite(job.parent, (int)job.comp_of_run[a], (int)job.comp_of_run[b]);
-            ++i;
-        });
-    }
-}
-
-// Cross-tile unions from the tiles' exported run lists (grids at most one tile wide along c): one thread per
+// Cross-tile unions from the tiles' exported run lists: one thread per
 // (tile, sign, row on a tile face, earlier neighbour row in ANOTHER tile) -- 46 such pairs of rows per tile -- merges
 // the two sorted run lists (a dozen two-pointer steps on LDS copies) and parks the distinct COMPONENT pairs in the
-// sharded buffers for k_union_edges.  Replaces the word-by-word enumeration of k_tile_edges there: ~10x fewer
+// sharded buffers for k_union_edges.  Replaces a word-by-word enumeration of 13 neighbour masks per word: ~10x fewer
 // instructions, no run -> component look-ups afterwards.  Lists of unit / empty tiles are empty (their companion
-// kernel unites those pairs).
+// kernel unites those pairs).  Grids wider than one tile add the c faces: first run of a row against the last runs
+// of the 9 rows around it in the tile to the left.
 constexpr int FACE_L = 16;   // runs of a row copied to LDS (longer rows read the rest from global memory)
 __global__ void __launch_bounds__(128) k_face_merge(Job job, TileDims td) {
     __shared__ uint32_t s_list[2][FACE_L][128];
@@ -897,7 +831,7 @@ __global__ void __launch_bounds__(128) k_face_merge(Job job, TileDims td) {
     const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6, t = lane;
     const VolDesc v0 = job.vols[0];
     const int ur = v0.dim[1], us = v0.dim[2];
-    const int tile = blockIdx.x, rt = tile % td.rtiles, st = tile / td.rtiles;
+    const int tile = blockIdx.x, ct = tile % td.ctiles, rt = (tile / td.ctiles) % td.rtiles, st = tile / (td.ctiles * td.rtiles);
     int rl = 0, sl = 0, dr = 0, ds = -1;
     bool task = q < td.n_planes;
     if (t < 8) { rl = 0; sl = t; dr = -1; ds = 0; }
@@ -911,7 +845,7 @@ __global__ void __launch_bounds__(128) k_face_merge(Job job, TileDims td) {
     if (r >= ur || s >= us || r2 < 0 || r2 >= ur || s2 < 0) task = false;
     uint32_t fa = 0, na = 0, fb = 0, nb = 0, tile_b = 0;
     if (task) {
-        tile_b = (uint32_t)((s2 >> 3) * td.rtiles + (r2 >> 3));
+        tile_b = (uint32_t)(((s2 >> 3) * td.rtiles + (r2 >> 3)) * td.ctiles + ct);   // the r / s faces join tiles of one c column
         const uint32_t ra = job.face_rows[((size_t)tile * 2 + q) * 64 + sl * TILE_R + rl];
         const uint32_t rb = job.face_rows[((size_t)tile_b * 2 + q) * 64 + (s2 & 7) * TILE_R + (r2 & 7)];
         fa = ra & 0xffffu; na = ra >> 16; fb = rb & 0xffffu; nb = rb >> 16;
@@ -949,8 +883,46 @@ __global__ void __launch_bounds__(128) k_face_merge(Job job, TileDims td) {
             if (adv_a) { if (++i == na) break; va = ea(i); }
             else { if (++j == nb) break; vb = eb(j); }
         }
-        if (n > (uint32_t)EDGE_Q) n = EDGE_Q;
     }
+    // c faces (grids wider than one tile): row `lane` of this tile starts with a run at position 0; the rows around it
+    // (9 offsets, itself included) in the tile to the LEFT may end with a run at that tile's last position -- they touch.
+    if (ct > 0 && q < td.n_planes) {
+        const int crl = lane & 7, csl = lane >> 3;
+        const int cr = rt * TILE_R + crl, cs = st * TILE_S + csl;
+        const uint32_t mine = (cr < ur && cs < us) ? job.face_rows[((size_t)tile * 2 + q) * 64 + lane] : 0u;
+        if ((mine >> 16) != 0u) {
+            const uint32_t first = job.face_runs[(size_t)tile * RCAP + (mine & 0xffffu)];
+            if ((first & 0xffu) == 0u) {
+                const uint32_t ca = (uint32_t)tile * CCAP + (first >> 16);
+                uint32_t rows9[9], tiles9[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const int r9 = cr + k % 3 - 1, s9 = cs + k / 3 - 1;
+                    const bool ok = r9 >= 0 && r9 < ur && s9 >= 0 && s9 < us;
+                    tiles9[k] = ok ? (uint32_t)(((s9 >> 3) * td.rtiles + (r9 >> 3)) * td.ctiles + ct - 1) : 0u;
+                    rows9[k] = ok ? job.face_rows[((size_t)tiles9[k] * 2 + q) * 64 + (s9 & 7) * TILE_R + (r9 & 7)] : 0u;
+                }
+                uint32_t last9[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    last9[k] = (rows9[k] >> 16) ? job.face_runs[(size_t)tiles9[k] * RCAP + (rows9[k] & 0xffffu) + (rows9[k] >> 16) - 1u] : 0u;
+                uint32_t last_b = ~0u;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    if ((rows9[k] >> 16) != 0u && ((last9[k] >> 8) & 0xffu) == (uint32_t)(td.cw * 64 - 1)) {
+                        const uint32_t cb = tiles9[k] * CCAP + (last9[k] >> 16);
+                        if (cb != last_b) {
+                            if (n < (uint32_t)EDGE_Q) s_stage[n][tid] = make_uint2(ca, cb);
+                            else uf_unite(job.parent, (int)ca, (int)cb);
+                            ++n;
+                            last_b = cb;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (n > (uint32_t)EDGE_Q) n = EDGE_Q;
     uint32_t x = n;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
