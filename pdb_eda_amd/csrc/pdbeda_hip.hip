@@ -614,6 +614,7 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
     td.rtiles = (ur + TILE_R - 1) / TILE_R;
     td.stiles = (us + TILE_S - 1) / TILE_S;
     td.n_planes = n_planes;
+    td.uc = uc; td.ur = ur; td.us = us; td.row_words = row_words;
     td.cut[0] = want_pos ? cut_pos : cut_neg;
     td.sign[0] = want_pos ? 1 : -1;
     td.cut[1] = cut_neg;

@@ -42,6 +42,7 @@ struct TileDims {
     int cw;                       // words per tile along c (1..4)
     int ctiles, rtiles, stiles;   // tile grid
     int n_planes;
+    int uc, ur, us, row_words;    // the unique box (a copy of the volume descriptor: kernel argument, not a dependent load)
     float cut[2];                 // threshold of plane p
     int sign[2];                  // +1: density >= cut, -1: density <= cut
 };
@@ -829,8 +830,7 @@ __global__ void __launch_bounds__(128) k_face_merge(Job job, TileDims td) {
     __shared__ uint2 s_stage[EDGE_Q][128];
     __shared__ uint32_t s_wsum[2], s_base;
     const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6, t = lane;
-    const VolDesc v0 = job.vols[0];
-    const int ur = v0.dim[1], us = v0.dim[2];
+    const int ur = td.ur, us = td.us;
     const int tile = blockIdx.x, ct = tile % td.ctiles, rt = (tile / td.ctiles) % td.rtiles, st = tile / (td.ctiles * td.rtiles);
     int rl = 0, sl = 0, dr = 0, ds = -1;
     bool task = q < td.n_planes;
@@ -1124,8 +1124,7 @@ __global__ void __launch_bounds__(256) k_labels_tiles(Job job, TileDims td, int3
     __shared__ uint64_t s_m[2][256];
     __shared__ uint32_t s_rb[2][256];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const VolDesc v0 = job.vols[0];
-    const int uc = v0.dim[0], ur = v0.dim[1], us = v0.dim[2], row_words = v0.row_words;
+    const int uc = td.uc, ur = td.ur, us = td.us, row_words = td.row_words;
     int t = blockIdx.x;
     const int ct = t % td.ctiles; t /= td.ctiles;
     const int rt = t % td.rtiles; t /= td.rtiles;
