@@ -122,6 +122,10 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as entry
+    if world > 1:                 # one rank compiles (if anything is stale), the others wait and then only load
+        if rank == 0:
+            entry.build()
+        dist.barrier()
     entry.build()
     from pdb_eda_amd import _native, ccp4, synthetic
 
