@@ -15,6 +15,7 @@ Load the reference's ``conf/optimized_params.json`` (or your own) with :func:`lo
 import collections
 import gzip
 import json
+import math
 import os
 
 import numpy as np
@@ -124,6 +125,11 @@ class SymAtom(object):
 
     def __getattr__(self, attr):
         return getattr(self.atom, attr)
+
+
+def _norm3(x):
+    """np.linalg.norm of a 1-D float64 vector, as numpy computes it (sqrt(x.dot(x))), without the dispatch overhead."""
+    return math.sqrt(float(x.dot(x)))
 
 
 def _crs_keys(crs):
@@ -281,12 +287,16 @@ class DensityAnalysis(object):
             by_coord[tuple(atom.coord)] = ai
         src = [by_coord[tuple(atom.coord)] for _, atom, _ in elig]
 
-        def atom_cloud_distances(ai):
-            s = src[ai]
-            cen = cst["centroid"][first_cloud[s]:last_cloud[s]]
-            return np.linalg.norm(elig[ai][1].coord - cen, axis=1) if len(cen) else np.zeros(0)
-
-        centroidDistances = [atom_cloud_distances(ai).min() for ai in range(len(elig)) if last_cloud[src[ai]] > first_cloud[src[ai]]]
+        # distance of every cloud centroid to its atom, all atoms at once: the same row-wise float64 arithmetic as the
+        # reference's per-atom np.linalg.norm(coord - centroids, axis=1) (float32 coordinates promote exactly)
+        cloud_dist = np.linalg.norm(xyz[cgroup] - cst["centroid"], axis=1) if len(cgroup) else np.zeros(0)
+        src = np.asarray(src, dtype=np.int64)
+        has_cloud = last_cloud[src] > first_cloud[src]
+        min_dist = np.full(len(elig), np.nan)
+        owners_with = np.nonzero(last_cloud > first_cloud)[0]
+        if len(owners_with):
+            min_dist[owners_with] = np.minimum.reduceat(cloud_dist, first_cloud[owners_with])
+        centroidDistances = min_dist[src][has_cloud]
         centroidDistanceCutoff = np.nanmedian(centroidDistances) + 2.5 * np.nanstd(centroidDistances)
 
         # pass 2: best cloud per atom, pooled clouds per residue
@@ -303,11 +313,9 @@ class DensityAnalysis(object):
             if hi - lo == 1:
                 best = lo
             else:
-                distances = atom_cloud_distances(ai)
-                minDistance = distances.min()
-                if minDistance > centroidDistanceCutoff:
+                if min_dist[s] > centroidDistanceCutoff:
                     continue
-                best = lo + int(np.argmin(distances))
+                best = lo + int(np.argmin(cloud_dist[lo:hi]))
             res_atom_clouds[ri][resAtom] = list(range(len(pool_cloud), len(pool_cloud) + (hi - lo)))
             for ci in range(lo, hi):
                 pool_cloud.append(ci)
@@ -317,7 +325,7 @@ class DensityAnalysis(object):
             centroid = list(cst["centroid"][best])
             atomList.append([residue.parent.id, residue.id[1], atom.parent.resname, atom.name, typeMap[resAtom],
                              cst["totalDensity"][best] / electronsMap[resAtom] / atom.get_occupancy(), int(cst["n"][best]),
-                             electronsMap[resAtom], atom.get_bfactor(), np.linalg.norm(atom.coord - np.asarray(centroid)), centroid])
+                             electronsMap[resAtom], atom.get_bfactor(), _norm3(atom.coord - cst["centroid"][best]), centroid])
         if not pool_cloud:
             return
         pool_cloud = np.asarray(pool_cloud)
@@ -496,15 +504,17 @@ class DensityAnalysis(object):
         rot = np.array([np.asarray(m, dtype=np.float64) for m in self.pdbObj.header.rotationMats])
         idx, sym, xyz = densityObj._ctx.symmetry_atoms(coords, rot, np.asarray(header.orthoMat, dtype=np.float64), lo, hi)
         allAtoms = []
-        for a, s4, x in zip(idx, sym, xyz):
-            s4 = tuple(int(v) for v in s4)
-            allAtoms.append(SymAtom(atoms[a], atoms[a].coord if s4 == (0, 0, 0, 0) else x, s4))
+        identity = (0, 0, 0, 0)
+        for a, s4, x in zip(idx.tolist(), map(tuple, sym.tolist()), xyz):
+            allAtoms.append(SymAtom(atoms[a], atoms[a].coord if s4 == identity else x, s4))
+        ident = ~np.any(sym != 0, axis=1)
+        allCoords = np.where(ident[:, None], coords[idx], xyz)      # == np.asarray([atom.coord ...]): float32 coordinates promote exactly
         self._symmetryAtoms = allAtoms
-        self._symmetryAtomCoords = np.asarray([atom.coord for atom in allAtoms])
-        self._symmetryOnlyAtoms = [atom for atom in allAtoms if atom.symmetry != (0, 0, 0, 0)]
-        self._symmetryOnlyAtomCoords = np.asarray([atom.coord for atom in self._symmetryOnlyAtoms])
-        self._asymmetryAtoms = [atom for atom in allAtoms if atom.symmetry == (0, 0, 0, 0)]
-        self._asymmetryAtomCoords = np.asarray([atom.coord for atom in self._asymmetryAtoms])
+        self._symmetryAtomCoords = allCoords
+        self._symmetryOnlyAtoms = [atom for atom, i in zip(allAtoms, ident.tolist()) if not i]
+        self._symmetryOnlyAtomCoords = allCoords[~ident]
+        self._asymmetryAtoms = [atom for atom, i in zip(allAtoms, ident.tolist()) if i]
+        self._asymmetryAtomCoords = allCoords[ident]
 
     # ---- blob statistics (ref densityAnalysis.py:914-939) --------------------------------------
     def calculateAtomSpecificBlobStatistics(self, blobList):
