@@ -662,7 +662,7 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
     const unsigned comp_grid = grid_for(max_runs, 256, 2048);
     { PROF(ctx, "k_face_merge"); hipLaunchKernelGGL(k_face_merge, dim3((unsigned)tiles_pp), dim3(128), 0, st, job, td); }
     { PROF(ctx, "k_union_edges"); hipLaunchKernelGGL(k_union_edges, dim3(32, ESHARDS), dim3(256), 0, st, job); }
-    { PROF(ctx, "k_resolve"); hipLaunchKernelGGL(k_resolve_tiles, dim3((unsigned)tiles_pp + 64u), dim3(256), 0, st, job, (int)tiles_pp); }
+    { PROF(ctx, "k_resolve_tiles"); hipLaunchKernelGGL(k_resolve_tiles, dim3((unsigned)tiles_pp + 64u), dim3(256), 0, st, job, (int)tiles_pp); }
     { PROF(ctx, "k_paint_keys"); hipLaunchKernelGGL(k_paint_keys, dim3(comp_grid), dim3(256), 0, st, job); }
     { PROF(ctx, "k_key_chunks"); hipLaunchKernelGGL(k_key_chunks, dim3(job.n_chunks), dim3(KEY_CHUNK), 0, st, job); }
     { PROF(ctx, "k_chunk_scan"); hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, st, job); }
