@@ -521,16 +521,16 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
                 }
                 __syncthreads();
                 // flatten: every used slot points at its root again (chains are as long as the hooks of this round)
-#pragma unroll
-                for (int t = 0; t < SLOTS; ++t) {
-                    if (ji[t] != 0xffffffffu) {
-                        uint32_t x = s_parent[ji[t]], y = s_parent[x];
-                        if (x != y) {
-                            while (x != y) { x = y; y = s_parent[x]; }
-                            s_parent[ji[t]] = (uint16_t)x;
-                        }
+                auto flatten = [&](uint32_t slot) {
+                    if (slot == 0xffffffffu) return;
+                    uint32_t x = s_parent[slot], y = s_parent[x];
+                    if (x != y) {
+                        while (x != y) { x = y; y = s_parent[x]; }
+                        s_parent[slot] = (uint16_t)x;
                     }
-                }
+                };
+                static_assert(SLOTS == 3, "three run slots per thread");
+                flatten(ji[0]); flatten(ji[1]); flatten(ji[2]);
                 // (the barrier at the top of the loop orders these writes before the next round's reads, and the
                 //  s_changed reset after everybody's read above)
             }
