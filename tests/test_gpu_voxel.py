@@ -376,6 +376,37 @@ def test_protein_like_map_vs_oracle(gpu_ctx, nsd):
     assert np.array_equal(red.stats()["n"], wr["n"])
 
 
+def test_shapes_fuzz(gpu_ctx):
+    """Seeded sweep over grid shapes and cutoffs: partial tiles on every axis, 1 .. 5 mask words per row (one, two and
+    three tiles along c of equal and unequal width), one-sign and fused jobs, labels on -- all against the oracle."""
+    from oracle import oracle as ora
+    from pdb_eda_amd import synthetic
+    rng = np.random.default_rng(20240607)
+    widths = [1, 7, 63, 64, 65, 100, 129, 192, 200, 256, 257, 300, 320, 321, 400, 513]
+    for k in range(36):
+        nc = int(widths[k % len(widths)])
+        nr = int(rng.integers(1, 41))
+        ns = int(rng.integers(1, 41 if nc < 300 else 21))
+        nsd = float(rng.choice([0.6, 1.0, 1.5, 2.5]))
+        g = synthetic.smooth_noise((ns, nr, nc), 100 + k, float(rng.choice([0.8, 1.5, 2.5])))
+        dm = _dm(g, gpu_ctx)
+        o = ora.Oracle(dm.header, g)
+        cut = dm.meanDensity + nsd * dm.stdDensity
+        if not np.isfinite(cut) or cut <= 0:
+            continue
+        lists = dm._map.full_blobs_pm(cut, -cut, labels=True) if k % 3 else (dm._map.full_blobs(cut, labels=True), dm._map.full_blobs(-cut, labels=True))
+        for bl, c in zip(lists, (cut, -cut)):
+            want = o.full_blobs(c, labels=True)
+            st = bl.stats()
+            assert np.array_equal(st["n"], want["n"]), (k, (ns, nr, nc), nsd)
+            assert np.array_equal(st["firstKey"], want["firstKey"]), (k, (ns, nr, nc), nsd)
+            assert np.allclose(st["totalDensity"], want["totalDensity"], rtol=REL), (k, (ns, nr, nc), nsd)
+            assert np.allclose(st["centroid"], want["centroid"], rtol=REL, atol=1e-9), (k, (ns, nr, nc), nsd)
+            assert np.array_equal(bl.labels(dm._map.unique_shape), want["labels"]), (k, (ns, nr, nc), nsd)
+        for bl in lists:
+            bl.free()
+
+
 def test_full_size_properties(gpu_ctx):
     """BASELINE config 2 size (256^3): size-independent properties + oracle equality."""
     from oracle import oracle as ora
