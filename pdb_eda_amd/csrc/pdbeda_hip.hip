@@ -579,7 +579,9 @@ static void launch_tile_label(pdbeda_ctx *ctx, unsigned n_tiles, const Job &job,
                               const JobInit &init) {
     { PROF(ctx, "k_tile_label"); hipLaunchKernelGGL((k_tile_label<CW, PDBEDA_TILE_NT>), dim3(n_tiles), dim3(PDBEDA_TILE_NT), 0, ctx->stream, job, dens, geom_dev, td, init); }
     // tiles that overflowed LDS (rare): their labelling and their pairs sit behind one launch that normally exits at once
-    { PROF(ctx, "k_unit_fallback"); hipLaunchKernelGGL((k_unit_fallback<CW>), dim3(512), dim3(256), 0, ctx->stream, job, dens, geom_dev, td); }
+    // (128 workgroups: its grid barrier needs the whole grid resident; a device holds >= 1280 such workgroups, so ten streams can
+    //  sit in their barriers at once without starving each other of slots)
+    { PROF(ctx, "k_unit_fallback"); hipLaunchKernelGGL((k_unit_fallback<CW>), dim3(128), dim3(256), 0, ctx->stream, job, dens, geom_dev, td); }
 }
 
 static void launch_labels(pdbeda_ctx *ctx, const Job &job, const TileDims &td, int32_t *labels_dev) {

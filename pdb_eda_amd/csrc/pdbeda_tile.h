@@ -960,7 +960,7 @@ __device__ void unit_edges_word(const Job &job, const TileDims &td, const VolDes
 
 // The two unit-tile kernels behind ONE launch (the k_face_merge path): normally no tile overflowed and the kernel
 // exits on the epoch flag -- one launch floor instead of two.  Otherwise: label the unit tiles, grid barrier (the grid
-// is small enough to be co-resident on any occupancy: 512 workgroups), then unite every pair that has a unit tile on
+// is small enough to be co-resident many times over: 128 workgroups, so concurrent streams cannot deadlock each other), then unite every pair that has a unit tile on
 // either side.
 template <int CW>
 __global__ void __launch_bounds__(256) k_unit_fallback(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td) {
