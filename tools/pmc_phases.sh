@@ -8,4 +8,4 @@ for k in S11 S1 S2 main; do
   PDBEDA_LIB=$lib rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $out/$k -o p -- python3 $root/tools/profile_step.py > $out/$k.log 2>&1 || echo "fail $k"
 done
 cd $root
-python3 tools/pmc_summary.py $out/S11 $out/S1 $out/S2 $out/main 2>&1 | grep -E "pmc_ph|Counter|k_tile_label|k_tile_edges|k_union|k_resolve|k_labels"
+python3 tools/pmc_summary.py $out/S11 $out/S1 $out/S2 $out/main 2>&1 | grep -E "pmc_ph|Counter|k_tile_label|k_face_merge|k_union|k_resolve|k_labels"
