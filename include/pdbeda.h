@@ -82,6 +82,11 @@ int pdbeda_map_upload(pdbeda_ctx *ctx, const float *density, const pdbeda_geomet
 /* density_dev: a device pointer the caller keeps alive (zero-copy, e.g. a torch tensor). */
 int pdbeda_map_from_device(pdbeda_ctx *ctx, const float *density_dev, const pdbeda_geometry *geom, pdbeda_map **out);
 int pdbeda_map_free(pdbeda_map *map);
+/* A new map on the geometry of `a` with density  float32( double(a) + alpha * double(b) )  per voxel -- the Fc map of
+ * DensityAnalysis.fc is (2Fo-Fc) - 2 (Fo-Fc), densityAnalysis.py:426-435 (alpha = -2).  Same grid shape required. */
+int pdbeda_map_combine(pdbeda_map *a, pdbeda_map *b, double alpha, pdbeda_map **out);
+/* Copy the float32 grid [ns][nr][nc] back to the host (inspection; DensityMatrix.density of a derived map). */
+int pdbeda_map_download(pdbeda_map *map, float *density_out);
 
 /* ---- whole-map reductions --------------------------------------------------------- */
 /* DensityMatrix.meanDensity / stdDensity: np.mean / np.std (population) over ALL stored

@@ -66,6 +66,8 @@ _SIGS = {
     "pdbeda_map_upload": (C.c_int, [_p, _p, C.POINTER(Geometry), C.POINTER(_p)]),
     "pdbeda_map_from_device": (C.c_int, [_p, _p, C.POINTER(Geometry), C.POINTER(_p)]),
     "pdbeda_map_free": (C.c_int, [_p]),
+    "pdbeda_map_combine": (C.c_int, [_p, _p, C.c_double, C.POINTER(_p)]),
+    "pdbeda_map_download": (C.c_int, [_p, _p]),
     "pdbeda_map_stats": (C.c_int, [_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pdbeda_sum_of_abs": (C.c_int, [_p, C.c_float, C.POINTER(C.c_double)]),
     "pdbeda_point_density": (C.c_int, [_p, _p, _i64, _p]),
@@ -299,6 +301,23 @@ class DeviceMap(object):
         ctx.check(rc, "pdbeda_map_upload")
         self._h = h
         self.unique_shape = tuple(min(geometry.ncrs[k], geometry.xyz_interval[geometry.map2crs[k]]) for k in (2, 1, 0))
+
+    @classmethod
+    def combine(cls, a, b, alpha):
+        """A new resident map: float32(double(a) + alpha * double(b)) per voxel, on the geometry of ``a`` (device side)."""
+        self = cls.__new__(cls)
+        self._ctx, self._geom, self._keep, self.unique_shape = a._ctx, a._geom, None, a.unique_shape
+        h = C.c_void_p()
+        a._ctx.check(a._ctx._lib.pdbeda_map_combine(a._h, b._h, C.c_double(alpha), C.byref(h)), "pdbeda_map_combine")
+        self._h = h
+        return self
+
+    def download(self):
+        """The float32 grid [ns][nr][nc] copied back to the host."""
+        g = self._geom
+        out = np.empty((g.ncrs[2], g.ncrs[1], g.ncrs[0]), dtype=np.float32)
+        self._ctx.check(self._ctx._lib.pdbeda_map_download(self._h, _ptr(out)), "pdbeda_map_download")
+        return out
 
     # -- reductions ------------------------------------------------------------------
     def stats(self):

@@ -191,6 +191,19 @@ class DensityMatrix(object):
     computes from it; all methods call the C-ABI.
     """
 
+    @classmethod
+    def fromDeviceMap(cls, header, origin, device_map, pdbid, ctx):
+        """A DensityMatrix around a map that already lives in HBM (e.g. ``DeviceMap.combine``); ``density`` is downloaded
+        once, for inspection."""
+        self = cls.__new__(cls)
+        self.pdbid, self.header, self.origin = pdbid, header, origin
+        self._ctx, self._map = ctx, device_map
+        self.density = device_map.download()
+        self.densityArray = self.density.reshape(-1)
+        self._meanDensity = self._stdDensity = None
+        self._totalAbsDensity = {}
+        return self
+
     def __init__(self, header, origin, density, pdbid, ctx=None):
         self.pdbid = pdbid
         self.header = header

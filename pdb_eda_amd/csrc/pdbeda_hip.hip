@@ -351,6 +351,49 @@ extern "C" int pdbeda_map_from_device(pdbeda_ctx *ctx, const float *density_dev,
     return map_create(ctx, nullptr, density_dev, geom, out);
 }
 
+extern "C" int pdbeda_map_combine(pdbeda_map *a, pdbeda_map *b, double alpha, pdbeda_map **out) {
+    if (!a || !b || !out) return PDBEDA_ERR_ARGUMENT;
+    *out = nullptr;
+    pdbeda_ctx *ctx = a->ctx;
+    if (b->ctx != ctx) return fail(ctx, PDBEDA_ERR_ARGUMENT, "maps of different contexts");
+    if (a->n_vox != b->n_vox || memcmp(a->geom.ncrs, b->geom.ncrs, sizeof a->geom.ncrs) != 0)
+        return fail(ctx, PDBEDA_ERR_ARGUMENT, "maps of different shapes");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    pdbeda_map *m = new pdbeda_map();
+    m->ctx = ctx;
+    m->geom = a->geom;
+    m->n_vox = a->n_vox;
+    float *d = nullptr;
+    hipError_t e = hipMalloc((void **)&m->geom_dev, sizeof(Geom));
+    if (e == hipSuccess) e = hipMalloc((void **)&d, sizeof(float) * (size_t)m->n_vox);
+    if (e == hipSuccess) e = hipMemcpyAsync(m->geom_dev, &m->geom, sizeof(Geom), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_map_combine, dim3(grid_for(m->n_vox / 4 + 1, 256, 4096)), dim3(256), 0, ctx->stream, a->dens, b->dens, alpha, m->n_vox, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // (&m->geom is read by the copy above)
+    if (e != hipSuccess) {
+        if (d) (void)hipFree(d);
+        if (m->geom_dev) (void)hipFree(m->geom_dev);
+        delete m;
+        return fail(ctx, PDBEDA_ERR_DEVICE, "map combine: %s", hipGetErrorString(e));
+    }
+    m->dens = d;
+    m->own_dens = true;
+    ctx->live_handles++;
+    *out = m;
+    return PDBEDA_OK;
+}
+
+extern "C" int pdbeda_map_download(pdbeda_map *m, float *density_out) {
+    if (!m || !density_out) return PDBEDA_ERR_ARGUMENT;
+    pdbeda_ctx *ctx = m->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(density_out, m->dens, sizeof(float) * (size_t)m->n_vox, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PDBEDA_OK;
+}
+
 extern "C" int pdbeda_map_free(pdbeda_map *m) {
     if (!m) return PDBEDA_ERR_ARGUMENT;
     pdbeda_ctx *ctx = m->ctx;

@@ -721,6 +721,25 @@ __global__ void __launch_bounds__(256) k_region_reduce(const Geom *__restrict__ 
     }
 }
 
+// out = float32(double(a) + alpha * double(b)), float4 per thread (the Fc map: alpha = -2).
+__global__ void __launch_bounds__(256) k_map_combine(const float *__restrict__ a, const float *__restrict__ b, double alpha, int64_t n,
+                                                     float *__restrict__ out) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 x = reinterpret_cast<const float4 *>(a)[i], y = reinterpret_cast<const float4 *>(b)[i];
+        float4 r;
+        r.x = (float)((double)x.x + alpha * (double)y.x);
+        r.y = (float)((double)x.y + alpha * (double)y.y);
+        r.z = (float)((double)x.z + alpha * (double)y.z);
+        r.w = (float)((double)x.w + alpha * (double)y.w);
+        reinterpret_cast<float4 *>(out)[i] = r;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        out[i] = (float)((double)a[i] + alpha * (double)b[i]);
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // Whole-map reductions.  Deterministic two-stage fp64 sums: a fixed grid writes one
 // partial per block, a single block folds the partials in index order.

@@ -547,13 +547,13 @@ class DensityAnalysis(object):
 
         Reference behaviour kept on purpose: the reference makes a ``deepcopy`` of the 2Fo-Fc object and replaces only
         ``.density`` -- ``densityArray`` and the cached ``meanDensity`` / ``stdDensity`` / ``getTotalAbsDensity`` stay those
-        of the Fo map (golden ``fc_mean_std``).  The device copy of the grid is float32 (the reference's is float64):
+        of the Fo map (golden ``fc_mean_std``).  The grid is computed on the device (``pdbeda_map_combine``) and stored as
+        float32 (the reference's is float64):
         the metrics below therefore take Fc voxel values as ``fo - 2 * diff`` in float64 from the two gathered float32
         values, which is exact."""
         if self._fc is None:
             d = self.densityObj
-            grid = d.density.astype(np.float64) - self.diffDensityObj.density.astype(np.float64) * 2
-            fc = ccp4.DensityMatrix(d.header, d.origin, grid.astype(np.float32), d.pdbid, ctx=d._ctx)
+            fc = ccp4.DensityMatrix.fromDeviceMap(d.header, d.origin, type(d._map).combine(d._map, self.diffDensityObj._map, -2.0), d.pdbid, d._ctx)
             fc.densityArray = d.densityArray
             fc._meanDensity, fc._stdDensity = d.meanDensity, d.stdDensity
             fc._totalAbsDensity = d._totalAbsDensity

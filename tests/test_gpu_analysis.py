@@ -123,6 +123,10 @@ def test_rscc_rsr_metrics(analysis):
     assert np.allclose(an.medianAbsFoFc(), z["median_abs_fo_fc"], rtol=1e-9)
     fc = an.fc
     assert np.allclose([fc.meanDensity, fc.stdDensity], z["fc_mean_std"], rtol=1e-9)    # the reference's Fc keeps the Fo statistics
+    want_fc = (z["dens"].astype(np.float64) - 2 * z["diff"].astype(np.float64)).astype(np.float32)
+    assert np.array_equal(fc.density, want_fc)                                            # computed on the device, bit for bit
+    crs0 = [[3, 4, 5], [10, 2, 7]]
+    assert np.array_equal(fc._map.point_density(crs0), [float(want_fc[5, 4, 3]), float(want_fc[7, 2, 10])])
     # one explicit voxel set through the single-set entry point == the batched path
     atom = an.asymmetryAtoms[3]
     crs = an.densityObj.getSphereCrsFromXyz(atom.coord, an._metricsRadius(), 0.0)
