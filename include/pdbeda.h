@@ -85,6 +85,13 @@ int pdbeda_map_free(pdbeda_map *map);
 /* A new map on the geometry of `a` with density  float32( double(a) + alpha * double(b) )  per voxel -- the Fc map of
  * DensityAnalysis.fc is (2Fo-Fc) - 2 (Fo-Fc), densityAnalysis.py:426-435 (alpha = -2).  Same grid shape required. */
 int pdbeda_map_combine(pdbeda_map *a, pdbeda_map *b, double alpha, pdbeda_map **out);
+/* One digit of a radix select over the voxels of the unique box with |a| < cut_a and |a + alpha b| < cut_b (b may be NULL:
+ * then only the first test applies and which must be 0): the 65536-bin histogram of bits [shift, shift+16) of the key of the
+ * voxels whose key agrees with `prefix` on `prefix_mask`.  key = bits of float |a| (which = 0, 32 bits) or of double
+ * |a + alpha b| (which = 1, 64 bits) -- both orders are the numeric orders.  Host code walks the digits to an exact order
+ * statistic: DensityAnalysis.medianAbsFoFc (densityAnalysis.py:783-801) without moving the maps.  hist: 65536 uint32. */
+int pdbeda_abs_select_hist(pdbeda_map *a, pdbeda_map *b, double alpha, double cut_a, double cut_b, int which, int shift,
+                           unsigned long long prefix, unsigned long long prefix_mask, uint32_t *hist);
 /* Copy the float32 grid [ns][nr][nc] back to the host (inspection; DensityMatrix.density of a derived map). */
 int pdbeda_map_download(pdbeda_map *map, float *density_out);
 

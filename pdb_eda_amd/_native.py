@@ -68,6 +68,7 @@ _SIGS = {
     "pdbeda_map_free": (C.c_int, [_p]),
     "pdbeda_map_combine": (C.c_int, [_p, _p, C.c_double, C.POINTER(_p)]),
     "pdbeda_map_download": (C.c_int, [_p, _p]),
+    "pdbeda_abs_select_hist": (C.c_int, [_p, _p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_ulonglong, C.c_ulonglong, _p]),
     "pdbeda_map_stats": (C.c_int, [_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pdbeda_sum_of_abs": (C.c_int, [_p, C.c_float, C.POINTER(C.c_double)]),
     "pdbeda_point_density": (C.c_int, [_p, _p, _i64, _p]),
@@ -311,6 +312,32 @@ class DeviceMap(object):
         a._ctx.check(a._ctx._lib.pdbeda_map_combine(a._h, b._h, C.c_double(alpha), C.byref(h)), "pdbeda_map_combine")
         self._h = h
         return self
+
+    def abs_order_statistics(self, other, alpha, cut_a, cut_b, which, ranks=None):
+        """Exact order statistics of |a| (which = 0) or |a + alpha * other| (which = 1) over the voxels of the unique box with
+        |a| < cut_a and |a + alpha other| < cut_b: a radix select, 16 bits per device pass.  ranks=None -> the number of
+        selected voxels; else the values at those 0-based ranks (ascending), as float64."""
+        hist = np.zeros(65536, dtype=np.uint32)
+        oh = other._h if other is not None else None
+
+        def digit(shift, prefix, mask):
+            self._ctx.check(self._ctx._lib.pdbeda_abs_select_hist(self._h, oh, C.c_double(alpha), C.c_double(cut_a), C.c_double(cut_b), which, shift,
+                                                                  C.c_ulonglong(prefix), C.c_ulonglong(mask), _ptr(hist)), "pdbeda_abs_select_hist")
+            return hist.astype(np.int64)
+        bits = 64 if which else 32
+        if ranks is None:
+            return int(digit(bits - 16, 0, 0).sum())
+        out = []
+        for rank in ranks:
+            prefix, mask, remaining = 0, 0, int(rank)
+            for shift in range(bits - 16, -1, -16):
+                cs = np.cumsum(digit(shift, prefix, mask))
+                d = int(np.searchsorted(cs, remaining, side="right"))
+                remaining -= int(cs[d - 1]) if d else 0
+                prefix |= d << shift
+                mask |= 0xffff << shift
+            out.append(np.array([prefix], dtype=np.uint64).view(np.float64)[0] if which else float(np.array([prefix], dtype=np.uint32).view(np.float32)[0]))
+        return out
 
     def download(self):
         """The float32 grid [ns][nr][nc] copied back to the host."""

@@ -463,6 +463,25 @@ static int with_scratch(pdbeda_ctx *ctx, size_t bytes, Fn fn) {
     return 0;
 }
 
+extern "C" int pdbeda_abs_select_hist(pdbeda_map *a, pdbeda_map *b, double alpha, double cut_a, double cut_b, int which, int shift,
+                                      unsigned long long prefix, unsigned long long prefix_mask, uint32_t *hist) {
+    if (!a || !hist || shift < 0 || shift > 48 || (which != 0 && which != 1) || (which == 1 && !b)) return PDBEDA_ERR_ARGUMENT;
+    pdbeda_ctx *ctx = a->ctx;
+    if (b && (b->ctx != ctx || b->n_vox != a->n_vox || memcmp(a->geom.ncrs, b->geom.ncrs, sizeof a->geom.ncrs) != 0))
+        return fail(ctx, PDBEDA_ERR_ARGUMENT, "maps of different contexts or shapes");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t n = (int64_t)a->geom.unique_ncrs[0] * a->geom.unique_ncrs[1] * a->geom.unique_ncrs[2];
+    return with_scratch(ctx, 65536 * sizeof(uint32_t), [&](char *base) -> int {
+        unsigned int *d_hist = reinterpret_cast<unsigned int *>(base);
+        HIP_TRY(ctx, hipMemsetAsync(d_hist, 0, 65536 * sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(k_abs_select_hist, dim3(grid_for(n, 256, 4096)), dim3(256), 0, ctx->stream, a->geom_dev, a->dens, b ? b->dens : nullptr,
+                           alpha, cut_a, cut_b, which, shift, prefix, prefix_mask, d_hist);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(hist, d_hist, 65536 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        return 0;
+    });
+}
+
 extern "C" int pdbeda_point_density(pdbeda_map *m, const int32_t *crs, int64_t n, double *out) {
     if (!m || (n > 0 && (!crs || !out)) || n < 0) return PDBEDA_ERR_ARGUMENT;
     if (n == 0) return PDBEDA_OK;

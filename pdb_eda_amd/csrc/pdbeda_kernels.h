@@ -721,6 +721,30 @@ __global__ void __launch_bounds__(256) k_region_reduce(const Geom *__restrict__ 
     }
 }
 
+// One 16-bit digit of a radix select over the masked voxels of the unique box (see pdbeda_abs_select_hist).
+__global__ void __launch_bounds__(256) k_abs_select_hist(const Geom *__restrict__ gp, const float *__restrict__ a, const float *__restrict__ b,
+                                                         double alpha, double cut_a, double cut_b, int which, int shift,
+                                                         unsigned long long prefix, unsigned long long prefix_mask, unsigned int *__restrict__ hist) {
+    const Geom &g = *gp;
+    const int uc = g.unique_ncrs[0], ur = g.unique_ncrs[1], us = g.unique_ncrs[2];
+    const int64_t n = (int64_t)uc * ur * us;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % uc);
+        const int64_t row = i / uc;
+        const int64_t at = ((row / ur) * g.ncrs[1] + (row % ur)) * g.ncrs[0] + c;
+        const float va = a[at];
+        if (!(fabs((double)va) < cut_a)) continue;
+        double vc = 0.0;
+        if (b) {
+            vc = fabs((double)va + alpha * (double)b[at]);
+            if (!(vc < cut_b)) continue;
+        }
+        const unsigned long long key = which ? (unsigned long long)__double_as_longlong(vc) : (unsigned long long)__float_as_uint(fabsf(va));
+        if ((key & prefix_mask) != prefix) continue;
+        atomicAdd(&hist[(key >> shift) & 0xffffull], 1u);
+    }
+}
+
 // out = float32(double(a) + alpha * double(b)), float4 per thread (the Fc map: alpha = -2).
 __global__ void __launch_bounds__(256) k_map_combine(const float *__restrict__ a, const float *__restrict__ b, double alpha, int64_t n,
                                                      float *__restrict__ out) {

@@ -562,15 +562,17 @@ class DensityAnalysis(object):
 
     def medianAbsFoFc(self):
         """ref densityAnalysis.py:783-801: medians of |Fo| and |Fc| over the voxels of the unique box whose |Fo| and |Fc| are
-        both below mean + 1 sigma.  A whole-map order statistic of a diagnostic call: host numpy, like the reference's tail."""
+        both below mean + 1 sigma (the Fc statistics are those of Fo: see ``fc``).  Exact order statistics by a device-side
+        radix select (``pdbeda_abs_select_hist``): the maps do not move; Fc values are fo - 2 diff in float64 like the reference's."""
         fo, fc = self.fo, self.fc
         foCut = fo.meanDensity + 1.0 * fo.stdDensity
         fcCut = fc.meanDensity + 1.0 * fc.stdDensity
-        uc, ur, us = fo.header.uniqueNcrs
-        a = fo.density[:us, :ur, :uc].astype(np.float64)
-        b = a - self.diffDensityObj.density[:us, :ur, :uc].astype(np.float64) * 2
-        keep = (np.abs(a) < foCut) & (np.abs(b) < fcCut)
-        return (np.median(np.abs(a[keep])), np.median(np.abs(b[keep])))
+        a, b = fo._map, self.diffDensityObj._map
+        n = a.abs_order_statistics(b, -2.0, foCut, fcCut, 0)
+        if n == 0:
+            return (float("nan"), float("nan"))
+        ranks = [n // 2] if n % 2 else [n // 2 - 1, n // 2]
+        return tuple(float(np.mean(a.abs_order_statistics(b, -2.0, foCut, fcCut, which, ranks))) for which in (0, 1))
 
     residueMetricsHeaderList = ['chain', 'residue_number', 'residue_name', "rscc", "rsr", "mean_occupancy", "occupancy_weighted_mean_bfactor"]
     atomMetricsHeaderList = ['chain', 'residue_number', 'residue_name', "atom_name", "symmetry", "xyz", "rscc", "rsr", "occupancy", "bfactor"]
