@@ -98,7 +98,19 @@ def analysis_leg(ctx, n_res=400, edge=128, reps=5):
         if best is None or sum(t.values()) < sum(best.values()):
             best = t
     total = sum(best.values())
-    return {"workload": "synthetic ~2 A entry: %d^3 grid at 0.5 A, %d atoms (%d with clouds), 2Fo-Fc + Fo-Fc maps parsed from CCP4 bytes" %
+    # the sphere gathers are latency / gather bound -- their primary figure is voxels tested per second
+    # (sum over atoms of the (2R+2)^3 search box, cutils.pyx:241-243), from the HIP-event times of the region-sum batch
+    atoms = list(st.get_atoms())
+    box = 1
+    for k in range(3):
+        box *= 2 * int(round(3.5 / header.gridLength[k])) + 2
+    ctx.profile_begin()
+    an.calculateAtomRegionDiscrepancies(3.5, 3.0, "")
+    prof = ctx.profile_end()
+    dev_ms = sum(ms for _, ms in prof.values())
+    sphere = {"atoms": len(atoms), "radius_A": 3.5, "voxels_tested": box * len(atoms), "device_ms": dev_ms,
+              "voxels_tested_per_s": box * len(atoms) / (dev_ms * 1e-3) if dev_ms > 0 else None, "kernels_ms": {k: round(ms, 4) for k, (_, ms) in sorted(prof.items())}}
+    return {"sphere_region_sums": sphere, "workload": "synthetic ~2 A entry: %d^3 grid at 0.5 A, %d atoms (%d with clouds), 2Fo-Fc + Fo-Fc maps parsed from CCP4 bytes" %
                         (edge, len(list(st.get_atoms())), len(an.atomCloudDescriptions)),
             "ms": {k: round(1e3 * v, 2) for k, v in best.items()}, "ms_per_entry": 1e3 * total, "entries_per_min": 60.0 / total,
             "density_electron_ratio": an.densityElectronRatio,

@@ -1072,16 +1072,16 @@ static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, con
         HIP_TRY(ctx, hipMemcpyAsync(gs->d_item_group, item_group.data(), 4 * n_items, hipMemcpyHostToDevice, st));
     }
     HIP_TRY(ctx, hipMemsetAsync(gs->d_ctr, 0, sizeof(Counters), st));
-    hipLaunchKernelGGL(k_init_bounds, dim3(grid_for(3 * ng, 256)), dim3(256), 0, st, gs->g_lo, gs->g_hi, 3 * ng);
+    { PROF(ctx, "k_init_bounds"); hipLaunchKernelGGL(k_init_bounds, dim3(grid_for(3 * ng, 256)), dim3(256), 0, st, gs->g_lo, gs->g_hi, 3 * ng); }
     if (n_items > 0) {
         if (xyz)
-            hipLaunchKernelGGL(k_atom_boxes, dim3(grid_for(n_items, 256)), dim3(256), 0, st, m->geom_dev, gs->d_xyz, gs->d_radii,
-                               gs->d_item_group, n_items, gs->d_boxes, gs->g_lo, gs->g_hi);
+            { PROF(ctx, "k_atom_boxes"); hipLaunchKernelGGL(k_atom_boxes, dim3(grid_for(n_items, 256)), dim3(256), 0, st, m->geom_dev, gs->d_xyz, gs->d_radii,
+                               gs->d_item_group, n_items, gs->d_boxes, gs->g_lo, gs->g_hi); }
         else
-            hipLaunchKernelGGL(k_list_boxes, dim3(grid_for(n_items, 256)), dim3(256), 0, st, gs->d_crs, gs->d_item_group, n_items,
-                               gs->g_lo, gs->g_hi);
+            { PROF(ctx, "k_list_boxes"); hipLaunchKernelGGL(k_list_boxes, dim3(grid_for(n_items, 256)), dim3(256), 0, st, gs->d_crs, gs->d_item_group, n_items,
+                               gs->g_lo, gs->g_hi); }
     }
-    hipLaunchKernelGGL(k_make_vols, dim3(1), dim3(1024), 0, st, gs->g_lo, gs->g_hi, (int)n_groups, gs->d_vols, gs->d_ctr);
+    { PROF(ctx, "k_make_vols"); hipLaunchKernelGGL(k_make_vols, dim3(1), dim3(1024), 0, st, gs->g_lo, gs->g_hi, (int)n_groups, gs->d_vols, gs->d_ctr); }
     HIP_TRY(ctx, hipGetLastError());
     Counters ctr;
     HIP_TRY(ctx, hipMemcpyAsync(&ctr, gs->d_ctr, sizeof ctr, hipMemcpyDeviceToHost, st));
@@ -1115,8 +1115,8 @@ static int grouped_blobs(pdbeda_map *m, const double *xyz, const float *radii, c
     if (e == hipSuccess && job.total_words > 0) e = hipMemsetAsync(job.mask, 0, 8 * job.total_words, st);
     if (e == hipSuccess && n_items > 0) {
         if (xyz)
-            hipLaunchKernelGGL(k_sphere_paint, dim3((unsigned)n_items), dim3(256), 0, st, m->geom_dev, m->dens, gs.d_xyz, gs.d_radii,
-                               gs.d_item_group, gs.d_boxes, job.vols, job.mask, cutoff);
+            { PROF(ctx, "k_sphere_paint"); hipLaunchKernelGGL(k_sphere_paint, dim3((unsigned)n_items), dim3(256), 0, st, m->geom_dev, m->dens, gs.d_xyz, gs.d_radii,
+                               gs.d_item_group, gs.d_boxes, job.vols, job.mask, cutoff); }
         else
             hipLaunchKernelGGL(k_list_paint, dim3(grid_for(n_items, 256)), dim3(256), 0, st, gs.d_crs, gs.d_item_group, n_items, job.vols, job.mask);
         e = hipGetLastError();
@@ -1174,10 +1174,10 @@ extern "C" int pdbeda_region_sums(pdbeda_map *m, const double *xyz, const float 
     hipStream_t st = ctx->stream;
     hipError_t e = hipMemsetAsync(a.base, 0, cv.off, st);
     if (e == hipSuccess && n_atoms > 0) {
-        hipLaunchKernelGGL(k_sphere_paint, dim3((unsigned)n_atoms), dim3(256), 0, st, m->geom_dev, m->dens, gs.d_xyz, gs.d_radii,
-                           gs.d_item_group, gs.d_boxes, gs.d_vols, mask, 0.0f);
-        hipLaunchKernelGGL(k_region_reduce, dim3(grid_for(gs.total_words * 64, 256, 4096)), dim3(256), 0, st, m->geom_dev, m->dens, gs.d_vols,
-                           (int)n_groups, mask, gs.total_words, cutoff, d_pos, d_neg, d_cnt, d_inv);
+        { PROF(ctx, "k_sphere_paint"); hipLaunchKernelGGL(k_sphere_paint, dim3((unsigned)n_atoms), dim3(256), 0, st, m->geom_dev, m->dens, gs.d_xyz, gs.d_radii,
+                           gs.d_item_group, gs.d_boxes, gs.d_vols, mask, 0.0f); }
+        { PROF(ctx, "k_region_reduce"); hipLaunchKernelGGL(k_region_reduce, dim3(grid_for(gs.total_words * 64, 256, 4096)), dim3(256), 0, st, m->geom_dev, m->dens, gs.d_vols,
+                           (int)n_groups, mask, gs.total_words, cutoff, d_pos, d_neg, d_cnt, d_inv); }
         e = hipGetLastError();
     }
     std::vector<unsigned long long> h_cnt(n_groups);
