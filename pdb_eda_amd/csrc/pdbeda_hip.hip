@@ -1176,7 +1176,7 @@ extern "C" int pdbeda_region_sums(pdbeda_map *m, const double *xyz, const float 
     if (e == hipSuccess && n_atoms > 0) {
         { PROF(ctx, "k_sphere_paint"); hipLaunchKernelGGL(k_sphere_paint, dim3((unsigned)n_atoms), dim3(256), 0, st, m->geom_dev, m->dens, gs.d_xyz, gs.d_radii,
                            gs.d_item_group, gs.d_boxes, gs.d_vols, mask, 0.0f); }
-        { PROF(ctx, "k_region_reduce"); hipLaunchKernelGGL(k_region_reduce, dim3(grid_for(gs.total_words * 64, 256, 4096)), dim3(256), 0, st, m->geom_dev, m->dens, gs.d_vols,
+        { PROF(ctx, "k_region_reduce"); hipLaunchKernelGGL(k_region_reduce, dim3(grid_for(n_groups * 64, 256, 4096)), dim3(256), 0, st, m->geom_dev, m->dens, gs.d_vols,
                            (int)n_groups, mask, gs.total_words, cutoff, d_pos, d_neg, d_cnt, d_inv); }
         e = hipGetLastError();
     }

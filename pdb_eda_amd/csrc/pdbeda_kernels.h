@@ -687,26 +687,36 @@ __global__ void __launch_bounds__(256) k_region_reduce(const Geom *__restrict__ 
                                                        int64_t total_words, float cutoff, double *__restrict__ pos,
                                                        double *__restrict__ neg, unsigned long long *__restrict__ cnt,
                                                        unsigned int *__restrict__ invalid) {
+    // A wave per VOLUME (= group: the painted box of an atom or of a residue's atoms): it walks the volume's mask words,
+    // keeps the partial sums in registers and reduces / publishes ONCE -- no volume search, shuffles or atomics per word
+    // (a 16-voxel-wide atom box has 256 words of 16 voxels each).
     const int lane = lane_id();
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const Geom &g = *gp;
     const double cut = (double)cutoff;
-    for (int64_t w = wave; w < total_words; w += n_waves) {
-        const uint64_t m = mask[w];
-        if (m == 0ull) continue;
-        const VolDesc vd = vols[find_vol(vols, n_vols, w)];
-        const int64_t rem = w - vd.word_base;
-        const int wq = (int)(rem % vd.row_words);
-        const int64_t row = rem / vd.row_words;
-        const bool bit = (m >> lane) & 1ull;
-        bool ok = true;
-        double d = 0.0;
-        if (bit) d = (double)fetch_wrapped(g, dens, vd.org[0] + wq * 64 + lane, vd.org[1] + (int)(row % vd.dim[1]),
-                                           vd.org[2] + (int)(row / vd.dim[1]), &ok);
-        double p = (bit && d > cut) ? d : 0.0;
-        double q = (bit && d < -cut) ? d : 0.0;
-        unsigned long long bad = __ballot(bit && !ok);
+    for (int64_t v = wave; v < n_vols; v += n_waves) {
+        const VolDesc vd = vols[v];
+        const int64_t n_words = (int64_t)vd.row_words * vd.dim[1] * vd.dim[2];
+        double p = 0.0, q = 0.0;
+        unsigned long long n = 0;
+        bool bad = false;
+        for (int64_t k = 0; k < n_words; ++k) {
+            const uint64_t m = mask[vd.word_base + k];   // wave-uniform
+            if (m == 0ull) continue;
+            n += (unsigned long long)popc64(m);
+            if ((m >> lane) & 1ull) {
+                const int wq = (int)(k % vd.row_words);
+                const int64_t row = k / vd.row_words;
+                bool ok = true;
+                const double d = (double)fetch_wrapped(g, dens, vd.org[0] + wq * 64 + lane, vd.org[1] + (int)(row % vd.dim[1]),
+                                                       vd.org[2] + (int)(row / vd.dim[1]), &ok);
+                if (d > cut) p += d;
+                if (d < -cut) q += d;
+                bad = bad || !ok;
+            }
+        }
+        const unsigned long long any_bad = __ballot(bad);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             p += __shfl_down(p, off);
@@ -715,8 +725,8 @@ __global__ void __launch_bounds__(256) k_region_reduce(const Geom *__restrict__ 
         if (lane == 0) {
             if (p != 0.0) unsafeAtomicAdd(&pos[vd.group], p);
             if (q != 0.0) unsafeAtomicAdd(&neg[vd.group], q);
-            atomicAdd(&cnt[vd.group], (unsigned long long)popc64(m));
-            if (bad) atomicOr(&invalid[vd.group], 1u);
+            if (n) atomicAdd(&cnt[vd.group], n);
+            if (any_bad) atomicOr(&invalid[vd.group], 1u);
         }
     }
 }
