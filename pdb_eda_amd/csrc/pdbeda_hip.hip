@@ -649,10 +649,10 @@ static void launch_tile_label(pdbeda_ctx *ctx, unsigned n_tiles, const Job &job,
 static void launch_labels(pdbeda_ctx *ctx, const Job &job, const TileDims &td, int32_t *labels_dev) {
     const unsigned n_tiles = (unsigned)(td.ctiles * td.rtiles * td.stiles);
     switch (td.cw) {
-        case 1: hipLaunchKernelGGL((k_labels_tiles<1>), dim3(n_tiles), dim3(256), 0, ctx->stream, job, td, labels_dev); break;
-        case 2: hipLaunchKernelGGL((k_labels_tiles<2>), dim3(n_tiles), dim3(256), 0, ctx->stream, job, td, labels_dev); break;
-        case 3: hipLaunchKernelGGL((k_labels_tiles<3>), dim3(n_tiles), dim3(256), 0, ctx->stream, job, td, labels_dev); break;
-        default: hipLaunchKernelGGL((k_labels_tiles<4>), dim3(n_tiles), dim3(256), 0, ctx->stream, job, td, labels_dev); break;
+        case 1: hipLaunchKernelGGL((k_labels_tiles<1>), dim3(n_tiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev); break;
+        case 2: hipLaunchKernelGGL((k_labels_tiles<2>), dim3(n_tiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev); break;
+        case 3: hipLaunchKernelGGL((k_labels_tiles<3>), dim3(n_tiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev); break;
+        default: hipLaunchKernelGGL((k_labels_tiles<4>), dim3(n_tiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev); break;
     }
 }
 

@@ -1117,8 +1117,12 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
 // Unit tiles / tiles with too many runs take the global look-up path (same result).
 constexpr int LCAP = 4096;  // word-runs of a tile whose run -> component bytes fit the LDS table
 template <int CW>
-__global__ void __launch_bounds__(256) k_labels_tiles(Job job, TileDims td, int32_t *__restrict__ labels) {
+#ifndef PDBEDA_LABELS_NT_THREADS
+#define PDBEDA_LABELS_NT_THREADS 512
+#endif
+__global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS) k_labels_tiles(Job job, TileDims td, int32_t *__restrict__ labels) {
     constexpr int NU = 64 * CW;
+    constexpr int NTL = PDBEDA_LABELS_NT_THREADS, RPW = 64 / (NTL / 64);   // rows of the tile per wave
     __shared__ int32_t s_lab[CCAP];
     __shared__ uint8_t s_comp8[LCAP];
     __shared__ uint64_t s_m[2][256];
@@ -1140,21 +1144,24 @@ __global__ void __launch_bounds__(256) k_labels_tiles(Job job, TileDims td, int3
         const int r = r0 + (rowl & 7), s = s0 + (rowl >> 3);
         const bool valid = tid < NU && r < ur && s < us && w0 + wl < row_words;
         const int64_t w = ((int64_t)s * ur + r) * row_words + (w0 + wl);
+        if (tid < 256) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const bool has = valid && p < td.n_planes;
-            s_m[p][tid] = has ? job.mask[w + p * plane_words] : 0ull;
-            s_rb[p][tid] = has ? job.run_base[w + p * plane_words] : 0u;
+            for (int p = 0; p < 2; ++p) {
+                const bool has = valid && p < td.n_planes;
+                s_m[p][tid] = has ? job.mask[w + p * plane_words] : 0ull;
+                s_rb[p][tid] = has ? job.run_base[w + p * plane_words] : 0u;
+            }
         }
         if (fast) {
             if (tid < CCAP) s_lab[tid] = job.label_of_comp[cb + tid];
-            for (uint32_t i = tid; i < n_runs; i += 256) s_comp8[i] = (uint8_t)(job.comp_of_run[rb + i] - cb);
+            for (uint32_t i = tid; i < n_runs; i += NTL) s_comp8[i] = (uint8_t)(job.comp_of_run[rb + i] - cb);
         }
     }
     __syncthreads();
-    // wave wv writes rows wv*16 .. wv*16+15 of the tile; a lane owns 4 consecutive voxels of a 256-voxel row
-    for (int rr = 0; rr < 16; ++rr) {
-        const int rowl = wv * 16 + rr;
+    // wave wv writes RPW rows of the tile; a lane owns 4 consecutive voxels of a 256-voxel row (16 waves per tile: the
+    // per-row bit arithmetic is a dependent chain, and small maps leave one workgroup per CU to hide it)
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int rowl = wv * RPW + rr;
         const int r = r0 + (rowl & 7), s = s0 + (rowl >> 3);
         if (r >= ur || s >= us) continue;   // wave-uniform
         const int wl = lane >> 4, bit0 = (lane & 15) * 4;
