@@ -121,7 +121,8 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
     __shared__ uint16_t s_rowfirst[2][64];
     __shared__ uint16_t s_rowcnt[2][64];
     // per row-run sums sum(rho), sum(rho * (c - c_tile)) live in HBM/L2 (job.run_sums, 2 doubles per slot of this
-    // tile): written in A3 and read back in C2 by the SAME thread, so they cost no LDS (occupancy) and no atomics
+    // tile): written in A3b by the run's thread and read back in C2 by the thread of its first word -- barriers (with
+    // their workgroup-scope fences) lie between -- so they cost no LDS (occupancy) and no atomics
     double2 *g_run = job.run_sums + (size_t)blockIdx.x * RCAP;
     __shared__ uint16_t s_parent[RCAP];   // hook-and-jump parents (plain stores only, so 16 bits suffice)
     __shared__ uint16_t s_rse16[RCAP];    // bytes: run start / end position inside the tile row (0..255); later: component index
@@ -304,12 +305,9 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
             s_gcnt[0] = s_wsy[0] + s_wsy[1] + s_wsy[2] + s_wsy[3];
             if (over_slots) s_over = 1;
         }
-        // ---- A3 (same thread per word): exact fp64 sums of each run that STARTS in my word, from the parked
-        // values; a run that continues into the following word(s) of the row is followed by its owner, so every
-        // run has one writer: no atomics, sequential and deterministic.  Full lanes (95 % of the words of a
-        // +-1.5 sigma map are significant).
+        // ---- A3a (same thread per word and sign): extent of each run that STARTS in my word -- a run that continues into
+        // the following word(s) of the row is followed by its owner, so every run slot has one writer.
         const bool from_global = s_vover != 0;   // block-uniform (set before the barrier that ended A1)
-        const float *rowptr = dens + ((int64_t)(s0 + ((wt / CW) >> 3)) * nr + (r0 + ((wt / CW) & 7))) * nc + w0 * 64;   // my row inside the tile
         if (wt < NU && (a0 | a1) && !over_slots && s_over == 0) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -325,43 +323,57 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
                     const uint32_t slot = k == 0 ? fr : nx + k - 1u;
                     ++k;
                     if (a == 0 && kq) continue;   // continues a run of the previous word: its owner handles it
-                    double sum = 0.0, sumc = 0.0;
-                    int cur = wt, ca = a, wlc = wl, last_end = 0;
-                    while (true) {   // the piece in word `cur` starts at bit ca
-                        const uint64_t mc = s_mask[q][cur];
-                        const uint64_t bbc = s_mask[0][cur] | s_mask[1][cur];
-                        const int e = run_end_of(mc, ca);
-                        if (!from_global) {
-                            const uint32_t off = s_vbase[cur] + (uint32_t)popc64(bbc & bits_below(ca));
-                            for (int i = 0; i <= e - ca; ++i) {
-                                const double val = (double)s_val[off + i];
-                                sum += val;
-                                sumc += val * (double)(wlc * 64 + ca + i);
-                            }
-                        } else {   // dense tile: the values were not parked; 4 loads in flight per trip (clamped inside the run)
-                            const int p0 = wlc * 64 + ca, p1 = wlc * 64 + e;
-                            for (int pp = p0; pp <= p1; pp += 4) {
-                                float v4[4];
-#pragma unroll
-                                for (int t = 0; t < 4; ++t) v4[t] = rowptr[pp + t <= p1 ? pp + t : p1];
-#pragma unroll
-                                for (int t = 0; t < 4; ++t) {
-                                    if (pp + t <= p1) {
-                                        const double val = (double)v4[t];
-                                        sum += val;
-                                        sumc += val * (double)(pp + t);
-                                    }
-                                }
-                            }
-                        }
-                        last_end = wlc * 64 + e;
-                        if (e == 63 && wlc < CW - 1 && (s_mask[q][cur + 1] & 1ull)) { ++cur; ++wlc; ca = 0; } else break;
-                    }
-                    g_run[slot] = make_double2(sum, sumc);
+                    int cur = wt, wlc = wl, e = run_end_of(m, a);
+                    while (e == 63 && wlc < CW - 1 && (s_mask[q][cur + 1] & 1ull)) { ++cur; ++wlc; e = run_end_of(s_mask[q][cur], 0); }
                     s_rs[slot] = (uint8_t)(wl * 64 + a);
-                    s_re[slot] = (uint8_t)last_end;
+                    s_re[slot] = (uint8_t)(wlc * 64 + e);
                     s_rowof[slot] = (uint8_t)(wt / CW);
                 }
+            }
+        }
+        __syncthreads();
+        // ---- A3b (thread per RUN): exact fp64 (sum rho, sum rho * position), sequentially over the run's parked values.
+        // Per word this loop diverged badly (0 .. 6 runs of 1 .. 60 voxels per word: 13 % of the lane slots did work);
+        // per run a wave waits only for its longest run.
+        if (!over_slots && s_over == 0) {
+            const uint32_t n0 = s_alloc[0], n1 = s_alloc[1];
+#pragma unroll
+            for (int t = 0; t < SLOTS; ++t) {
+                const uint32_t lin = tid + (uint32_t)NT * t;
+                if (lin >= n0 + n1) continue;
+                const uint32_t slot = lin < n0 ? lin : (uint32_t)RCAP - n1 + (lin - n0);
+                const int q = lin < n0 ? 0 : 1;
+                const int row = s_rowof[slot], p0 = s_rs[slot], p1 = s_re[slot];
+                double sum = 0.0, sumc = 0.0;
+                if (!from_global) {
+                    for (int wlc = p0 >> 6; wlc <= (p1 >> 6); ++wlc) {   // the piece of the run in word wlc (almost always one piece)
+                        const int u = row * CW + wlc;
+                        const int ca = wlc == (p0 >> 6) ? (p0 & 63) : 0, ce = wlc == (p1 >> 6) ? (p1 & 63) : 63;
+                        const uint32_t off = s_vbase[u] + (uint32_t)popc64((s_mask[0][u] | s_mask[1][u]) & bits_below(ca));
+                        for (int i = 0; i <= ce - ca; ++i) {
+                            const double val = (double)s_val[off + i];
+                            sum += val;
+                            sumc += val * (double)(wlc * 64 + ca + i);
+                        }
+                    }
+                } else {   // dense tile: the values were not parked; re-read from L2, 4 loads in flight per trip (clamped inside the run)
+                    const float *rowptr = dens + ((int64_t)(s0 + (row >> 3)) * nr + (r0 + (row & 7))) * nc + w0 * 64;
+                    for (int pp = p0; pp <= p1; pp += 4) {
+                        float v4[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v4[k] = rowptr[pp + k <= p1 ? pp + k : p1];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (pp + k <= p1) {
+                                const double val = (double)v4[k];
+                                sum += val;
+                                sumc += val * (double)(pp + k);
+                            }
+                        }
+                    }
+                }
+                (void)q;
+                g_run[slot] = make_double2(sum, sumc);
             }
         }
         __syncthreads();
