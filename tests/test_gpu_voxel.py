@@ -407,6 +407,36 @@ def test_shapes_fuzz(gpu_ctx):
             bl.free()
 
 
+def test_map_combine_download_and_order_statistics(gpu_ctx):
+    """pdbeda_map_combine / pdbeda_map_download / pdbeda_abs_select_hist against numpy, and their argument checks."""
+    from pdb_eda_amd import _native, synthetic
+    a = synthetic.smooth_noise((21, 19, 70), 41, 1.2)
+    b = synthetic.smooth_noise((21, 19, 70), 42, 1.0)
+    da, db = _dm(a, gpu_ctx), _dm(b, gpu_ctx)
+    c = _native.DeviceMap.combine(da._map, db._map, -2.0)
+    want = (a.astype(np.float64) - 2.0 * b.astype(np.float64))
+    assert np.array_equal(c.download(), want.astype(np.float32))
+    assert np.array_equal(da._map.download(), a)
+    # order statistics of |a| and |a - 2 b| over the voxels where both are below their cut (here: the whole grid is the unique box)
+    cut_a, cut_b = float(np.abs(a).mean() * 1.3), float(np.abs(want).mean() * 1.1)
+    keep = (np.abs(a.astype(np.float64)) < cut_a) & (np.abs(want) < cut_b)
+    n = int(keep.sum())
+    assert da._map.abs_order_statistics(db._map, -2.0, cut_a, cut_b, 0) == n and n > 100
+    sa, sc = np.sort(np.abs(a.astype(np.float64))[keep]), np.sort(np.abs(want)[keep])
+    ranks = [0, 1, n // 3, n // 2, n - 1]
+    assert da._map.abs_order_statistics(db._map, -2.0, cut_a, cut_b, 0, ranks) == [float(sa[r]) for r in ranks]
+    assert da._map.abs_order_statistics(db._map, -2.0, cut_a, cut_b, 1, ranks) == [float(sc[r]) for r in ranks]
+    # |a| alone (no second map)
+    n1 = int((np.abs(a.astype(np.float64)) < cut_a).sum())
+    assert da._map.abs_order_statistics(None, 0.0, cut_a, 0.0, 0) == n1
+    # argument checks: shapes must agree, which = 1 needs the second map
+    small = _dm(synthetic.smooth_noise((5, 6, 7), 43, 1.0), gpu_ctx)
+    with pytest.raises(_native.PdbedaError):
+        _native.DeviceMap.combine(da._map, small._map, 1.0)
+    with pytest.raises(_native.PdbedaError):
+        da._map.abs_order_statistics(None, 0.0, cut_a, 0.0, 1)
+
+
 def test_full_size_properties(gpu_ctx):
     """BASELINE config 2 size (256^3): size-independent properties + oracle equality."""
     from oracle import oracle as ora
