@@ -131,8 +131,8 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
     // 14 KiB scratch: per-thread edge buffers in phase B, per-component accumulators in phase C
     __shared__ double s_scratch[tile_scratch_bytes(NT) / 8];
     double *s_rho = s_scratch, *s_rho_c = s_scratch + CCAP, *s_rho_r = s_scratch + 2 * CCAP, *s_rho_s = s_scratch + 3 * CCAP;
-    uint32_t *s_n = reinterpret_cast<uint32_t *>(s_scratch + 4 * CCAP), *s_c = s_n + CCAP, *s_r = s_n + 2 * CCAP, *s_s = s_n + 3 * CCAP,
-             *s_key = s_n + 4 * CCAP, *s_cplane = s_n + 5 * CCAP;
+    uint32_t *s_n = reinterpret_cast<uint32_t *>(s_scratch + 4 * CCAP), *s_r = s_n + 2 * CCAP, *s_key = s_n + 4 * CCAP, *s_cplane = s_n + 5 * CCAP;
+    // (phase C: s_n .. +2 CCAP holds the packed 64-bit integer sums, s_r the c sums; see s_pk / s_crel)
     uint16_t *s_edges = reinterpret_cast<uint16_t *>(s_scratch);
     uint16_t *s_cand = s_edges + EQ * NT;   // phase B: hook proposals (0xffff = none)
     static_assert(EQ * NT * 2 + RCAP * 2 <= tile_scratch_bytes(NT) && VCAP * 4 <= tile_scratch_bytes(NT), "phase-A/B tables must fit the scratch");
@@ -595,16 +595,19 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
         s_runbase = (uint32_t)blockIdx.x * (uint32_t)(NU * 32);
         s_compbase = (uint32_t)blockIdx.x * CCAP;
     }
+    // integer sums of a component, relative to the tile origin, packed so that a run costs two LDS atomics, not four:
+    // s_pk = voxels (20 bits) | sum (r - r0) << 20 (20 bits) | sum (s - s0) << 40;  s_crel = sum (c - c_tile)
+    unsigned long long *s_pk = reinterpret_cast<unsigned long long *>(s_n);   // (spans s_n and s_c)
+    uint32_t *s_crel = s_r;
     for (uint32_t i = tid; i < n_comp; i += NT) {
         s_rho[i] = 0.0; s_rho_c[i] = 0.0; s_rho_r[i] = 0.0; s_rho_s[i] = 0.0;
-        s_n[i] = 0u; s_c[i] = 0u; s_r[i] = 0u; s_s[i] = 0u; s_key[i] = 0xffffffffu; s_cplane[i] = 0u;
+        s_pk[i] = 0ull; s_crel[i] = 0u; s_key[i] = 0xffffffffu; s_cplane[i] = 0u;
     }
     __syncthreads();
-    // ---- C2 + flush (thread per word): fold run pieces into component sums; publish run -> comp ----
+    // ---- C2 (a) thread per word: publish run -> component for the label writer ----
     const uint32_t cb = s_compbase, rb = s_runbase;
     const uint32_t my_g = rb + ((wt < NU) ? s_gword[wt] : 0u);
     if (wt < NU && (m0 | m1)) {
-        const int r = r0 + my_rl, s = s0 + my_sl, cword = (w0 + my_wl) * 64, ctile = w0 * 64;
         for (int q = 0; q < n_planes; ++q) {
             if (NT == 512 && q != half) continue;
             const uint64_t m = q ? m1 : m0;
@@ -613,29 +616,34 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
             const uint32_t first = s_first[q][wt], next = (first & 0x7fffu) + 1u;
             uint32_t k = 0;
             while (todo) {
-                const int a = ctz64(todo);
                 todo &= todo - 1;
-                const int len = run_end_of(m, a) - a + 1;
                 const uint32_t slot = k == 0 ? (first & 0x7fffu) : next + k - 1u;
                 ++k;
-                const uint32_t comp = s_compidx[s_parent[slot]];
-                job.comp_of_run[g++] = cb + comp;
-                const bool owner = !(a == 0 && my_wl > 0 && (s_mask[q][wt - 1] >> 63));  // piece that starts the row-run
-                if (owner) {
-                    const double2 rs2 = g_run[slot];
-                    const double rho = rs2.x;
-                    unsafeAtomicAdd(&s_rho[comp], rho);
-                    unsafeAtomicAdd(&s_rho_c[comp], (double)ctile * rho + rs2.y);
-                    unsafeAtomicAdd(&s_rho_r[comp], (double)r * rho);
-                    unsafeAtomicAdd(&s_rho_s[comp], (double)s * rho);
-                    atomicMin(&s_key[comp], (uint32_t)(((int64_t)(cword + a) * ur + r) * us + s));
-                    if (q) s_cplane[comp] = 1u;
-                }
-                atomicAdd(&s_n[comp], (uint32_t)len);
-                atomicAdd(&s_c[comp], (uint32_t)(len * (cword + a) + len * (len - 1) / 2));
-                atomicAdd(&s_r[comp], (uint32_t)(len * r));
-                atomicAdd(&s_s[comp], (uint32_t)(len * s));
+                job.comp_of_run[g++] = cb + s_compidx[s_parent[slot]];
             }
+        }
+    }
+    // ---- C2 (b) thread per RUN (the thread that summed it in A3b): fold the run into its component ----
+    {
+        const int ctile = w0 * 64;
+#pragma unroll
+        for (int t = 0; t < SLOTS; ++t) {
+            const uint32_t slot = ex_slot[t];
+            if (slot == 0xffffffffu) continue;
+            const uint32_t comp = s_compidx[s_parent[slot]];
+            const int p0 = (int)(ex_se[t] & 0xffu), p1 = (int)((ex_se[t] >> 8) & 0xffu), row = s_rowof[slot];
+            const int rl = row & 7, sl = row >> 3, r = r0 + rl, sabs = s0 + sl;
+            const uint32_t len = (uint32_t)(p1 - p0 + 1);
+            const double2 rs2 = g_run[slot];
+            const double rho = rs2.x;
+            unsafeAtomicAdd(&s_rho[comp], rho);
+            unsafeAtomicAdd(&s_rho_c[comp], (double)ctile * rho + rs2.y);
+            unsafeAtomicAdd(&s_rho_r[comp], (double)r * rho);
+            unsafeAtomicAdd(&s_rho_s[comp], (double)sabs * rho);
+            atomicMin(&s_key[comp], (uint32_t)(((int64_t)(ctile + p0) * ur + r) * us + sabs));
+            if (slot >= (uint32_t)RCAP - al1) s_cplane[comp] = 1u;
+            atomicAdd(&s_pk[comp], (unsigned long long)len | ((unsigned long long)(len * (uint32_t)rl) << 20) | ((unsigned long long)(len * (uint32_t)sl) << 40));
+            atomicAdd(&s_crel[comp], len * (uint32_t)p0 + len * (len - 1u) / 2u);
         }
     }
     if (my_valid) {
@@ -650,14 +658,16 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
     for (uint32_t i = tid; i < n_comp; i += NT) {
         const uint32_t g = cb + i;
         job.parent[g] = (int32_t)g;
-        job.r_n[g] = s_n[i];
+        const unsigned long long pk = s_pk[i];
+        const long long n = (long long)(pk & 0xfffffull);
+        job.r_n[g] = (uint32_t)n;
         job.r_rho[g] = s_rho[i];
         job.r_rho_c[g] = s_rho_c[i];
         job.r_rho_r[g] = s_rho_r[i];
         job.r_rho_s[g] = s_rho_s[i];
-        job.r_c[g] = (long long)s_c[i];
-        job.r_r[g] = (long long)s_r[i];
-        job.r_s[g] = (long long)s_s[i];
+        job.r_c[g] = (long long)s_crel[i] + n * (w0 * 64);
+        job.r_r[g] = (long long)((pk >> 20) & 0xfffffull) + n * r0;
+        job.r_s[g] = (long long)(pk >> 40) + n * s0;
         job.r_key[g] = (unsigned long long)(s_cplane[i] ? keys_pp : 0) + s_key[i];
     }
     mark_comps_unused(job, cb, n_comp, tid, NT);
