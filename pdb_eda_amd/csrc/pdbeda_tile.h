@@ -125,8 +125,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
     // their workgroup-scope fences) lie between -- so they cost no LDS (occupancy) and no atomics
     double2 *g_run = job.run_sums + (size_t)blockIdx.x * RCAP;
     __shared__ uint16_t s_parent[RCAP];   // hook-and-jump parents (plain stores only, so 16 bits suffice)
-    __shared__ uint16_t s_rse16[RCAP];    // bytes: run start / end position inside the tile row (0..255); later: component index
-    uint8_t *s_rs = reinterpret_cast<uint8_t *>(s_rse16), *s_re = s_rs + RCAP;
+    __shared__ uint16_t s_rse16[RCAP];    // run start | end << 8: positions inside the tile row (0..255); later: component index
     __shared__ uint8_t s_rowof[RCAP];     // tile row (0..63) of every run slot
     // 14 KiB scratch: per-thread edge buffers in phase B, per-component accumulators in phase C
     __shared__ double s_scratch[tile_scratch_bytes(NT) / 8];
@@ -325,8 +324,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
                     if (a == 0 && kq) continue;   // continues a run of the previous word: its owner handles it
                     int cur = wt, wlc = wl, e = run_end_of(m, a);
                     while (e == 63 && wlc < CW - 1 && (s_mask[q][cur + 1] & 1ull)) { ++cur; ++wlc; e = run_end_of(s_mask[q][cur], 0); }
-                    s_rs[slot] = (uint8_t)(wl * 64 + a);
-                    s_re[slot] = (uint8_t)(wlc * 64 + e);
+                    s_rse16[slot] = (uint16_t)((wl * 64 + a) | ((wlc * 64 + e) << 8));
                     s_rowof[slot] = (uint8_t)(wt / CW);
                 }
             }
@@ -343,7 +341,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
                 if (lin >= n0 + n1) continue;
                 const uint32_t slot = lin < n0 ? lin : (uint32_t)RCAP - n1 + (lin - n0);
                 const int q = lin < n0 ? 0 : 1;
-                const int row = s_rowof[slot], p0 = s_rs[slot], p1 = s_re[slot];
+                const int row = s_rowof[slot], p0 = s_rse16[slot] & 0xff, p1 = s_rse16[slot] >> 8;
                 double sum = 0.0, sumc = 0.0;
                 if (!from_global) {
                     for (int wlc = p0 >> 6; wlc <= (p1 >> 6); ++wlc) {   // the piece of the run in word wlc (almost always one piece)
@@ -449,26 +447,25 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
             STAMP(9);
             uint32_t n_edges = 0;
             if (mi < na && mj < nb) {
-                int as = s_rs[a_first + mi], ae = s_re[a_first + mi], bs = s_rs[b_first + mj], be = s_re[b_first + mj];
+                // one 16-bit read per run (start | end << 8); the step is branch-light: compare, maybe park, advance ONE list
+                uint32_t va = s_rse16[a_first + mi], vb = s_rse16[b_first + mj];
                 while (true) {
-                    bool adv_a;
-                    if (be + 1 < as) adv_a = false;        // B run entirely before the A run
-                    else if (ae + 1 < bs) adv_a = true;    // A run entirely before the B run
-                    else {                                  // they touch (Chebyshev distance <= 1 along c)
+                    const int as = (int)(va & 0xffu), ae = (int)(va >> 8), bs = (int)(vb & 0xffu), be = (int)(vb >> 8);
+                    const bool a_before = ae + 1 < bs, b_before = be + 1 < as;   // entirely before the other run
+                    const bool touch = !(a_before || b_before);                   // Chebyshev distance <= 1 along c
+                    if (touch) {
                         if (n_edges == (uint32_t)EQ) break;           // buffer full: resume here in the next batch
                         s_edges[n_edges * NT + tid] = (uint16_t)((mi << 8) | mj);
                         const uint32_t i = a_first + mi, j = b_first + mj;
                         if (first_batch) s_cand[i > j ? i : j] = (uint16_t)(i > j ? j : i);
                         ++n_edges;
-                        adv_a = ae < be;                    // the run that ends first cannot touch anything further
                     }
-                    if (adv_a) {
-                        if (++mi == na) break;
-                        as = s_rs[a_first + mi]; ae = s_re[a_first + mi];
-                    } else {
-                        if (++mj == nb) break;
-                        bs = s_rs[b_first + mj]; be = s_re[b_first + mj];
-                    }
+                    const bool adv_a = a_before || (touch && ae < be);   // the run that ends first cannot touch anything further
+                    mi += adv_a ? 1u : 0u;
+                    mj += adv_a ? 0u : 1u;
+                    if (mi == na || mj == nb) break;
+                    va = s_rse16[a_first + mi];
+                    vb = s_rse16[b_first + mj];
                 }
             }
             if (mi < na && mj < nb) s_more = 1;
@@ -561,9 +558,9 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
     for (int t = 0; t < SLOTS; ++t) {
         const uint32_t lin = tid + (uint32_t)NT * t;
         ex_slot[t] = lin < al0 ? lin : (lin - al0 < al1 ? (uint32_t)RCAP - al1 + (lin - al0) : 0xffffffffu);
-        ex_se[t] = ex_slot[t] != 0xffffffffu ? ((uint32_t)s_rs[ex_slot[t]] | ((uint32_t)s_re[ex_slot[t]] << 8)) : 0u;
+        ex_se[t] = ex_slot[t] != 0xffffffffu ? (uint32_t)s_rse16[ex_slot[t]] : 0u;
     }
-    // ---- C1: number the tile-local components (s_rs / s_re are free now: reuse as u16 table) -----
+    // ---- C1: number the tile-local components (the run extents are free now: reuse as u16 table) -----
     __syncthreads();
     for (uint32_t i = tid; i < RCAP; i += NT)
         if (slot_used(i) && s_parent[i] == i) s_compidx[i] = (uint16_t)atomicAdd(&s_ncomp, 1u);
