@@ -20,7 +20,7 @@ from oracle import oracle as ora  # noqa: E402
 
 ccp4, _ = refload.load(with_density_analysis=False)
 rows = []
-for edge, nsd in ((64, 3.0), (100, 3.0), (128, 3.0), (48, 1.5), (64, 1.5)):
+for edge, nsd in ((64, 3.0), (100, 3.0), (128, 3.0), (200, 3.0), (48, 1.5), (64, 1.5)):
     spec = synthetic.MapSpec(ncrs=(edge, edge, edge), spacing=0.4)
     grid = synthetic.smooth_noise((edge, edge, edge), seed=7, sigma_voxels=1.5)
     blob = synthetic.ccp4_bytes(spec, grid)
