@@ -114,7 +114,8 @@ def analysis_leg(ctx, n_res=400, edge=128, reps=5):
                         (edge, len(list(st.get_atoms())), len(an.atomCloudDescriptions)),
             "ms": {k: round(1e3 * v, 2) for k, v in best.items()}, "ms_per_entry": 1e3 * total, "entries_per_min": 60.0 / total,
             "density_electron_ratio": an.densityElectronRatio,
-            "note": "single host thread + one stream; the reference measured in the build container (SURVEY 6): calculateAtomRegionDiscrepancies ~33 ms per ATOM"}
+            "note": "single host thread + one stream; the reference (Cython path, one core, build container) needs 158 s for this same entry and "
+                    "reaches the same density_electron_ratio: profiles/r01_reference_analysis_cpu.json"}
 
 
 def main():
