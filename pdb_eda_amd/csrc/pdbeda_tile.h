@@ -121,8 +121,8 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
     __shared__ uint16_t s_rowfirst[2][64];
     __shared__ uint16_t s_rowcnt[2][64];
     // per row-run sums sum(rho), sum(rho * (c - c_tile)) live in HBM/L2 (job.run_sums, 2 doubles per slot of this
-    // tile): written in A3b by the run's thread and read back in C2 by the thread of its first word -- barriers (with
-    // their workgroup-scope fences) lie between -- so they cost no LDS (occupancy) and no atomics
+    // tile): written in A3b and read back in C2 by the SAME thread (it owns the same <= 3 run slots in both), so they cost
+    // no LDS (occupancy) and no atomics.  (Holding them in registers instead spills: the kernel sits at 64 VGPRs.)
     double2 *g_run = job.run_sums + (size_t)blockIdx.x * RCAP;
     __shared__ uint16_t s_parent[RCAP];   // hook-and-jump parents (plain stores only, so 16 bits suffice)
     __shared__ uint16_t s_rse16[RCAP];    // run start | end << 8: positions inside the tile row (0..255); later: component index
