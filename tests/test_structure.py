@@ -1,0 +1,103 @@
+"""The minimal PDB reader (ATOM / HETATM / REMARK 290 for the fields the path consumes) and the file-based
+drop-in entry points ``fromFile`` / ``fromPDBid`` (ref densityAnalysis.py:88-229)."""
+import gzip
+import io
+import os
+
+import numpy as np
+import pytest
+
+PDB_TEXT = """HEADER    TEST PROTEIN                            01-JAN-00   1ABC
+REMARK   2 RESOLUTION.    1.80 ANGSTROMS.
+REMARK 290 SYMMETRY OPERATORS FOR SPACE GROUP: P 21 21 21
+REMARK 290   SMTRY1   1  1.000000  0.000000  0.000000        0.00000
+REMARK 290   SMTRY2   1  0.000000  1.000000  0.000000        0.00000
+REMARK 290   SMTRY3   1  0.000000  0.000000  1.000000        0.00000
+REMARK 290   SMTRY1   2 -1.000000  0.000000  0.000000       10.50000
+REMARK 290   SMTRY2   2  0.000000 -1.000000  0.000000        0.00000
+REMARK 290   SMTRY3   2  0.000000  0.000000  1.000000       12.25000
+MODEL        1
+ATOM      1  N   ALA A   1      11.104   6.134  -6.504  1.00 10.00           N
+ATOM      2  CA AALA A   1      11.639   6.071  -5.147  0.40 11.00           C
+ATOM      3  CA BALA A   1      11.700   6.100  -5.100  0.60 12.00           C
+ATOM      4  C   ALA A   1      13.100   6.500  -5.100  1.00 13.00           C
+ATOM      5  O   ALA A   1      13.500   7.600  -5.500  0.00 14.00           O
+ATOM      6  N   GLY B   2       1.000   2.000   3.000  1.00 15.00           N
+HETATM    7  O   HOH A 101       5.000   5.000   5.000  1.00 30.00           O
+HETATM    8 ZN    ZN A 201       7.000   7.000   7.000  1.00 20.00          ZN
+ENDMDL
+MODEL        2
+ATOM      9  N   ALA A   1      99.000  99.000  99.000  1.00 10.00           N
+ENDMDL
+END
+"""
+
+
+def test_read_pdb_fields_order_and_selection():
+    from pdb_eda_amd import structure
+    st, pdb = structure.read_pdb(io.StringIO(PDB_TEXT), "1abc")
+    atoms = list(st.get_atoms())
+    assert [a.name for a in atoms] == ["N", "CA", "C", "O", "O", "ZN", "N"]            # first model only; chain -> residue -> atom (Bio.PDB order)
+    ca = atoms[1]
+    assert ca.get_occupancy() == pytest.approx(0.6) and ca.get_bfactor() == 12.0        # the higher-occupancy conformer
+    assert ca.coord.dtype == np.float32 and np.allclose(ca.coord, [11.7, 6.1, -5.1])
+    assert atoms[3].get_occupancy() == 0.0
+    residues = list(st.get_residues())
+    assert [(r.parent.id, r.id[0], r.id[1]) for r in residues] == [("A", " ", 1), ("A", "W", 101), ("A", "H_ZN", 201), ("B", " ", 2)]
+    assert residues[0].resname == "ALA" and residues[3].resname == "GLY"
+    assert atoms[0].parent.parent.parent.id == 0                                          # model id
+    assert atoms[5].element == "ZN"
+    assert st.header["resolution"] == pytest.approx(1.8)
+    h = pdb.header
+    assert h.pdbid == "1ABC" and h.spaceGroup == "P_21_21_21" and len(h.rotationMats) == 2
+    assert np.allclose(h.rotationMats[1], [[-1, 0, 0, 10.5], [0, -1, 0, 0], [0, 0, 1, 12.25]])
+
+
+def test_read_pdb_gz_path(tmp_path):
+    from pdb_eda_amd import structure
+    path = tmp_path / "pdb1abc.ent.gz"
+    with gzip.open(path, "wt") as fh:
+        fh.write(PDB_TEXT)
+    st, pdb = structure.read_pdb(str(path), "1abc")
+    assert len(list(st.get_atoms())) == 7
+
+
+@pytest.mark.gpu
+def test_from_file_and_from_pdbid(tmp_path, monkeypatch, gpu_ctx):
+    """The reference's file-based constructors on files on disk: CCP4 maps written by the synthetic generator and a PDB file
+    written from the golden structure give the golden density-electron ratio; a missing file gives 0 (Q7-style contract)."""
+    from conftest import load_analysis_case
+    from pdb_eda_amd import synthetic, densityAnalysis
+    z, spec, st, pdb, params = load_analysis_case("orth")
+    densityAnalysis.setGlobals(params)
+    (tmp_path / "ccp4_data").mkdir()
+    (tmp_path / "pdb_data").mkdir()
+    with open(tmp_path / "ccp4_data" / "9xyz.ccp4", "wb") as fh:
+        fh.write(synthetic.ccp4_bytes(spec, z["dens"]))
+    with open(tmp_path / "ccp4_data" / "9xyz_diff.ccp4", "wb") as fh:
+        fh.write(synthetic.ccp4_bytes(spec, z["diff"]))
+    lines = ["HEADER    SYNTHETIC                               01-JAN-00   9XYZ", "REMARK   2 RESOLUTION.    2.00 ANGSTROMS."]
+    for k, m in enumerate(pdb.header.rotationMats):
+        for row in range(3):
+            lines.append("REMARK 290   SMTRY%d %3d%10.6f%10.6f%10.6f%15.5f" % (row + 1, k + 1, m[row][0], m[row][1], m[row][2], m[row][3]))
+    serial = 0
+    for a in st.get_atoms():
+        serial += 1
+        res = a.parent
+        tag = "ATOM  " if res.id[0] == " " else "HETATM"
+        name = a.name if len(a.name) == 4 else " " + a.name.ljust(3)
+        lines.append("%s%5d %s %3s %s%4d    %8.3f%8.3f%8.3f%6.2f%6.2f          %2s" % (tag, serial, name, res.resname, res.parent.id, res.id[1],
+                                                                                    a.coord[0], a.coord[1], a.coord[2], a.get_occupancy(), a.get_bfactor(), a.element.rjust(2)))
+    lines.append("END")
+    with gzip.open(tmp_path / "pdb_data" / "pdb9xyz.ent.gz", "wt") as fh:
+        fh.write("\n".join(lines) + "\n")
+    monkeypatch.chdir(tmp_path)
+    an = densityAnalysis.fromPDBid("9XYZ")
+    assert an != 0 and an.pdbid == "9xyz"
+    # coordinates went through %8.3f: the ratio is close to, not bit-equal with, the golden one
+    assert an.densityElectronRatio == pytest.approx(float(z["ratio"]), rel=2e-2)
+    an2 = densityAnalysis.fromFile(str(tmp_path / "pdb_data" / "pdb9xyz.ent.gz"), str(tmp_path / "ccp4_data" / "9xyz.ccp4"), str(tmp_path / "ccp4_data" / "9xyz_diff.ccp4"))
+    assert an2 != 0 and an2.densityElectronRatio == pytest.approx(an.densityElectronRatio, rel=1e-12)
+    assert len(an2.greenBlobList) == len(an.greenBlobList)
+    assert densityAnalysis.fromPDBid("0000") == 0
+    assert densityAnalysis.fromFile(str(tmp_path / "nope.pdb")) == 0
