@@ -6,11 +6,13 @@
 //      masks ARE the wave ballots -> bit masks of both signs (fused green/red); the significant values
 //      are compacted into LDS
 //   A2 runs of every word (bit tricks), one block scan -> per-row run slots
-//   A3 exact fp64 (sum rho, sum rho*c) of every run, sequentially by the thread that owns its first word
+//   A3 run extents by the thread of the run's first word, then exact fp64 (sum rho, sum rho*c) of every run,
+//      sequentially by a thread per RUN (a thread owns the same <= 3 run slots from here to the end)
 //   B  26-connected components INSIDE the tile: one two-pointer merge per (sign, row, earlier neighbour
 //      row) lists the touching run pairs; hook-and-jump rounds in LDS unite them (no returning atomics)
-//   C  per-component fp64 / integer sums and the c-major first key; one record per tile component is
-//      flushed to HBM, run -> component ids are published for the label writer.
+//   C  a thread per run folds it into its component (fp64 sums, packed integer sums, c-major first key); one
+//      record per tile component is flushed to HBM, run -> component ids are published for the label writer,
+//      the runs (start, end, component) are exported for the face merge.
 // Only component pairs that touch across a tile face are united globally (k_face_merge ->
 // k_union_edges), and only non-root tile components cost global atomics (k_resolve_tiles, after an
 // LDS pre-reduction per tile).  A tile whose run or component count exceeds the LDS capacity falls
