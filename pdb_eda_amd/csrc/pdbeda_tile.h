@@ -471,6 +471,9 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
                 }
             }
             if (mi < na && mj < nb) s_more = 1;
+#if defined(PDBEDA_STOP_AFTER) && PDBEDA_STOP_AFTER == 12
+            if (s_over != 0xffffffffu) return;
+#endif
             STAMP(3);
             uint32_t wmax = n_edges;   // wave maximum of the pair counts
 #pragma unroll
