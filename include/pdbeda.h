@@ -38,7 +38,8 @@ typedef enum pdbeda_status {
     PDBEDA_ERR_ARGUMENT = -2, /* bad argument */
     PDBEDA_ERR_MEMORY = -3,   /* device or host allocation failed */
     PDBEDA_ERR_CAPACITY = -4, /* caller buffer too small */
-    PDBEDA_ERR_STATE = -5     /* handle used in the wrong state */
+    PDBEDA_ERR_STATE = -5,    /* handle used in the wrong state */
+    PDBEDA_ERR_TIMEOUT = -6   /* the per-entry watchdog expired; the context is abandoned (see pdbeda_ctx_set_timeout) */
 } pdbeda_status;
 
 typedef struct pdbeda_ctx pdbeda_ctx;           /* device + stream + reusable workspace */
@@ -69,6 +70,12 @@ int pdbeda_ctx_create_on_stream(int device_id, void *hip_stream, pdbeda_ctx **ou
 int pdbeda_ctx_destroy(pdbeda_ctx *ctx);
 int pdbeda_ctx_synchronize(pdbeda_ctx *ctx);
 void *pdbeda_ctx_stream(pdbeda_ctx *ctx); /* the hipStream_t the kernels are launched on */
+/* Per-entry watchdog: the reference wraps every entry of `pdb_eda multiple` in a SIGALRM time-out
+ * (multipleStructures.py:297-304, 359-377), which threads cannot use.  With seconds > 0 every wait of this context on its
+ * stream is a timed hipStreamQuery loop; when it expires the call returns PDBEDA_ERR_TIMEOUT, the context is marked
+ * abandoned (every later call on it or its handles fails at once with the same status) and pdbeda_ctx_destroy releases the
+ * host object without waiting for the stream.  seconds == 0 disarms it (plain hipStreamSynchronize). */
+int pdbeda_ctx_set_timeout(pdbeda_ctx *ctx, double seconds);
 const char *pdbeda_last_error(pdbeda_ctx *ctx);
 /* Per-kernel timing with HIP events recorded on the context's stream (measurement aid for
  * bench.py; no reference counterpart).  profile_end synchronises and writes one

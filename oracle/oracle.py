@@ -23,7 +23,9 @@ class OraMap(C.Structure):
 
 def build(force=False):
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "pdbeda_oracle.c")):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libpdbeda_oracle.so"])
+        tmp = "libpdbeda_oracle.%d.tmp.so" % os.getpid()     # never leave a half-written library where another process may load it
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "OUT=" + tmp, tmp])
+        os.replace(os.path.join(_HERE, tmp), _SO)
     return _SO
 
 
@@ -58,6 +60,8 @@ def lib():
         _lib.ora_valid_xyz.argtypes = [mp, p, C.c_float]
         _lib.ora_sum_of_abs.restype = C.c_double
         _lib.ora_sum_of_abs.argtypes = [p, i64, C.c_float]
+        _lib.ora_mean_std.restype = None
+        _lib.ora_mean_std.argtypes = [p, i64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib.ora_test_overlap.restype = C.c_int
         _lib.ora_test_overlap.argtypes = [p, i64, p, i64]
         _lib.ora_symmetry_atoms.restype = i64
@@ -173,6 +177,13 @@ class Oracle(object):
     def valid_xyz(self, xyz, radius):
         x = np.asarray(xyz, dtype=np.float64)
         return bool(self.L.ora_valid_xyz(C.byref(self.m), _ptr(x), C.c_float(radius)))
+
+    def mean_std(self):
+        """(np.mean, np.std) of all stored voxels with numpy's own summation tree (ccp4.py:343-363)."""
+        a = self.density.reshape(-1)
+        m, s = C.c_double(), C.c_double()
+        self.L.ora_mean_std(_ptr(a), a.size, C.byref(m), C.byref(s))
+        return m.value, s.value
 
     def sum_of_abs(self, cutoff):
         a = self.density.reshape(-1)

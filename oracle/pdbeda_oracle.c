@@ -297,6 +297,54 @@ double ora_sum_of_abs(const float *a, int64_t n, float cutoff) {
     return s;
 }
 
+/* ccp4.py:343-363 meanDensity / stdDensity = np.mean / np.std of the tuple of Python floats, i.e. of a contiguous float64
+ * array.  The summation tree belongs to a third-party dependency that is not under /root/reference: numpy (2.2.6 in the
+ * environment the golden vectors were made in).  Its published algorithm, restated here:
+ *   - add.reduce hands the inner loop at most `bufsize` = 8192 elements at a time and accumulates the calls in order:
+ *     out = 0; for each block of 8192: out += pairwise_sum(block)           (numpy/_core/src/umath/reduction.c, ufunc bufsize)
+ *   - pairwise_sum(a, n) (numpy/_core/src/umath/loops_utils.h.src, @TYPE@_pairwise_sum):
+ *       n < 8:    plain left-to-right sum
+ *       n <= 128: 8 interleaved accumulators r[j] += a[8 i + j], combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)),
+ *                 then the n % 8 tail added one by one
+ *       else:     n2 = n / 2 rounded down to a multiple of 8;  pairwise_sum(a, n2) + pairwise_sum(a + n2, n - n2)
+ *   - np.mean = sum / n;  np.std (numpy/_core/_methods.py _var): m = sum / n; x = a - m; x = x * x; sqrt(sum(x) / n).
+ * mode 0: a[i]   mode 1: (a[i] - shift)^2.   Pinned by the `mean` / `std` of every golden case (== , not approx). */
+static double np_elem(const float *a, int64_t i, int mode, double shift) {
+    double v = (double)a[i];
+    if (mode == 1) { v = v - shift; v = v * v; }
+    return v;
+}
+static double np_pairwise(const float *a, int64_t off, int64_t n, int mode, double shift) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int64_t i = 0; i < n; ++i) res += np_elem(a, off + i, mode, shift);
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = np_elem(a, off + j, mode, shift);
+        int64_t i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += np_elem(a, off + i + j, mode, shift);
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += np_elem(a, off + i, mode, shift);
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise(a, off, n2, mode, shift) + np_pairwise(a, off + n2, n - n2, mode, shift);
+}
+static double np_add_reduce(const float *a, int64_t n, int mode, double shift) {
+    double out = 0.0;
+    for (int64_t off = 0; off < n; off += 8192) out += np_pairwise(a, off, n - off < 8192 ? n - off : 8192, mode, shift);
+    return out;
+}
+void ora_mean_std(const float *a, int64_t n, double *mean, double *std) {
+    const double m = np_add_reduce(a, n, 0, 0.0) / (double)n;
+    *mean = m;
+    *std = sqrt(np_add_reduce(a, n, 1, m) / (double)n);
+}
+
 /* cutils.pyx:8-25 testOverlap: any pair with Chebyshev distance <= 1. */
 int ora_test_overlap(const int32_t *a, int64_t na, const int32_t *b, int64_t nb) {
     for (int64_t i = 0; i < na; ++i)

@@ -17,7 +17,14 @@ PDBEDA_FLAG_LABELS = 1
 
 
 class PdbedaError(RuntimeError):
-    pass
+    """A device / library failure (never an entry-level condition): callers must not swallow it."""
+
+
+class PdbedaTimeout(PdbedaError):
+    """The per-entry watchdog of a context expired (PDBEDA_ERR_TIMEOUT): that context is abandoned."""
+
+
+PDBEDA_ERR_TIMEOUT = -6
 
 
 class Geometry(C.Structure):
@@ -60,6 +67,7 @@ _SIGS = {
     "pdbeda_ctx_destroy": (C.c_int, [_p]),
     "pdbeda_ctx_synchronize": (C.c_int, [_p]),
     "pdbeda_ctx_stream": (_p, [_p]),
+    "pdbeda_ctx_set_timeout": (C.c_int, [_p, C.c_double]),
     "pdbeda_last_error": (C.c_char_p, [_p]),
     "pdbeda_ctx_profile_begin": (C.c_int, [_p]),
     "pdbeda_ctx_profile_end": (C.c_int, [_p, C.c_char_p, _i64]),
@@ -131,7 +139,12 @@ class Context(object):
     def check(self, rc, what):
         if rc != 0:
             msg = self._lib.pdbeda_last_error(self._h)
-            raise PdbedaError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+            cls = PdbedaTimeout if rc == PDBEDA_ERR_TIMEOUT else PdbedaError
+            raise cls("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+    def set_timeout(self, seconds):
+        """Arm (seconds > 0) or disarm (0) the per-entry watchdog: see pdbeda_ctx_set_timeout in include/pdbeda.h."""
+        self.check(self._lib.pdbeda_ctx_set_timeout(self._h, C.c_double(float(seconds))), "pdbeda_ctx_set_timeout")
 
     def synchronize(self):
         self.check(self._lib.pdbeda_ctx_synchronize(self._h), "pdbeda_ctx_synchronize")

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -45,6 +47,11 @@ struct pdbeda_ctx {
     bool debug_poison = false;
     int64_t debug_edge_cap = 0;
     uint32_t next_epoch = 1;            // whole-map job numbers (Job::epoch)
+    // per-entry watchdog (multipleStructures.py:359-377 wraps every entry in a SIGALRM timeout; threads cannot): when
+    // timeout_s > 0 every wait on the stream is a timed hipStreamQuery loop; a wait that expires marks the context
+    // abandoned: every later call fails at once with PDBEDA_ERR_TIMEOUT and destroy does not wait for the stream.
+    double timeout_s = 0.0;
+    bool timed_out = false;
 };
 
 struct ProfScope {
@@ -103,6 +110,7 @@ static int fail(pdbeda_ctx *ctx, int code, const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
+    if (ctx && ctx->timed_out) return PDBEDA_ERR_TIMEOUT;   // (the watchdog's message stays)
     if (ctx) ctx->err = buf;
     return code;
 }
@@ -111,8 +119,28 @@ static int fail(pdbeda_ctx *ctx, int code, const char *fmt, ...) {
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
         if (e_ != hipSuccess)                                                                      \
-            return fail(ctx, PDBEDA_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return (ctx) && (ctx)->timed_out ? PDBEDA_ERR_TIMEOUT                                  \
+                                             : fail(ctx, PDBEDA_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
+
+// Wait for the context's stream: plain hipStreamSynchronize, or (watchdog armed) a timed query loop.
+static hipError_t ctx_sync(pdbeda_ctx *ctx) {
+    if (ctx->timed_out) return hipErrorNotReady;
+    if (ctx->timeout_s <= 0.0) return hipStreamSynchronize(ctx->stream);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t q = hipStreamQuery(ctx->stream);
+        if (q != hipErrorNotReady) return q;
+        if (spins > 256) {   // first ~0.3 ms: busy poll (the usual wait is tens of microseconds), then back off
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > ctx->timeout_s) {
+                ctx->timed_out = true;
+                ctx->err = "watchdog: the stream did not drain within the per-entry time-out; context abandoned";
+                return hipErrorNotReady;
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(spins > 4096 ? 200 : 20));
+        }
+    }
+}
 
 static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
@@ -125,6 +153,7 @@ static int arena_get(pdbeda_ctx *ctx, size_t bytes, Arena *out) {
 }
 
 static int arena_get_raw(pdbeda_ctx *ctx, size_t bytes, Arena *out) {
+    if (ctx->timed_out) return PDBEDA_ERR_TIMEOUT;
     bytes = align_up(std::max<size_t>(bytes, 256));
     auto it = ctx->pool.lower_bound(bytes);
     if (it != ctx->pool.end() && it->first <= bytes * 2 + (1u << 20)) {
@@ -184,6 +213,22 @@ static inline unsigned grid_for(int64_t n, int block, int64_t cap = 1 << 20) {
 }
 
 // ------------------------------------------------------------------------------------
+// Small batched helpers: stage host arrays through a scratch arena
+// ------------------------------------------------------------------------------------
+template <typename Fn>
+static int with_scratch(pdbeda_ctx *ctx, size_t bytes, Fn fn) {
+    Arena a;
+    int rc = arena_get(ctx, bytes, &a);
+    if (rc) return rc;
+    rc = fn(a.base);
+    hipError_t e = ctx_sync(ctx);
+    arena_put(ctx, a);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(ctx, PDBEDA_ERR_DEVICE, "stream sync: %s", hipGetErrorString(e));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
 // Library / context
 // ------------------------------------------------------------------------------------
 extern "C" const char *pdbeda_version(void) { return "pdbeda-hip 0.1 (gfx950)"; }
@@ -224,7 +269,11 @@ extern "C" int pdbeda_ctx_create(int device_id, pdbeda_ctx **out) { return pdbed
 extern "C" int pdbeda_ctx_destroy(pdbeda_ctx *ctx) {
     if (!ctx) return PDBEDA_ERR_ARGUMENT;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->timed_out) {   // abandoned by the watchdog: its stream may never drain -- leak the device memory rather than hang in hipFree
+        delete ctx;
+        return PDBEDA_OK;
+    }
+    (void)ctx_sync(ctx);
     for (auto &kv : ctx->pool) (void)hipFree(kv.second.base);
     ctx->pool.clear();
     if (ctx->partials) (void)hipFree(ctx->partials);
@@ -236,7 +285,7 @@ extern "C" int pdbeda_ctx_destroy(pdbeda_ctx *ctx) {
 
 extern "C" int pdbeda_ctx_synchronize(pdbeda_ctx *ctx) {
     if (!ctx) return PDBEDA_ERR_ARGUMENT;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, ctx_sync(ctx));
     return PDBEDA_OK;
 }
 
@@ -252,7 +301,7 @@ extern "C" int pdbeda_ctx_profile_begin(pdbeda_ctx *ctx) {
 extern "C" int pdbeda_ctx_profile_end(pdbeda_ctx *ctx, char *buf, int64_t cap) {
     if (!ctx || !buf || cap <= 0) return PDBEDA_ERR_ARGUMENT;
     ctx->profiling = false;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, ctx_sync(ctx));
     std::map<std::string, std::pair<int64_t, double>> agg;
     for (auto &r : ctx->prof) {
         float ms = 0.f;
@@ -269,6 +318,12 @@ extern "C" int pdbeda_ctx_profile_end(pdbeda_ctx *ctx, char *buf, int64_t cap) {
     }
     if ((int64_t)out.size() + 1 > cap) return fail(ctx, PDBEDA_ERR_CAPACITY, "profile buffer too small");
     memcpy(buf, out.c_str(), out.size() + 1);
+    return PDBEDA_OK;
+}
+
+extern "C" int pdbeda_ctx_set_timeout(pdbeda_ctx *ctx, double seconds) {
+    if (!ctx || !(seconds >= 0.0)) return PDBEDA_ERR_ARGUMENT;
+    ctx->timeout_s = seconds;
     return PDBEDA_OK;
 }
 
@@ -332,7 +387,7 @@ static int map_create(pdbeda_ctx *ctx, const float *host, const float *dev, cons
         }
         m->dens = dev;
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // host buffers may be released on return
+    if (e == hipSuccess) e = ctx_sync(ctx);  // host buffers may be released on return
     if (e != hipSuccess) {
         if (m->own_dens) (void)hipFree((void *)m->dens);
         (void)hipFree(m->geom_dev);
@@ -371,7 +426,7 @@ extern "C" int pdbeda_map_combine(pdbeda_map *a, pdbeda_map *b, double alpha, pd
         hipLaunchKernelGGL(k_map_combine, dim3(grid_for(m->n_vox / 4 + 1, 256, 4096)), dim3(256), 0, ctx->stream, a->dens, b->dens, alpha, m->n_vox, d);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // (&m->geom is read by the copy above)
+    if (e == hipSuccess) e = ctx_sync(ctx);   // (&m->geom is read by the copy above)
     if (e != hipSuccess) {
         if (d) (void)hipFree(d);
         if (m->geom_dev) (void)hipFree(m->geom_dev);
@@ -390,7 +445,7 @@ extern "C" int pdbeda_map_download(pdbeda_map *m, float *density_out) {
     pdbeda_ctx *ctx = m->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(density_out, m->dens, sizeof(float) * (size_t)m->n_vox, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, ctx_sync(ctx));
     return PDBEDA_OK;
 }
 
@@ -398,9 +453,11 @@ extern "C" int pdbeda_map_free(pdbeda_map *m) {
     if (!m) return PDBEDA_ERR_ARGUMENT;
     pdbeda_ctx *ctx = m->ctx;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    if (m->own_dens) (void)hipFree((void *)m->dens);
-    (void)hipFree(m->geom_dev);
+    if (!ctx->timed_out) {   // (an abandoned context leaks its device memory: hipFree would wait for the stream that hangs)
+        (void)ctx_sync(ctx);
+        if (m->own_dens) (void)hipFree((void *)m->dens);
+        (void)hipFree(m->geom_dev);
+    }
     ctx->live_handles--;
     delete m;
     return PDBEDA_OK;
@@ -422,14 +479,21 @@ extern "C" int pdbeda_map_stats(pdbeda_map *m, double *mean, double *std) {
     pdbeda_ctx *ctx = m->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     double *res = ctx->partials + N_PARTIAL;
-    const double inv_n = 1.0 / (double)m->n_vox;
-    int rc = reduce_launch(m, 0, nullptr, 0.0, inv_n, 0, res);
-    if (rc) return rc;
-    rc = reduce_launch(m, 1, res, 0.0, inv_n, 1, res + 1);
-    if (rc) return rc;
+    // numpy's own summation tree (k_np_chunk_sums / k_np_final): == np.mean / np.std, not merely close
+    const int64_t n_full = m->n_vox / NP_CHUNK;
     double host[2];
-    HIP_TRY(ctx, hipMemcpyAsync(host, res, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = with_scratch(ctx, 8 * (size_t)std::max<int64_t>(n_full, 1), [&](char *base) -> int {
+        double *chunk_sums = reinterpret_cast<double *>(base);
+        hipStream_t st = ctx->stream;
+        for (int mode = 0; mode < 2; ++mode) {
+            if (n_full > 0) { PROF(ctx, "k_np_chunk_sums"); hipLaunchKernelGGL(k_np_chunk_sums, dim3((unsigned)std::min<int64_t>(n_full, 1 << 16)), dim3(256), 0, st, m->dens, n_full, mode, res, chunk_sums); }
+            { PROF(ctx, "k_np_final"); hipLaunchKernelGGL(k_np_final, dim3(1), dim3(256), 0, st, m->dens, m->n_vox, n_full, mode, res, chunk_sums, mode, res + mode); }
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(host, res, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+        return 0;
+    });
+    if (rc) return rc;
     if (mean) *mean = host[0];
     if (std) *std = host[1];
     return PDBEDA_OK;
@@ -443,24 +507,8 @@ extern "C" int pdbeda_sum_of_abs(pdbeda_map *m, float cutoff, double *out) {
     int rc = reduce_launch(m, 2, nullptr, (double)cutoff, 1.0, 0, res);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(out, res, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, ctx_sync(ctx));
     return PDBEDA_OK;
-}
-
-// ------------------------------------------------------------------------------------
-// Small batched helpers: stage host arrays through a scratch arena
-// ------------------------------------------------------------------------------------
-template <typename Fn>
-static int with_scratch(pdbeda_ctx *ctx, size_t bytes, Fn fn) {
-    Arena a;
-    int rc = arena_get(ctx, bytes, &a);
-    if (rc) return rc;
-    rc = fn(a.base);
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    arena_put(ctx, a);
-    if (rc) return rc;
-    if (e != hipSuccess) return fail(ctx, PDBEDA_ERR_DEVICE, "stream sync: %s", hipGetErrorString(e));
-    return 0;
 }
 
 extern "C" int pdbeda_abs_select_hist(pdbeda_map *a, pdbeda_map *b, double alpha, double cut_a, double cut_b, int which, int shift,
@@ -577,7 +625,6 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.unit_flag = n_tiles ? cv.take<uint32_t>(1) : nullptr;
     job.tile_mode = n_tiles ? cv.take<uint8_t>(n_tiles) : nullptr;
     job.tile_runs = n_tiles ? cv.take<uint32_t>(n_tiles) : nullptr;
-    job.stamps = n_tiles ? cv.take<unsigned long long>(16 * n_tiles) : nullptr;
     job.run_sums = n_tiles ? cv.take<double2>((size_t)n_tiles * RCAP) : nullptr;
     job.edge_cap = n_tiles ? (std::max<int64_t>(1 << 18, 2 * total_words) + ESHARDS - 1) / ESHARDS * ESHARDS : 0;
     if (n_tiles && edge_cap_override > 0) job.edge_cap = (edge_cap_override + ESHARDS - 1) / ESHARDS * ESHARDS;
@@ -786,7 +833,7 @@ static int list_resolve_counts(pdbeda_bloblist *bl) {
     HIP_TRY(ctx, hipMemcpyAsync(&ctr, job.ctr, sizeof ctr, hipMemcpyDeviceToHost, ctx->stream));
     if (job.n_vols > 0)
         HIP_TRY(ctx, hipMemcpyAsync(vols.data(), job.vols, sizeof(VolDesc) * job.n_vols, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, ctx_sync(ctx));
     auto rank_at = [&](int64_t key, int64_t *out) -> int {
         // number of blobs with first key < key
         if (key <= 0) { *out = 0; return 0; }
@@ -795,9 +842,9 @@ static int list_resolve_counts(pdbeda_bloblist *bl) {
         int64_t kw = key >> 6;
         uint32_t cp = 0, kr = 0;
         uint64_t bits = 0;
-        HIP_TRY(ctx, hipMemcpy(&cp, job.chunk_prefix + kw / KEY_CHUNK, 4, hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(&kr, job.key_rank + kw, 4, hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(&bits, job.key_bits + kw, 8, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpyAsync(&cp, job.chunk_prefix + kw / KEY_CHUNK, 4, hipMemcpyDeviceToHost, ctx->stream)); HIP_TRY(ctx, ctx_sync(ctx));
+        HIP_TRY(ctx, hipMemcpyAsync(&kr, job.key_rank + kw, 4, hipMemcpyDeviceToHost, ctx->stream)); HIP_TRY(ctx, ctx_sync(ctx));
+        HIP_TRY(ctx, hipMemcpyAsync(&bits, job.key_bits + kw, 8, hipMemcpyDeviceToHost, ctx->stream)); HIP_TRY(ctx, ctx_sync(ctx));
         *out = (int64_t)cp + kr + popc64(bits & bits_below((int)(key & 63)));
         return 0;
     };
@@ -824,13 +871,13 @@ extern "C" int pdbeda_bloblist_counters(pdbeda_bloblist *bl, int64_t *out) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     Counters c;
     HIP_TRY(ctx, hipMemcpyAsync(&c, bl->job.ctr, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, ctx_sync(ctx));
     out[0] = c.n_runs; out[1] = c.n_comps; out[2] = c.n_edges; out[3] = c.n_blobs;
     out[4] = out[5] = out[6] = out[7] = 0;
     if (bl->whole_map && bl->job.edge_fill) {   // cross-tile pairs parked in the shard buffers (demand, also when a shard overflowed)
         uint32_t fill[ESHARDS];
         HIP_TRY(ctx, hipMemcpyAsync(fill, bl->job.edge_fill, sizeof fill, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, ctx_sync(ctx));
         out[2] = 0;
         for (uint32_t v : fill) out[2] += v;
     }
@@ -838,36 +885,12 @@ extern "C" int pdbeda_bloblist_counters(pdbeda_bloblist *bl, int64_t *out) {
         const int64_t n_tiles = (int64_t)bl->td.ctiles * bl->td.rtiles * bl->td.stiles;
         std::vector<uint8_t> mode(n_tiles);
         HIP_TRY(ctx, hipMemcpyAsync(mode.data(), bl->job.tile_mode, n_tiles, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, ctx_sync(ctx));
         for (uint8_t v : mode) { if (v == 1) ++out[4]; else if (v == 3) ++out[6]; }
     }
     return PDBEDA_OK;
 }
 
-#ifdef PDBEDA_COUNT_FIND
-extern "C" int pdbeda_debug_find_counters(unsigned long long *out, int reset) {
-    unsigned long long z = 0;
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(&out[0], HIP_SYMBOL(pdbeda::g_find_calls), 8);
-    (void)hipMemcpyFromSymbol(&out[1], HIP_SYMBOL(pdbeda::g_find_steps), 8);
-    (void)hipMemcpyFromSymbol(&out[2], HIP_SYMBOL(pdbeda::g_unite_retries), 8);
-    (void)hipMemcpyFromSymbol(&out[3], HIP_SYMBOL(pdbeda::g_unite_ticks_max), 8);
-    (void)hipMemcpyFromSymbol(&out[4], HIP_SYMBOL(pdbeda::g_unite_ticks_sum), 8);
-    (void)hipMemcpyFromSymbol(&out[5], HIP_SYMBOL(pdbeda::g_unite_n), 8);
-    if (reset) { (void)hipMemcpyToSymbol(HIP_SYMBOL(pdbeda::g_unite_ticks_max), &z, 8); (void)hipMemcpyToSymbol(HIP_SYMBOL(pdbeda::g_unite_ticks_sum), &z, 8); (void)hipMemcpyToSymbol(HIP_SYMBOL(pdbeda::g_unite_n), &z, 8); }
-    if (reset) { (void)hipMemcpyToSymbol(HIP_SYMBOL(pdbeda::g_find_calls), &z, 8); (void)hipMemcpyToSymbol(HIP_SYMBOL(pdbeda::g_find_steps), &z, 8); (void)hipMemcpyToSymbol(HIP_SYMBOL(pdbeda::g_unite_retries), &z, 8); }
-    return 0;
-}
-#endif
-
-// Diagnostic builds only (-DPDBEDA_STAMPS): 8 s_memtime stamps per tile of the whole-map tile kernel.
-extern "C" int pdbeda_bloblist_stamps(pdbeda_bloblist *bl, unsigned long long *out, int64_t n_tiles) {
-    if (!bl || bl->freed || !out || !bl->job.stamps) return PDBEDA_ERR_ARGUMENT;
-    pdbeda_ctx *ctx = bl->ctx;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(out, bl->job.stamps, 128 * n_tiles, hipMemcpyDeviceToHost));
-    return PDBEDA_OK;
-}
 
 extern "C" int64_t pdbeda_bloblist_count(pdbeda_bloblist *bl) {
     if (!bl || bl->freed) return PDBEDA_ERR_ARGUMENT;
@@ -893,7 +916,7 @@ extern "C" int pdbeda_bloblist_stats(pdbeda_bloblist *bl, int64_t *n, double *to
     if (volume) HIP_TRY(ctx, hipMemcpyAsync(volume, job.b_volume + lo, 8 * cnt, hipMemcpyDeviceToHost, st));
     if (first_key) HIP_TRY(ctx, hipMemcpyAsync(first_key, job.b_key + lo, 8 * cnt, hipMemcpyDeviceToHost, st));
     if (group) HIP_TRY(ctx, hipMemcpyAsync(group, job.b_group + lo, 4 * cnt, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, ctx_sync(ctx));
     return PDBEDA_OK;
 }
 
@@ -909,7 +932,7 @@ static int list_materialise_voxels(pdbeda_bloblist *bl) {
     Job &job = ow->job;
     Counters ctr;
     HIP_TRY(ctx, hipMemcpyAsync(&ctr, job.ctr, sizeof ctr, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, ctx_sync(ctx));
     const int64_t nb = ctr.n_blobs;
     // total voxels unknown until the offsets scan; bound by key bits
     const int64_t max_vox = job.key_words * 64;
@@ -927,7 +950,7 @@ static int list_materialise_voxels(pdbeda_bloblist *bl) {
         hipLaunchKernelGGL(k_voxel_lists, dim3(grid_for(job.total_words * 64, 256, 8192)), dim3(256), 0, st, job, ow->offsets_dev,
                            ow->cursor_dev, ow->crs_dev);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, ctx_sync(ctx));
     ow->voxels_done = true;
     return 0;
 }
@@ -942,8 +965,8 @@ extern "C" int64_t pdbeda_bloblist_num_voxels(pdbeda_bloblist *bl) {
     pdbeda_ctx *ctx = bl->ctx;
     pdbeda_bloblist *ow = owner_of(bl);
     int64_t off[2] = {0, 0};
-    HIP_TRY(ctx, hipMemcpy(&off[0], ow->offsets_dev + bl->rank_lo, 8, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(&off[1], ow->offsets_dev + bl->rank_hi, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpyAsync(&off[0], ow->offsets_dev + bl->rank_lo, 8, hipMemcpyDeviceToHost, ctx->stream)); HIP_TRY(ctx, ctx_sync(ctx));
+    HIP_TRY(ctx, hipMemcpyAsync(&off[1], ow->offsets_dev + bl->rank_hi, 8, hipMemcpyDeviceToHost, ctx->stream)); HIP_TRY(ctx, ctx_sync(ctx));
     bl->n_voxels = off[1] - off[0];
     return bl->n_voxels;
 }
@@ -956,11 +979,11 @@ extern "C" int pdbeda_bloblist_voxels(pdbeda_bloblist *bl, int32_t *crs, int64_t
     pdbeda_bloblist *ow = owner_of(bl);
     const int64_t cnt = bl->rank_hi - bl->rank_lo;
     std::vector<int64_t> off(cnt + 1);
-    HIP_TRY(ctx, hipMemcpy(off.data(), ow->offsets_dev + bl->rank_lo, 8 * (cnt + 1), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpyAsync(off.data(), ow->offsets_dev + bl->rank_lo, 8 * (cnt + 1), hipMemcpyDeviceToHost, ctx->stream)); HIP_TRY(ctx, ctx_sync(ctx));
     const int64_t base = off[0];
     if (blob_offsets)
         for (int64_t i = 0; i <= cnt; ++i) blob_offsets[i] = off[i] - base;
-    if (crs && nv > 0) HIP_TRY(ctx, hipMemcpy(crs, ow->crs_dev + 3 * base, 12 * nv, hipMemcpyDeviceToHost));
+    if (crs && nv > 0) HIP_TRY(ctx, hipMemcpyAsync(crs, ow->crs_dev + 3 * base, 12 * nv, hipMemcpyDeviceToHost, ctx->stream)); HIP_TRY(ctx, ctx_sync(ctx));
     return PDBEDA_OK;
 }
 
@@ -986,7 +1009,7 @@ extern "C" int pdbeda_bloblist_labels(pdbeda_bloblist *bl, int32_t *labels_host)
     }
     hipLaunchKernelGGL(k_labels_decode, dim3(grid_for(nvox, 256, 4096)), dim3(256), 0, ctx->stream, signed_vol, nvox, bl->sign, decoded);
     hipError_t e = hipMemcpyAsync(labels_host, decoded, 4 * nvox, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = ctx_sync(ctx);
     arena_put(ctx, a);
     if (e != hipSuccess) return fail(ctx, PDBEDA_ERR_DEVICE, "labels: %s", hipGetErrorString(e));
     return PDBEDA_OK;
@@ -1085,7 +1108,7 @@ static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, con
     HIP_TRY(ctx, hipGetLastError());
     Counters ctr;
     HIP_TRY(ctx, hipMemcpyAsync(&ctr, gs->d_ctr, sizeof ctr, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));  // item_group (host vector) is also safe to drop now
+    HIP_TRY(ctx, ctx_sync(ctx));  // item_group (host vector) is also safe to drop now
     gs->total_words = ctr.total_words;
     gs->total_keys = ctr.total_keys;
     if (gs->total_words >= (1ll << 31) * 2) return fail(ctx, PDBEDA_ERR_ARGUMENT, "sphere batch too large (%lld mask words)", (long long)gs->total_words);
@@ -1123,7 +1146,7 @@ static int grouped_blobs(pdbeda_map *m, const double *xyz, const float *radii, c
     }
     if (e == hipSuccess) rc = engine_enqueue(ctx, m, job, max_runs);
     // inputs are consumed by the paint kernel; wait before recycling their arena
-    if (e == hipSuccess && rc == 0) e = hipStreamSynchronize(st);
+    if (e == hipSuccess && rc == 0) e = ctx_sync(ctx);
     arena_put(ctx, gs.in_arena);
     if (e != hipSuccess || rc) {
         arena_put(ctx, arena);
@@ -1186,7 +1209,7 @@ extern "C" int pdbeda_region_sums(pdbeda_map *m, const double *xyz, const float 
     if (e == hipSuccess && neg) e = hipMemcpyAsync(neg, d_neg, 8 * n_groups, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(h_cnt.data(), d_cnt, 8 * n_groups, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(h_inv.data(), d_inv, 4 * n_groups, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = ctx_sync(ctx);
     arena_put(ctx, a);
     arena_put(ctx, gs.in_arena);
     if (e != hipSuccess) return fail(ctx, PDBEDA_ERR_DEVICE, "region sums: %s", hipGetErrorString(e));

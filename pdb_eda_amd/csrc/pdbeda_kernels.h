@@ -67,7 +67,6 @@ struct Job {
     uint8_t *tile_mode;       // per tile: 0 = united in LDS, 1 = unit tile
     uint32_t *tile_runs;      // per tile: number of word-runs (ids tile * runs_per_tile ...)
     double2 *run_sums;        // whole-map tiles: per run slot (sum rho, sum rho*(c - c_tile)), RCAP per tile
-    unsigned long long *stamps;   // diagnostic builds (-DPDBEDA_STAMPS): 8 s_memtime stamps per tile
     uint2 *edges;             // cross-tile component pairs parked by k_face_merge (ESHARDS equal regions)
     uint32_t *edge_fill;      // pairs written per region
     int64_t edge_cap;
@@ -216,25 +215,12 @@ __global__ void __launch_bounds__(256) k_run_index(Job job, const float *__restr
 // (k_union_edges 40 -> 35 us).
 // ------------------------------------------------------------------------------------
 __device__ inline int uf_load(const int32_t *p, int x) {
-#ifndef PDBEDA_UF_AGENT_LOADS
     return __hip_atomic_load(p + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
-    return __hip_atomic_load(p + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
 }
 // find with path halving by fire-and-forget atomic min (monotone: never undoes a union)
-#ifdef PDBEDA_COUNT_FIND
-__device__ unsigned long long g_find_steps, g_find_calls, g_unite_retries, g_unite_ticks_max, g_unite_ticks_sum, g_unite_n;
-#endif
 __device__ inline int uf_find(int32_t *p, int x) {
     int q;
-#ifdef PDBEDA_COUNT_FIND
-    atomicAdd(&g_find_calls, 1ull);
-#endif
     while ((q = uf_load(p, x)) != x) {
-#ifdef PDBEDA_COUNT_FIND
-        atomicAdd(&g_find_steps, 1ull);
-#endif
         const int gp = uf_load(p, q);
         if (gp != q) atomicMin(p + x, gp);
         x = gp;
@@ -242,9 +228,6 @@ __device__ inline int uf_find(int32_t *p, int x) {
     return x;
 }
 __device__ inline void uf_unite(int32_t *p, int a, int b) {
-#ifdef PDBEDA_COUNT_FIND
-    unsigned long long my_retries = 0;
-#endif
     while (true) {
         a = uf_find(p, a);
         b = uf_find(p, b);
@@ -252,10 +235,6 @@ __device__ inline void uf_unite(int32_t *p, int a, int b) {
         if (a < b) { int t = a; a = b; b = t; }
         int old = atomicMin(p + a, b);
         if (old == a) return;
-#ifdef PDBEDA_COUNT_FIND
-        atomicAdd(&g_unite_retries, 1ull);
-        atomicMax(&g_find_calls, (++my_retries) << 40);   // max retries of one unite in the top bits
-#endif
         a = old;
     }
 }
@@ -827,6 +806,150 @@ __global__ void __launch_bounds__(256) k_reduce_final(const double *__restrict__
     const double t = block_sum(acc, s_part);
     if (threadIdx.x == 0) {
         double v = t * scale;
+        out[0] = take_sqrt ? __dsqrt_rn(v) : v;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// meanDensity / stdDensity exactly as numpy computes them (ccp4.py:343-363: np.mean / np.std of the voxel tuple, i.e. of a
+// contiguous float64 array).  The default cutoffs (densityAnalysis.py:131-132,148) are float32(mean + k std): one ulp of
+// the mean can flip a voxel, so the summation TREE is reproduced, not just the value to 1e-12:
+//   add.reduce feeds the inner loop 8192 elements at a time and adds the calls up in order; each call is numpy's
+//   pairwise sum: blocks of 128 summed with 8 interleaved accumulators, ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), blocks
+//   combined by a balanced binary tree (8192 = 64 leaves); an array tail < 8192 follows the general recursion
+//   n2 = (n/2) & ~7.  np.std: m = sum/n; x = a - m; x = x*x; sqrt(sum(x)/n)  (_methods._var).
+// k_np_chunk_sums: one workgroup per 8192-element chunk: coalesced 16-B loads -> LDS (leaf stride 136 floats: the
+// 8 x 4 (lane j, leaf) reads of a 32-lane group hit 32 different banks), thread (leaf, j) adds its 16 values in order,
+// wave butterflies build the tree.  k_np_final: the tail chunk + the in-order accumulation of the chunk sums (one thread:
+// the order IS the result), then the division / square root.
+// mode 0: x   mode 1: (x - mean)^2
+// ------------------------------------------------------------------------------------
+constexpr int NP_CHUNK = 8192, NP_LSTRIDE = 136;
+
+__device__ __forceinline__ double np_elem(float v, int mode, double shift) {
+    double d = (double)v;
+    if (mode == 1) { d = d - shift; d = d * d; }
+    return d;
+}
+
+__global__ void __launch_bounds__(256) k_np_chunk_sums(const float *__restrict__ x, int64_t n_full, int mode, const double *__restrict__ mean_p,
+                                                       double *__restrict__ chunk_sums) {
+    __shared__ __attribute__((aligned(16))) float s_x[64 * NP_LSTRIDE];
+    __shared__ double s_node[8];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double shift = mode == 1 ? mean_p[0] : 0.0;
+    for (int64_t chunk = blockIdx.x; chunk < n_full; chunk += gridDim.x) {   // block-uniform
+        const float4 *src = reinterpret_cast<const float4 *>(x + chunk * NP_CHUNK);
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = src[tid + 256 * k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = 4 * (tid + 256 * k);
+            *reinterpret_cast<float4 *>(&s_x[(idx >> 7) * NP_LSTRIDE + (idx & 127)]) = v[k];
+        }
+        __syncthreads();
+        double node[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float *p = s_x + (h * 32 + (tid >> 3)) * NP_LSTRIDE + (tid & 7);
+            double r = np_elem(p[0], mode, shift);
+#pragma unroll
+            for (int i = 1; i < 16; ++i) r += np_elem(p[8 * i], mode, shift);
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) r += __shfl_xor(r, d);   // 8 accumulators -> leaf -> the 8 leaves of this wave
+            node[h] = r;
+        }
+        if (lane == 0) { s_node[wv] = node[0]; s_node[4 + wv] = node[1]; }
+        __syncthreads();
+        if (tid == 0) chunk_sums[chunk] = ((s_node[0] + s_node[1]) + (s_node[2] + s_node[3])) + ((s_node[4] + s_node[5]) + (s_node[6] + s_node[7]));
+    }
+}
+
+__global__ void __launch_bounds__(256) k_np_final(const float *__restrict__ x, int64_t n, int64_t n_full, int mode, const double *__restrict__ mean_p,
+                                                  const double *__restrict__ chunk_sums, int take_sqrt, double *__restrict__ out) {
+    __shared__ int s_off[160], s_len[160], s_nleaf;
+    __shared__ double s_leaf[160];
+    __shared__ double s_buf[1024];
+    const int tid = threadIdx.x;
+    const double shift = mode == 1 ? mean_p[0] : 0.0;
+    const int rem = (int)(n - n_full * NP_CHUNK);
+    const float *xr = x + n_full * NP_CHUNK;
+    // ---- the tail chunk: leaves of the recursion in order (explicit stack), their sums in parallel ----
+    if (tid == 0) {
+        int nl = 0;
+        if (rem > 0) {
+            int so[16], sl[16], sp = 0;
+            so[0] = 0; sl[0] = rem;
+            while (sp >= 0) {
+                const int o = so[sp], l = sl[sp];
+                --sp;
+                if (l <= 128) { s_off[nl] = o; s_len[nl] = l; ++nl; continue; }
+                int n2 = l / 2;
+                n2 -= n2 % 8;
+                ++sp; so[sp] = o + n2; sl[sp] = l - n2;   // right: popped second
+                ++sp; so[sp] = o; sl[sp] = n2;            // left: popped first
+            }
+        }
+        s_nleaf = nl;
+    }
+    __syncthreads();
+    const int nleaf = s_nleaf;
+    for (int task = tid; task < nleaf * 8; task += 256) {   // (leaf, accumulator j): the 8 lanes of a leaf are neighbours
+        const int leaf = task >> 3, j = task & 7, o = s_off[leaf], l = s_len[leaf];
+        double r = 0.0;
+        if (l >= 8) {
+            r = np_elem(xr[o + j], mode, shift);
+            for (int i = 8; i < l - (l % 8); i += 8) r += np_elem(xr[o + i + j], mode, shift);
+        }
+        r += __shfl_xor(r, 1);
+        r += __shfl_xor(r, 2);
+        r += __shfl_xor(r, 4);
+        if (j == 0) {
+            double res = l >= 8 ? r : 0.0;
+            for (int i = l >= 8 ? l - (l % 8) : 0; i < l; ++i) res += np_elem(xr[o + i], mode, shift);
+            s_leaf[leaf] = res;
+        }
+    }
+    __syncthreads();
+    double total = 0.0;
+    // ---- chunk sums in order (staged through LDS, added by ONE thread) ----
+    for (int64_t base = 0; base < n_full; base += 1024) {
+        for (int k = tid; k < 1024; k += 256) s_buf[k] = base + k < n_full ? chunk_sums[base + k] : 0.0;
+        __syncthreads();
+        if (tid == 0) {
+            const int cnt = n_full - base < 1024 ? (int)(n_full - base) : 1024;
+            for (int k = 0; k < cnt; ++k) total += s_buf[k];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (nleaf > 0) {   // combine the tail's leaves along the recursion tree (post-order, explicit stack)
+            int len[16], stage[16], sp = 0, next = 0;
+            double left[16], ret = 0.0;
+            len[0] = rem; stage[0] = 0;
+            while (sp >= 0) {
+                if (stage[sp] == 0) {
+                    if (len[sp] <= 128) { ret = s_leaf[next++]; --sp; continue; }
+                    int n2 = len[sp] / 2;
+                    n2 -= n2 % 8;
+                    stage[sp] = 1;
+                    ++sp; len[sp] = n2; stage[sp] = 0;
+                } else if (stage[sp] == 1) {
+                    int n2 = len[sp] / 2;
+                    n2 -= n2 % 8;
+                    left[sp] = ret;
+                    stage[sp] = 2;
+                    const int rl = len[sp] - n2;
+                    ++sp; len[sp] = rl; stage[sp] = 0;
+                } else {
+                    ret = left[sp] + ret;
+                    --sp;
+                }
+            }
+            total += ret;
+        }
+        const double v = total / (double)n;
         out[0] = take_sqrt ? __dsqrt_rn(v) : v;
     }
 }

@@ -92,25 +92,17 @@ __device__ inline void mark_comps_unused(const Job &job, uint32_t cb, uint32_t f
     }
 }
 
-#ifdef PDBEDA_STAMPS
-#define STAMP(k) do { if (threadIdx.x == 0) job.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define STAMP(k) do { } while (0)
-#endif
 
 // NT = 512 threads: the same tile with twice the waves -- the kernel is one round of co-resident workgroups (1024
 // tiles at 256^3, 4 per CU), so its duration is the critical path of ONE tile; 8 waves halve the serial word loop of
 // A1, split A3 / C2 by sign (threads 256.. own the "<= cutoff" plane) and halve the pair tasks per thread.
-#ifndef PDBEDA_CHU_ALL
-#define PDBEDA_CHU_ALL 0
-#endif
 template <int CW, int NT>
 __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td,
                                                                        JobInit init) {
     constexpr int NW = NT / 64;   // waves
     constexpr int NU = 64 * CW;   // (row, word) units of the tile = threads that own a word
     constexpr int UPW = NU / NW;  // units per wave (whole rows)
-    constexpr int CHU = PDBEDA_CHU_ALL ? UPW : (UPW < 16 ? UPW : ((CW == 3) ? 12 : 16));  // units per chunk: whole rows
+    constexpr int CHU = UPW < 16 ? UPW : ((CW == 3) ? 12 : 16);  // units per chunk: whole rows
     constexpr int VREG = VMAIN / NW;
     constexpr int EQ = tile_eq(NT);
     constexpr int SLOTS = (RCAP + NT - 1) / NT;   // run slots a thread owns in phase B
@@ -158,7 +150,6 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
     const int row_words = (uc + 63) >> 6;
     const int n_planes = td.n_planes;
 
-    STAMP(0);
     if (tid == 0) { s_over = 0; s_vover = 0; s_ncomp = 0; s_alloc[0] = 0; s_alloc[1] = 0; s_vpool = 0; }
     if (blockIdx.x == 0 && tid < ESHARDS) job.edge_fill[tid] = 0u;
     if (blockIdx.x == 0 && tid == 0) {   // read by the kernels that follow; nothing in this kernel touches them
@@ -259,11 +250,6 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
         if (interior) stream(std::true_type{}); else stream(std::false_type{});
     }
     __syncthreads();
-    STAMP(1);
-#if defined(PDBEDA_STOP_AFTER) && PDBEDA_STOP_AFTER == 11
-    if (s_over == 0xffffffffu) return;
-    if (true) return;
-#endif
 
     // ---- A2 (thread per word): run counts, row continuation, ONE block scan -> run slots ---------
     // Runs are tracked per ROW: a run that continues from the previous word keeps that word's last
@@ -385,10 +371,6 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
     }
     __syncthreads();
 
-    STAMP(2);
-#if defined(PDBEDA_STOP_AFTER) && PDBEDA_STOP_AFTER == 1
-    if (s_over != 0xffffffffu) return;
-#endif
     // my word (threads tid < NU own unit tid)
     const int my_wl = wt % CW, my_rowl = (wt / CW) & 63;
     const int my_rl = my_rowl & 7, my_sl = my_rowl >> 3;
@@ -443,10 +425,8 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
         uint32_t mi = 0, mj = 0;   // merge state (kept across batches)
         bool first_batch = true;   // parents are still the identity: B1 itself is the first hook pass
         while (true) {  // batches of at most EQ parked pairs per thread (almost always one batch)
-            STAMP(8);
             if (tid == 0) s_more = 0;
             __syncthreads();
-            STAMP(9);
             uint32_t n_edges = 0;
             if (mi < na && mj < nb) {
                 // one 16-bit read per run (start | end << 8); the step is branch-light: compare, maybe park, advance ONE list
@@ -471,10 +451,6 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
                 }
             }
             if (mi < na && mj < nb) s_more = 1;
-#if defined(PDBEDA_STOP_AFTER) && PDBEDA_STOP_AFTER == 12
-            if (s_over != 0xffffffffu) return;
-#endif
-            STAMP(3);
             uint32_t wmax = n_edges;   // wave maximum of the pair counts
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(wmax, d); wmax = o > wmax ? o : wmax; }
@@ -553,10 +529,6 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
             if (!more) break;
         }
     }
-    STAMP(4);
-#if defined(PDBEDA_STOP_AFTER) && PDBEDA_STOP_AFTER == 2
-    if (s_over != 0xffffffffu) return;
-#endif
     // the run extents of my slots, for the face export below (C1 reuses their LDS bytes)
     uint32_t ex_slot[SLOTS], ex_se[SLOTS];
 #pragma unroll
@@ -571,10 +543,6 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
         if (slot_used(i) && s_parent[i] == i) s_compidx[i] = (uint16_t)atomicAdd(&s_ncomp, 1u);
     __syncthreads();
     const uint32_t n_comp = s_ncomp;
-    STAMP(5);
-#if defined(PDBEDA_STOP_AFTER) && PDBEDA_STOP_AFTER == 3
-    if (s_over != 0xffffffffu) return;
-#endif
     if (n_comp > CCAP) {  // block-uniform: too many components for LDS -> unit tile
         if (my_valid) {
             job.mask[my_word] = m0;
@@ -655,7 +623,6 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
     }
     if (tid == 0) job.tile_mode[tile_id] = 0;
     __syncthreads();
-    STAMP(6);
     const int64_t keys_pp = (int64_t)uc * ur * us;
     for (uint32_t i = tid; i < n_comp; i += NT) {
         const uint32_t g = cb + i;
@@ -674,7 +641,6 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
     }
     mark_comps_unused(job, cb, n_comp, tid, NT);
     if (tid == 0) job.tile_runs[blockIdx.x] = n_wordruns;
-    STAMP(7);
 }
 
 // Generic labelling of the tiles k_tile_label could not hold in LDS ("unit tiles"): every run
@@ -1016,9 +982,7 @@ __global__ void __launch_bounds__(256) k_unit_fallback(Job job, const float *__r
 // Thread per parked run pair: map to tile components, global union-find with device-scope atomics.
 // Consecutive pairs of a word mostly name the same two components: a lane whose pair equals its
 // left neighbour's is dropped (wave shuffle), as are pairs already inside one component.
-#ifndef PDBEDA_DEDUP_WINDOW
-#define PDBEDA_DEDUP_WINDOW 16
-#endif
+constexpr int DEDUP_WINDOW = 16;   // lanes a k_union_edges thread looks back for a repeat of its component pair
 __global__ void __launch_bounds__(256) k_union_edges(Job job) {
     const uint32_t shard_cap = (uint32_t)(job.edge_cap / ESHARDS);
     const int lane = lane_id();
@@ -1038,27 +1002,18 @@ __global__ void __launch_bounds__(256) k_union_edges(Job job) {
             if (a > b) { const int t = a; a = b; b = t; }   // unordered pair
             bool dup = false;
 #pragma unroll
-            for (int d = 1; d <= PDBEDA_DEDUP_WINDOW; ++d) {   // the same two components a few lanes back (pairs of one tile face interleave)
+            for (int d = 1; d <= DEDUP_WINDOW; ++d) {   // the same two components a few lanes back (pairs of one tile face interleave)
                 const int pa = __shfl_up(a, d), pb = __shfl_up(b, d);
                 dup = dup || (lane >= d && pa == a && pb == b);
             }
-#ifdef PDBEDA_COUNT_FIND
-            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-            if (i < n && a != b && !dup) uf_unite(job.parent, a, b);
-            const unsigned long long dt = __builtin_amdgcn_s_memtime() - t0;
-            if (i < n && a != b && !dup) { atomicMax(&g_unite_ticks_max, dt); atomicAdd(&g_unite_ticks_sum, dt); atomicAdd(&g_unite_n, 1ull); }
-#else
             if (i < n && a != b && !dup) {
-#ifndef PDBEDA_NO_PAIR_FILTER
                 // the same two components meet on many rows / sections of a tile face, in other workgroups: a lossy global
                 // set (one CAS) keeps all but the first of them away from the union-find, where repeats only contend
                 const unsigned long long key = ((unsigned long long)(uint32_t)a << 32) | (uint32_t)b;
                 const uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & job.pair_filter_mask;
                 if (atomicCAS(&job.pair_filter[h], 0ull, key) != key)
-#endif
                     uf_unite(job.parent, a, b);
             }
-#endif
         }
     }
 }
@@ -1216,12 +1171,7 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS) k_labels_tiles(Job j
         }
         int32_t *dst = labels + ((int64_t)s * ur + r) * uc + c;
         if (c + 3 < uc && ((uc & 3) == 0)) {
-#ifdef PDBEDA_LABELS_NT
-            __builtin_nontemporal_store(out[0], dst); __builtin_nontemporal_store(out[1], dst + 1);
-            __builtin_nontemporal_store(out[2], dst + 2); __builtin_nontemporal_store(out[3], dst + 3);
-#else
             *reinterpret_cast<int4 *>(dst) = make_int4(out[0], out[1], out[2], out[3]);
-#endif
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q)

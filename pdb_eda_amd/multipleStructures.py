@@ -42,80 +42,134 @@ def shard(entries, rank, world_size):
     return [entries[i] for i in order[rank::world_size]]
 
 
-def analyzeEntry(entry, ctx=None):
-    """ref multipleStructures.py:320-356: one entry -> result record, or 0 when the entry fails
-    (load error, or no density-electron ratio: Q7).  A failed entry never poisons the pool."""
-    startTime = time.process_time()
+def _drop(pdbid, reason, failures, silent):
+    """ref multipleStructures.py:277-282, 297-304: a failed entry is reported on stderr (unless --silent) and dropped."""
+    if failures is not None:
+        failures[pdbid] = reason
+    if not silent:
+        print(pdbid, reason, file=sys.stderr)
+    return 0
+
+
+def analyzeEntry(entry, ctx=None, failures=None, silent=False):
+    """ref multipleStructures.py:320-356: one entry -> result record, or 0 when the ENTRY fails (its files do not load or
+    parse, the analysis raises, or there is no density-electron ratio: Q7); the reason goes to ``failures[pdbid]`` and to
+    stderr like the reference's processFunction (277-282).  Device / library failures (``_native.PdbedaError``: no memory,
+    a HIP fault, a missing library, the watchdog) are NOT entry failures: they propagate."""
+    startTime = time.thread_time()
     try:
         dens_bytes, diff_bytes, biopdbObj, pdbObj = entry.loader()
         densityObj = ccp4.parse(io.BytesIO(dens_bytes), entry.pdbid, ctx=ctx)
         diffDensityObj = ccp4.parse(io.BytesIO(diff_bytes), entry.pdbid, ctx=ctx)
         densityAnalysis._attachCutoffs(densityObj, diffDensityObj)
         analyzer = densityAnalysis.DensityAnalysis(entry.pdbid, densityObj, diffDensityObj, biopdbObj, pdbObj)
-    except Exception:
-        return 0
-    if not analyzer.densityElectronRatio:
-        return 0
-    ratio = analyzer.densityElectronRatio
+        ratio = analyzer.densityElectronRatio
+    except _native.PdbedaError:
+        raise
+    except Exception as exception:
+        return _drop(entry.pdbid, "%s: %s" % (type(exception).__name__, exception), failures, silent)
+    if not ratio:
+        return _drop(entry.pdbid, "no density-electron ratio (total aggregated electrons below the minimum)", failures, True)
     corrected = analyzer.medians['corrected_density_electron_ratio']
     diffs = {atomType: ((corrected[atomType] - ratio) / ratio) if atomType in corrected else 0 for atomType in sorted(densityAnalysis.paramsGlobal["radii"])}
     complete = sum(analyzer.atomTypeOverlapCompleteness.values())
     incomplete = sum(analyzer.atomTypeOverlapIncompleteness.values())
     if complete > 0 or incomplete > 0:
         complete = complete / (complete + incomplete)
+    # 'f000' needs the structure factors' F000 estimate (densityAnalysis.py F000, out of scope: DESIGN.md 7): None
     stats = {'density_electron_ratio': ratio, 'voxel_volume': densityObj.header.unitVolume, 'f000': None,
              'num_voxels_aggregated': analyzer.numVoxelsAggregated, 'total_aggregated_electrons': analyzer.totalAggregatedElectrons,
              'density_mean': densityObj.header.densityMean, 'diff_density_mean': diffDensityObj.header.densityMean,
              'resolution': pdbObj.header.resolution, 'space_group': pdbObj.header.spaceGroup,
              'num_atoms_analyzed': len(analyzer.atomCloudDescriptions), 'num_residue_clouds_analyzed': len(analyzer.residueCloudDescriptions),
              'num_domain_clouds_analyzed': len(analyzer.domainCloudDescriptions), 'atom_overlap_completeness': complete}
-    properties = {'residue_counts': dict(collections.Counter(residue.resname for residue in biopdbObj.get_residues())),
-                  'element_counts': dict(collections.Counter(atom.element for atom in biopdbObj.get_atoms()))}
+    properties = dict(getattr(biopdbObj, "header", None) or {})          # the structure header items (ref 346)
+    properties['residue_counts'] = dict(collections.Counter(residue.resname for residue in biopdbObj.get_residues()))
+    properties['element_counts'] = dict(collections.Counter(atom.element for atom in biopdbObj.get_atoms()))
     slopes = {t: float(v) for t, v in analyzer.medians['slopes'].items() if not np.isnan(v)}
     return {"pdbid": entry.pdbid, "diffs": {k: float(v) for k, v in diffs.items()}, "stats": stats, "slopes": slopes,
             "atomtype_overlap_completeness": dict(analyzer.atomTypeOverlapCompleteness),
             "atomtype_overlap_incompleteness": dict(analyzer.atomTypeOverlapIncompleteness),
-            "execution_time": time.process_time() - startTime, "properties": properties}
+            "execution_time": time.thread_time() - startTime, "properties": properties}
 
 
 class StreamPool(object):
-    """N worker threads on one GPU, each with its own context (HIP stream + device arena cache)."""
+    """N worker threads on one GPU, each with its own context (HIP stream + device arena cache).
 
-    def __init__(self, device=0, n_streams=4):
+    ``map(fn, items)`` calls ``fn(item, ctx)`` and returns the results in order.  Per item:
+      * an ordinary exception drops the item (result 0) with its reason in ``self.failures[index]`` and on stderr
+        (multipleStructures.py:297-304);
+      * ``time_out`` seconds (the reference's --time-out, 359-377) arm the library's watchdog: a stream that does not
+        drain fails the item with reason "Timeout", the worker ABANDONS that context (never waits on it again, never
+        re-execs the process) and carries on with a fresh one;
+      * any other ``PdbedaError`` is a device failure: the pool stops handing out work, joins its threads and re-raises it.
+    """
+
+    def __init__(self, device=0, n_streams=4, time_out=0.0, silent=False):
         self.device = device
         self.n_streams = max(1, int(n_streams))
+        self.time_out = float(time_out or 0.0)
+        self.silent = silent
+        self.failures = {}
 
     def map(self, fn, entries):
         todo = queue.Queue()
         for i, e in enumerate(entries):
             todo.put((i, e))
         results = [0] * len(entries)
+        fatal = []
+        stop = threading.Event()
+        self.failures = {}
+
+        def new_context():
+            ctx = _native.Context(self.device)
+            if self.time_out > 0:
+                ctx.set_timeout(self.time_out)
+            return ctx
 
         def work():
-            ctx = _native.Context(self.device)
+            ctx = None
             try:
-                while True:
+                ctx = new_context()
+                while not stop.is_set():
                     try:
                         i, e = todo.get_nowait()
                     except queue.Empty:
-                        return
+                        break
                     try:
                         results[i] = fn(e, ctx)
-                    except Exception:
-                        results[i] = 0          # per-entry failure is dropped, like multipleStructures.py:297-304
-            finally:
-                ctx.synchronize()
+                    except _native.PdbedaTimeout:
+                        _drop(getattr(e, "pdbid", i), "Timeout", None, self.silent)
+                        self.failures[i] = "Timeout"
+                        ctx = new_context()          # the old context is abandoned with whatever still runs on it
+                    except _native.PdbedaError:
+                        raise
+                    except Exception as exception:
+                        self.failures[i] = "%s: %s" % (type(exception).__name__, exception)
+                        _drop(getattr(e, "pdbid", i), self.failures[i], None, self.silent)
+                if ctx is not None and not stop.is_set():
+                    ctx.synchronize()
+            except BaseException as exception:       # device failure (or interpreter shutdown): stop the pool, report once
+                fatal.append(exception)
+                stop.set()
         threads = [threading.Thread(target=work) for _ in range(min(self.n_streams, max(1, len(entries))))]
         for t in threads:
             t.start()
         for t in threads:
             t.join()
+        if fatal:
+            raise fatal[0]
         return results
 
 
-def processEntries(entries, device=0, n_streams=4):
-    """The per-GPU part of ``pdb_eda multiple``: {pdbid: record} for the entries that succeed."""
-    records = StreamPool(device, n_streams).map(analyzeEntry, entries)
+def processEntries(entries, device=0, n_streams=4, time_out=0.0, silent=False, failures=None):
+    """The per-GPU part of ``pdb_eda multiple``: {pdbid: record} for the entries that succeed; the reasons of the ones that
+    do not are collected in ``failures`` ({pdbid: reason}) when a dict is passed."""
+    pool = StreamPool(device, n_streams, time_out, silent)
+    reasons = {} if failures is None else failures
+    records = pool.map(lambda e, ctx: analyzeEntry(e, ctx, reasons, silent), entries)
+    for i, why in pool.failures.items():
+        reasons.setdefault(entries[i].pdbid, why)
     return {r["pdbid"]: r for r in records if r}
 
 

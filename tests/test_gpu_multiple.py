@@ -25,9 +25,11 @@ def test_stream_pool_matches_sequential(gpu_ctx):
     from pdb_eda_amd import synthetic, densityAnalysis, multipleStructures
     densityAnalysis.setGlobals(synthetic.synthetic_params())
     entries = _entries()
-    seq = {e.pdbid: multipleStructures.analyzeEntry(e, gpu_ctx) for e in entries}
-    par = multipleStructures.processEntries(entries, device=0, n_streams=3)
+    seq = {e.pdbid: multipleStructures.analyzeEntry(e, gpu_ctx, silent=True) for e in entries}
+    reasons = {}
+    par = multipleStructures.processEntries(entries, device=0, n_streams=3, silent=True, failures=reasons)
     assert "broken" not in par and seq["broken"] == 0
+    assert set(reasons) == {"broken"} and reasons["broken"]            # the dropped entry carries its reason (ref 277-282)
     assert set(par) == {k for k, v in seq.items() if v}
     for k, rec in par.items():
         want = seq[k]
@@ -75,3 +77,52 @@ def test_unit_fallback_on_many_streams():
     assert all(r != 0 for r in res)
     assert all(ok for r in res for ok, _ in r)
     assert all(n_unit > 0 for r in res for _, n_unit in r)      # the fallback path really ran
+
+
+def test_device_failure_stops_the_pool():
+    """A library / device failure is not an entry failure: the pool re-raises it instead of reporting 0."""
+    from pdb_eda_amd import _native, multipleStructures
+
+    def work(k, ctx):
+        if k == 2:
+            ctx.check(-1, "synthetic device failure")
+        return k + 1
+    with pytest.raises(_native.PdbedaError):
+        multipleStructures.StreamPool(device=0, n_streams=2, silent=True).map(work, list(range(6)))
+
+
+@pytest.mark.timeout(120)
+def test_watchdog_abandons_a_context():
+    """--time-out (multipleStructures.py:297-304, 359-377): a stream that does not drain in time fails ITS entry with the
+    reason "Timeout"; the context is abandoned (every later call on it fails at once, destroy does not wait) and the
+    worker carries on with a fresh one."""
+    from pdb_eda_amd import _native, ccp4, synthetic, multipleStructures
+    g = synthetic.smooth_noise((256, 256, 256), 7, 1.5)
+    spec = synthetic.MapSpec(ncrs=(256, 256, 256))
+    header = ccp4.DensityHeader.fromFileHeader(synthetic.ccp4_header_bytes(spec))
+    cut = float(g.std()) * 1.5
+
+    def work(k, ctx):
+        dmap = _native.DeviceMap(ctx, g, header.geometry())
+        if k == 1:            # ~0.3 s of queued labelling steps against a 50 ms allowance
+            for _ in range(2000):
+                last = dmap.full_blobs_pm(cut, -cut, labels=True)      # (dropping the previous lists recycles their arena)
+            raise AssertionError("the watchdog did not fire (%d blobs)" % len(last[0]))
+        green, red = dmap.full_blobs_pm(cut, -cut)
+        return len(green) + len(red)
+    pool = multipleStructures.StreamPool(device=0, n_streams=1, time_out=0.05, silent=True)
+    res = pool.map(work, [0, 1, 2])
+    assert res[0] > 0 and res[0] == res[2] and res[1] == 0
+    assert pool.failures == {1: "Timeout"}
+    # a timed-out context stays dead, a disarmed one waits as long as it takes
+    ctx = _native.Context(0)
+    dmap = _native.DeviceMap(ctx, g, header.geometry())
+    ctx.set_timeout(0.02)
+    for _ in range(1500):
+        last = dmap.full_blobs_pm(cut, -cut, labels=True)
+    with pytest.raises(_native.PdbedaTimeout):
+        ctx.synchronize()
+    with pytest.raises(_native.PdbedaTimeout):
+        dmap.stats()
+    ctx2 = _native.Context(0)
+    assert len(_native.DeviceMap(ctx2, g, header.geometry()).full_blobs(cut)) == res[0] - len(_native.DeviceMap(ctx2, g, header.geometry()).full_blobs(-cut))

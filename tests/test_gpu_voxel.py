@@ -44,8 +44,9 @@ def case(request, gpu_ctx):
 
 def test_stats_and_sum_of_abs(case):
     _, z, dm = case
-    assert dm.meanDensity == pytest.approx(float(z["mean"]), rel=1e-12, abs=1e-15)
-    assert dm.stdDensity == pytest.approx(float(z["std"]), rel=1e-12)
+    # == , not approx: the device reproduces numpy's summation tree (the default cutoffs are float32(mean + k std))
+    assert dm.meanDensity == float(z["mean"])
+    assert dm.stdDensity == float(z["std"])
     for cut, want in zip(z["soa_cut"], z["soa"]):
         assert dm.getTotalAbsDensity(float(cut)) == pytest.approx(want, rel=1e-12)
 
@@ -437,27 +438,61 @@ def test_map_combine_download_and_order_statistics(gpu_ctx):
         da._map.abs_order_statistics(None, 0.0, cut_a, 0.0, 1)
 
 
-def test_full_size_properties(gpu_ctx):
-    """BASELINE config 2 size (256^3): size-independent properties + oracle equality."""
+def _full_size_case(g, gpu_ctx, nsd, **spec_kw):
+    """Size-independent properties of a fused green/red labelling + oracle equality of BOTH lists (labels, order, sums)."""
     from oracle import oracle as ora
-    from pdb_eda_amd import synthetic
-    g = synthetic.smooth_noise((256, 256, 256), 7, 1.5)
-    dm = _dm(g, gpu_ctx)
-    cut = dm.meanDensity + 1.5 * dm.stdDensity
+    dm = _dm(g, gpu_ctx, **spec_kw)
+    o = ora.Oracle(dm.header, g)
+    mean, std = o.mean_std()
+    assert (dm.meanDensity, dm.stdDensity) == (mean, std)                     # numpy's tree, also at 16.8 M voxels
+    cut = dm.meanDensity + nsd * dm.stdDensity
+    us, ur, uc = dm._map.unique_shape
+    gu = g[:us, :ur, :uc]
     green, red = dm._map.full_blobs_pm(cut, -cut, labels=True)
     for bl, sign in ((green, 1), (red, -1)):
         st = bl.stats()
-        lab = bl.labels((256, 256, 256))
-        mask = (g >= np.float32(cut)) if sign > 0 else (g <= np.float32(-cut))
+        lab = bl.labels((us, ur, uc))
+        mask = (gu >= np.float32(cut)) if sign > 0 else (gu <= np.float32(-cut))
         assert np.array_equal(lab >= 0, mask)                                 # every significant voxel labelled, nothing else
         assert st["n"].sum() == mask.sum()
         assert np.array_equal(np.bincount(lab[mask], minlength=len(st["n"])), st["n"])
-        assert st["totalDensity"].sum() == pytest.approx(float(g[mask].astype(np.float64).sum()), rel=1e-10)
+        assert st["totalDensity"].sum() == pytest.approx(float(gu[mask].astype(np.float64).sum()), rel=1e-10)
         assert (np.diff(st["firstKey"]) > 0).all()                            # reference emission order
-        # idempotence: labelling the label-derived mask again gives the same partition
+        # idempotence: a one-sign job gives the same partition
         again = dm._map.full_blobs(cut if sign > 0 else -cut)
         assert np.array_equal(again.stats()["n"], st["n"])
-    o = ora.Oracle(dm.header, g)
-    want = o.full_blobs(cut, labels=True)
-    assert np.array_equal(green.labels((256, 256, 256)), want["labels"])
-    assert np.allclose(green.stats()["totalDensity"], want["totalDensity"], rtol=REL)
+        want = o.full_blobs(cut if sign > 0 else -cut, labels=True)
+        assert np.array_equal(lab, want["labels"])
+        assert np.array_equal(st["n"], want["n"]) and np.array_equal(st["firstKey"], want["firstKey"])
+        assert np.allclose(st["totalDensity"], want["totalDensity"], rtol=REL)
+        assert np.allclose(st["centroid"], want["centroid"], rtol=REL, atol=1e-9)
+        assert np.allclose(st["coordCenter"], want["coordCenter"], rtol=REL, atol=1e-9)
+    assert green.counters()["unit_tiles_runs"] + green.counters()["unit_tiles_comps"] == 0   # the LDS fast path, not the fallback
+    return len(green), len(red)
+
+
+@pytest.mark.parametrize("nsd", [1.5, 3.0])
+def test_full_size_properties(gpu_ctx, nsd):
+    """BASELINE configs[1] at its full size (256^3): blue-style 1.5 sigma (~13 % of the voxels set) and the
+    sparse green/red regime at 3 sigma (~0.27 %, almost every tile empty): properties + oracle equality, both signs."""
+    from pdb_eda_amd import synthetic
+    g = synthetic.smooth_noise((256, 256, 256), 7, 1.5)
+    n_green, n_red = _full_size_case(g, gpu_ctx, nsd, spacing=0.4)
+    assert n_green > 1000 and n_red > 1000
+
+
+@pytest.mark.parametrize("nsd", [1.5, 3.0])
+def test_full_size_non_orthogonal(gpu_ctx, nsd):
+    """SURVEY 8d-2's second variant at full size: gamma = 120 degrees, axis order (2, 1, 3), crsStart != 0 and
+    interval > ncrs (so crs2xyz takes the matrix path, centroids go through the skewed basis)."""
+    from pdb_eda_amd import synthetic
+    g = synthetic.smooth_noise((256, 256, 256), 11, 1.5)
+    _full_size_case(g, gpu_ctx, nsd, interval=(272, 264, 280), crs_start=(-9, 5, 17), axis_order=(2, 1, 3),
+                    cell=(105.6, 108.8, 112.0), angles=(90.0, 90.0, 120.0))
+
+
+def test_full_size_repeating_map(gpu_ctx):
+    """ncrs > interval along two axes (the stored box repeats the cell): only the unique box is labelled (ccp4.py:262-269)."""
+    from pdb_eda_amd import synthetic
+    g = synthetic.smooth_noise((200, 256, 256), 13, 1.5)
+    _full_size_case(g, gpu_ctx, 1.5, interval=(232, 256, 180), cell=(92.8, 102.4, 72.0))

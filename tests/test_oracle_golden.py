@@ -27,6 +27,22 @@ def test_header_fields_bit_exact(case):
     assert np.array_equal(np.array(ints, dtype=np.int64), z["h_ints"])
 
 
+def test_mean_std_numpy_tree(case):
+    """meanDensity / stdDensity (ref ccp4.py:343-363): the restated numpy summation tree gives the reference's values
+    bit for bit, and numpy's own on sizes that exercise full 8192-blocks plus an irregular tail."""
+    _, z, _, grid, o = case
+    assert o.mean_std() == (float(z["mean"]), float(z["std"]))
+    rng = np.random.default_rng(int(grid.size))
+    for n in (7, 129, 8191, 8192 * 3 + 5, 100003):
+        a = (rng.standard_normal(n) * 10 ** rng.uniform(-2, 2, n)).astype(np.float32)
+
+        class H(object):
+            pass
+        m, s = ora.Oracle.__new__(ora.Oracle), None
+        m.L, m.density = ora.lib(), a
+        assert m.mean_std() == (float(np.mean(a.astype(np.float64))), float(np.std(a.astype(np.float64)))), n
+
+
 def test_point_density_wrap_contract(case):
     """getPointDensityFromCrs / testValidCrs (ref cutils.pyx:125-167)."""
     _, z, _, _, o = case
