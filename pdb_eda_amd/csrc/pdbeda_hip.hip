@@ -34,8 +34,13 @@ struct pdbeda_ctx {
     std::string err;
     std::multimap<size_t, Arena> pool;  // free device arenas by capacity (reused: no hipMalloc in steady state)
     double *partials = nullptr;         // reduction partials (N_PARTIAL doubles) + 4 result slots
-    void *pinned = nullptr;             // small pinned staging buffer
-    size_t pinned_cap = 0;
+    // device -> host results are staged through pinned memory: the copies are truly asynchronous (a copy into pageable
+    // memory blocks inside the runtime, where no watchdog can see it) and land in the caller's buffers when ctx_sync()
+    // has seen the stream drain
+    char *pinned = nullptr;
+    size_t pinned_cap = 0, pinned_used = 0;
+    struct Pending { void *dst; size_t off, bytes; };
+    std::vector<Pending> pending;
     int live_handles = 0;
     // optional per-kernel timing with HIP events on ctx->stream (bench.py's roofline leg)
     bool profiling = false;
@@ -110,6 +115,7 @@ static int fail(pdbeda_ctx *ctx, int code, const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
+    if (ctx) { ctx->pending.clear(); ctx->pinned_used = 0; }   // results of a failed call are never delivered
     if (ctx && ctx->timed_out) return PDBEDA_ERR_TIMEOUT;   // (the watchdog's message stays)
     if (ctx) ctx->err = buf;
     return code;
@@ -119,12 +125,12 @@ static int fail(pdbeda_ctx *ctx, int code, const char *fmt, ...) {
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
         if (e_ != hipSuccess)                                                                      \
-            return (ctx) && (ctx)->timed_out ? PDBEDA_ERR_TIMEOUT                                  \
-                                             : fail(ctx, PDBEDA_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return fail(ctx, PDBEDA_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-// Wait for the context's stream: plain hipStreamSynchronize, or (watchdog armed) a timed query loop.
-static hipError_t ctx_sync(pdbeda_ctx *ctx) {
+// Wait for the context's stream: plain hipStreamSynchronize, or (watchdog armed) a timed query loop; then deliver the
+// staged device -> host results.
+static hipError_t ctx_wait(pdbeda_ctx *ctx) {
     if (ctx->timed_out) return hipErrorNotReady;
     if (ctx->timeout_s <= 0.0) return hipStreamSynchronize(ctx->stream);
     const auto t0 = std::chrono::steady_clock::now();
@@ -140,6 +146,30 @@ static hipError_t ctx_sync(pdbeda_ctx *ctx) {
             std::this_thread::sleep_for(std::chrono::microseconds(spins > 4096 ? 200 : 20));
         }
     }
+}
+
+static hipError_t ctx_sync(pdbeda_ctx *ctx) {
+    const hipError_t e = ctx_wait(ctx);
+    if (e == hipSuccess)
+        for (const auto &p : ctx->pending) memcpy(p.dst, ctx->pinned + p.off, p.bytes);
+    ctx->pending.clear();
+    ctx->pinned_used = 0;
+    return e;
+}
+
+// Device -> host copy of a result, complete after the next ctx_sync(): staged through the pinned buffer when it fits,
+// otherwise the stream is drained first (timed) so that the blocking copy into pageable memory has nothing to wait for.
+static hipError_t d2h(pdbeda_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return hipSuccess;
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (ctx->pinned && ctx->pinned_used + need <= ctx->pinned_cap) {
+        const hipError_t e = hipMemcpyAsync(ctx->pinned + ctx->pinned_used, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) { ctx->pending.push_back({dst, ctx->pinned_used, bytes}); ctx->pinned_used += need; }
+        return e;
+    }
+    hipError_t e = ctx_sync(ctx);
+    if (e == hipSuccess) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    return e;
 }
 
 static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -191,19 +221,6 @@ struct Carver {
         return p;
     }
 };
-
-static int pinned_get(pdbeda_ctx *ctx, size_t bytes, void **out) {
-    if (ctx->pinned_cap < bytes) {
-        if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-        ctx->pinned = nullptr;
-        ctx->pinned_cap = 0;
-        size_t cap = std::max<size_t>(bytes, 1 << 16);
-        HIP_TRY(ctx, hipHostMalloc(&ctx->pinned, cap, hipHostMallocDefault));
-        ctx->pinned_cap = cap;
-    }
-    *out = ctx->pinned;
-    return 0;
-}
 
 static inline unsigned grid_for(int64_t n, int block, int64_t cap = 1 << 20) {
     int64_t g = (n + block - 1) / block;
@@ -258,6 +275,7 @@ extern "C" int pdbeda_ctx_create_on_stream(int device_id, void *hip_stream, pdbe
         delete ctx;
         return PDBEDA_ERR_MEMORY;
     }
+    if (hipHostMalloc((void **)&ctx->pinned, 1 << 20, hipHostMallocDefault) == hipSuccess) ctx->pinned_cap = 1 << 20;   // (without it results are copied directly)
     if (const char *v = getenv("PDBEDA_DEBUG_POISON")) ctx->debug_poison = v[0] && v[0] != '0';
     if (const char *v = getenv("PDBEDA_DEBUG_EDGE_CAP")) ctx->debug_edge_cap = atoll(v);
     *out = ctx;
@@ -444,7 +462,7 @@ extern "C" int pdbeda_map_download(pdbeda_map *m, float *density_out) {
     if (!m || !density_out) return PDBEDA_ERR_ARGUMENT;
     pdbeda_ctx *ctx = m->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMemcpyAsync(density_out, m->dens, sizeof(float) * (size_t)m->n_vox, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, d2h(ctx, density_out, m->dens, sizeof(float) * (size_t)m->n_vox));
     HIP_TRY(ctx, ctx_sync(ctx));
     return PDBEDA_OK;
 }
@@ -490,7 +508,7 @@ extern "C" int pdbeda_map_stats(pdbeda_map *m, double *mean, double *std) {
             { PROF(ctx, "k_np_final"); hipLaunchKernelGGL(k_np_final, dim3(1), dim3(256), 0, st, m->dens, m->n_vox, n_full, mode, res, chunk_sums, mode, res + mode); }
         }
         HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipMemcpyAsync(host, res, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, d2h(ctx, host, res, 2 * sizeof(double)));
         return 0;
     });
     if (rc) return rc;
@@ -506,7 +524,7 @@ extern "C" int pdbeda_sum_of_abs(pdbeda_map *m, float cutoff, double *out) {
     double *res = ctx->partials + N_PARTIAL + 2;
     int rc = reduce_launch(m, 2, nullptr, (double)cutoff, 1.0, 0, res);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(out, res, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, d2h(ctx, out, res, sizeof(double)));
     HIP_TRY(ctx, ctx_sync(ctx));
     return PDBEDA_OK;
 }
@@ -525,7 +543,7 @@ extern "C" int pdbeda_abs_select_hist(pdbeda_map *a, pdbeda_map *b, double alpha
         hipLaunchKernelGGL(k_abs_select_hist, dim3(grid_for(n, 256, 4096)), dim3(256), 0, ctx->stream, a->geom_dev, a->dens, b ? b->dens : nullptr,
                            alpha, cut_a, cut_b, which, shift, prefix, prefix_mask, d_hist);
         HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipMemcpyAsync(hist, d_hist, 65536 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, d2h(ctx, hist, d_hist, 65536 * sizeof(uint32_t)));
         return 0;
     });
 }
@@ -541,7 +559,7 @@ extern "C" int pdbeda_point_density(pdbeda_map *m, const int32_t *crs, int64_t n
         double *d_out = cv.take<double>(n);
         HIP_TRY(ctx, hipMemcpyAsync(d_crs, crs, 12 * n, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(k_point_density, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->geom_dev, m->dens, d_crs, n, d_out, (uint8_t *)nullptr);
-        HIP_TRY(ctx, hipMemcpyAsync(out, d_out, 8 * n, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, d2h(ctx, out, d_out, 8 * n));
         return 0;
     });
 }
@@ -557,7 +575,7 @@ extern "C" int pdbeda_valid_crs(pdbeda_map *m, const int32_t *crs, int64_t n, ui
         uint8_t *d_out = cv.take<uint8_t>(n);
         HIP_TRY(ctx, hipMemcpyAsync(d_crs, crs, 12 * n, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(k_point_density, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->geom_dev, m->dens, d_crs, n, (double *)nullptr, d_out);
-        HIP_TRY(ctx, hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, d2h(ctx, out, d_out, n));
         return 0;
     });
 }
@@ -573,7 +591,7 @@ extern "C" int pdbeda_crs2xyz(pdbeda_map *m, const int32_t *crs, int64_t n, doub
         double *d_xyz = cv.take<double>(3 * n);
         HIP_TRY(ctx, hipMemcpyAsync(d_crs, crs, 12 * n, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(k_crs2xyz, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->geom_dev, d_crs, n, d_xyz);
-        HIP_TRY(ctx, hipMemcpyAsync(xyz, d_xyz, 24 * n, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, d2h(ctx, xyz, d_xyz, 24 * n));
         return 0;
     });
 }
@@ -589,7 +607,7 @@ extern "C" int pdbeda_xyz2crs(pdbeda_map *m, const double *xyz, int64_t n, int32
         int32_t *d_crs = cv.take<int32_t>(3 * n);
         HIP_TRY(ctx, hipMemcpyAsync(d_xyz, xyz, 24 * n, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(k_xyz2crs, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->geom_dev, d_xyz, n, d_crs);
-        HIP_TRY(ctx, hipMemcpyAsync(crs, d_crs, 12 * n, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, d2h(ctx, crs, d_crs, 12 * n));
         return 0;
     });
 }
@@ -830,9 +848,9 @@ static int list_resolve_counts(pdbeda_bloblist *bl) {
     // chunk_prefix/key_rank give prefix counts at arbitrary key words.
     std::vector<VolDesc> vols(job.n_vols);
     Counters ctr;
-    HIP_TRY(ctx, hipMemcpyAsync(&ctr, job.ctr, sizeof ctr, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, d2h(ctx, &ctr, job.ctr, sizeof ctr));
     if (job.n_vols > 0)
-        HIP_TRY(ctx, hipMemcpyAsync(vols.data(), job.vols, sizeof(VolDesc) * job.n_vols, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, d2h(ctx, vols.data(), job.vols, sizeof(VolDesc) * job.n_vols));
     HIP_TRY(ctx, ctx_sync(ctx));
     auto rank_at = [&](int64_t key, int64_t *out) -> int {
         // number of blobs with first key < key
@@ -842,9 +860,10 @@ static int list_resolve_counts(pdbeda_bloblist *bl) {
         int64_t kw = key >> 6;
         uint32_t cp = 0, kr = 0;
         uint64_t bits = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&cp, job.chunk_prefix + kw / KEY_CHUNK, 4, hipMemcpyDeviceToHost, ctx->stream)); HIP_TRY(ctx, ctx_sync(ctx));
-        HIP_TRY(ctx, hipMemcpyAsync(&kr, job.key_rank + kw, 4, hipMemcpyDeviceToHost, ctx->stream)); HIP_TRY(ctx, ctx_sync(ctx));
-        HIP_TRY(ctx, hipMemcpyAsync(&bits, job.key_bits + kw, 8, hipMemcpyDeviceToHost, ctx->stream)); HIP_TRY(ctx, ctx_sync(ctx));
+        HIP_TRY(ctx, d2h(ctx, &cp, job.chunk_prefix + kw / KEY_CHUNK, 4));
+        HIP_TRY(ctx, d2h(ctx, &kr, job.key_rank + kw, 4));
+        HIP_TRY(ctx, d2h(ctx, &bits, job.key_bits + kw, 8));
+        HIP_TRY(ctx, ctx_sync(ctx));
         *out = (int64_t)cp + kr + popc64(bits & bits_below((int)(key & 63)));
         return 0;
     };
@@ -870,13 +889,13 @@ extern "C" int pdbeda_bloblist_counters(pdbeda_bloblist *bl, int64_t *out) {
     pdbeda_ctx *ctx = bl->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     Counters c;
-    HIP_TRY(ctx, hipMemcpyAsync(&c, bl->job.ctr, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, d2h(ctx, &c, bl->job.ctr, sizeof c));
     HIP_TRY(ctx, ctx_sync(ctx));
     out[0] = c.n_runs; out[1] = c.n_comps; out[2] = c.n_edges; out[3] = c.n_blobs;
     out[4] = out[5] = out[6] = out[7] = 0;
     if (bl->whole_map && bl->job.edge_fill) {   // cross-tile pairs parked in the shard buffers (demand, also when a shard overflowed)
         uint32_t fill[ESHARDS];
-        HIP_TRY(ctx, hipMemcpyAsync(fill, bl->job.edge_fill, sizeof fill, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, d2h(ctx, fill, bl->job.edge_fill, sizeof fill));
         HIP_TRY(ctx, ctx_sync(ctx));
         out[2] = 0;
         for (uint32_t v : fill) out[2] += v;
@@ -884,7 +903,7 @@ extern "C" int pdbeda_bloblist_counters(pdbeda_bloblist *bl, int64_t *out) {
     if (bl->whole_map && bl->job.tile_mode) {   // unit tiles by cause: tile_mode 1 = run slots / values, 3 = component table
         const int64_t n_tiles = (int64_t)bl->td.ctiles * bl->td.rtiles * bl->td.stiles;
         std::vector<uint8_t> mode(n_tiles);
-        HIP_TRY(ctx, hipMemcpyAsync(mode.data(), bl->job.tile_mode, n_tiles, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, d2h(ctx, mode.data(), bl->job.tile_mode, n_tiles));
         HIP_TRY(ctx, ctx_sync(ctx));
         for (uint8_t v : mode) { if (v == 1) ++out[4]; else if (v == 3) ++out[6]; }
     }
@@ -908,14 +927,13 @@ extern "C" int pdbeda_bloblist_stats(pdbeda_bloblist *bl, int64_t *n, double *to
     const Job &job = bl->job;
     const int64_t lo = bl->rank_lo, cnt = bl->rank_hi - bl->rank_lo;
     if (cnt == 0) return PDBEDA_OK;
-    hipStream_t st = ctx->stream;
-    if (n) HIP_TRY(ctx, hipMemcpyAsync(n, job.b_n + lo, 8 * cnt, hipMemcpyDeviceToHost, st));
-    if (total_density) HIP_TRY(ctx, hipMemcpyAsync(total_density, job.b_total + lo, 8 * cnt, hipMemcpyDeviceToHost, st));
-    if (centroid) HIP_TRY(ctx, hipMemcpyAsync(centroid, job.b_centroid + 3 * lo, 24 * cnt, hipMemcpyDeviceToHost, st));
-    if (coord_center) HIP_TRY(ctx, hipMemcpyAsync(coord_center, job.b_center + 3 * lo, 24 * cnt, hipMemcpyDeviceToHost, st));
-    if (volume) HIP_TRY(ctx, hipMemcpyAsync(volume, job.b_volume + lo, 8 * cnt, hipMemcpyDeviceToHost, st));
-    if (first_key) HIP_TRY(ctx, hipMemcpyAsync(first_key, job.b_key + lo, 8 * cnt, hipMemcpyDeviceToHost, st));
-    if (group) HIP_TRY(ctx, hipMemcpyAsync(group, job.b_group + lo, 4 * cnt, hipMemcpyDeviceToHost, st));
+    if (n) HIP_TRY(ctx, d2h(ctx, n, job.b_n + lo, 8 * cnt));
+    if (total_density) HIP_TRY(ctx, d2h(ctx, total_density, job.b_total + lo, 8 * cnt));
+    if (centroid) HIP_TRY(ctx, d2h(ctx, centroid, job.b_centroid + 3 * lo, 24 * cnt));
+    if (coord_center) HIP_TRY(ctx, d2h(ctx, coord_center, job.b_center + 3 * lo, 24 * cnt));
+    if (volume) HIP_TRY(ctx, d2h(ctx, volume, job.b_volume + lo, 8 * cnt));
+    if (first_key) HIP_TRY(ctx, d2h(ctx, first_key, job.b_key + lo, 8 * cnt));
+    if (group) HIP_TRY(ctx, d2h(ctx, group, job.b_group + lo, 4 * cnt));
     HIP_TRY(ctx, ctx_sync(ctx));
     return PDBEDA_OK;
 }
@@ -931,7 +949,7 @@ static int list_materialise_voxels(pdbeda_bloblist *bl) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     Job &job = ow->job;
     Counters ctr;
-    HIP_TRY(ctx, hipMemcpyAsync(&ctr, job.ctr, sizeof ctr, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, d2h(ctx, &ctr, job.ctr, sizeof ctr));
     HIP_TRY(ctx, ctx_sync(ctx));
     const int64_t nb = ctr.n_blobs;
     // total voxels unknown until the offsets scan; bound by key bits
@@ -965,8 +983,9 @@ extern "C" int64_t pdbeda_bloblist_num_voxels(pdbeda_bloblist *bl) {
     pdbeda_ctx *ctx = bl->ctx;
     pdbeda_bloblist *ow = owner_of(bl);
     int64_t off[2] = {0, 0};
-    HIP_TRY(ctx, hipMemcpyAsync(&off[0], ow->offsets_dev + bl->rank_lo, 8, hipMemcpyDeviceToHost, ctx->stream)); HIP_TRY(ctx, ctx_sync(ctx));
-    HIP_TRY(ctx, hipMemcpyAsync(&off[1], ow->offsets_dev + bl->rank_hi, 8, hipMemcpyDeviceToHost, ctx->stream)); HIP_TRY(ctx, ctx_sync(ctx));
+    HIP_TRY(ctx, d2h(ctx, &off[0], ow->offsets_dev + bl->rank_lo, 8));
+    HIP_TRY(ctx, d2h(ctx, &off[1], ow->offsets_dev + bl->rank_hi, 8));
+    HIP_TRY(ctx, ctx_sync(ctx));
     bl->n_voxels = off[1] - off[0];
     return bl->n_voxels;
 }
@@ -979,11 +998,11 @@ extern "C" int pdbeda_bloblist_voxels(pdbeda_bloblist *bl, int32_t *crs, int64_t
     pdbeda_bloblist *ow = owner_of(bl);
     const int64_t cnt = bl->rank_hi - bl->rank_lo;
     std::vector<int64_t> off(cnt + 1);
-    HIP_TRY(ctx, hipMemcpyAsync(off.data(), ow->offsets_dev + bl->rank_lo, 8 * (cnt + 1), hipMemcpyDeviceToHost, ctx->stream)); HIP_TRY(ctx, ctx_sync(ctx));
+    HIP_TRY(ctx, d2h(ctx, off.data(), ow->offsets_dev + bl->rank_lo, 8 * (cnt + 1))); HIP_TRY(ctx, ctx_sync(ctx));
     const int64_t base = off[0];
     if (blob_offsets)
         for (int64_t i = 0; i <= cnt; ++i) blob_offsets[i] = off[i] - base;
-    if (crs && nv > 0) HIP_TRY(ctx, hipMemcpyAsync(crs, ow->crs_dev + 3 * base, 12 * nv, hipMemcpyDeviceToHost, ctx->stream)); HIP_TRY(ctx, ctx_sync(ctx));
+    if (crs && nv > 0) HIP_TRY(ctx, d2h(ctx, crs, ow->crs_dev + 3 * base, 12 * nv)); HIP_TRY(ctx, ctx_sync(ctx));
     return PDBEDA_OK;
 }
 
@@ -1008,7 +1027,7 @@ extern "C" int pdbeda_bloblist_labels(pdbeda_bloblist *bl, int32_t *labels_host)
         signed_vol = tmp;
     }
     hipLaunchKernelGGL(k_labels_decode, dim3(grid_for(nvox, 256, 4096)), dim3(256), 0, ctx->stream, signed_vol, nvox, bl->sign, decoded);
-    hipError_t e = hipMemcpyAsync(labels_host, decoded, 4 * nvox, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e = d2h(ctx, labels_host, decoded, 4 * nvox);
     if (e == hipSuccess) e = ctx_sync(ctx);
     arena_put(ctx, a);
     if (e != hipSuccess) return fail(ctx, PDBEDA_ERR_DEVICE, "labels: %s", hipGetErrorString(e));
@@ -1107,7 +1126,7 @@ static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, con
     { PROF(ctx, "k_make_vols"); hipLaunchKernelGGL(k_make_vols, dim3(1), dim3(1024), 0, st, gs->g_lo, gs->g_hi, (int)n_groups, gs->d_vols, gs->d_ctr); }
     HIP_TRY(ctx, hipGetLastError());
     Counters ctr;
-    HIP_TRY(ctx, hipMemcpyAsync(&ctr, gs->d_ctr, sizeof ctr, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, d2h(ctx, &ctr, gs->d_ctr, sizeof ctr));
     HIP_TRY(ctx, ctx_sync(ctx));  // item_group (host vector) is also safe to drop now
     gs->total_words = ctr.total_words;
     gs->total_keys = ctr.total_keys;
@@ -1205,10 +1224,10 @@ extern "C" int pdbeda_region_sums(pdbeda_map *m, const double *xyz, const float 
     }
     std::vector<unsigned long long> h_cnt(n_groups);
     std::vector<unsigned int> h_inv(n_groups);
-    if (e == hipSuccess && pos) e = hipMemcpyAsync(pos, d_pos, 8 * n_groups, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess && neg) e = hipMemcpyAsync(neg, d_neg, 8 * n_groups, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(h_cnt.data(), d_cnt, 8 * n_groups, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(h_inv.data(), d_inv, 4 * n_groups, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && pos) e = d2h(ctx, pos, d_pos, 8 * n_groups);
+    if (e == hipSuccess && neg) e = d2h(ctx, neg, d_neg, 8 * n_groups);
+    if (e == hipSuccess) e = d2h(ctx, h_cnt.data(), d_cnt, 8 * n_groups);
+    if (e == hipSuccess) e = d2h(ctx, h_inv.data(), d_inv, 4 * n_groups);
     if (e == hipSuccess) e = ctx_sync(ctx);
     arena_put(ctx, a);
     arena_put(ctx, gs.in_arena);
@@ -1246,7 +1265,7 @@ extern "C" int pdbeda_test_overlap(pdbeda_ctx *ctx, const int32_t *crs, const in
         HIP_TRY(ctx, hipMemcpyAsync(d_b, b_idx, 4 * n_pairs, hipMemcpyHostToDevice, st));
         HIP_TRY(ctx, hipMemsetAsync(d_out, 0, 4 * n_pairs, st));
         hipLaunchKernelGGL(k_test_overlap, dim3((unsigned)n_pairs), dim3(256), 0, st, d_crs, d_off, d_a, d_b, d_out);
-        HIP_TRY(ctx, hipMemcpyAsync(h_out.data(), d_out, 4 * n_pairs, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, d2h(ctx, h_out.data(), d_out, 4 * n_pairs));
         return 0;
     });
     if (rc) return rc;
@@ -1281,8 +1300,8 @@ extern "C" int pdbeda_symmetry_atoms(pdbeda_ctx *ctx, const double *xyz, int64_t
         HIP_TRY(ctx, hipMemcpyAsync(d_lo, bbox_lo, 24, hipMemcpyHostToDevice, st));
         HIP_TRY(ctx, hipMemcpyAsync(d_hi, bbox_hi, 24, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_symmetry_atoms, dim3(grid_for(total, 256)), dim3(256), 0, st, d_xyz, n_atoms, d_rot, (int)n_ops, d_ortho, d_lo, d_hi, d_out, d_keep);
-        HIP_TRY(ctx, hipMemcpyAsync(h_xyz.data(), d_out, 24 * total, hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipMemcpyAsync(h_keep.data(), d_keep, total, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, d2h(ctx, h_xyz.data(), d_out, 24 * total));
+        HIP_TRY(ctx, d2h(ctx, h_keep.data(), d_keep, total));
         return 0;
     });
     if (rc) return rc;
@@ -1318,8 +1337,8 @@ extern "C" int pdbeda_nearest_atom(pdbeda_ctx *ctx, const double *centroids, int
         HIP_TRY(ctx, hipMemcpyAsync(d_c, centroids, 24 * n_centroids, hipMemcpyHostToDevice, st));
         HIP_TRY(ctx, hipMemcpyAsync(d_a, atom_xyz, 24 * n_atoms, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_nearest_atom, dim3((unsigned)n_centroids), dim3(256), 0, st, d_c, d_a, n_atoms, d_i, d_d);
-        HIP_TRY(ctx, hipMemcpyAsync(index, d_i, 8 * n_centroids, hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipMemcpyAsync(distance, d_d, 8 * n_centroids, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, d2h(ctx, index, d_i, 8 * n_centroids));
+        HIP_TRY(ctx, d2h(ctx, distance, d_d, 8 * n_centroids));
         return 0;
     });
 }

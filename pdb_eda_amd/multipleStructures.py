@@ -94,9 +94,11 @@ def analyzeEntry(entry, ctx=None, failures=None, silent=False):
 
 
 class StreamPool(object):
-    """N worker threads on one GPU, each with its own context (HIP stream + device arena cache).
+    """N worker threads on one GPU, each with its own context (HIP stream + device arena cache); the contexts live as long
+    as the pool, so repeated ``map`` / ``each`` calls (the iterations of optimise mode) reuse streams and arenas.
 
-    ``map(fn, items)`` calls ``fn(item, ctx)`` and returns the results in order.  Per item:
+    ``map(fn, items)`` calls ``fn(item, ctx)`` from whichever worker is free and returns the results in order;
+    ``each(fn)`` calls ``fn(k, ctx_k)`` once on every worker k (work pinned to a stream).  Per item:
       * an ordinary exception drops the item (result 0) with its reason in ``self.failures[index]`` and on stderr
         (multipleStructures.py:297-304);
       * ``time_out`` seconds (the reference's --time-out, 359-377) arm the library's watchdog: a stream that does not
@@ -111,54 +113,77 @@ class StreamPool(object):
         self.time_out = float(time_out or 0.0)
         self.silent = silent
         self.failures = {}
+        self._ctx = [None] * self.n_streams
 
-    def map(self, fn, entries):
-        todo = queue.Queue()
-        for i, e in enumerate(entries):
-            todo.put((i, e))
-        results = [0] * len(entries)
-        fatal = []
-        stop = threading.Event()
-        self.failures = {}
-
-        def new_context():
+    def context(self, k, fresh=False):
+        if fresh or self._ctx[k] is None:
             ctx = _native.Context(self.device)
             if self.time_out > 0:
                 ctx.set_timeout(self.time_out)
-            return ctx
+            self._ctx[k] = ctx
+        return self._ctx[k]
 
-        def work():
-            ctx = None
+    def close(self):
+        self._ctx = [None] * self.n_streams
+
+    def _run(self, n_workers, body):
+        fatal = []
+        stop = threading.Event()
+
+        def work(k):
             try:
-                ctx = new_context()
-                while not stop.is_set():
-                    try:
-                        i, e = todo.get_nowait()
-                    except queue.Empty:
-                        break
-                    try:
-                        results[i] = fn(e, ctx)
-                    except _native.PdbedaTimeout:
-                        _drop(getattr(e, "pdbid", i), "Timeout", None, self.silent)
-                        self.failures[i] = "Timeout"
-                        ctx = new_context()          # the old context is abandoned with whatever still runs on it
-                    except _native.PdbedaError:
-                        raise
-                    except Exception as exception:
-                        self.failures[i] = "%s: %s" % (type(exception).__name__, exception)
-                        _drop(getattr(e, "pdbid", i), self.failures[i], None, self.silent)
+                body(k, stop)
+                ctx = self._ctx[k]
                 if ctx is not None and not stop.is_set():
-                    ctx.synchronize()
+                    try:
+                        ctx.synchronize()
+                    except _native.PdbedaTimeout:
+                        self.context(k, fresh=True)
             except BaseException as exception:       # device failure (or interpreter shutdown): stop the pool, report once
                 fatal.append(exception)
                 stop.set()
-        threads = [threading.Thread(target=work) for _ in range(min(self.n_streams, max(1, len(entries))))]
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(n_workers)]
         for t in threads:
             t.start()
         for t in threads:
             t.join()
         if fatal:
             raise fatal[0]
+
+    def _call(self, fn, k, index, item, results):
+        try:
+            results[index] = fn(item, self.context(k))
+        except _native.PdbedaTimeout:
+            self.failures[index] = "Timeout"
+            _drop(getattr(item, "pdbid", index), "Timeout", None, self.silent)
+            self.context(k, fresh=True)              # the old context is abandoned with whatever still runs on it
+        except _native.PdbedaError:
+            raise
+        except Exception as exception:
+            self.failures[index] = "%s: %s" % (type(exception).__name__, exception)
+            _drop(getattr(item, "pdbid", index), self.failures[index], None, self.silent)
+
+    def map(self, fn, entries):
+        todo = queue.Queue()
+        for i, e in enumerate(entries):
+            todo.put((i, e))
+        results = [0] * len(entries)
+        self.failures = {}
+
+        def body(k, stop):
+            while not stop.is_set():
+                try:
+                    i, e = todo.get_nowait()
+                except queue.Empty:
+                    return
+                self._call(fn, k, i, e, results)
+        self._run(min(self.n_streams, max(1, len(entries))), body)
+        return results
+
+    def each(self, fn):
+        results = [0] * self.n_streams
+        self.failures = {}
+        self._run(self.n_streams, lambda k, stop: self._call(fn, k, k, k, results))
         return results
 
 

@@ -21,8 +21,9 @@ def gather_rows(local_rows, width):
     """All-gather a ragged list of fixed-width float64 rows (NaN = missing)."""
     torch, dist = _dist()
     rows = np.asarray(local_rows, dtype=np.float64).reshape(-1, width)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return rows
+    if not (dist.is_available() and dist.is_initialized()):
+        return rows                      # no process group: a single process holds every record
+    # (a 1-rank group still goes through the collectives: the RCCL path is the same code at every world size)
     device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=device)
     counts = [torch.zeros_like(n) for _ in range(dist.get_world_size())]
@@ -40,7 +41,7 @@ def gather_rows(local_rows, width):
 def reduce_counts(local_counts):
     torch, dist = _dist()
     c = np.asarray(local_counts, dtype=np.int64)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return c
     device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     t = torch.from_numpy(c.copy()).to(device)

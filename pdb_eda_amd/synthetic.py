@@ -183,3 +183,18 @@ def synthetic_params():
                          "ALA_O": ["ALA_C"], "ALA_CB": ["ALA_CA"]},
         "leaving_atoms": [],
     }
+
+
+def sweep_param_sets():
+    """Parameter sets of a short optimise-mode radius sweep (BASELINE configs[4]; optimizeParams.py:232-243 changes ONE atom
+    type's radius per iteration and carries the slopes of the last accepted iteration): the base table, then three
+    steps.  Shared by the golden generator (reference run) and the tests / bench (MI355X run).  Made-up values."""
+    base = synthetic_params()
+    steps = [("C.syn.methyl", +0.10, {}), ("O.syn.carbonyl", -0.08, {"O.syn.carbonyl": -0.41}), ("N.syn.amide", +0.05, {"C.syn.alpha": -0.66, "N.syn.amide": -0.5})]
+    sets = [base]
+    for atom_type, delta, slopes in steps:
+        prev = sets[-1]
+        radii = dict(prev["radii"])
+        radii[atom_type] = round(radii[atom_type] + delta, 6)
+        sets.append({**prev, "radii": radii, "slopes": {**prev["slopes"], **slopes}})
+    return sets

@@ -95,34 +95,28 @@ def test_device_failure_stops_the_pool():
 def test_watchdog_abandons_a_context():
     """--time-out (multipleStructures.py:297-304, 359-377): a stream that does not drain in time fails ITS entry with the
     reason "Timeout"; the context is abandoned (every later call on it fails at once, destroy does not wait) and the
-    worker carries on with a fresh one."""
-    from pdb_eda_amd import _native, ccp4, synthetic, multipleStructures
-    g = synthetic.smooth_noise((256, 256, 256), 7, 1.5)
-    spec = synthetic.MapSpec(ncrs=(256, 256, 256))
-    header = ccp4.DensityHeader.fromFileHeader(synthetic.ccp4_header_bytes(spec))
-    cut = float(g.std()) * 1.5
+    worker carries on with a fresh one.  The slow job is real work that takes ~0.5 s on ONE compute unit: a single
+    testOverlap pair of two far-apart sets of 10^5 voxels each (10^10 coordinate comparisons in one workgroup)."""
+    from pdb_eda_amd import _native, multipleStructures
+    n = 100000
+    a = np.stack([np.arange(n), np.zeros(n), np.zeros(n)], axis=1).astype(np.int32)
+    b = a + np.array([0, 50, 50], dtype=np.int32)
+    crs, off = np.concatenate([a, b]), np.array([0, n, 2 * n], dtype=np.int64)
 
     def work(k, ctx):
-        dmap = _native.DeviceMap(ctx, g, header.geometry())
-        if k == 1:            # ~0.3 s of queued labelling steps against a 50 ms allowance
-            for _ in range(2000):
-                last = dmap.full_blobs_pm(cut, -cut, labels=True)      # (dropping the previous lists recycles their arena)
-            raise AssertionError("the watchdog did not fire (%d blobs)" % len(last[0]))
-        green, red = dmap.full_blobs_pm(cut, -cut)
-        return len(green) + len(red)
+        if k == 1:
+            return bool(ctx.test_overlap(crs, off, [0], [1])[0]) + 10
+        return bool(ctx.test_overlap(crs[:50], np.array([0, 25, 50], dtype=np.int64), [0], [1])[0]) + 1
     pool = multipleStructures.StreamPool(device=0, n_streams=1, time_out=0.05, silent=True)
     res = pool.map(work, [0, 1, 2])
-    assert res[0] > 0 and res[0] == res[2] and res[1] == 0
+    assert res == [2, 0, 2]                      # (25 consecutive voxels next to the following 25: they touch)
     assert pool.failures == {1: "Timeout"}
-    # a timed-out context stays dead, a disarmed one waits as long as it takes
+    # a timed-out context stays dead; a disarmed one waits as long as it takes
     ctx = _native.Context(0)
-    dmap = _native.DeviceMap(ctx, g, header.geometry())
     ctx.set_timeout(0.02)
-    for _ in range(1500):
-        last = dmap.full_blobs_pm(cut, -cut, labels=True)
+    with pytest.raises(_native.PdbedaTimeout):
+        ctx.test_overlap(crs, off, [0], [1])
     with pytest.raises(_native.PdbedaTimeout):
         ctx.synchronize()
-    with pytest.raises(_native.PdbedaTimeout):
-        dmap.stats()
     ctx2 = _native.Context(0)
-    assert len(_native.DeviceMap(ctx2, g, header.geometry()).full_blobs(cut)) == res[0] - len(_native.DeviceMap(ctx2, g, header.geometry()).full_blobs(-cut))
+    assert not ctx2.test_overlap(crs, off, [0], [1])[0]
