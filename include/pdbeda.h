@@ -183,6 +183,51 @@ int pdbeda_region_sums(pdbeda_map *map, const double *xyz, const float *radii, i
                        const int64_t *group_offsets, int64_t n_groups, float cutoff,
                        double *pos, double *neg, int64_t *n_region, uint8_t *valid);
 
+/* ---- aggregateCloud ------------------------------------------------------------------ */
+/* DensityAnalysis.aggregateCloud up to its statistics tail (densityAnalysis.py:571-731) as ONE call: the clouds of every
+ * eligible atom (findAberrantBlobs, 603), the centroid-distance cut-off over all atoms (607), the best cloud and the pooled
+ * clouds per atom (622-642), the bonded-atom overlap completeness (652-659), the residue clouds = clusters of a residue's
+ * pooled clouds under testOverlap, merged (644-650, 661-690), the domain clouds = the same over everything pooled
+ * (692-712) and the totals behind densityElectronRatio (714-731).  Voxel lists never leave the device.
+ *
+ * The caller flattens what the reference reads from the structure, in the reference's iteration order
+ * (residues with id[0] == ' ', their child atoms whose residue_atom name has an atom type and whose occupancy != 0): */
+typedef struct pdbeda_cloud_atoms {
+    int64_t n;                 /* eligible atoms */
+    const double *xyz;         /* n x 3: atom.coord (float32 promoted exactly) */
+    const float *radius;       /* n: radii[atom type]                                         densityAnalysis.py:603 */
+    const double *weight;      /* n: electrons[residue_atom] * occupancy                      densityAnalysis.py:690, 718 */
+    const int32_t *residue;    /* n: ordinal of the atom's residue, non-decreasing */
+    const int32_t *alias;      /* n: LAST eligible atom with the same coordinate (allAtomClouds is keyed by coordinate, 604) */
+    const int32_t *key;        /* n: id of (residue, residue_atom name); atomCloudIndeces is keyed by the name (640) */
+    int64_t n_keys;
+    const int64_t *bonded_off; /* n_keys + 1: CSR over keys ... */
+    const int32_t *bonded;     /* ... of the keys of bondedAtoms[name] that exist in the same residue      (656) */
+    int64_t n_owners;          /* child atoms (ANY occupancy) of ATOM residues whose name has a key, in iteration order (653-655) */
+    const int32_t *owner_key;
+} pdbeda_cloud_atoms;
+
+typedef struct pdbeda_cloud pdbeda_cloud; /* the result tables (host memory owned by the library) */
+
+int pdbeda_aggregate_cloud(pdbeda_map *map, const pdbeda_cloud_atoms *atoms, float density_cutoff, double min_cloud_electrons,
+                           pdbeda_cloud **out);
+/* counts[4] = atom rows, residue-cloud rows, domain-cloud rows, owners;
+ * totals[4] = numVoxels, totalElectrons, totalDensity (718-721, over ALL domain clouds), centroidDistanceCutoff (607). */
+int pdbeda_cloud_counts(pdbeda_cloud *c, int64_t counts[4], double totals[4]);
+/* One row per atom that has a best cloud, in iteration order (atomList, 642): index into the eligible atoms, the best
+ * cloud's totalDensity, voxel count, centroid (x3) and |atom - centroid|.  Any pointer may be NULL. */
+int pdbeda_cloud_atom_rows(pdbeda_cloud *c, int32_t *atom, double *total_density, int64_t *n_voxels, double *centroid, double *distance);
+/* Residue clouds with >= min_cloud_electrons, in the reference's emission order (residue by residue; inside a residue by
+ * lowest pooled-cloud index -- the reference's own order there follows CPython's set iteration): residue ordinal,
+ * totalDensity, voxels, electrons, centroid (x3). */
+int pdbeda_cloud_residue_rows(pdbeda_cloud *c, int32_t *residue, double *total_density, int64_t *n_voxels, double *electrons, double *centroid);
+/* Domain clouds with >= min_cloud_electrons (unsorted: the caller sorts by ratio, 730): a representative residue ordinal
+ * (the reference's is set-order dependent), totalDensity, voxels, electrons, centroid (x3). */
+int pdbeda_cloud_domain_rows(pdbeda_cloud *c, int32_t *residue, double *total_density, int64_t *n_voxels, double *electrons, double *centroid);
+/* Per owner: 0 = its name has no pooled cloud, 1 = every bonded partner's clouds touch its own, 2 = some do not (656-659). */
+int pdbeda_cloud_owner_states(pdbeda_cloud *c, uint8_t *state);
+int pdbeda_cloud_free(pdbeda_cloud *c);
+
 /* ---- voxel-set adjacency ---------------------------------------------------------- */
 /* utils.testOverlap (cutils.pyx:8-25) batched: pair p tests set a_idx[p] against set
  * b_idx[p]; sets are slices [set_offsets[i], set_offsets[i+1]) of crs. */

@@ -34,6 +34,13 @@ class Geometry(C.Structure):
                 ("grid_len", C.c_double * 3), ("unit_volume", C.c_double)]
 
 
+class CloudAtoms(C.Structure):
+    """pdbeda_cloud_atoms (include/pdbeda.h): the flattened input of pdbeda_aggregate_cloud."""
+    _fields_ = [("n", C.c_int64), ("xyz", C.c_void_p), ("radius", C.c_void_p), ("weight", C.c_void_p), ("residue", C.c_void_p),
+                ("alias", C.c_void_p), ("key", C.c_void_p), ("n_keys", C.c_int64), ("bonded_off", C.c_void_p), ("bonded", C.c_void_p),
+                ("n_owners", C.c_int64), ("owner_key", C.c_void_p)]
+
+
 def make_geometry(ncrs, crs_start, xyz_interval, map2xyz, map2crs, orthogonal, ortho, deortho, origin, grid_len, unit_volume):
     g = Geometry()
     for k in range(3):
@@ -95,6 +102,13 @@ _SIGS = {
     "pdbeda_bloblist_free": (C.c_int, [_p]),
     "pdbeda_bloblist_counters": (C.c_int, [_p, _p]),
     "pdbeda_region_sums": (C.c_int, [_p, _p, _p, _i64, _p, _i64, C.c_float, _p, _p, _p, _p]),
+    "pdbeda_aggregate_cloud": (C.c_int, [_p, C.POINTER(CloudAtoms), C.c_float, C.c_double, C.POINTER(_p)]),
+    "pdbeda_cloud_counts": (C.c_int, [_p, _p, _p]),
+    "pdbeda_cloud_atom_rows": (C.c_int, [_p, _p, _p, _p, _p, _p]),
+    "pdbeda_cloud_residue_rows": (C.c_int, [_p, _p, _p, _p, _p, _p]),
+    "pdbeda_cloud_domain_rows": (C.c_int, [_p, _p, _p, _p, _p, _p]),
+    "pdbeda_cloud_owner_states": (C.c_int, [_p, _p]),
+    "pdbeda_cloud_free": (C.c_int, [_p]),
     "pdbeda_test_overlap": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i64, _p]),
     "pdbeda_symmetry_atoms": (C.c_int, [_p, _p, _i64, _p, C.c_int32, _p, _p, _p, _p, _p, _p, _i64, C.POINTER(_i64)]),
     "pdbeda_nearest_atom": (C.c_int, [_p, _p, _i64, _p, _i64, _p, _p]),
@@ -450,6 +464,40 @@ class DeviceMap(object):
         self._ctx.check(self._ctx._lib.pdbeda_region_sums(self._h, _ptr(xyz), _ptr(radii), len(xyz), _ptr(off), ng, C.c_float(cutoff),
                                                           _ptr(pos), _ptr(neg), _ptr(cnt), _ptr(valid)), "pdbeda_region_sums")
         return pos, neg, cnt, valid.astype(bool)
+
+    def aggregate_cloud(self, xyz, radius, weight, residue, alias, key, bonded_off, bonded, owner_key, cutoff, min_cloud_electrons):
+        """pdbeda_aggregate_cloud: everything of aggregateCloud that touches voxels, in one call.  Returns a dict of arrays:
+        atoms (eligible index, totalDensity, voxels, centroid, distance), residue / domain cloud rows, owner states, totals."""
+        lib, ctx = self._ctx._lib, self._ctx
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+        arrs = {"radius": np.ascontiguousarray(radius, dtype=np.float32), "weight": np.ascontiguousarray(weight, dtype=np.float64),
+                "residue": np.ascontiguousarray(residue, dtype=np.int32), "alias": np.ascontiguousarray(alias, dtype=np.int32),
+                "key": np.ascontiguousarray(key, dtype=np.int32), "bonded_off": np.ascontiguousarray(bonded_off, dtype=np.int64),
+                "bonded": np.ascontiguousarray(bonded, dtype=np.int32), "owner_key": np.ascontiguousarray(owner_key, dtype=np.int32)}
+        n = len(xyz)
+        assert all(len(arrs[k]) == n for k in ("radius", "weight", "residue", "alias", "key"))
+        at = CloudAtoms(n, xyz.ctypes.data, *[arrs[k].ctypes.data for k in ("radius", "weight", "residue", "alias", "key")],
+                        len(arrs["bonded_off"]) - 1, arrs["bonded_off"].ctypes.data, arrs["bonded"].ctypes.data,
+                        len(arrs["owner_key"]), arrs["owner_key"].ctypes.data)
+        h = C.c_void_p()
+        ctx.check(lib.pdbeda_aggregate_cloud(self._h, C.byref(at), C.c_float(cutoff), C.c_double(min_cloud_electrons), C.byref(h)), "pdbeda_aggregate_cloud")
+        try:
+            counts, totals = np.zeros(4, np.int64), np.zeros(4, np.float64)
+            ctx.check(lib.pdbeda_cloud_counts(h, _ptr(counts), _ptr(totals)), "pdbeda_cloud_counts")
+            na, nr, nd, no = (int(v) for v in counts)
+            out = {"numVoxels": int(totals[0]), "totalElectrons": float(totals[1]), "totalDensity": float(totals[2]), "centroidDistanceCutoff": float(totals[3]),
+                   "atom": np.zeros(na, np.int32), "atom_total": np.zeros(na), "atom_n": np.zeros(na, np.int64), "atom_centroid": np.zeros((na, 3)),
+                   "atom_distance": np.zeros(na), "owner_state": np.zeros(no, np.uint8)}
+            ctx.check(lib.pdbeda_cloud_atom_rows(h, _ptr(out["atom"]), _ptr(out["atom_total"]), _ptr(out["atom_n"]), _ptr(out["atom_centroid"]),
+                                                 _ptr(out["atom_distance"])), "pdbeda_cloud_atom_rows")
+            for tag, cnt, fn in (("res", nr, lib.pdbeda_cloud_residue_rows), ("dom", nd, lib.pdbeda_cloud_domain_rows)):
+                t = {"residue": np.zeros(cnt, np.int32), "total": np.zeros(cnt), "n": np.zeros(cnt, np.int64), "electrons": np.zeros(cnt), "centroid": np.zeros((cnt, 3))}
+                ctx.check(fn(h, _ptr(t["residue"]), _ptr(t["total"]), _ptr(t["n"]), _ptr(t["electrons"]), _ptr(t["centroid"])), "pdbeda_cloud_rows")
+                out[tag] = t
+            ctx.check(lib.pdbeda_cloud_owner_states(h, _ptr(out["owner_state"])), "pdbeda_cloud_owner_states")
+        finally:
+            lib.pdbeda_cloud_free(h)
+        return out
 
     def test_overlap(self, a, b):
         crs = np.concatenate([np.asarray(a, np.int32).reshape(-1, 3), np.asarray(b, np.int32).reshape(-1, 3)])

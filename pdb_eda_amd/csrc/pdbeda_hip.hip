@@ -1080,14 +1080,9 @@ static int expand_groups(const int64_t *group_offsets, int64_t n_groups, int64_t
     return 0;
 }
 
-// Upload atoms (or explicit voxels), compute group bounding volumes on the device, read
-// the totals back (the one host round trip of a sphere / list batch).
-static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, const int32_t *crs, int64_t n_items,
-                       const int64_t *group_offsets, int64_t n_groups, GroupSetup *gs) {
-    pdbeda_ctx *ctx = m->ctx;
+// Scratch of a sphere / list batch: inputs, boxes, group bounds, volume descriptors.
+static int group_alloc(pdbeda_ctx *ctx, int64_t n_items, int64_t n_groups, GroupSetup *gs) {
     if (n_groups >= (1ll << 31) || n_items >= (1ll << 40)) return fail(ctx, PDBEDA_ERR_ARGUMENT, "batch too large");
-    std::vector<int32_t> item_group;
-    if (expand_groups(group_offsets, n_groups, n_items, item_group)) return fail(ctx, PDBEDA_ERR_ARGUMENT, "bad group_offsets");
     const int64_t ni = std::max<int64_t>(n_items, 1), ng = std::max<int64_t>(n_groups, 1);
     size_t need = align_up(24 * ni) + align_up(4 * ni) + align_up(4 * ni) + align_up(sizeof(AtomBox) * ni) + align_up(12 * ni) +
                   2 * align_up(12 * ng) + align_up(sizeof(VolDesc) * ng) + align_up(sizeof(Counters));
@@ -1103,20 +1098,19 @@ static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, con
     gs->g_hi = cv.take<int32_t>(3 * ng);
     gs->d_vols = cv.take<VolDesc>(ng);
     gs->d_ctr = cv.take<Counters>(1);
+    return 0;
+}
+
+// Inputs are on the device (d_xyz + d_radii, or d_crs; d_item_group): group bounding volumes, volume descriptors, and the
+// totals read back (the one host round trip of a sphere / list batch).
+static int group_bounds(pdbeda_map *m, GroupSetup *gs, int64_t n_items, int64_t n_groups, bool spheres) {
+    pdbeda_ctx *ctx = m->ctx;
     hipStream_t st = ctx->stream;
-    if (n_items > 0) {
-        if (xyz) {
-            HIP_TRY(ctx, hipMemcpyAsync(gs->d_xyz, xyz, 24 * n_items, hipMemcpyHostToDevice, st));
-            HIP_TRY(ctx, hipMemcpyAsync(gs->d_radii, radii, 4 * n_items, hipMemcpyHostToDevice, st));
-        } else {
-            HIP_TRY(ctx, hipMemcpyAsync(gs->d_crs, crs, 12 * n_items, hipMemcpyHostToDevice, st));
-        }
-        HIP_TRY(ctx, hipMemcpyAsync(gs->d_item_group, item_group.data(), 4 * n_items, hipMemcpyHostToDevice, st));
-    }
+    const int64_t ng = std::max<int64_t>(n_groups, 1);
     HIP_TRY(ctx, hipMemsetAsync(gs->d_ctr, 0, sizeof(Counters), st));
     { PROF(ctx, "k_init_bounds"); hipLaunchKernelGGL(k_init_bounds, dim3(grid_for(3 * ng, 256)), dim3(256), 0, st, gs->g_lo, gs->g_hi, 3 * ng); }
     if (n_items > 0) {
-        if (xyz)
+        if (spheres)
             { PROF(ctx, "k_atom_boxes"); hipLaunchKernelGGL(k_atom_boxes, dim3(grid_for(n_items, 256)), dim3(256), 0, st, m->geom_dev, gs->d_xyz, gs->d_radii,
                                gs->d_item_group, n_items, gs->d_boxes, gs->g_lo, gs->g_hi); }
         else
@@ -1127,26 +1121,43 @@ static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, con
     HIP_TRY(ctx, hipGetLastError());
     Counters ctr;
     HIP_TRY(ctx, d2h(ctx, &ctr, gs->d_ctr, sizeof ctr));
-    HIP_TRY(ctx, ctx_sync(ctx));  // item_group (host vector) is also safe to drop now
+    HIP_TRY(ctx, ctx_sync(ctx));  // (host-side staging vectors of the caller are also safe to drop now)
     gs->total_words = ctr.total_words;
     gs->total_keys = ctr.total_keys;
     if (gs->total_words >= (1ll << 31) * 2) return fail(ctx, PDBEDA_ERR_ARGUMENT, "sphere batch too large (%lld mask words)", (long long)gs->total_words);
     return 0;
 }
 
-static int grouped_blobs(pdbeda_map *m, const double *xyz, const float *radii, const int32_t *crs, int64_t n_items,
-                         const int64_t *group_offsets, int64_t n_groups, float cutoff, pdbeda_bloblist **out) {
+// Upload atoms (or explicit voxels), then group_bounds.
+static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, const int32_t *crs, int64_t n_items,
+                       const int64_t *group_offsets, int64_t n_groups, GroupSetup *gs) {
     pdbeda_ctx *ctx = m->ctx;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    GroupSetup gs;
-    int rc = group_setup(m, xyz, radii, crs, n_items, group_offsets, n_groups, &gs);
-    if (rc) { arena_put(ctx, gs.in_arena); return rc; }
+    std::vector<int32_t> item_group;
+    if (expand_groups(group_offsets, n_groups, n_items, item_group)) return fail(ctx, PDBEDA_ERR_ARGUMENT, "bad group_offsets");
+    int rc = group_alloc(ctx, n_items, n_groups, gs);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    if (n_items > 0) {
+        if (xyz) {
+            HIP_TRY(ctx, hipMemcpyAsync(gs->d_xyz, xyz, 24 * n_items, hipMemcpyHostToDevice, st));
+            HIP_TRY(ctx, hipMemcpyAsync(gs->d_radii, radii, 4 * n_items, hipMemcpyHostToDevice, st));
+        } else {
+            HIP_TRY(ctx, hipMemcpyAsync(gs->d_crs, crs, 12 * n_items, hipMemcpyHostToDevice, st));
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(gs->d_item_group, item_group.data(), 4 * n_items, hipMemcpyHostToDevice, st));
+    }
+    return group_bounds(m, gs, n_items, n_groups, xyz != nullptr);   // (synchronises: item_group may go)
+}
+
+// Paint the group volumes and enqueue the labelling engine on them; the input scratch is recycled in stream order.
+static int grouped_job(pdbeda_map *m, GroupSetup &gs, int64_t n_items, int64_t n_groups, bool spheres, float cutoff, pdbeda_bloblist **out) {
+    pdbeda_ctx *ctx = m->ctx;
     const int64_t max_runs = gs.total_keys / 2 + gs.total_words + 1;
     Job job;
     memset(&job, 0, sizeof job);
     size_t need = job_carve(job, nullptr, (int)n_groups, gs.total_words, gs.total_keys, max_runs, max_runs, 0, nullptr);
     Arena arena;
-    rc = arena_get(ctx, need, &arena);
+    int rc = arena_get(ctx, need, &arena);
     if (rc) { arena_put(ctx, gs.in_arena); return rc; }
     job_carve(job, arena.base, (int)n_groups, gs.total_words, gs.total_keys, max_runs, max_runs, 0, nullptr);
     hipStream_t st = ctx->stream;
@@ -1156,16 +1167,15 @@ static int grouped_blobs(pdbeda_map *m, const double *xyz, const float *radii, c
     if (e == hipSuccess && job.key_words > 0) e = hipMemsetAsync(job.key_bits, 0, 8 * job.key_words, st);
     if (e == hipSuccess && job.total_words > 0) e = hipMemsetAsync(job.mask, 0, 8 * job.total_words, st);
     if (e == hipSuccess && n_items > 0) {
-        if (xyz)
+        if (spheres)
             { PROF(ctx, "k_sphere_paint"); hipLaunchKernelGGL(k_sphere_paint, dim3((unsigned)n_items), dim3(256), 0, st, m->geom_dev, m->dens, gs.d_xyz, gs.d_radii,
                                gs.d_item_group, gs.d_boxes, job.vols, job.mask, cutoff); }
         else
-            hipLaunchKernelGGL(k_list_paint, dim3(grid_for(n_items, 256)), dim3(256), 0, st, gs.d_crs, gs.d_item_group, n_items, job.vols, job.mask);
+            { PROF(ctx, "k_list_paint"); hipLaunchKernelGGL(k_list_paint, dim3(grid_for(n_items, 256)), dim3(256), 0, st, gs.d_crs, gs.d_item_group, n_items, job.vols, job.mask); }
         e = hipGetLastError();
     }
     if (e == hipSuccess) rc = engine_enqueue(ctx, m, job, max_runs);
-    // inputs are consumed by the paint kernel; wait before recycling their arena
-    if (e == hipSuccess && rc == 0) e = ctx_sync(ctx);
+    // (the inputs are consumed by the paint kernel: whoever gets their arena next is enqueued behind it on this stream)
     arena_put(ctx, gs.in_arena);
     if (e != hipSuccess || rc) {
         arena_put(ctx, arena);
@@ -1178,6 +1188,16 @@ static int grouped_blobs(pdbeda_map *m, const double *xyz, const float *radii, c
     bl->vol_hi = (int)n_groups;
     *out = bl;
     return PDBEDA_OK;
+}
+
+static int grouped_blobs(pdbeda_map *m, const double *xyz, const float *radii, const int32_t *crs, int64_t n_items,
+                         const int64_t *group_offsets, int64_t n_groups, float cutoff, pdbeda_bloblist **out) {
+    pdbeda_ctx *ctx = m->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GroupSetup gs;
+    int rc = group_setup(m, xyz, radii, crs, n_items, group_offsets, n_groups, &gs);
+    if (rc) { arena_put(ctx, gs.in_arena); return rc; }
+    return grouped_job(m, gs, n_items, n_groups, xyz != nullptr, cutoff, out);
 }
 
 extern "C" int pdbeda_sphere_blobs(pdbeda_map *m, const double *xyz, const float *radii, int64_t n_atoms, const int64_t *group_offsets,
@@ -1341,4 +1361,331 @@ extern "C" int pdbeda_nearest_atom(pdbeda_ctx *ctx, const double *centroids, int
         HIP_TRY(ctx, d2h(ctx, distance, d_d, 8 * n_centroids));
         return 0;
     });
+}
+
+// ------------------------------------------------------------------------------------
+// aggregateCloud (densityAnalysis.py:571-731) behind one call
+// ------------------------------------------------------------------------------------
+struct pdbeda_cloud {
+    pdbeda_ctx *ctx = nullptr;
+    std::vector<int32_t> atom_idx;
+    std::vector<double> atom_total, atom_centroid, atom_dist;
+    std::vector<int64_t> atom_nvox;
+    struct Row { int32_t residue; double total; int64_t n; double electrons; double cen[3]; };
+    std::vector<Row> res_rows, dom_rows;
+    std::vector<uint8_t> owner_state;
+    double totals[4] = {0.0, 0.0, 0.0, 0.0};
+};
+
+// numpy's add.reduce over a contiguous float64 array (see k_np_chunk_sums): blocks of 8192 accumulated in order, each a
+// pairwise sum.  mode 1: (x - shift)^2.  The centroid-distance cut-off (densityAnalysis.py:607) decides which atoms are
+// pooled, so np.nanmedian + 2.5 * np.nanstd is reproduced operation by operation, not approximated.
+static double np_elem_h(const double *a, int64_t i, int mode, double shift) {
+    double v = a[i];
+    if (mode == 1) { v = v - shift; v = v * v; }
+    return v;
+}
+static double np_pairwise_h(const double *a, int64_t off, int64_t n, int mode, double shift) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int64_t i = 0; i < n; ++i) res += np_elem_h(a, off + i, mode, shift);
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = np_elem_h(a, off + j, mode, shift);
+        int64_t i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += np_elem_h(a, off + i + j, mode, shift);
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += np_elem_h(a, off + i, mode, shift);
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_h(a, off, n2, mode, shift) + np_pairwise_h(a, off + n2, n - n2, mode, shift);
+}
+static double np_sum_h(const double *a, int64_t n, int mode, double shift) {
+    double out = 0.0;
+    for (int64_t off = 0; off < n; off += 8192) out += np_pairwise_h(a, off, std::min<int64_t>(8192, n - off), mode, shift);
+    return out;
+}
+static double np_median_h(std::vector<double> v) {   // np.median of a NaN-free 1-D array
+    const size_t n = v.size();
+    if (n == 0) return NAN;
+    std::sort(v.begin(), v.end());
+    return (n & 1) ? v[n / 2] : (v[n / 2 - 1] + v[n / 2]) / 2.0;
+}
+static double np_std_h(const std::vector<double> &v) {   // np.std (population) of a NaN-free 1-D array
+    const int64_t n = (int64_t)v.size();
+    if (n == 0) return NAN;
+    const double mean = np_sum_h(v.data(), n, 0, 0.0) / (double)n;
+    return std::sqrt(np_sum_h(v.data(), n, 1, mean) / (double)n);
+}
+
+static inline double norm3(const double *a, const double *b) {   // np.linalg.norm(a - b): sqrt((dx^2 + dy^2) + dz^2)
+    const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    return std::sqrt((dx * dx + dy * dy) + dz * dz);
+}
+
+extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *at, float density_cutoff, double min_cloud_electrons,
+                                      pdbeda_cloud **out) {
+    if (!m || !at || !out || at->n < 0 || at->n_keys < 0 || at->n_owners < 0) return PDBEDA_ERR_ARGUMENT;
+    *out = nullptr;
+    pdbeda_ctx *ctx = m->ctx;
+    const int64_t n = at->n;
+    if (n > 0 && (!at->xyz || !at->radius || !at->weight || !at->residue || !at->alias || !at->key)) return PDBEDA_ERR_ARGUMENT;
+    if (at->n_keys > 0 && !at->bonded_off) return PDBEDA_ERR_ARGUMENT;
+    if (at->n_owners > 0 && !at->owner_key) return PDBEDA_ERR_ARGUMENT;
+    if (n >= (1ll << 31)) return fail(ctx, PDBEDA_ERR_ARGUMENT, "too many atoms");
+    for (int64_t i = 0; i < n; ++i) {
+        if (at->alias[i] < 0 || at->alias[i] >= n || at->key[i] < 0 || at->key[i] >= at->n_keys || (i > 0 && at->residue[i] < at->residue[i - 1]))
+            return fail(ctx, PDBEDA_ERR_ARGUMENT, "atom %lld: alias / key out of range or residues not in order", (long long)i);
+    }
+    for (int64_t o = 0; o < at->n_owners; ++o)
+        if (at->owner_key[o] < 0 || at->owner_key[o] >= at->n_keys) return fail(ctx, PDBEDA_ERR_ARGUMENT, "owner key out of range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    pdbeda_cloud *res = new pdbeda_cloud();
+    res->ctx = ctx;
+    res->owner_state.assign((size_t)at->n_owners, 0);
+    res->totals[3] = NAN;
+    *out = res;
+    if (n == 0) return PDBEDA_OK;
+    hipStream_t st = ctx->stream;
+
+    // ---- 1. the clouds of every atom: one sphere batch, a group per atom (findAberrantBlobs, 603) ----
+    pdbeda_bloblist *clouds = nullptr;
+    {
+        std::vector<int64_t> goff((size_t)n + 1);
+        for (int64_t i = 0; i <= n; ++i) goff[(size_t)i] = i;
+        int rc = grouped_blobs(m, at->xyz, at->radius, nullptr, n, goff.data(), n, density_cutoff, &clouds);
+        if (rc) { delete res; *out = nullptr; return rc; }
+    }
+    auto bail = [&](int rc, pdbeda_bloblist *a, pdbeda_bloblist *b) { if (a) pdbeda_bloblist_free(a); if (b) pdbeda_bloblist_free(b); delete res; *out = nullptr; return rc; };
+    const int64_t nb = pdbeda_bloblist_count(clouds);
+    if (nb < 0) return bail((int)nb, clouds, nullptr);
+    std::vector<int64_t> c_n((size_t)nb);
+    std::vector<double> c_tot((size_t)nb), c_cen(3 * (size_t)nb);
+    std::vector<int32_t> c_grp((size_t)nb);
+    int rc = pdbeda_bloblist_stats(clouds, c_n.data(), c_tot.data(), c_cen.data(), nullptr, nullptr, nullptr, c_grp.data());
+    if (rc) return bail(rc, clouds, nullptr);
+
+    // ---- 2. host: centroid-distance cut-off, best cloud, pool (604-642) ----
+    std::vector<int64_t> first((size_t)n + 1, 0);       // clouds of atom a: [first[a], first[a + 1])  (sorted by group)
+    for (int64_t c = 0; c < nb; ++c) first[(size_t)c_grp[(size_t)c] + 1]++;
+    for (int64_t a = 0; a < n; ++a) first[(size_t)a + 1] += first[(size_t)a];
+    std::vector<double> c_dist((size_t)nb), min_dist((size_t)n, NAN);
+    std::vector<double> centroidDistances;
+    for (int64_t a = 0; a < n; ++a) {
+        double mn = NAN;
+        for (int64_t c = first[(size_t)a]; c < first[(size_t)a + 1]; ++c) {
+            c_dist[(size_t)c] = norm3(at->xyz + 3 * a, c_cen.data() + 3 * c);
+            if (c == first[(size_t)a] || c_dist[(size_t)c] < mn) mn = c_dist[(size_t)c];
+        }
+        min_dist[(size_t)a] = mn;
+        if (first[(size_t)a + 1] > first[(size_t)a]) centroidDistances.push_back(mn);
+    }
+    const double cutoff = np_median_h(centroidDistances) + 2.5 * np_std_h(centroidDistances);
+    res->totals[3] = cutoff;
+    std::vector<int32_t> pool_cloud, pool_atom;
+    std::vector<int32_t> pooled_of_key((size_t)at->n_keys, -1);
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t s = at->alias[i], lo = first[(size_t)s], hi = first[(size_t)s + 1];
+        if (hi == lo) continue;
+        int64_t best = lo;
+        if (hi - lo > 1) {
+            if (min_dist[(size_t)s] > cutoff) continue;
+            for (int64_t c = lo + 1; c < hi; ++c)
+                if (c_dist[(size_t)c] < c_dist[(size_t)best]) best = c;      // the first minimum (distances.index(min))
+        }
+        for (int64_t c = lo; c < hi; ++c) { pool_cloud.push_back((int32_t)c); pool_atom.push_back((int32_t)i); }
+        pooled_of_key[(size_t)at->key[i]] = (int32_t)i;                      // the last atom of a name wins (640)
+        res->atom_idx.push_back((int32_t)i);
+        res->atom_total.push_back(c_tot[(size_t)best]);
+        res->atom_nvox.push_back(c_n[(size_t)best]);
+        for (int k = 0; k < 3; ++k) res->atom_centroid.push_back(c_cen[3 * (size_t)best + k]);
+        res->atom_dist.push_back(norm3(at->xyz + 3 * i, c_cen.data() + 3 * best));
+    }
+    const int64_t n_pool = (int64_t)pool_cloud.size();
+    if (n_pool == 0) { pdbeda_bloblist_free(clouds); return PDBEDA_OK; }
+
+    // ---- 3. device: voxel lists of the clouds; pooled voxels -> union job (a group per residue + the domain group) ----
+    rc = list_materialise_voxels(clouds);
+    if (rc) return bail(rc, clouds, nullptr);
+    pdbeda_bloblist *cow = owner_of(clouds);
+    std::vector<int32_t> pool_group((size_t)n_pool), group_res;     // compact residue groups in increasing order
+    for (int64_t p = 0; p < n_pool; ++p) {
+        const int32_t r = at->residue[pool_atom[(size_t)p]];
+        if (group_res.empty() || group_res.back() != r) group_res.push_back(r);
+        pool_group[(size_t)p] = (int32_t)group_res.size() - 1;
+    }
+    const int n_rg = (int)group_res.size(), n_groups = n_rg + 1;
+    std::vector<int64_t> pool_voff((size_t)n_pool + 1, 0), set_off((size_t)n + 1, 0);
+    for (int64_t p = 0; p < n_pool; ++p) pool_voff[(size_t)p + 1] = pool_voff[(size_t)p] + c_n[(size_t)pool_cloud[(size_t)p]];
+    const int64_t V = pool_voff[(size_t)n_pool];
+    {   // voxel slice (all clouds) of every atom inside the sphere job's list, for the overlap tests
+        std::vector<int64_t> coff((size_t)nb + 1, 0);
+        for (int64_t c = 0; c < nb; ++c) coff[(size_t)c + 1] = coff[(size_t)c] + c_n[(size_t)c];
+        for (int64_t a = 0; a <= n; ++a) set_off[(size_t)a] = coff[(size_t)first[(size_t)a]];
+    }
+    // bonded pairs between pooled names (656): owner o tests its name's atom against every bonded partner that is pooled
+    std::vector<int32_t> pair_a, pair_b, pair_owner;
+    for (int64_t o = 0; o < at->n_owners; ++o) {
+        const int32_t k = at->owner_key[o], ia = pooled_of_key[(size_t)k];
+        if (ia < 0) continue;
+        res->owner_state[(size_t)o] = 1;
+        for (int64_t q = at->bonded_off[k]; q < at->bonded_off[k + 1]; ++q) {
+            const int32_t k2 = at->bonded[q];
+            if (k2 < 0 || k2 >= at->n_keys) return bail(fail(ctx, PDBEDA_ERR_ARGUMENT, "bonded key out of range"), clouds, nullptr);
+            const int32_t ib = pooled_of_key[(size_t)k2];
+            if (ib < 0) continue;
+            pair_a.push_back(at->alias[ia]); pair_b.push_back(at->alias[ib]); pair_owner.push_back((int32_t)o);
+        }
+    }
+    const int64_t n_pairs = (int64_t)pair_a.size();
+
+    GroupSetup gs;
+    rc = group_alloc(ctx, 2 * V, n_groups, &gs);
+    if (rc) return bail(rc, clouds, nullptr);
+    Arena aux;
+    rc = arena_get(ctx, 2 * align_up(4 * n_pool) + align_up(8 * (n_pool + 1)) + align_up(8 * n_pool) + align_up(8 * (n + 1)) + 3 * align_up(4 * std::max<int64_t>(n_pairs, 1)), &aux);
+    if (rc) { arena_put(ctx, gs.in_arena); return bail(rc, clouds, nullptr); }
+    Carver cv(aux.base);
+    int32_t *d_pool_cloud = cv.take<int32_t>(n_pool), *d_pool_group = cv.take<int32_t>(n_pool);
+    int64_t *d_pool_voff = cv.take<int64_t>(n_pool + 1);
+    int32_t *d_comp = cv.take<int32_t>(2 * n_pool);
+    int64_t *d_set_off = cv.take<int64_t>(n + 1);
+    int32_t *d_pa = cv.take<int32_t>(std::max<int64_t>(n_pairs, 1)), *d_pb = cv.take<int32_t>(std::max<int64_t>(n_pairs, 1));
+    unsigned int *d_touch = cv.take<unsigned int>(std::max<int64_t>(n_pairs, 1));
+    auto fail_dev = [&](hipError_t e, pdbeda_bloblist *u) {
+        arena_put(ctx, aux);
+        return bail(fail(ctx, PDBEDA_ERR_DEVICE, "aggregate cloud: %s", hipGetErrorString(e)), clouds, u);
+    };
+    hipError_t e = hipMemcpyAsync(d_pool_cloud, pool_cloud.data(), 4 * n_pool, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pool_group, pool_group.data(), 4 * n_pool, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pool_voff, pool_voff.data(), 8 * (n_pool + 1), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_set_off, set_off.data(), 8 * (n + 1), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && n_pairs > 0) e = hipMemcpyAsync(d_pa, pair_a.data(), 4 * n_pairs, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && n_pairs > 0) e = hipMemcpyAsync(d_pb, pair_b.data(), 4 * n_pairs, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && n_pairs > 0) e = hipMemsetAsync(d_touch, 0, 4 * n_pairs, st);
+    if (e != hipSuccess) { arena_put(ctx, gs.in_arena); return fail_dev(e, nullptr); }
+    { PROF(ctx, "k_pool_gather"); hipLaunchKernelGGL(k_pool_gather, dim3(grid_for(2 * V, 256)), dim3(256), 0, st, cow->crs_dev, cow->offsets_dev, d_pool_cloud, d_pool_voff,
+                                                     d_pool_group, (int)n_pool, V, n_rg, gs.d_crs, gs.d_item_group); }
+    if (n_pairs > 0) { PROF(ctx, "k_test_overlap"); hipLaunchKernelGGL(k_test_overlap, dim3((unsigned)n_pairs), dim3(256), 0, st, cow->crs_dev, d_set_off, d_pa, d_pb, d_touch); }
+    rc = group_bounds(m, &gs, 2 * V, n_groups, false);      // (synchronises: the host staging vectors above are free again)
+    if (rc) { arena_put(ctx, gs.in_arena); arena_put(ctx, aux); return bail(rc, clouds, nullptr); }
+    pdbeda_bloblist *uni = nullptr;
+    rc = grouped_job(m, gs, 2 * V, n_groups, false, 0.0f, &uni);
+    if (rc) { arena_put(ctx, aux); return bail(rc, clouds, nullptr); }
+    { PROF(ctx, "k_pool_component"); hipLaunchKernelGGL(k_pool_component, dim3(grid_for(2 * n_pool, 256)), dim3(256), 0, st, uni->job, cow->crs_dev, cow->offsets_dev, d_pool_cloud,
+                                                        d_pool_group, (int)n_pool, n_rg, d_comp); }
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail_dev(e, uni);
+    std::vector<int32_t> comp(2 * (size_t)n_pool);
+    std::vector<unsigned int> touch((size_t)n_pairs);
+    e = d2h(ctx, comp.data(), d_comp, 8 * n_pool);
+    if (e == hipSuccess && n_pairs > 0) e = d2h(ctx, touch.data(), d_touch, 4 * n_pairs);
+    if (e != hipSuccess) return fail_dev(e, uni);
+    const int64_t nu = pdbeda_bloblist_count(uni);          // (synchronises: comp / touch have landed)
+    if (nu < 0) { arena_put(ctx, aux); return bail((int)nu, clouds, uni); }
+    arena_put(ctx, aux);
+    std::vector<int64_t> u_n((size_t)nu);
+    std::vector<double> u_tot((size_t)nu), u_cen(3 * (size_t)nu);
+    std::vector<int32_t> u_grp((size_t)nu);
+    rc = pdbeda_bloblist_stats(uni, u_n.data(), u_tot.data(), u_cen.data(), nullptr, nullptr, nullptr, u_grp.data());
+    pdbeda_bloblist_free(uni);
+    pdbeda_bloblist_free(clouds);
+    if (rc) { delete res; *out = nullptr; return rc; }
+
+    // ---- 4. host: overlap completeness, electrons per union component, emission order, totals (652-731) ----
+    for (int64_t q = 0; q < n_pairs; ++q)
+        if (!touch[(size_t)q]) res->owner_state[(size_t)pair_owner[(size_t)q]] = 2;
+    std::vector<double> electrons((size_t)nu, 0.0);
+    std::vector<int32_t> last_atom((size_t)nu, -1);
+    std::vector<int64_t> first_pool((size_t)nu, n_pool);
+    for (int kind = 0; kind < 2; ++kind) {
+        for (int64_t p = 0; p < n_pool; ++p) {
+            const int32_t k = comp[(size_t)(kind * n_pool + p)];
+            if (k < 0 || k >= nu) { delete res; *out = nullptr; return fail(ctx, PDBEDA_ERR_STATE, "aggregate cloud: component rank out of range"); }
+            if (last_atom[(size_t)k] != pool_atom[(size_t)p]) {      // a cloud's atoms are distinct atoms: each adds its electrons once (690, 718)
+                electrons[(size_t)k] += at->weight[pool_atom[(size_t)p]];
+                last_atom[(size_t)k] = pool_atom[(size_t)p];
+            }
+            if (p < first_pool[(size_t)k]) first_pool[(size_t)k] = p;
+        }
+    }
+    std::vector<int64_t> order((size_t)nu);
+    for (int64_t k = 0; k < nu; ++k) order[(size_t)k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+        const bool da = u_grp[(size_t)a] == n_rg, db = u_grp[(size_t)b] == n_rg;
+        if (da != db) return db;                                   // residue clouds first, then the domain clouds
+        return first_pool[(size_t)a] < first_pool[(size_t)b];
+    });
+    double num_voxels = 0.0, total_electrons = 0.0, total_density = 0.0;
+    for (int64_t idx = 0; idx < nu; ++idx) {
+        const int64_t k = order[(size_t)idx];
+        const bool dom = u_grp[(size_t)k] == n_rg;
+        pdbeda_cloud::Row row;
+        row.total = u_tot[(size_t)k]; row.n = u_n[(size_t)k]; row.electrons = electrons[(size_t)k];
+        for (int q = 0; q < 3; ++q) row.cen[q] = u_cen[3 * (size_t)k + q];
+        if (dom) {
+            total_electrons += row.electrons;
+            num_voxels += (double)row.n;
+            total_density += row.total;
+            row.residue = at->residue[pool_atom[(size_t)first_pool[(size_t)k]]];
+            if (row.electrons >= min_cloud_electrons) res->dom_rows.push_back(row);
+        } else {
+            row.residue = group_res[(size_t)u_grp[(size_t)k]];
+            if (row.electrons >= min_cloud_electrons) res->res_rows.push_back(row);
+        }
+    }
+    res->totals[0] = num_voxels; res->totals[1] = total_electrons; res->totals[2] = total_density;
+    return PDBEDA_OK;
+}
+
+extern "C" int pdbeda_cloud_counts(pdbeda_cloud *c, int64_t counts[4], double totals[4]) {
+    if (!c) return PDBEDA_ERR_ARGUMENT;
+    if (counts) { counts[0] = (int64_t)c->atom_idx.size(); counts[1] = (int64_t)c->res_rows.size(); counts[2] = (int64_t)c->dom_rows.size(); counts[3] = (int64_t)c->owner_state.size(); }
+    if (totals) for (int k = 0; k < 4; ++k) totals[k] = c->totals[k];
+    return PDBEDA_OK;
+}
+
+extern "C" int pdbeda_cloud_atom_rows(pdbeda_cloud *c, int32_t *atom, double *total_density, int64_t *n_voxels, double *centroid, double *distance) {
+    if (!c) return PDBEDA_ERR_ARGUMENT;
+    const size_t n = c->atom_idx.size();
+    if (atom) memcpy(atom, c->atom_idx.data(), 4 * n);
+    if (total_density) memcpy(total_density, c->atom_total.data(), 8 * n);
+    if (n_voxels) memcpy(n_voxels, c->atom_nvox.data(), 8 * n);
+    if (centroid) memcpy(centroid, c->atom_centroid.data(), 24 * n);
+    if (distance) memcpy(distance, c->atom_dist.data(), 8 * n);
+    return PDBEDA_OK;
+}
+
+static int cloud_rows_out(const std::vector<pdbeda_cloud::Row> &rows, int32_t *residue, double *total_density, int64_t *n_voxels, double *electrons, double *centroid) {
+    for (size_t i = 0; i < rows.size(); ++i) {
+        if (residue) residue[i] = rows[i].residue;
+        if (total_density) total_density[i] = rows[i].total;
+        if (n_voxels) n_voxels[i] = rows[i].n;
+        if (electrons) electrons[i] = rows[i].electrons;
+        if (centroid) for (int q = 0; q < 3; ++q) centroid[3 * i + q] = rows[i].cen[q];
+    }
+    return PDBEDA_OK;
+}
+extern "C" int pdbeda_cloud_residue_rows(pdbeda_cloud *c, int32_t *residue, double *total_density, int64_t *n_voxels, double *electrons, double *centroid) {
+    if (!c) return PDBEDA_ERR_ARGUMENT;
+    return cloud_rows_out(c->res_rows, residue, total_density, n_voxels, electrons, centroid);
+}
+extern "C" int pdbeda_cloud_domain_rows(pdbeda_cloud *c, int32_t *residue, double *total_density, int64_t *n_voxels, double *electrons, double *centroid) {
+    if (!c) return PDBEDA_ERR_ARGUMENT;
+    return cloud_rows_out(c->dom_rows, residue, total_density, n_voxels, electrons, centroid);
+}
+extern "C" int pdbeda_cloud_owner_states(pdbeda_cloud *c, uint8_t *state) {
+    if (!c || (!state && !c->owner_state.empty())) return PDBEDA_ERR_ARGUMENT;
+    if (!c->owner_state.empty()) memcpy(state, c->owner_state.data(), c->owner_state.size());
+    return PDBEDA_OK;
+}
+extern "C" int pdbeda_cloud_free(pdbeda_cloud *c) {
+    if (!c) return PDBEDA_ERR_ARGUMENT;
+    delete c;
+    return PDBEDA_OK;
 }

@@ -710,6 +710,50 @@ __global__ void __launch_bounds__(256) k_region_reduce(const Geom *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------
+// aggregateCloud (densityAnalysis.py:571-731) on device-resident voxel lists: the clouds of the atoms stay where the
+// sphere batch left them (voxel list grouped by cloud); pooled clouds are gathered straight into a second job whose
+// groups are the residues (all-pairs testOverlap clustering + merge == 26-connected components of the union of the
+// pooled voxels, 663-687) plus ONE extra group holding everything pooled (the domain clouds, 692-712).
+// ------------------------------------------------------------------------------------
+// Thread per gathered voxel: item i < V goes to the residue group of its cloud's atom, item V + i to the domain group.
+__global__ void __launch_bounds__(256) k_pool_gather(const int32_t *__restrict__ src_crs, const int64_t *__restrict__ src_off,
+                                                     const int32_t *__restrict__ pool_cloud, const int64_t *__restrict__ pool_voff,
+                                                     const int32_t *__restrict__ pool_group, int n_pool, int64_t V, int domain_group,
+                                                     int32_t *__restrict__ out_crs, int32_t *__restrict__ out_group) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * V) return;
+    const bool dom = i >= V;
+    const int64_t j = dom ? i - V : i;
+    int lo = 0, hi = n_pool - 1;   // the pooled cloud that holds voxel j: pool_voff[p] <= j < pool_voff[p + 1]
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (pool_voff[mid] <= j) lo = mid; else hi = mid - 1;
+    }
+    const int64_t src = src_off[pool_cloud[lo]] + (j - pool_voff[lo]);
+    out_crs[3 * i] = src_crs[3 * src];
+    out_crs[3 * i + 1] = src_crs[3 * src + 1];
+    out_crs[3 * i + 2] = src_crs[3 * src + 2];
+    out_group[i] = dom ? domain_group : pool_group[lo];
+}
+
+// Thread per (pooled cloud, union kind): the rank (row of the union job's blob table) of the component that contains the
+// cloud -- looked up through its first voxel.  out[kind * n_pool + p].
+__global__ void __launch_bounds__(256) k_pool_component(Job job, const int32_t *__restrict__ src_crs, const int64_t *__restrict__ src_off,
+                                                        const int32_t *__restrict__ pool_cloud, const int32_t *__restrict__ pool_group, int n_pool,
+                                                        int domain_group, int32_t *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * n_pool) return;
+    const int kind = i >= n_pool ? 1 : 0, p = kind ? i - n_pool : i;
+    const int64_t v = src_off[pool_cloud[p]];
+    const VolDesc vd = job.vols[kind ? domain_group : pool_group[p]];
+    const int lc = src_crs[3 * v] - vd.org[0], lr = src_crs[3 * v + 1] - vd.org[1], ls = src_crs[3 * v + 2] - vd.org[2];
+    const int64_t w = vd.word_base + ((int64_t)ls * vd.dim[1] + lr) * vd.row_words + (lc >> 6);
+    const uint32_t run = job.run_base[w] + run_ordinal(run_starts(job.mask[w]), lc & 63);
+    const uint32_t comp = job.comp_of_run ? job.comp_of_run[run] : run;
+    out[i] = (int32_t)job.r_rank[(uint32_t)job.parent[comp]];
+}
+
 // One 16-bit digit of a radix select over the masked voxels of the unique box (see pdbeda_abs_select_hist).
 __global__ void __launch_bounds__(256) k_abs_select_hist(const Geom *__restrict__ gp, const float *__restrict__ a, const float *__restrict__ b,
                                                          double alpha, double cut_a, double cut_b, int which, int shift,

@@ -127,6 +127,36 @@ class SymAtom(object):
         return getattr(self.atom, attr)
 
 
+class _SymAtomList(object):
+    """The list of SymAtom objects createSymmetryAtoms returns (cutils.pyx:73-103), materialised item by item."""
+
+    def __init__(self, atoms, idx, sym, xyz, ident, rows=None):
+        self._atoms, self._idx, self._sym, self._xyz, self._ident = atoms, idx, sym, xyz, ident
+        self._rows = np.arange(len(idx)) if rows is None else np.asarray(rows)
+        self._made = {}
+
+    def subset(self, rows):
+        return _SymAtomList(self._atoms, self._idx, self._sym, self._xyz, self._ident, self._rows[rows])
+
+    def __len__(self):
+        return len(self._rows)
+
+    def _make(self, r):
+        atom = self._atoms[int(self._idx[r])]
+        return SymAtom(atom, atom.coord if self._ident[r] else self._xyz[r], tuple(int(v) for v in self._sym[r]))
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        r = int(self._rows[i])
+        if r not in self._made:
+            self._made[r] = self._make(r)
+        return self._made[r]
+
+    def __iter__(self):
+        return (self[k] for k in range(len(self)))
+
+
 def _norm3(x):
     """np.linalg.norm of a 1-D float64 vector, as numpy computes it (sqrt(x.dot(x))), without the dispatch overhead."""
     return math.sqrt(float(x.dot(x)))
@@ -242,241 +272,86 @@ class DensityAnalysis(object):
         return self.densityObj
 
     # ---- aggregateCloud (ref densityAnalysis.py:571-780) --------------------------------------
+    def _cloudInputs(self):
+        """Flatten what aggregateCloud reads from the structure (densityAnalysis.py:596-603, 617-621, 653-656) into the arrays
+        of ``pdbeda_cloud_atoms``: the eligible atoms in the reference's iteration order, a key per (residue, residue_atom
+        name), the bonded-name table restricted to each residue, and the 'owners' of the completeness count."""
+        typeMap, electronsMap, radii = fullAtomNameMapAtomTypeGlobal, fullAtomNameMapElectronsGlobal, radiiGlobal
+        residues = [res for res in self.biopdbObj.get_residues() if res.id[0] == ' ']
+        atoms, resAtoms, residue_of, key_of = [], [], [], []
+        keys = {}                       # (residue ordinal, residue_atom name) -> key id
+        children = []                   # (residue ordinal, residue_atom name) of EVERY child atom, for the owners
+        for ri, residue in enumerate(residues):
+            for atom in residue.child_list:
+                resAtom = residueAtomName(atom)
+                children.append((ri, resAtom))
+                if resAtom not in typeMap or atom.get_occupancy() == 0:
+                    continue
+                atoms.append(atom)
+                resAtoms.append(resAtom)
+                residue_of.append(ri)
+                key_of.append(keys.setdefault((ri, resAtom), len(keys)))
+        n = len(atoms)
+        coords = np.array([a.coord for a in atoms], dtype=np.float64).reshape(n, 3)
+        last = {}
+        for i, a in enumerate(atoms):
+            last[a.coord.tobytes()] = i                       # allAtomClouds is keyed by the coordinate: the last one wins (604)
+        alias = np.fromiter((last[a.coord.tobytes()] for a in atoms), dtype=np.int32, count=n)
+        bonded_off, bonded = [0], []
+        for (ri, resAtom) in keys:                            # (dicts keep insertion order = key id order)
+            bonded.extend(keys[(ri, r2)] for r2 in bondedAtomsGlobal[resAtom] if (ri, r2) in keys)
+            bonded_off.append(len(bonded))
+        owner_key = [keys[c] for c in children if c in keys]
+        owner_type = [typeMap[c[1]] for c in children if c in keys]
+        occupancy = np.fromiter((a.get_occupancy() for a in atoms), dtype=np.float64, count=n)
+        electrons = np.fromiter((electronsMap[ra] for ra in resAtoms), dtype=np.float64, count=n)
+        return {"residues": residues, "atoms": atoms, "resAtoms": resAtoms, "xyz": coords, "occupancy": occupancy, "electrons": electrons,
+                "radius": np.fromiter((radii[typeMap[ra]] for ra in resAtoms), dtype=np.float32, count=n),
+                "residue": np.asarray(residue_of, dtype=np.int32), "alias": alias, "key": np.asarray(key_of, dtype=np.int32),
+                "bonded_off": np.asarray(bonded_off, dtype=np.int64), "bonded": np.asarray(bonded, dtype=np.int32),
+                "owner_key": np.asarray(owner_key, dtype=np.int32), "owner_type": owner_type}
+
     def aggregateCloud(self, minCloudElectrons=25.0, minTotalElectrons=400.0):
         """Aggregate the 2Fo-Fc clouds by atom, residue and domain; sets ``densityElectronRatio``,
         ``medians`` and the description tables.  Same silent-failure contract as the reference
         (Q7): everything stays ``None`` below ``minTotalElectrons`` or if the statistics tail fails.
 
-        Device work: (1) one sphere batch -- a group per atom -- gives every atom's clouds
-        (getSphereCrsFromXyz + createCrsLists + fromCrsList); (2) the all-pairs ``testOverlap``
-        clustering of the reference equals the 26-connected components of the union of the pooled
-        clouds' voxels, so residue clouds are ONE list batch with a group per residue and domain
-        clouds one more with a single group; (3) the bonded-atom completeness tests are one batched
-        voxel-set adjacency call.  The host only keeps the tables.
-        """
+        Everything that touches voxels -- the clouds of every atom, best cloud and pooling, bonded-atom completeness, the
+        residue and domain unions -- is ONE library call (``pdbeda_aggregate_cloud``: voxel lists stay on the device); the
+        host flattens the structure into arrays before it and keeps the reference's host-side statistics tail after it."""
         _requireParams()
-        from scipy import stats
         densityObj = self.densityObj
-        dmap = densityObj._map
         unitVolume = densityObj.header.unitVolume
-        radii, electronsMap, typeMap = radiiGlobal, fullAtomNameMapElectronsGlobal, fullAtomNameMapAtomTypeGlobal
-
-        # eligible atoms in the reference's iteration order
-        residues = [res for res in self.biopdbObj.get_residues() if res.id[0] == ' ']
-        elig = []            # (residue index, atom, resAtom)
-        for ri, residue in enumerate(residues):
-            for atom in residue.child_list:
-                resAtom = residueAtomName(atom)
-                if resAtom not in typeMap or atom.get_occupancy() == 0:
-                    continue
-                elig.append((ri, atom, resAtom))
-        if not elig:
+        typeMap = fullAtomNameMapAtomTypeGlobal
+        inp = self._cloudInputs()
+        if not inp["atoms"]:
             return
-        xyz = np.array([a.coord for _, a, _ in elig], dtype=np.float64)
-        rad = np.array([radii[typeMap[ra]] for _, _, ra in elig], dtype=np.float32)
-        clouds = dmap.sphere_blobs(xyz, rad, np.arange(len(elig) + 1), densityObj.densityCutoff)
-        cst = clouds.stats()
-        ccrs, coff = clouds.voxels()
-        cgroup = cst["group"]
-        first_cloud = np.searchsorted(cgroup, np.arange(len(elig)), side="left")
-        last_cloud = np.searchsorted(cgroup, np.arange(len(elig)), side="right")
-
-        # duplicates of an atom coordinate share one dict entry in the reference (last one wins)
-        by_coord = {}
-        for ai, (_, atom, _) in enumerate(elig):
-            by_coord[tuple(atom.coord)] = ai
-        src = [by_coord[tuple(atom.coord)] for _, atom, _ in elig]
-
-        # distance of every cloud centroid to its atom, all atoms at once: the same row-wise float64 arithmetic as the
-        # reference's per-atom np.linalg.norm(coord - centroids, axis=1) (float32 coordinates promote exactly)
-        cloud_dist = np.linalg.norm(xyz[cgroup] - cst["centroid"], axis=1) if len(cgroup) else np.zeros(0)
-        src = np.asarray(src, dtype=np.int64)
-        has_cloud = last_cloud[src] > first_cloud[src]
-        min_dist = np.full(len(elig), np.nan)
-        owners_with = np.nonzero(last_cloud > first_cloud)[0]
-        if len(owners_with):
-            min_dist[owners_with] = np.minimum.reduceat(cloud_dist, first_cloud[owners_with])
-        centroidDistances = min_dist[src][has_cloud]
-        centroidDistanceCutoff = np.nanmedian(centroidDistances) + 2.5 * np.nanstd(centroidDistances)
-
-        # pass 2: best cloud per atom, pooled clouds per residue
-        atomList = []
-        pool_cloud = []      # pooled cloud -> device cloud index
-        pool_atom = []       # pooled cloud -> eligible atom index
-        pool_res = []        # pooled cloud -> residue index
-        res_atom_clouds = collections.defaultdict(dict)   # residue -> {resAtom: [pool indices]}
-        for ai, (ri, atom, resAtom) in enumerate(elig):
-            s = src[ai]
-            lo, hi = first_cloud[s], last_cloud[s]
-            if hi == lo:
-                continue
-            if hi - lo == 1:
-                best = lo
-            else:
-                if min_dist[s] > centroidDistanceCutoff:
-                    continue
-                best = lo + int(np.argmin(cloud_dist[lo:hi]))
-            res_atom_clouds[ri][resAtom] = list(range(len(pool_cloud), len(pool_cloud) + (hi - lo)))
-            for ci in range(lo, hi):
-                pool_cloud.append(ci)
-                pool_atom.append(ai)
-                pool_res.append(ri)
-            residue = residues[ri]
-            centroid = list(cst["centroid"][best])
-            atomList.append([residue.parent.id, residue.id[1], atom.parent.resname, atom.name, typeMap[resAtom],
-                             cst["totalDensity"][best] / electronsMap[resAtom] / atom.get_occupancy(), int(cst["n"][best]),
-                             electronsMap[resAtom], atom.get_bfactor(), _norm3(atom.coord - cst["centroid"][best]), centroid])
-        if not pool_cloud:
+        res = densityObj._map.aggregate_cloud(inp["xyz"], inp["radius"], inp["electrons"] * inp["occupancy"], inp["residue"], inp["alias"], inp["key"],
+                                              inp["bonded_off"], inp["bonded"], inp["owner_key"], densityObj.densityCutoff, minCloudElectrons)
+        if not len(res["atom"]):
             return
-        pool_cloud = np.asarray(pool_cloud)
-        pool_atom = np.asarray(pool_atom)
-        pool_res = np.asarray(pool_res)
-        weights = np.array([electronsMap[ra] * a.get_occupancy() for _, a, ra in elig], dtype=np.float64)
-
-        # bonded-atom overlap completeness (densityAnalysis.py:652-659): one batched adjacency call.
-        # Voxel sets: all clouds of an atom = a contiguous slice of the sphere batch's voxel list.
         completely = collections.defaultdict(int)
         incompletely = collections.defaultdict(int)
-        pair_a, pair_b, pair_owner = [], [], []
-        atom_of_key = {}
-        for ai, (ri, atom, resAtom) in enumerate(elig):
-            if resAtom in res_atom_clouds.get(ri, {}):
-                atom_of_key[(ri, resAtom)] = ai      # the reference's dict keeps the LAST atom of a name
-        owners = []
-        for ri, residue in enumerate(residues):
-            have = res_atom_clouds.get(ri, {})
-            for atom in residue.child_list:
-                resAtom = residueAtomName(atom)
-                if resAtom in have:
-                    owner = len(owners)
-                    owners.append((typeMap[resAtom], 0))
-                    for resAtom2 in bondedAtomsGlobal[resAtom]:
-                        if resAtom2 in have:
-                            pair_a.append(src[atom_of_key[(ri, resAtom)]])
-                            pair_b.append(src[atom_of_key[(ri, resAtom2)]])
-                            pair_owner.append(owner)
-        atom_set_off = np.concatenate([coff[first_cloud], [coff[-1]]]).astype(np.int64)   # voxel slice (all clouds) per eligible atom
-        touching = dmap._ctx.test_overlap(ccrs, atom_set_off, pair_a, pair_b) if pair_a else np.zeros(0, bool)
-        fails = np.zeros(len(owners), dtype=np.int64)
-        np.add.at(fails, np.asarray(pair_owner, dtype=np.int64), (~touching).astype(np.int64))
-        for (atomType, _), bad in zip(owners, fails):
-            if bad == 0:
+        for atomType, state in zip(inp["owner_type"], res["owner_state"].tolist()):
+            if state == 1:
                 completely[atomType] += 1
-            else:
+            elif state == 2:
                 incompletely[atomType] += 1
+        residues = inp["residues"]
 
-        # residue clouds: 26-connected components of each residue's pooled voxels
-        def components(group_of_pool, n_groups):
-            """Union the pooled clouds' voxels per group on the device (createBlobList on the union
-            == the reference's all-pairs testOverlap clustering + merge); returns the component
-            statistics and, for every pooled cloud, the component that contains it."""
-            order = np.argsort(group_of_pool, kind="stable")
-            starts = coff[pool_cloud[order]]
-            lens = coff[pool_cloud[order] + 1] - starts
-            ends = np.cumsum(lens)
-            idx = np.repeat(starts - (ends - lens), lens) + np.arange(int(ends[-1]) if len(ends) else 0)
-            goff = np.zeros(n_groups + 1, dtype=np.int64)
-            np.add.at(goff, group_of_pool[order] + 1, lens)
-            goff = np.cumsum(goff)
-            bl = dmap.list_blobs(ccrs[idx], goff)
-            st = bl.stats()
-            vcrs, voff = bl.voxels()
-            comp_of_voxel = np.repeat(np.arange(len(st["n"])), np.diff(voff))
-            vgroup = st["group"][comp_of_voxel].astype(np.int64)
-            vk = _crs_keys(vcrs)
-            qk = _crs_keys(ccrs[coff[pool_cloud]])          # first voxel of every pooled cloud
-            uniq, inv = np.unique(np.concatenate([vk, qk]), return_inverse=True)
-            big = len(uniq)
-            vcomb = vgroup * big + inv[:len(vk)]
-            qcomb = group_of_pool.astype(np.int64) * big + inv[len(vk):]
-            srt = np.argsort(vcomb)
-            return st, comp_of_voxel[srt][np.searchsorted(vcomb[srt], qcomb)]
-
-        res_ids, res_group = np.unique(pool_res, return_inverse=True)
-        rst, res_comp_of_pool = components(res_group, len(res_ids))
-        residueList = []
-        n_rcomp = len(rst["n"])
-        # electrons of a residue cloud = distinct atoms that contribute a pooled cloud to it
-        pairs = np.unique(np.stack([res_comp_of_pool, pool_atom], axis=1), axis=0)
-        relectrons = np.zeros(n_rcomp)
-        np.add.at(relectrons, pairs[:, 0], weights[pairs[:, 1]])
-        # emission order of the reference: by residue, then by the lowest pooled-cloud index in the component
-        first_pool = np.full(n_rcomp, len(pool_cloud), dtype=np.int64)
-        np.minimum.at(first_pool, res_comp_of_pool, np.arange(len(pool_cloud)))
-        for k in np.argsort(first_pool, kind="stable"):
-            if relectrons[k] >= minCloudElectrons:
-                residue = residues[res_ids[rst["group"][k]]]
-                residueList.append([residue.parent.id, residue.id[1], residue.resname, rst["totalDensity"][k] / relectrons[k], int(rst["n"][k]),
-                                    relectrons[k], int(rst["n"][k]) * unitVolume, list(rst["centroid"][k])])
-
-        # domain clouds: components of the union of everything pooled
-        dst, dom_comp_of_pool = components(np.zeros(len(pool_cloud), dtype=np.int64), 1)
-        n_dcomp = len(dst["n"])
-        pairs = np.unique(np.stack([dom_comp_of_pool, pool_atom], axis=1), axis=0)
-        delectrons = np.zeros(n_dcomp)
-        np.add.at(delectrons, pairs[:, 0], weights[pairs[:, 1]])
-        first_pool = np.full(n_dcomp, len(pool_cloud), dtype=np.int64)
-        np.minimum.at(first_pool, dom_comp_of_pool, np.arange(len(pool_cloud)))
-        numVoxels = 0
-        totalElectrons = 0
-        totalDensity = 0
-        domainList = []
-        for k in np.argsort(first_pool, kind="stable"):
-            totalElectrons += delectrons[k]
-            numVoxels += int(dst["n"][k])
-            totalDensity += dst["totalDensity"][k]
-            if delectrons[k] >= minCloudElectrons:
-                rep = residues[pool_res[first_pool[k]]]   # a representative residue (the reference's is set-order dependent)
-                domainList.append([rep.parent.id, rep.id[1], rep.resname, dst["totalDensity"][k] / delectrons[k], int(dst["n"][k]), delectrons[k],
-                                   int(dst["n"][k]) * unitVolume, list(dst["centroid"][k])])
+        def cloudRows(t):
+            return [[residues[ri].parent.id, residues[ri].id[1], residues[ri].resname, tot / el, int(nv), el, int(nv) * unitVolume, list(cen)]
+                    for ri, tot, nv, el, cen in zip(t["residue"].tolist(), t["total"].tolist(), t["n"].tolist(), t["electrons"].tolist(), t["centroid"].tolist())]
+        residueList = cloudRows(res["res"])
+        domainList = cloudRows(res["dom"])
+        numVoxels, totalElectrons, totalDensity = res["numVoxels"], res["totalElectrons"], res["totalDensity"]
         if totalElectrons < minTotalElectrons:
             return
         densityElectronRatio = totalDensity / totalElectrons
         domainList.sort(key=lambda x: x[3])
 
-        # ---- host-side statistics tail (densityAnalysis.py:734-767), numpy/scipy like the reference ----
-        currentSlopes = slopesGlobal
-
-        def calcSlope(data, atom_type):
-            if len(data['chain']) <= 2 or len(np.unique(data['bfactor'])) == 1:
-                return currentSlopes[atom_type]
-            slope, intercept, r_value, p_value, std_err = stats.linregress(np.log(data['bfactor']), (data['adj_density_electron_ratio'] - densityElectronRatio) / densityElectronRatio)
-            return currentSlopes[atom_type] if p_value > 0.05 else slope
-
         try:
-            dataType = np.dtype([('chain', np.dtype(('U', 20))), ('residue_number', int), ('residue_name', np.dtype(('U', 10))), ('atom_name', np.dtype(('U', 10))),
-                                 ('atom_type', np.dtype(('U', atomTypeLengthGlobal))), ('density_electron_ratio', float), ('num_voxels', int), ('electrons', int),
-                                 ('bfactor', float), ('centroid_distance', float), ('centroid_xyz', float, (3,)), ('adj_density_electron_ratio', float),
-                                 ('domain_fraction', float), ('corrected_fraction', float), ('corrected_density_electron_ratio', float), ('volume', float)])
-            atoms = np.asarray([tuple(atom + [0.0 for x in range(5)]) for atom in atomList], dataType)
-            if not np.isnan(atoms['centroid_distance']).all():
-                centroidCutoff = np.nanmedian(atoms['centroid_distance']) + np.nanstd(atoms['centroid_distance']) * 2
-                atoms = atoms[atoms['centroid_distance'] < centroidCutoff]
-            atom_types = np.unique(atoms['atom_type'])
-
-            def med(column, mask_extra=None):
-                out = {}
-                for t in atom_types:
-                    sel = atoms['atom_type'] == t
-                    if mask_extra is not None:
-                        sel = sel & mask_extra
-                    out[t] = np.nanmedian(atoms[column][sel])
-                return out
-
-            medians = {'num_voxels': med('num_voxels')}
-            lookup = np.vectorize(lambda column, atom_type: medians[column][atom_type])
-            atoms['adj_density_electron_ratio'] = atoms['density_electron_ratio'] / atoms['num_voxels'] * lookup('num_voxels', atoms['atom_type'])
-            atoms['volume'] = atoms['num_voxels'] * unitVolume
-            for column in ['density_electron_ratio', 'centroid_distance', 'adj_density_electron_ratio', 'volume']:
-                medians[column] = med(column)
-            medians['bfactor'] = med('bfactor', atoms['bfactor'] > 0)
-            atoms['bfactor'][atoms['bfactor'] <= 0] = lookup('bfactor', atoms['atom_type'])[atoms['bfactor'] <= 0]
-            medians['slopes'] = {t: calcSlope(atoms[atoms['atom_type'] == t], t) for t in atom_types}
-            atoms['domain_fraction'] = (atoms['adj_density_electron_ratio'] - densityElectronRatio) / densityElectronRatio
-            atoms['corrected_fraction'] = atoms['domain_fraction'] - (np.log(atoms['bfactor']) - np.log(lookup('bfactor', atoms['atom_type']))) * lookup('slopes', atoms['atom_type'])
-            atoms['corrected_density_electron_ratio'] = atoms['corrected_fraction'] * densityElectronRatio + densityElectronRatio
-            for column in ['domain_fraction', 'corrected_fraction', 'corrected_density_electron_ratio']:
-                medians[column] = med(column)
+            atoms, medians = self._cloudStatistics(inp, res, densityElectronRatio, unitVolume, typeMap)
         except Exception:
             return
 
@@ -491,6 +366,80 @@ class DensityAnalysis(object):
         self._atomTypeOverlapCompleteness = completely
         self._atomTypeOverlapIncompleteness = incompletely
 
+    @staticmethod
+    def _cloudStatistics(inp, res, ratio, unitVolume, typeMap):
+        """The host-side statistics over the atom table (what densityAnalysis.py:734-767 computes), on whole columns: the
+        per-atom-type medians come from ONE sort per column instead of a masked nanmedian per (column, type)."""
+        from scipy import stats
+        idx = res["atom"]
+        n = len(idx)
+        table = np.zeros(n, dtype=np.dtype([
+            ('chain', 'U20'), ('residue_number', int), ('residue_name', 'U10'), ('atom_name', 'U10'), ('atom_type', 'U%d' % atomTypeLengthGlobal),
+            ('density_electron_ratio', float), ('num_voxels', int), ('electrons', int), ('bfactor', float), ('centroid_distance', float),
+            ('centroid_xyz', float, (3,)), ('adj_density_electron_ratio', float), ('domain_fraction', float), ('corrected_fraction', float),
+            ('corrected_density_electron_ratio', float), ('volume', float)]))
+        picked = [inp["atoms"][i] for i in idx.tolist()]
+        table['chain'] = [a.parent.parent.id for a in picked]
+        table['residue_number'] = [a.parent.id[1] for a in picked]
+        table['residue_name'] = [a.parent.resname for a in picked]
+        table['atom_name'] = [a.name for a in picked]
+        table['atom_type'] = [typeMap[inp["resAtoms"][i]] for i in idx.tolist()]
+        table['density_electron_ratio'] = res["atom_total"] / inp["electrons"][idx] / inp["occupancy"][idx]
+        table['num_voxels'] = res["atom_n"]
+        table['electrons'] = inp["electrons"][idx]
+        table['bfactor'] = [a.get_bfactor() for a in picked]
+        table['centroid_distance'] = res["atom_distance"]
+        table['centroid_xyz'] = res["atom_centroid"]
+        dist = table['centroid_distance']
+        if not np.isnan(dist).all():
+            table = table[dist < np.nanmedian(dist) + np.nanstd(dist) * 2]
+        atom_types, group = np.unique(table['atom_type'], return_inverse=True)
+        n_types = len(atom_types)
+
+        def typeMedians(values, keep=None):
+            """np.nanmedian of ``values`` per atom type: sort once by (type, value) -- NaNs and dropped rows last -- and take
+            the middle one or the mean of the middle two of every type's run."""
+            v = np.asarray(values, dtype=np.float64)
+            if keep is not None:
+                v = np.where(keep, v, np.nan)
+            order = np.lexsort((v, group))
+            sv = v[order]
+            start = np.searchsorted(group[order], np.arange(n_types))
+            count = np.bincount(group, weights=~np.isnan(v), minlength=n_types).astype(np.int64)
+            lo, hi = start + np.maximum(count - 1, 0) // 2, start + count // 2
+            safe = np.minimum(np.stack([lo, hi]), max(len(sv) - 1, 0))
+            med = (sv[safe[0]] + sv[safe[1]]) / 2.0 if len(sv) else np.full(n_types, np.nan)
+            return np.where(count > 0, med, np.nan)
+
+        def asDict(per_type):
+            return dict(zip(atom_types.tolist(), per_type))
+        medians = {}
+        m_vox = typeMedians(table['num_voxels'])
+        medians['num_voxels'] = asDict(m_vox)
+        table['adj_density_electron_ratio'] = table['density_electron_ratio'] / table['num_voxels'] * m_vox[group]
+        table['volume'] = table['num_voxels'] * unitVolume
+        for column in ('density_electron_ratio', 'centroid_distance', 'adj_density_electron_ratio', 'volume'):
+            medians[column] = asDict(typeMedians(table[column]))
+        m_b = typeMedians(table['bfactor'], table['bfactor'] > 0)
+        medians['bfactor'] = asDict(m_b)
+        missing = table['bfactor'] <= 0
+        table['bfactor'][missing] = m_b[group][missing]
+        # slope of the b-factor dependence per atom type: linear regression where there is something to fit, else the table's slope
+        fraction = (table['adj_density_electron_ratio'] - ratio) / ratio
+        log_b = np.log(table['bfactor'])
+        slopes = np.zeros(n_types)
+        for k, atom_type in enumerate(atom_types.tolist()):
+            sel = group == k
+            fit = stats.linregress(log_b[sel], fraction[sel]) if (sel.sum() > 2 and len(np.unique(table['bfactor'][sel])) != 1) else None
+            slopes[k] = slopesGlobal[atom_type] if (fit is None or fit.pvalue > 0.05) else fit.slope
+        medians['slopes'] = asDict(slopes)
+        table['domain_fraction'] = fraction
+        table['corrected_fraction'] = fraction - (log_b - np.log(m_b[group])) * slopes[group]
+        table['corrected_density_electron_ratio'] = table['corrected_fraction'] * ratio + ratio
+        for column in ('domain_fraction', 'corrected_fraction', 'corrected_density_electron_ratio'):
+            medians[column] = asDict(typeMedians(table[column]))
+        return table, medians
+
     # ---- symmetry atoms (ref densityAnalysis.py:885-912 + cutils.pyx:73-103) -------------------
     def _calculateSymmetryAtoms(self):
         densityObj = self.densityObj
@@ -503,17 +452,15 @@ class DensityAnalysis(object):
         coords = np.array([a.coord for a in atoms], dtype=np.float64)
         rot = np.array([np.asarray(m, dtype=np.float64) for m in self.pdbObj.header.rotationMats])
         idx, sym, xyz = densityObj._ctx.symmetry_atoms(coords, rot, np.asarray(header.orthoMat, dtype=np.float64), lo, hi)
-        allAtoms = []
-        identity = (0, 0, 0, 0)
-        for a, s4, x in zip(idx.tolist(), map(tuple, sym.tolist()), xyz):
-            allAtoms.append(SymAtom(atoms[a], atoms[a].coord if s4 == identity else x, s4))
         ident = ~np.any(sym != 0, axis=1)
         allCoords = np.where(ident[:, None], coords[idx], xyz)      # == np.asarray([atom.coord ...]): float32 coordinates promote exactly
+        # the SymAtom objects are made on demand: a blob-statistics table touches a few hundred of the thousands there are
+        allAtoms = _SymAtomList(atoms, idx, sym, xyz, ident)
         self._symmetryAtoms = allAtoms
         self._symmetryAtomCoords = allCoords
-        self._symmetryOnlyAtoms = [atom for atom, i in zip(allAtoms, ident.tolist()) if not i]
+        self._symmetryOnlyAtoms = allAtoms.subset(np.nonzero(~ident)[0])
         self._symmetryOnlyAtomCoords = allCoords[~ident]
-        self._asymmetryAtoms = [atom for atom, i in zip(allAtoms, ident.tolist()) if i]
+        self._asymmetryAtoms = allAtoms.subset(np.nonzero(ident)[0])
         self._asymmetryAtomCoords = allCoords[ident]
 
     # ---- blob statistics (ref densityAnalysis.py:914-939) --------------------------------------
