@@ -33,6 +33,9 @@ struct pdbeda_ctx {
     bool own_stream = false;
     std::string err;
     std::multimap<size_t, Arena> pool;  // free device arenas by capacity (reused: no hipMalloc in steady state)
+    size_t pool_bytes = 0;              // bytes parked in the pool ...
+    size_t pool_cap = (size_t)24 << 30; // ... trimmed (largest first) beyond this (PDBEDA_POOL_CAP_MB): streams x live lists x multi-GB
+                                        // whole-map arenas must not creep up on the 288 GB until hipMalloc fails
     double *partials = nullptr;         // reduction partials (N_PARTIAL doubles) + 4 result slots
     // device -> host results are staged through pinned memory: the copies are truly asynchronous (a copy into pageable
     // memory blocks inside the runtime, where no watchdog can see it) and land in the caller's buffers when ctx_sync()
@@ -77,6 +80,8 @@ struct pdbeda_map {
     pdbeda_ctx *ctx = nullptr;
     const float *dens = nullptr;
     bool own_dens = false;
+    Arena arena;                      // geometry (+ the grid when the library owns it): from the context's arena pool, recycled in
+                                      // stream order -- a stream pool analysing entry after entry never calls hipMalloc / hipFree
     Geom geom;
     Geom *geom_dev = nullptr;
     int64_t n_vox = 0;
@@ -188,6 +193,7 @@ static int arena_get_raw(pdbeda_ctx *ctx, size_t bytes, Arena *out) {
     auto it = ctx->pool.lower_bound(bytes);
     if (it != ctx->pool.end() && it->first <= bytes * 2 + (1u << 20)) {
         *out = it->second;
+        ctx->pool_bytes -= it->second.cap;
         ctx->pool.erase(it);
         return 0;
     }
@@ -197,6 +203,7 @@ static int arena_get_raw(pdbeda_ctx *ctx, size_t bytes, Arena *out) {
         // drop the cache and retry once
         for (auto &kv : ctx->pool) (void)hipFree(kv.second.base);
         ctx->pool.clear();
+        ctx->pool_bytes = 0;
         e = hipMalloc(&p, bytes);
         if (e != hipSuccess) return fail(ctx, PDBEDA_ERR_MEMORY, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     }
@@ -206,9 +213,15 @@ static int arena_get_raw(pdbeda_ctx *ctx, size_t bytes, Arena *out) {
 }
 
 static void arena_put(pdbeda_ctx *ctx, Arena &a) {
-    if (a.base) ctx->pool.emplace(a.cap, a);
+    if (a.base) { ctx->pool.emplace(a.cap, a); ctx->pool_bytes += a.cap; }
     a.base = nullptr;
     a.cap = 0;
+    while (ctx->pool_bytes > ctx->pool_cap && !ctx->pool.empty() && !ctx->timed_out) {   // trim: the largest parked arena goes back to the
+        auto last = std::prev(ctx->pool.end());                                            // driver (hipFree waits for the device: rare by design)
+        ctx->pool_bytes -= last->second.cap;
+        (void)hipFree(last->second.base);
+        ctx->pool.erase(last);
+    }
 }
 
 struct Carver {
@@ -278,6 +291,7 @@ extern "C" int pdbeda_ctx_create_on_stream(int device_id, void *hip_stream, pdbe
     if (hipHostMalloc((void **)&ctx->pinned, 1 << 20, hipHostMallocDefault) == hipSuccess) ctx->pinned_cap = 1 << 20;   // (without it results are copied directly)
     if (const char *v = getenv("PDBEDA_DEBUG_POISON")) ctx->debug_poison = v[0] && v[0] != '0';
     if (const char *v = getenv("PDBEDA_DEBUG_EDGE_CAP")) ctx->debug_edge_cap = atoll(v);
+    if (const char *v = getenv("PDBEDA_POOL_CAP_MB")) ctx->pool_cap = (size_t)std::max<long long>(atoll(v), 0) << 20;
     *out = ctx;
     return PDBEDA_OK;
 }
@@ -386,29 +400,23 @@ static int map_create(pdbeda_ctx *ctx, const float *host, const float *dev, cons
     if (rc) { delete m; return rc; }
     m->n_vox = (int64_t)geom->ncrs[0] * geom->ncrs[1] * geom->ncrs[2];
     if (m->n_vox >= (1ll << 32)) { delete m; return fail(ctx, PDBEDA_ERR_ARGUMENT, "grids of 2^32 voxels or more are not supported"); }
-    hipError_t e = hipMalloc((void **)&m->geom_dev, sizeof(Geom));
-    if (e != hipSuccess) { delete m; return fail(ctx, PDBEDA_ERR_MEMORY, "hipMalloc geom: %s", hipGetErrorString(e)); }
-    e = hipMemcpyAsync(m->geom_dev, &m->geom, sizeof(Geom), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && host) {
-        float *d = nullptr;
-        e = hipMalloc((void **)&d, sizeof(float) * (size_t)m->n_vox);
-        if (e == hipSuccess) {
-            m->dens = d;
-            m->own_dens = true;
-            e = hipMemcpyAsync(d, host, sizeof(float) * (size_t)m->n_vox, hipMemcpyHostToDevice, ctx->stream);
-        }
-    } else if (e == hipSuccess) {
-        if (((uintptr_t)dev & 15u) != 0) {
-            (void)hipFree(m->geom_dev);
-            delete m;
-            return fail(ctx, PDBEDA_ERR_ARGUMENT, "device density pointer must be 16-byte aligned");
-        }
+    if (dev && ((uintptr_t)dev & 15u) != 0) { delete m; return fail(ctx, PDBEDA_ERR_ARGUMENT, "device density pointer must be 16-byte aligned"); }
+    rc = arena_get(ctx, align_up(sizeof(Geom)) + (host ? align_up(sizeof(float) * (size_t)m->n_vox) : 0), &m->arena);
+    if (rc) { delete m; return rc; }
+    Carver cv(m->arena.base);
+    m->geom_dev = cv.take<Geom>(1);
+    hipError_t e = hipMemcpyAsync(m->geom_dev, &m->geom, sizeof(Geom), hipMemcpyHostToDevice, ctx->stream);
+    if (host) {
+        float *d = cv.take<float>((size_t)m->n_vox);
+        m->dens = d;
+        m->own_dens = true;
+        if (e == hipSuccess) e = hipMemcpyAsync(d, host, sizeof(float) * (size_t)m->n_vox, hipMemcpyHostToDevice, ctx->stream);
+    } else {
         m->dens = dev;
     }
     if (e == hipSuccess) e = ctx_sync(ctx);  // host buffers may be released on return
     if (e != hipSuccess) {
-        if (m->own_dens) (void)hipFree((void *)m->dens);
-        (void)hipFree(m->geom_dev);
+        arena_put(ctx, m->arena);
         delete m;
         return fail(ctx, PDBEDA_ERR_DEVICE, "map upload: %s", hipGetErrorString(e));
     }
@@ -436,18 +444,19 @@ extern "C" int pdbeda_map_combine(pdbeda_map *a, pdbeda_map *b, double alpha, pd
     m->ctx = ctx;
     m->geom = a->geom;
     m->n_vox = a->n_vox;
-    float *d = nullptr;
-    hipError_t e = hipMalloc((void **)&m->geom_dev, sizeof(Geom));
-    if (e == hipSuccess) e = hipMalloc((void **)&d, sizeof(float) * (size_t)m->n_vox);
-    if (e == hipSuccess) e = hipMemcpyAsync(m->geom_dev, &m->geom, sizeof(Geom), hipMemcpyHostToDevice, ctx->stream);
+    int rc = arena_get(ctx, align_up(sizeof(Geom)) + align_up(sizeof(float) * (size_t)m->n_vox), &m->arena);
+    if (rc) { delete m; return rc; }
+    Carver cv(m->arena.base);
+    m->geom_dev = cv.take<Geom>(1);
+    float *d = cv.take<float>((size_t)m->n_vox);
+    hipError_t e = hipMemcpyAsync(m->geom_dev, &m->geom, sizeof(Geom), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_map_combine, dim3(grid_for(m->n_vox / 4 + 1, 256, 4096)), dim3(256), 0, ctx->stream, a->dens, b->dens, alpha, m->n_vox, d);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = ctx_sync(ctx);   // (&m->geom is read by the copy above)
     if (e != hipSuccess) {
-        if (d) (void)hipFree(d);
-        if (m->geom_dev) (void)hipFree(m->geom_dev);
+        arena_put(ctx, m->arena);
         delete m;
         return fail(ctx, PDBEDA_ERR_DEVICE, "map combine: %s", hipGetErrorString(e));
     }
@@ -470,12 +479,9 @@ extern "C" int pdbeda_map_download(pdbeda_map *m, float *density_out) {
 extern "C" int pdbeda_map_free(pdbeda_map *m) {
     if (!m) return PDBEDA_ERR_ARGUMENT;
     pdbeda_ctx *ctx = m->ctx;
-    (void)hipSetDevice(ctx->device);
-    if (!ctx->timed_out) {   // (an abandoned context leaks its device memory: hipFree would wait for the stream that hangs)
-        (void)ctx_sync(ctx);
-        if (m->own_dens) (void)hipFree((void *)m->dens);
-        (void)hipFree(m->geom_dev);
-    }
+    // the arena goes back to the context's pool: whoever gets it next is enqueued on this stream behind the last kernel that
+    // reads the map -- no wait, no hipFree (which would synchronise the whole device under the other streams of a pool)
+    arena_put(ctx, m->arena);
     ctx->live_handles--;
     delete m;
     return PDBEDA_OK;
@@ -752,7 +758,9 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
     if (tiles_pp >= (1ll << 31)) return fail(ctx, PDBEDA_ERR_ARGUMENT, "grid too large");
     // run / component ids: a fixed range per tile (no allocation atomics) + worst case of the unit tiles above them
     const int64_t max_runs = tiles_pp * td.cw * 64 * 32 + (int64_t)((uc + 1) / 2) * ur * us * n_planes + 1;
-    if (max_runs >= (1ll << 31)) return fail(ctx, PDBEDA_ERR_ARGUMENT, "grid too large");
+    if (max_runs >= (1ll << 31))
+        return fail(ctx, PDBEDA_ERR_ARGUMENT, "grid too large for whole-map labelling: %d x %d x %d voxels need %lld run ids (limit 2^31: about 1100^3 for a fused job)",
+                    uc, ur, us, (long long)max_runs);
 
     const bool faces = true;   // cross-tile unions from the tiles' exported run lists (k_face_merge)
     Job job;
