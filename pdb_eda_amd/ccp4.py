@@ -325,12 +325,13 @@ class DensityBlob(object):
     def listFromDevice(cls, bl, densityMatrix):
         st = bl.stats()
         out = []
-        for i in range(len(st["n"])):
-            blob = cls(list(st["centroid"][i]), list(st["coordCenter"][i]), float(st["totalDensity"][i]),
-                       float(st["volume"][i]), None, densityMatrix)
-            blob._numVoxels = int(st["n"][i])
+        columns = zip(st["centroid"].tolist(), st["coordCenter"].tolist(), st["totalDensity"].tolist(), st["volume"].tolist(), st["n"].tolist(),
+                      st["firstKey"].tolist())
+        for i, (centroid, center, total, volume, n, key) in enumerate(columns):
+            blob = cls(centroid, center, total, volume, None, densityMatrix)
+            blob._numVoxels = n
             blob._lazy = (bl, i)
-            blob.firstKey = int(st["firstKey"][i])
+            blob.firstKey = key
             out.append(blob)
         return out
 

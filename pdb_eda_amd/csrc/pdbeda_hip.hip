@@ -629,15 +629,19 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.n_vols = n_vols;
     job.total_words = total_words;
     job.key_words = (total_keys + 63) / 64;
-    job.n_chunks = (int32_t)((job.key_words + KEY_CHUNK - 1) / KEY_CHUNK);
+    job.n_fine = (int32_t)((job.key_words + KEY_FINE - 1) / KEY_FINE);
+    job.fine_per_coarse = std::max(128, (job.n_fine + KEY_COARSE_MAX - 1) / KEY_COARSE_MAX);
+    job.n_coarse = (job.n_fine + job.fine_per_coarse - 1) / job.fine_per_coarse;
     job.ctr = cv.take<Counters>(1);
     job.vols = cv.take<VolDesc>(std::max(n_vols, 1));
     job.mask = cv.take<uint64_t>(total_words);
     job.key_bits = cv.take<uint64_t>(job.key_words);
+    {   // the rank counters sit right behind the bitmap: ONE clear covers all three (fine and coarse are adjacent)
+        uint32_t *cnt = cv.take<uint32_t>((size_t)std::max(job.n_fine + job.n_coarse, 1));
+        job.fine_count = cnt;
+        job.coarse_count = cnt ? cnt + job.n_fine : nullptr;
+    }
     job.run_base = cv.take<uint32_t>(total_words);
-    job.key_rank = cv.take<uint32_t>(job.key_words);
-    job.chunk_count = cv.take<uint32_t>(std::max(job.n_chunks, 1));
-    job.chunk_prefix = cv.take<uint32_t>(std::max(job.n_chunks, 1));
     job.comps_are_runs = n_tiles ? 0 : 1;
     job.comp_of_run = n_tiles ? cv.take<uint32_t>(max_runs) : nullptr;
     job.label_of_comp = n_tiles ? cv.take<int32_t>(max_runs) : nullptr;
@@ -689,9 +693,8 @@ static int engine_enqueue(pdbeda_ctx *ctx, pdbeda_map *m, Job &job, int64_t max_
         { PROF(ctx, "k_resolve"); hipLaunchKernelGGL(k_resolve, dim3(run_grid), dim3(256), 0, st, job); }
         { PROF(ctx, "k_paint_keys"); hipLaunchKernelGGL(k_paint_keys, dim3(run_grid), dim3(256), 0, st, job); }
     }
-    if (job.n_chunks > 0) { PROF(ctx, "k_key_chunks"); hipLaunchKernelGGL(k_key_chunks, dim3(job.n_chunks), dim3(KEY_CHUNK), 0, st, job); }
-    { PROF(ctx, "k_chunk_scan"); hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, st, job); }
-    if (job.total_words > 0) { PROF(ctx, "k_emit"); hipLaunchKernelGGL(k_emit, dim3(run_grid), dim3(256), 0, st, job, m->geom_dev); }
+    // (k_emit also runs for an empty job: its first block publishes the blob count)
+    { PROF(ctx, "k_emit"); hipLaunchKernelGGL(k_emit, dim3(job.total_words > 0 ? run_grid : 1u), dim3(256), 0, st, job, m->geom_dev); }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -801,8 +804,6 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
     { PROF(ctx, "k_union_edges"); hipLaunchKernelGGL(k_union_edges, dim3(32, ESHARDS), dim3(256), 0, st, job); }
     { PROF(ctx, "k_resolve_tiles"); hipLaunchKernelGGL(k_resolve_tiles, dim3((unsigned)tiles_pp + 64u), dim3(256), 0, st, job, (int)tiles_pp); }
     { PROF(ctx, "k_paint_keys"); hipLaunchKernelGGL(k_paint_keys, dim3(comp_grid), dim3(256), 0, st, job); }
-    { PROF(ctx, "k_key_chunks"); hipLaunchKernelGGL(k_key_chunks, dim3(job.n_chunks), dim3(KEY_CHUNK), 0, st, job); }
-    { PROF(ctx, "k_chunk_scan"); hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, st, job); }
     { PROF(ctx, "k_emit"); hipLaunchKernelGGL(k_emit, dim3(comp_grid), dim3(256), 0, st, job, m->geom_dev); }
     if (labels) {
         PROF(ctx, "k_labels_tiles");
@@ -852,40 +853,16 @@ static int list_resolve_counts(pdbeda_bloblist *bl) {
     pdbeda_ctx *ctx = bl->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const Job &job = bl->job;
-    // rank range of this list = blobs whose key lies in [key_base(vol_lo), key_end(vol_hi-1)):
-    // chunk_prefix/key_rank give prefix counts at arbitrary key words.
-    std::vector<VolDesc> vols(job.n_vols);
+    // rank range of this list inside the job's blob table: a list is the whole job, or one plane of a fused whole-map job
+    // (k_emit published the split)
     Counters ctr;
     HIP_TRY(ctx, d2h(ctx, &ctr, job.ctr, sizeof ctr));
-    if (job.n_vols > 0)
-        HIP_TRY(ctx, d2h(ctx, vols.data(), job.vols, sizeof(VolDesc) * job.n_vols));
     HIP_TRY(ctx, ctx_sync(ctx));
-    auto rank_at = [&](int64_t key, int64_t *out) -> int {
-        // number of blobs with first key < key
-        if (key <= 0) { *out = 0; return 0; }
-        int64_t total_keys = job.key_words * 64;
-        if (key >= total_keys) { *out = ctr.n_blobs; return 0; }
-        int64_t kw = key >> 6;
-        uint32_t cp = 0, kr = 0;
-        uint64_t bits = 0;
-        HIP_TRY(ctx, d2h(ctx, &cp, job.chunk_prefix + kw / KEY_CHUNK, 4));
-        HIP_TRY(ctx, d2h(ctx, &kr, job.key_rank + kw, 4));
-        HIP_TRY(ctx, d2h(ctx, &bits, job.key_bits + kw, 8));
-        HIP_TRY(ctx, ctx_sync(ctx));
-        *out = (int64_t)cp + kr + popc64(bits & bits_below((int)(key & 63)));
-        return 0;
-    };
-    int64_t k_lo = 0, k_hi = 0;
-    if (job.n_vols > 0 && bl->vol_lo < job.n_vols) {
-        k_lo = vols[bl->vol_lo].key_base;
-        const VolDesc &last = vols[bl->vol_hi - 1];
-        k_hi = last.key_base + (int64_t)last.dim[0] * last.dim[1] * last.dim[2];
-    }
-    int rc = rank_at(k_lo, &bl->rank_lo);
-    if (rc) return rc;
-    rc = rank_at(k_hi, &bl->rank_hi);
-    if (rc) return rc;
     if (bl->vol_lo == 0 && bl->vol_hi == job.n_vols) { bl->rank_lo = 0; bl->rank_hi = ctr.n_blobs; }
+    else if (bl->whole_map && job.n_vols == 2 && bl->vol_hi == bl->vol_lo + 1) {
+        bl->rank_lo = bl->vol_lo == 0 ? 0 : ctr.n_blobs_vol0;
+        bl->rank_hi = bl->vol_lo == 0 ? ctr.n_blobs_vol0 : ctr.n_blobs;
+    } else return fail(ctx, PDBEDA_ERR_STATE, "blob list covers an unexpected volume range");
     bl->have_counts = true;
     return 0;
 }
@@ -1172,7 +1149,8 @@ static int grouped_job(pdbeda_map *m, GroupSetup &gs, int64_t n_items, int64_t n
     hipError_t e = hipSuccess;
     if (n_groups > 0) e = hipMemcpyAsync(job.vols, gs.d_vols, sizeof(VolDesc) * n_groups, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess) e = hipMemsetAsync(job.ctr, 0, sizeof(Counters), st);
-    if (e == hipSuccess && job.key_words > 0) e = hipMemsetAsync(job.key_bits, 0, 8 * job.key_words, st);
+    if (e == hipSuccess)   // first-key bitmap + both levels of rank counters (adjacent in the arena)
+        e = hipMemsetAsync(job.key_bits, 0, (size_t)((char *)(job.fine_count + job.n_fine + job.n_coarse) - (char *)job.key_bits), st);
     if (e == hipSuccess && job.total_words > 0) e = hipMemsetAsync(job.mask, 0, 8 * job.total_words, st);
     if (e == hipSuccess && n_items > 0) {
         if (spheres)

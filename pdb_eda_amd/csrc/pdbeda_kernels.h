@@ -30,6 +30,7 @@ struct Counters {
     unsigned int n_comps;
     unsigned int n_edges;
     unsigned int n_blobs;
+    unsigned int n_blobs_vol0;   // blobs whose first key lies in volume 0 (the split of a fused green / red job's table)
     unsigned int barrier;        // arrivals at the grid barrier of k_unit_fallback
     unsigned int unit_tiles[3];  // whole-map tiles that fell back to unit mode: run slots / edge buffer / component table full
     unsigned long long n_voxels;
@@ -45,10 +46,11 @@ struct Job {
     uint64_t *mask;
     uint32_t *run_base;
     uint64_t *key_bits;
-    uint32_t *key_rank;      // per key word: set bits before it inside its chunk
-    uint32_t *chunk_count;   // per chunk of KEY_CHUNK key words
-    uint32_t *chunk_prefix;
-    int32_t n_chunks;
+    // rank of a key = set bits of key_bits below it, from two levels of counters that k_paint_keys maintains beside the bitmap
+    // (no scan kernels): fine_count per KEY_FINE key words, coarse_count per fine_per_coarse fine counters (<= KEY_COARSE_MAX of them)
+    uint32_t *fine_count;
+    uint32_t *coarse_count;
+    int32_t n_fine, n_coarse, fine_per_coarse;
     Counters *ctr;
     // union-find elements ("components"): tile-local components on the whole-map fast path,
     // single runs (comp_of_run == nullptr, identity) on the generic path
@@ -84,7 +86,8 @@ struct Job {
     int32_t *b_group;
 };
 
-constexpr int KEY_CHUNK = 256;  // key words per chunk (= threads per block of k_key_chunks)
+constexpr int KEY_FINE = 32;          // key words per fine counter (2048 keys)
+constexpr int KEY_COARSE_MAX = 4096;  // coarse counters a block scans in LDS
 constexpr int WAVE = 64;
 
 __device__ inline int lane_id() { return threadIdx.x & 63; }
@@ -333,88 +336,85 @@ __global__ void __launch_bounds__(256) k_resolve(Job job) {
 
 // Blob order = ascending key of the blob's first voxel in the reference's c-major
 // enumeration (cutils.pyx:199 + 59-69).  Keys are unique positions, so the rank of a blob
-// is a prefix population count over a bitmap of first-voxel keys -- no sort needed.
+// is a prefix population count over a bitmap of first-voxel keys -- no sort needed.  The prefix counts are kept as two
+// levels of counters bumped at paint time, so ranking costs no scan launch: rank(key) = coarse prefix (a block-local scan
+// of <= 4096 counters in LDS) + the fine counters of its coarse bucket before it + the bitmap words of its fine bucket.
 __global__ void __launch_bounds__(256) k_paint_keys(Job job) {
     const uint32_t n_runs = n_components(job);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_runs; i += gridDim.x * blockDim.x) {
         if (job.parent[i] != (int32_t)i || job.r_n[i] == 0u) continue;   // not a root / unused id
         const unsigned long long key = job.r_key[i];
+        const uint32_t f = (uint32_t)(key >> 6) / KEY_FINE;
         atomicOr((unsigned long long *)&job.key_bits[key >> 6], 1ull << (key & 63));
+        atomicAdd(&job.fine_count[f], 1u);
+        atomicAdd(&job.coarse_count[f / (uint32_t)job.fine_per_coarse], 1u);
     }
 }
 
-__global__ void __launch_bounds__(KEY_CHUNK) k_key_chunks(Job job) {
-    __shared__ uint32_t s_wsum[KEY_CHUNK / 64];
+// Exclusive scan of the coarse counters into LDS (every block of k_emit does its own: <= 16 KiB from L2); returns the total.
+__device__ inline uint32_t coarse_scan_lds(const Job &job, uint32_t *s_pre /* [KEY_COARSE_MAX] */, uint32_t *s_wave /* [4] */) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t kw = (int64_t)blockIdx.x * KEY_CHUNK + tid;
-    uint32_t cnt = kw < job.key_words ? (uint32_t)popc64(job.key_bits[kw]) : 0u;
-    uint32_t x = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t y = __shfl_up(x, d);
-        if (lane >= d) x += y;
-    }
-    if (lane == 63) s_wsum[wv] = x;
-    __syncthreads();
-    uint32_t pre = 0;
-    for (int k = 0; k < wv; ++k) pre += s_wsum[k];
-    if (kw < job.key_words) job.key_rank[kw] = pre + x - cnt;
-    if (tid == KEY_CHUNK - 1) job.chunk_count[blockIdx.x] = pre + x;
-}
-
-// Single block: exclusive scan of chunk_count -> chunk_prefix, total -> n_blobs.
-__global__ void __launch_bounds__(1024) k_chunk_scan(Job job) {
-    __shared__ uint32_t s_w[16];
-    __shared__ uint32_t s_carry;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (int base = 0; base < job.n_chunks; base += 1024) {
+    uint32_t carry = 0;
+    for (int base = 0; base < job.n_coarse; base += 256) {   // block-uniform
         const int i = base + tid;
-        uint32_t v = i < job.n_chunks ? job.chunk_count[i] : 0u;
+        const uint32_t v = i < job.n_coarse ? job.coarse_count[i] : 0u;
         uint32_t x = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            uint32_t y = __shfl_up(x, d);
+            const uint32_t y = __shfl_up(x, d);
             if (lane >= d) x += y;
         }
-        if (lane == 63) s_w[wv] = x;
+        if (lane == 63) s_wave[wv] = x;
         __syncthreads();
-        uint32_t pre = s_carry;
-        for (int k = 0; k < wv; ++k) pre += s_w[k];
-        if (i < job.n_chunks) job.chunk_prefix[i] = pre + x - v;
-        __syncthreads();
-        if (tid == 1023) s_carry = pre + x;
+        uint32_t pre = carry;
+        for (int k = 0; k < wv; ++k) pre += s_wave[k];
+        if (i < job.n_coarse) s_pre[i] = pre + x - v;
+        carry += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
         __syncthreads();
     }
-    if (tid == 0) job.ctr->n_blobs = s_carry;
+    return carry;
+}
+
+// Number of painted keys below `key` (s_pre: this block's coarse_scan_lds).
+__device__ inline uint32_t rank_of_key(const Job &job, const uint32_t *s_pre, unsigned long long key) {
+    const int64_t kw = (int64_t)(key >> 6);
+    const int64_t f = kw / KEY_FINE, c = f / job.fine_per_coarse;
+    uint32_t rank = s_pre[c];
+    for (int64_t j = c * job.fine_per_coarse; j < f; ++j) rank += job.fine_count[j];
+    for (int64_t j = f * KEY_FINE; j < kw; ++j) rank += (uint32_t)popc64(job.key_bits[j]);
+    return rank + (uint32_t)popc64(job.key_bits[kw] & bits_below((int)(key & 63)));
 }
 
 // Thread per component: final label of the component; roots also write their blob table row
-// (DensityBlob.fromCrsList, ccp4.py:542-545).
+// (DensityBlob.fromCrsList, ccp4.py:542-545).  Block 0 publishes the blob counts.
 __global__ void __launch_bounds__(256) k_emit(Job job, const Geom *__restrict__ gp) {
+    __shared__ uint32_t s_pre[KEY_COARSE_MAX];
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_below1;
+    const uint32_t total = coarse_scan_lds(job, s_pre, s_wave);
+    const bool whole_map = job.label_of_comp != nullptr;
+    if (threadIdx.x == 0) {
+        uint32_t below1 = total;   // blobs before volume 1 (fused green / red job); every blob when there is one volume
+        if (job.n_vols > 1 && whole_map) below1 = rank_of_key(job, s_pre, (unsigned long long)job.vols[1].key_base);
+        s_below1 = below1;
+        if (blockIdx.x == 0) { job.ctr->n_blobs = total; job.ctr->n_blobs_vol0 = below1; }
+    }
+    __syncthreads();
     const uint32_t n_comp = n_components(job);
     const Geom &g = *gp;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_comp; i += gridDim.x * blockDim.x) {
         const uint32_t root = (uint32_t)job.parent[i];
         if (job.r_n[root] == 0u) continue;   // unused component id
         const unsigned long long key = job.r_key[root];
-        const int64_t kw = (int64_t)(key >> 6);
-        const uint32_t rank = job.chunk_prefix[kw / KEY_CHUNK] + job.key_rank[kw] +
-                              (uint32_t)popc64(job.key_bits[kw] & bits_below((int)(key & 63)));
-        const int vi = find_vol_by_key(job.vols, job.n_vols, (int64_t)key);
-        const VolDesc vd = job.vols[vi];
-        if (job.label_of_comp) {
+        const uint32_t rank = rank_of_key(job, s_pre, key);
+        const int vi = whole_map ? ((job.n_vols > 1 && (int64_t)key >= job.vols[1].key_base) ? 1 : 0) : find_vol_by_key(job.vols, job.n_vols, (int64_t)key);
+        if (whole_map) {
             // whole-map jobs: blob index inside its own list, signed by the list
-            uint32_t below = 0;
-            if (vd.key_base > 0) {
-                const int64_t kb = vd.key_base, kbw = kb >> 6;
-                below = job.chunk_prefix[kbw / KEY_CHUNK] + job.key_rank[kbw] + (uint32_t)popc64(job.key_bits[kbw] & bits_below((int)(kb & 63)));
-            }
-            const int32_t k = (int32_t)(rank - below);
-            job.label_of_comp[i] = job.vol_sign[vi > 1 ? 1 : vi] > 0 ? 1 + k : -1 - k;
+            const int32_t k = (int32_t)(rank - (vi ? s_below1 : 0u));
+            job.label_of_comp[i] = job.vol_sign[vi] > 0 ? 1 + k : -1 - k;
         }
         if (root != i) continue;
+        const VolDesc vd = job.vols[vi];
         job.r_rank[i] = rank;
         const double n = (double)job.r_n[i];
         const double tot = job.r_rho[i];

@@ -61,14 +61,6 @@ struct JobInit {
     unsigned int runs0, comps0;
 };
 
-// Number of blobs whose first key is < key.
-__device__ inline uint32_t rank_below(const Job &job, int64_t key) {
-    if (key <= 0) return 0u;
-    if (key >= job.key_words * 64) return job.ctr->n_blobs;
-    const int64_t kw = key >> 6;
-    return job.chunk_prefix[kw / KEY_CHUNK] + job.key_rank[kw] + (uint32_t)popc64(job.key_bits[kw] & bits_below((int)(key & 63)));
-}
-
 // number of set bits of a wave-uniform 64-bit mask at lane positions < the calling lane
 __device__ inline uint32_t mbcnt_lt(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -165,6 +157,9 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
         const int64_t per = (job.key_words + gridDim.x - 1) / gridDim.x;
         const int64_t lo = per * blockIdx.x, hi = lo + per < job.key_words ? lo + per : job.key_words;
         for (int64_t i = lo + tid; i < hi; i += NT) job.key_bits[i] = 0ull;
+        const int64_t nfc = (int64_t)job.n_fine + job.n_coarse;   // ... and of the rank counters (fine and coarse are adjacent)
+        const int64_t perc = (nfc + gridDim.x - 1) / gridDim.x, clo = perc * blockIdx.x, chi = clo + perc < nfc ? clo + perc : nfc;
+        for (int64_t i = clo + tid; i < chi; i += NT) job.fine_count[i] = 0u;
         const int64_t nf = (int64_t)job.pair_filter_mask + 1, perf = (nf + gridDim.x - 1) / gridDim.x;   // and of the pair filter
         const int64_t flo = perf * blockIdx.x, fhi = flo + perf < nf ? flo + perf : nf;
         for (int64_t i = flo + tid; i < fhi; i += NT) job.pair_filter[i] = 0ull;

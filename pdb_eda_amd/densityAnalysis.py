@@ -214,6 +214,7 @@ class DensityAnalysis(object):
         self._atomTypeOverlapCompleteness = None
         self._atomTypeOverlapIncompleteness = None
         self._fc = None
+        self._atomTableCache = None
 
     # ---- lazy properties (ref densityAnalysis.py:326-565) ------------------------------------
     def _lazy(name, trigger):
@@ -608,9 +609,10 @@ class DensityAnalysis(object):
     # ---- region density / discrepancy (ref densityAnalysis.py:948-1211), batched ---------------
     def _regionBatch(self, dm, groups, radii, cutoff):
         """groups: list of lists of coordinates; radii: per-coordinate list of lists.  One device call."""
+        sizes = np.fromiter((len(g) for g in groups), dtype=np.int64, count=len(groups))
         xyz = np.array([c for g in groups for c in g], dtype=np.float64).reshape(-1, 3)
-        rad = np.array([r for g in radii for r in g], dtype=np.float32)
-        off = np.concatenate([[0], np.cumsum([len(g) for g in groups])]).astype(np.int64)
+        rad = np.fromiter((r for g in radii for r in g), dtype=np.float32, count=int(sizes.sum()))
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
         return dm._map.region_sums(xyz, rad, off, cutoff)
 
     def _needRatio(self):
@@ -623,22 +625,30 @@ class DensityAnalysis(object):
         dm = self.densityObj
         cutoff = dm.meanDensity + numSD * dm.stdDensity
         pos, neg, cnt, valid = self._regionBatch(dm, groups, radii, cutoff)
-        rows = [[float(p), float(p) / ratio] for p in pos]
+        rows = np.stack([pos, pos / ratio], axis=1).tolist()
         return (rows, valid) if want_valid else rows
 
     def _discrepancyRows(self, groups, radii, numSD, want_valid):
+        """The ten columns of regionDiscrepancyHeader for every group, computed on whole columns (densityAnalysis.py:1200-1211)."""
         ratio = self._needRatio()
         dm = self.diffDensityObj
         cutoff = dm.meanDensity + numSD * dm.stdDensity
         pos, neg, cnt, valid = self._regionBatch(dm, groups, radii, cutoff)
         avg = dm.getTotalAbsDensity(cutoff) / dm.densityArray.size
-        rows = []
-        for p, n, c in zip(pos, neg, cnt):
-            p, n = float(p), float(n)
-            absd = abs(p) + abs(n)
-            expected = avg * int(c)
-            rows.append([absd, absd / ratio, expected, expected / ratio, p + n, (p + n) / ratio, p, p / ratio, n, n / ratio])
+        absd = np.abs(pos) + np.abs(neg)
+        expected = avg * cnt
+        net = pos + neg
+        rows = np.stack([absd, absd / ratio, expected, expected / ratio, net, net / ratio, pos, pos / ratio, neg, neg / ratio], axis=1).tolist()
         return (rows, valid) if want_valid else rows
+
+    def _atomTable(self):
+        """All atoms of the structure with the leading columns of the per-atom tables (model, chain, residue number, residue name,
+        atom name, occupancy: densityAnalysis.py:966-971), built once per analysis."""
+        if self._atomTableCache is None:
+            atoms = list(self.biopdbObj.get_atoms())
+            lead = [[a.parent.parent.parent.id, a.parent.parent.id, a.parent.id[1], a.parent.resname, a.name, a.get_occupancy()] for a in atoms]
+            self._atomTableCache = (atoms, lead)
+        return self._atomTableCache
 
     def calculateRegionDensity(self, xyzCoordList, radius, numSD=1.5, testValidCrs=False):
         """ref densityAnalysis.py:1037-1068."""
@@ -658,9 +668,10 @@ class DensityAnalysis(object):
 
     def calculateAtomRegionDensity(self, radius, numSD=1.5, type="", useOptimizedRadii=False):
         """ref densityAnalysis.py:948-973 (all atoms in ONE device batch)."""
-        atoms = [a for a in self.biopdbObj.get_atoms() if not type or a.name == type]
-        rows = self._densityRows([[a.coord] for a in atoms], [[self._atomRadius(a, radius, useOptimizedRadii)] for a in atoms], numSD, False)
-        return [[a.parent.parent.parent.id, a.parent.parent.id, a.parent.id[1], a.parent.resname, a.name, a.get_occupancy()] + r for a, r in zip(atoms, rows)]
+        atoms, lead = self._atomTable()
+        pick = [i for i, a in enumerate(atoms) if not type or a.name == type]
+        rows = self._densityRows([[atoms[i].coord] for i in pick], [[self._atomRadius(atoms[i], radius, useOptimizedRadii)] for i in pick], numSD, False)
+        return [lead[i] + r for i, r in zip(pick, rows)]
 
     def calculateSymmetryAtomRegionDensity(self, radius, numSD=1.5, type="", useOptimizedRadii=False):
         """ref densityAnalysis.py:975-999."""
@@ -685,9 +696,10 @@ class DensityAnalysis(object):
 
     def calculateAtomRegionDiscrepancies(self, radius, numSD=3.0, type=""):
         """ref densityAnalysis.py:1081-1104 (33 ms/atom in the reference; ONE device batch here)."""
-        atoms = [a for a in self.biopdbObj.get_atoms() if not type or a.name == type]
-        rows = self._discrepancyRows([[a.coord] for a in atoms], [[radius] for a in atoms], numSD, False)
-        return [[a.parent.parent.parent.id, a.parent.parent.id, a.parent.id[1], a.parent.resname, a.name, a.get_occupancy()] + r for a, r in zip(atoms, rows)]
+        atoms, lead = self._atomTable()
+        pick = [i for i, a in enumerate(atoms) if not type or a.name == type]
+        rows = self._discrepancyRows([[atoms[i].coord] for i in pick], [[radius]] * len(pick), numSD, False)
+        return [lead[i] + r for i, r in zip(pick, rows)]
 
     def calculateSymmetryAtomRegionDiscrepancies(self, radius, numSD=3.0, type=""):
         """ref densityAnalysis.py:1106-1128."""
