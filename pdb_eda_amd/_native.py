@@ -297,7 +297,7 @@ class BlobList(object):
     def counters(self):
         out = np.zeros(8, dtype=np.int64)
         self._ctx.check(self._ctx._lib.pdbeda_bloblist_counters(self._h, _ptr(out)), "pdbeda_bloblist_counters")
-        return dict(zip(["runs", "tile_components", "cross_tile_pairs", "blobs", "unit_tiles_runs", "unit_tiles_edges", "unit_tiles_comps"], out[:7].tolist()))
+        return {"run_ids": int(out[0]), "component_ids": int(out[1]), "blobs": int(out[3]), "unit_tiles_runs": int(out[4]), "unit_tiles_comps": int(out[6])}
 
     def free(self):
         if self._h is not None and self._ctx._h:

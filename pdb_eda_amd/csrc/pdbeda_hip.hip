@@ -624,40 +624,30 @@ extern "C" int pdbeda_xyz2crs(pdbeda_map *m, const double *xyz, int64_t n, int32
 // Carve a job out of an arena.  max_runs / max_blobs are worst-case bounds (a run needs a
 // gap: <= bits/2 + 1 per word; a blob owns >= one 2x2x2 cell... we simply bound blobs by runs).
 static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, int64_t total_keys, int64_t max_runs,
-                        int64_t max_blobs, size_t extra_labels, int32_t **labels_out, int64_t n_tiles = 0, int64_t edge_cap_override = 0, bool faces = false) {
+                        int64_t max_blobs, size_t extra_labels, int32_t **labels_out, int64_t n_tiles = 0) {
     Carver cv(base);
     job.n_vols = n_vols;
     job.total_words = total_words;
     job.key_words = (total_keys + 63) / 64;
     job.n_fine = (int32_t)((job.key_words + KEY_FINE - 1) / KEY_FINE);
-    job.fine_per_coarse = std::max(128, (job.n_fine + KEY_COARSE_MAX - 1) / KEY_COARSE_MAX);
-    job.n_coarse = (job.n_fine + job.fine_per_coarse - 1) / job.fine_per_coarse;
+    job.fine_per_group = std::max(8, ((job.n_fine + KEY_GROUPS - 1) / KEY_GROUPS + 3) / 4 * 4);
     job.ctr = cv.take<Counters>(1);
     job.vols = cv.take<VolDesc>(std::max(n_vols, 1));
     job.mask = cv.take<uint64_t>(total_words);
     job.key_bits = cv.take<uint64_t>(job.key_words);
-    {   // the rank counters sit right behind the bitmap: ONE clear covers all three (fine and coarse are adjacent)
-        uint32_t *cnt = cv.take<uint32_t>((size_t)std::max(job.n_fine + job.n_coarse, 1));
-        job.fine_count = cnt;
-        job.coarse_count = cnt ? cnt + job.n_fine : nullptr;
-    }
+    // the rank counters sit right behind the bitmap (ONE clear covers both), padded to whole groups
+    job.n_fine_alloc = (int32_t)((job.n_fine + job.fine_per_group - 1) / job.fine_per_group * job.fine_per_group);
+    job.fine_count = cv.take<uint32_t>((size_t)std::max(job.n_fine_alloc, 4));
     job.run_base = cv.take<uint32_t>(total_words);
     job.comps_are_runs = n_tiles ? 0 : 1;
     job.comp_of_run = n_tiles ? cv.take<uint32_t>(max_runs) : nullptr;
     job.label_of_comp = n_tiles ? cv.take<int32_t>(max_runs) : nullptr;
-    job.pair_filter_mask = n_tiles ? (1u << 18) - 1u : 0u;
-    job.pair_filter = n_tiles ? cv.take<unsigned long long>((size_t)job.pair_filter_mask + 1) : nullptr;
-    job.face_runs = (n_tiles && faces) ? cv.take<uint32_t>((size_t)n_tiles * RCAP) : nullptr;
-    job.face_rows = (n_tiles && faces) ? cv.take<uint32_t>((size_t)n_tiles * 128) : nullptr;
-    job.edges_hold_comps = (n_tiles && faces) ? 1 : 0;
+    job.face_runs = n_tiles ? cv.take<uint32_t>((size_t)n_tiles * RCAP) : nullptr;
+    job.face_rows = n_tiles ? cv.take<uint32_t>((size_t)n_tiles * 128) : nullptr;
     job.unit_flag = n_tiles ? cv.take<uint32_t>(1) : nullptr;
     job.tile_mode = n_tiles ? cv.take<uint8_t>(n_tiles) : nullptr;
     job.tile_runs = n_tiles ? cv.take<uint32_t>(n_tiles) : nullptr;
     job.run_sums = n_tiles ? cv.take<double2>((size_t)n_tiles * RCAP) : nullptr;
-    job.edge_cap = n_tiles ? (std::max<int64_t>(1 << 18, 2 * total_words) + ESHARDS - 1) / ESHARDS * ESHARDS : 0;
-    if (n_tiles && edge_cap_override > 0) job.edge_cap = (edge_cap_override + ESHARDS - 1) / ESHARDS * ESHARDS;
-    job.edges = n_tiles ? cv.take<uint2>(job.edge_cap) : nullptr;
-    job.edge_fill = n_tiles ? cv.take<uint32_t>(ESHARDS) : nullptr;
     job.vol_sign[0] = job.vol_sign[1] = 1;
     job.parent = cv.take<int32_t>(max_runs);
     job.r_n = cv.take<uint32_t>(max_runs);
@@ -694,7 +684,7 @@ static int engine_enqueue(pdbeda_ctx *ctx, pdbeda_map *m, Job &job, int64_t max_
         { PROF(ctx, "k_paint_keys"); hipLaunchKernelGGL(k_paint_keys, dim3(run_grid), dim3(256), 0, st, job); }
     }
     // (k_emit also runs for an empty job: its first block publishes the blob count)
-    { PROF(ctx, "k_emit"); hipLaunchKernelGGL(k_emit, dim3(job.total_words > 0 ? run_grid : 1u), dim3(256), 0, st, job, m->geom_dev); }
+    { PROF(ctx, "k_emit"); hipLaunchKernelGGL(k_emit, dim3(job.total_words > 0 ? std::min(run_grid, 512u) : 1u), dim3(256), 0, st, job, m->geom_dev); }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -712,12 +702,10 @@ static pdbeda_bloblist *new_list(pdbeda_ctx *ctx, pdbeda_map *m) {
 #endif
 template <int CW>
 static void launch_tile_label(pdbeda_ctx *ctx, unsigned n_tiles, const Job &job, const float *dens, const Geom *geom_dev, const TileDims &td,
-                              const JobInit &init) {
+                              const JobInit &init, int pair_slots) {
     { PROF(ctx, "k_tile_label"); hipLaunchKernelGGL((k_tile_label<CW, PDBEDA_TILE_NT>), dim3(n_tiles), dim3(PDBEDA_TILE_NT), 0, ctx->stream, job, dens, geom_dev, td, init); }
-    // tiles that overflowed LDS (rare): their labelling and their pairs sit behind one launch that normally exits at once
-    // (128 workgroups: its grid barrier needs the whole grid resident; a device holds >= 1280 such workgroups, so ten streams can
-    //  sit in their barriers at once without starving each other of slots)
-    { PROF(ctx, "k_unit_fallback"); hipLaunchKernelGGL((k_unit_fallback<CW>), dim3(128), dim3(256), 0, ctx->stream, job, dens, geom_dev, td); }
+    // cross-tile unions; the first UNIT_BLOCKS workgroups are the fallback for tiles that overflowed LDS (rare: they exit at once)
+    { PROF(ctx, "k_face_merge"); hipLaunchKernelGGL((k_face_merge<CW>), dim3(n_tiles + UNIT_BLOCKS), dim3(256), 0, ctx->stream, job, dens, geom_dev, td, pair_slots); }
 }
 
 static void launch_labels(pdbeda_ctx *ctx, const Job &job, const TileDims &td, int32_t *labels_dev) {
@@ -765,15 +753,14 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
         return fail(ctx, PDBEDA_ERR_ARGUMENT, "grid too large for whole-map labelling: %d x %d x %d voxels need %lld run ids (limit 2^31: about 1100^3 for a fused job)",
                     uc, ur, us, (long long)max_runs);
 
-    const bool faces = true;   // cross-tile unions from the tiles' exported run lists (k_face_merge)
     Job job;
     memset(&job, 0, sizeof job);
-    size_t need = job_carve(job, nullptr, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, nullptr, tiles_pp, ctx->debug_edge_cap, faces);
+    size_t need = job_carve(job, nullptr, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, nullptr, tiles_pp);
     Arena arena;
     int rc = arena_get(ctx, need, &arena);
     if (rc) return rc;
     int32_t *labels_dev = nullptr;
-    job_carve(job, arena.base, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, &labels_dev, tiles_pp, ctx->debug_edge_cap, faces);
+    job_carve(job, arena.base, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, &labels_dev, tiles_pp);
     job.vol_sign[0] = td.sign[0];
     job.vol_sign[1] = td.sign[1];
     job.epoch = ctx->next_epoch++;
@@ -793,18 +780,18 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
     init.runs0 = (unsigned)(tiles_pp * td.cw * 64 * 32);
     init.comps0 = (unsigned)(tiles_pp * CCAP);
     hipStream_t st = ctx->stream;
+    int pair_slots = PAIR_SLOTS;   // test hook: a tiny LDS pair set overflows on small inputs (PDBEDA_DEBUG_EDGE_CAP = slots, a power of two)
+    if (ctx->debug_edge_cap > 0) { pair_slots = 1; while (pair_slots * 2 <= std::min<int64_t>(ctx->debug_edge_cap, PAIR_SLOTS)) pair_slots *= 2; }
     switch (td.cw) {
-        case 1: launch_tile_label<1>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init); break;
-        case 2: launch_tile_label<2>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init); break;
-        case 3: launch_tile_label<3>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init); break;
-        default: launch_tile_label<4>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init); break;
+        case 1: launch_tile_label<1>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init, pair_slots); break;
+        case 2: launch_tile_label<2>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init, pair_slots); break;
+        case 3: launch_tile_label<3>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init, pair_slots); break;
+        default: launch_tile_label<4>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init, pair_slots); break;
     }
     const unsigned comp_grid = grid_for(max_runs, 256, 2048);
-    { PROF(ctx, "k_face_merge"); hipLaunchKernelGGL(k_face_merge, dim3((unsigned)tiles_pp), dim3(128), 0, st, job, td); }
-    { PROF(ctx, "k_union_edges"); hipLaunchKernelGGL(k_union_edges, dim3(32, ESHARDS), dim3(256), 0, st, job); }
     { PROF(ctx, "k_resolve_tiles"); hipLaunchKernelGGL(k_resolve_tiles, dim3((unsigned)tiles_pp + 64u), dim3(256), 0, st, job, (int)tiles_pp); }
     { PROF(ctx, "k_paint_keys"); hipLaunchKernelGGL(k_paint_keys, dim3(comp_grid), dim3(256), 0, st, job); }
-    { PROF(ctx, "k_emit"); hipLaunchKernelGGL(k_emit, dim3(comp_grid), dim3(256), 0, st, job, m->geom_dev); }
+    { PROF(ctx, "k_emit"); hipLaunchKernelGGL(k_emit, dim3(std::min(comp_grid, 512u)), dim3(256), 0, st, job, m->geom_dev); }
     if (labels) {
         PROF(ctx, "k_labels_tiles");
         launch_labels(ctx, job, td, labels_dev);
@@ -868,7 +855,7 @@ static int list_resolve_counts(pdbeda_bloblist *bl) {
 }
 
 // Diagnostic: device counters of the labelling job behind a list:
-// out[0..7] = runs, tile components, cross-tile pairs, blobs, unit tiles by cause (run slots, edge buffer, component table), 0.
+// out[0..7] = run ids, component ids, 0, blobs, unit tiles by cause (run slots, -, component table), 0.
 extern "C" int pdbeda_bloblist_counters(pdbeda_bloblist *bl, int64_t *out) {
     if (!bl || bl->freed || !out) return PDBEDA_ERR_ARGUMENT;
     pdbeda_ctx *ctx = bl->ctx;
@@ -876,15 +863,8 @@ extern "C" int pdbeda_bloblist_counters(pdbeda_bloblist *bl, int64_t *out) {
     Counters c;
     HIP_TRY(ctx, d2h(ctx, &c, bl->job.ctr, sizeof c));
     HIP_TRY(ctx, ctx_sync(ctx));
-    out[0] = c.n_runs; out[1] = c.n_comps; out[2] = c.n_edges; out[3] = c.n_blobs;
+    out[0] = c.n_runs; out[1] = c.n_comps; out[2] = 0; out[3] = c.n_blobs;
     out[4] = out[5] = out[6] = out[7] = 0;
-    if (bl->whole_map && bl->job.edge_fill) {   // cross-tile pairs parked in the shard buffers (demand, also when a shard overflowed)
-        uint32_t fill[ESHARDS];
-        HIP_TRY(ctx, d2h(ctx, fill, bl->job.edge_fill, sizeof fill));
-        HIP_TRY(ctx, ctx_sync(ctx));
-        out[2] = 0;
-        for (uint32_t v : fill) out[2] += v;
-    }
     if (bl->whole_map && bl->job.tile_mode) {   // unit tiles by cause: tile_mode 1 = run slots / values, 3 = component table
         const int64_t n_tiles = (int64_t)bl->td.ctiles * bl->td.rtiles * bl->td.stiles;
         std::vector<uint8_t> mode(n_tiles);
@@ -1150,7 +1130,7 @@ static int grouped_job(pdbeda_map *m, GroupSetup &gs, int64_t n_items, int64_t n
     if (n_groups > 0) e = hipMemcpyAsync(job.vols, gs.d_vols, sizeof(VolDesc) * n_groups, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess) e = hipMemsetAsync(job.ctr, 0, sizeof(Counters), st);
     if (e == hipSuccess)   // first-key bitmap + both levels of rank counters (adjacent in the arena)
-        e = hipMemsetAsync(job.key_bits, 0, (size_t)((char *)(job.fine_count + job.n_fine + job.n_coarse) - (char *)job.key_bits), st);
+        e = hipMemsetAsync(job.key_bits, 0, (size_t)((char *)(job.fine_count + job.n_fine_alloc) - (char *)job.key_bits), st);
     if (e == hipSuccess && job.total_words > 0) e = hipMemsetAsync(job.mask, 0, 8 * job.total_words, st);
     if (e == hipSuccess && n_items > 0) {
         if (spheres)

@@ -28,7 +28,6 @@ struct VolDesc {
 struct Counters {
     unsigned int n_runs;
     unsigned int n_comps;
-    unsigned int n_edges;
     unsigned int n_blobs;
     unsigned int n_blobs_vol0;   // blobs whose first key lies in volume 0 (the split of a fused green / red job's table)
     unsigned int barrier;        // arrivals at the grid barrier of k_unit_fallback
@@ -46,11 +45,11 @@ struct Job {
     uint64_t *mask;
     uint32_t *run_base;
     uint64_t *key_bits;
-    // rank of a key = set bits of key_bits below it, from two levels of counters that k_paint_keys maintains beside the bitmap
-    // (no scan kernels): fine_count per KEY_FINE key words, coarse_count per fine_per_coarse fine counters (<= KEY_COARSE_MAX of them)
+    // rank of a key = set bits of key_bits below it.  k_paint_keys keeps one counter per KEY_FINE key words beside the bitmap
+    // (spread over many cache lines: same-line atomics serialise); every block of k_emit turns them into a prefix table of
+    // <= KEY_GROUPS entries in LDS (fine_per_group counters per entry, a multiple of 4) -- no scan kernels
     uint32_t *fine_count;
-    uint32_t *coarse_count;
-    int32_t n_fine, n_coarse, fine_per_coarse;
+    int32_t n_fine, n_fine_alloc, fine_per_group;
     Counters *ctr;
     // union-find elements ("components"): tile-local components on the whole-map fast path,
     // single runs (comp_of_run == nullptr, identity) on the generic path
@@ -61,17 +60,11 @@ struct Job {
     // first slot | count << 16: k_face_merge unites across tile faces by merging two such lists (grids <= 256 wide)
     uint32_t *face_runs;               // [tile][RCAP]
     uint32_t *face_rows;               // [tile][2][64]
-    int edges_hold_comps;              // the parked pairs are component ids (k_face_merge), not run ids
-    unsigned long long *pair_filter;   // lossy set of the component pairs already handed to the global union-find (0 = empty slot)
-    uint32_t pair_filter_mask;         // slots - 1 (a power of two)
     uint32_t *unit_flag;      // == epoch iff some tile of THIS job fell back to unit mode (stale values of a recycled arena never match)
     uint32_t epoch;           // job number of the context (never 0)
     uint8_t *tile_mode;       // per tile: 0 = united in LDS, 1 = unit tile
     uint32_t *tile_runs;      // per tile: number of word-runs (ids tile * runs_per_tile ...)
     double2 *run_sums;        // whole-map tiles: per run slot (sum rho, sum rho*(c - c_tile)), RCAP per tile
-    uint2 *edges;             // cross-tile component pairs parked by k_face_merge (ESHARDS equal regions)
-    uint32_t *edge_fill;      // pairs written per region
-    int64_t edge_cap;
     int32_t vol_sign[2];      // whole-map jobs: +1 / -1 list of volume p
     // per-component records
     int32_t *parent;
@@ -86,8 +79,8 @@ struct Job {
     int32_t *b_group;
 };
 
-constexpr int KEY_FINE = 32;          // key words per fine counter (2048 keys)
-constexpr int KEY_COARSE_MAX = 4096;  // coarse counters a block scans in LDS
+constexpr int KEY_FINE = 32;      // key words per fine counter (2048 keys)
+constexpr int KEY_GROUPS = 2048;  // entries of the prefix table a k_emit block builds in LDS
 constexpr int WAVE = 64;
 
 __device__ inline int lane_id() { return threadIdx.x & 63; }
@@ -215,7 +208,7 @@ __global__ void __launch_bounds__(256) k_run_index(Job job, const float *__restr
 // parent at some time, i.e. a smaller-or-equal id of the SAME set, so walking it, halving with it (atomic min) and
 // comparing roots stay valid, and a unite only ends on the memory-side return value of its atomic min.  That is why
 // find() may use cached (workgroup-scope) loads: an L2 hit instead of a trip to the memory side on this multi-XCD part
-// (k_union_edges 40 -> 35 us).
+// (the cross-tile union phase: 40 -> 35 us).
 // ------------------------------------------------------------------------------------
 __device__ inline int uf_load(const int32_t *p, int x) {
     return __hip_atomic_load(p + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -336,28 +329,31 @@ __global__ void __launch_bounds__(256) k_resolve(Job job) {
 
 // Blob order = ascending key of the blob's first voxel in the reference's c-major
 // enumeration (cutils.pyx:199 + 59-69).  Keys are unique positions, so the rank of a blob
-// is a prefix population count over a bitmap of first-voxel keys -- no sort needed.  The prefix counts are kept as two
-// levels of counters bumped at paint time, so ranking costs no scan launch: rank(key) = coarse prefix (a block-local scan
-// of <= 4096 counters in LDS) + the fine counters of its coarse bucket before it + the bitmap words of its fine bucket.
+// is a prefix population count over a bitmap of first-voxel keys -- no sort needed, and no scan launch: k_paint_keys
+// bumps a counter per 2048 keys beside the bit, every k_emit block sums the counters into a <= 2048-entry prefix table
+// in LDS (64 KiB of L2 reads at 256^3), and rank(key) = table entry + <= 7 counters + <= 31 bitmap words.
 __global__ void __launch_bounds__(256) k_paint_keys(Job job) {
     const uint32_t n_runs = n_components(job);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_runs; i += gridDim.x * blockDim.x) {
         if (job.parent[i] != (int32_t)i || job.r_n[i] == 0u) continue;   // not a root / unused id
         const unsigned long long key = job.r_key[i];
-        const uint32_t f = (uint32_t)(key >> 6) / KEY_FINE;
         atomicOr((unsigned long long *)&job.key_bits[key >> 6], 1ull << (key & 63));
-        atomicAdd(&job.fine_count[f], 1u);
-        atomicAdd(&job.coarse_count[f / (uint32_t)job.fine_per_coarse], 1u);
+        atomicAdd(&job.fine_count[(key >> 6) / KEY_FINE], 1u);
     }
 }
 
-// Exclusive scan of the coarse counters into LDS (every block of k_emit does its own: <= 16 KiB from L2); returns the total.
-__device__ inline uint32_t coarse_scan_lds(const Job &job, uint32_t *s_pre /* [KEY_COARSE_MAX] */, uint32_t *s_wave /* [4] */) {
+// Exclusive prefix table over groups of fine_per_group counters, built by the calling block in LDS; returns the total.
+// (fine_count is padded to whole groups by the allocation and cleared with the bitmap.)
+__device__ inline uint32_t rank_table_lds(const Job &job, uint32_t *s_pre /* [KEY_GROUPS] */, uint32_t *s_wave /* [4] */) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int G = job.fine_per_group, n_groups = (job.n_fine + G - 1) / G;
+    const uint4 *fine4 = reinterpret_cast<const uint4 *>(job.fine_count);
     uint32_t carry = 0;
-    for (int base = 0; base < job.n_coarse; base += 256) {   // block-uniform
-        const int i = base + tid;
-        const uint32_t v = i < job.n_coarse ? job.coarse_count[i] : 0u;
+    for (int base = 0; base < n_groups; base += 256) {   // block-uniform
+        const int e = base + tid;
+        uint32_t v = 0;
+        if (e < n_groups)
+            for (int k = 0; k < G / 4; ++k) { const uint4 q = fine4[(size_t)e * (G / 4) + k]; v += (q.x + q.y) + (q.z + q.w); }
         uint32_t x = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -368,30 +364,43 @@ __device__ inline uint32_t coarse_scan_lds(const Job &job, uint32_t *s_pre /* [K
         __syncthreads();
         uint32_t pre = carry;
         for (int k = 0; k < wv; ++k) pre += s_wave[k];
-        if (i < job.n_coarse) s_pre[i] = pre + x - v;
+        if (e < n_groups) s_pre[e] = pre + x - v;
         carry += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
         __syncthreads();
     }
     return carry;
 }
 
-// Number of painted keys below `key` (s_pre: this block's coarse_scan_lds).
+// Number of painted keys below `key` (s_pre: this block's rank_table_lds).
 __device__ inline uint32_t rank_of_key(const Job &job, const uint32_t *s_pre, unsigned long long key) {
     const int64_t kw = (int64_t)(key >> 6);
-    const int64_t f = kw / KEY_FINE, c = f / job.fine_per_coarse;
-    uint32_t rank = s_pre[c];
-    for (int64_t j = c * job.fine_per_coarse; j < f; ++j) rank += job.fine_count[j];
-    for (int64_t j = f * KEY_FINE; j < kw; ++j) rank += (uint32_t)popc64(job.key_bits[j]);
+    const int G = job.fine_per_group;
+    const int64_t f = kw / KEY_FINE, e = f / G;
+    uint32_t rank = s_pre[e];
+    const uint4 *fine4 = reinterpret_cast<const uint4 *>(job.fine_count) + e * (G / 4);
+    const int nf = (int)(f - e * G);                       // counters of my group before mine: < G
+    for (int k = 0; k * 4 < nf; ++k) {
+        const uint4 q = fine4[k];
+        const int left = nf - k * 4;
+        rank += q.x + (left > 1 ? q.y : 0u) + (left > 2 ? q.z : 0u) + (left > 3 ? q.w : 0u);
+    }
+    const ulonglong2 *bits2 = reinterpret_cast<const ulonglong2 *>(job.key_bits + f * KEY_FINE);   // (32 words: 16-B aligned)
+    const int nw = (int)(kw - f * KEY_FINE);               // whole words of my fine bucket before mine: < 32
+#pragma unroll 4
+    for (int k = 0; k * 2 < nw; ++k) {
+        const ulonglong2 q = bits2[k];
+        rank += (uint32_t)popc64(q.x) + (nw - k * 2 > 1 ? (uint32_t)popc64(q.y) : 0u);
+    }
     return rank + (uint32_t)popc64(job.key_bits[kw] & bits_below((int)(key & 63)));
 }
 
-// Thread per component: final label of the component; roots also write their blob table row
-// (DensityBlob.fromCrsList, ccp4.py:542-545).  Block 0 publishes the blob counts.
+// Thread per ROOT component: its rank, its final signed label (whole-map jobs; the label writer follows parent[] to it) and
+// its blob table row (DensityBlob.fromCrsList, ccp4.py:542-545).  Block 0 publishes the blob counts.
 __global__ void __launch_bounds__(256) k_emit(Job job, const Geom *__restrict__ gp) {
-    __shared__ uint32_t s_pre[KEY_COARSE_MAX];
+    __shared__ uint32_t s_pre[KEY_GROUPS];
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_below1;
-    const uint32_t total = coarse_scan_lds(job, s_pre, s_wave);
+    const uint32_t total = rank_table_lds(job, s_pre, s_wave);
     const bool whole_map = job.label_of_comp != nullptr;
     if (threadIdx.x == 0) {
         uint32_t below1 = total;   // blobs before volume 1 (fused green / red job); every blob when there is one volume
@@ -403,17 +412,14 @@ __global__ void __launch_bounds__(256) k_emit(Job job, const Geom *__restrict__ 
     const uint32_t n_comp = n_components(job);
     const Geom &g = *gp;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_comp; i += gridDim.x * blockDim.x) {
-        const uint32_t root = (uint32_t)job.parent[i];
-        if (job.r_n[root] == 0u) continue;   // unused component id
-        const unsigned long long key = job.r_key[root];
+        if (job.parent[i] != (int32_t)i || job.r_n[i] == 0u) continue;   // not a root / unused component id
+        const unsigned long long key = job.r_key[i];
         const uint32_t rank = rank_of_key(job, s_pre, key);
         const int vi = whole_map ? ((job.n_vols > 1 && (int64_t)key >= job.vols[1].key_base) ? 1 : 0) : find_vol_by_key(job.vols, job.n_vols, (int64_t)key);
-        if (whole_map) {
-            // whole-map jobs: blob index inside its own list, signed by the list
+        if (whole_map) {   // blob index inside its own list, signed by the list
             const int32_t k = (int32_t)(rank - (vi ? s_below1 : 0u));
             job.label_of_comp[i] = job.vol_sign[vi] > 0 ? 1 + k : -1 - k;
         }
-        if (root != i) continue;
         const VolDesc vd = job.vols[vi];
         job.r_rank[i] = rank;
         const double n = (double)job.r_n[i];

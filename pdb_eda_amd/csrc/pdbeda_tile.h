@@ -13,8 +13,8 @@
 //   C  a thread per run folds it into its component (fp64 sums, packed integer sums, c-major first key); one
 //      record per tile component is flushed to HBM, run -> component ids are published for the label writer,
 //      the runs (start, end, component) are exported for the face merge.
-// Only component pairs that touch across a tile face are united globally (k_face_merge ->
-// k_union_edges), and only non-root tile components cost global atomics (k_resolve_tiles, after an
+// Only component pairs that touch across a tile face are united globally (k_face_merge, after an LDS
+// de-duplication per tile), and only non-root tile components cost global atomics (k_resolve_tiles, after an
 // LDS pre-reduction per tile).  A tile whose run or component count exceeds the LDS capacity falls
 // back to "unit mode" (k_unit_fallback: every run its own component, united globally): slower, same result.
 #pragma once
@@ -37,8 +37,6 @@ constexpr int tile_scratch_bytes(int nt) {
     return tile_eq(nt) * nt * 2 + RCAP * 2 > 4 * CCAP * 8 + 6 * CCAP * 4 ? tile_eq(nt) * nt * 2 + RCAP * 2 : 4 * CCAP * 8 + 6 * CCAP * 4;
 }
 
-constexpr int EDGE_Q = 16;   // cross-tile component pairs one k_face_merge thread stages in LDS (more are united on the spot)
-constexpr int ESHARDS = 64;  // cross-tile pair buffers (one allocation counter each: a single counter serialises at ~88 atomics/us)
 
 struct TileDims {
     int cw;                       // words per tile along c (1..4)
@@ -143,7 +141,6 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
     const int n_planes = td.n_planes;
 
     if (tid == 0) { s_over = 0; s_vover = 0; s_ncomp = 0; s_alloc[0] = 0; s_alloc[1] = 0; s_vpool = 0; }
-    if (blockIdx.x == 0 && tid < ESHARDS) job.edge_fill[tid] = 0u;
     if (blockIdx.x == 0 && tid == 0) {   // read by the kernels that follow; nothing in this kernel touches them
         job.vols[0] = init.v[0];
         if (td.n_planes > 1) job.vols[1] = init.v[1];
@@ -157,12 +154,9 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
         const int64_t per = (job.key_words + gridDim.x - 1) / gridDim.x;
         const int64_t lo = per * blockIdx.x, hi = lo + per < job.key_words ? lo + per : job.key_words;
         for (int64_t i = lo + tid; i < hi; i += NT) job.key_bits[i] = 0ull;
-        const int64_t nfc = (int64_t)job.n_fine + job.n_coarse;   // ... and of the rank counters (fine and coarse are adjacent)
+        const int64_t nfc = job.n_fine_alloc;   // ... and of the rank counters
         const int64_t perc = (nfc + gridDim.x - 1) / gridDim.x, clo = perc * blockIdx.x, chi = clo + perc < nfc ? clo + perc : nfc;
         for (int64_t i = clo + tid; i < chi; i += NT) job.fine_count[i] = 0u;
-        const int64_t nf = (int64_t)job.pair_filter_mask + 1, perf = (nf + gridDim.x - 1) / gridDim.x;   // and of the pair filter
-        const int64_t flo = perf * blockIdx.x, fhi = flo + perf < nf ? flo + perf : nf;
-        for (int64_t i = flo + tid; i < fhi; i += NT) job.pair_filter[i] = 0ull;
     }
     for (int i = tid; i < RCAP; i += NT) s_parent[i] = (uint16_t)i;
     __syncthreads();
@@ -706,7 +700,7 @@ __device__ void unit_quarter_tile(const Job &job, const float *__restrict__ dens
 // are issued up front and unconditionally -- one memory latency instead of one per neighbour --
 // then the touching RUN pairs are enumerated from registers.  Pairs inside one normally
 // processed tile were already united in LDS and are skipped (their neighbour mask is zeroed).
-// emit(runA, runB) with global run ids; k_union_edges maps them to components.
+// emit(runA, runB) with global run ids (the caller maps them to components).
 struct NbWords {
     uint64_t m[13];     // [0] = previous word of my row; [1 + nb*3 + (dw+1)] = neighbour rows
     uint32_t base[13];
@@ -804,21 +798,89 @@ __device__ inline void cross_tile_pairs(uint64_t m, uint32_t my_base, const NbWo
 
 // Cross-tile unions from the tiles' exported run lists: one thread per
 // (tile, sign, row on a tile face, earlier neighbour row in ANOTHER tile) -- 46 such pairs of rows per tile -- merges
-// the two sorted run lists (a dozen two-pointer steps on LDS copies) and parks the distinct COMPONENT pairs in the
-// sharded buffers for k_union_edges.  Replaces a word-by-word enumeration of 13 neighbour masks per word: ~10x fewer
-// instructions, no run -> component look-ups afterwards.  Lists of unit / empty tiles are empty (their companion
-// kernel unites those pairs).  Grids wider than one tile add the c faces: first run of a row against the last runs
-// of the 9 rows around it in the tile to the left.
-constexpr int FACE_L = 16;   // runs of a row copied to LDS (longer rows read the rest from global memory)
-__global__ void __launch_bounds__(128) k_face_merge(Job job, TileDims td) {
+// the two sorted run lists (a dozen two-pointer steps on LDS copies); the distinct COMPONENT pairs of the tile go into an
+// LDS hash set (the runs of a blob cross a face row after row: ~350 touching run pairs per tile are ~110 distinct component
+// pairs), and the set's slots are then united in the global union-find, about one pair per thread -- no pair buffer in
+// HBM, no second launch.  Replaces a word-by-word enumeration of 13 neighbour masks per word: ~10x fewer instructions, no
+// run -> component look-ups afterwards.  Lists of unit / empty tiles are empty (the unit path unites those pairs).  Grids
+// wider than one tile add the c faces: first run of a row against the last runs of the 9 rows around it in the tile to the left.
+//
+// The first `n_unit_blocks` workgroups of the launch are the unit-tile fallback (tiles that overflowed LDS in
+// k_tile_label): normally no tile did and they exit on the epoch flag at once -- the rare path costs no launch of its own.
+// Otherwise they label the unit tiles run by run, meet at a grid barrier of their own (they are the first workgroups
+// dispatched and few enough to be co-resident many times over, so concurrent streams cannot starve each other), then
+// unite every pair that has a unit tile on either side.
+constexpr int FACE_L = 16;       // runs of a row copied to LDS (longer rows read the rest from global memory)
+constexpr int PAIR_SLOTS = 1024; // LDS hash set of a tile's distinct cross-face component pairs (a full set unites on the spot)
+constexpr int UNIT_BLOCKS = 128; // workgroups of the unit-tile fallback
+
+// One mask word of the unit-tile companion of k_face_merge: it owns EVERY pair that has a unit tile on either side
+// (all rows), and unites on the spot.
+__device__ void unit_edges_word(const Job &job, const TileDims &td, const VolDesc &v0, int plane, int sl, int r, int wq) {
+    const int rw = v0.row_words;
+    const int64_t w = (int64_t)plane * rw * v0.dim[1] * v0.dim[2] + ((int64_t)sl * v0.dim[1] + r) * rw + wq;
+    const uint64_t m = job.mask[w];
+    if (m == 0ull) return;
+    NbWords nw;
+    uint32_t my_base;
+    if (!load_cross_tile(job, td, w, m, nw, my_base, true)) return;
+    cross_tile_pairs(m, my_base, nw, [&](uint32_t a, uint32_t b) { uf_unite(job.parent, (int)job.comp_of_run[a], (int)job.comp_of_run[b]); });
+}
+
+template <int CW>
+__device__ void unit_fallback_blocks(const Job &job, const float *__restrict__ dens, const Geom *__restrict__ gp, const TileDims &td, int block, int n_blocks) {
+    const int n_qt = td.ctiles * td.rtiles * td.stiles * 4;
+    for (int qt = block; qt < n_qt; qt += n_blocks) {   // block-uniform trip count
+        unit_quarter_tile<CW>(job, dens, gp, td, qt);
+        __syncthreads();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();   // publish run bases / records / run -> component ids
+        atomicAdd(&job.ctr->barrier, 1u);
+        while (__hip_atomic_load(&job.ctr->barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)n_blocks) __builtin_amdgcn_s_sleep(8);
+        __threadfence();
+    }
+    __syncthreads();
+    const VolDesc v0 = job.vols[0];
+    const int64_t per_plane = (int64_t)v0.row_words * v0.dim[1] * v0.dim[2], total = per_plane * td.n_planes;
+    for (int64_t L = (int64_t)block * blockDim.x + threadIdx.x; L < total; L += (int64_t)n_blocks * blockDim.x) {
+        const int plane = (int)(L / per_plane);
+        const int64_t rem = L % per_plane;
+        const int wq = (int)(rem % v0.row_words);
+        const int64_t row = rem / v0.row_words;
+        unit_edges_word(job, td, v0, plane, (int)(row / v0.dim[1]), (int)(row % v0.dim[1]), wq);
+    }
+}
+
+template <int CW>
+__global__ void __launch_bounds__(256) k_face_merge(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td, int pair_slots) {
+    if ((int)blockIdx.x < UNIT_BLOCKS) {   // block-uniform
+        if (*job.unit_flag != job.epoch) return;
+        unit_fallback_blocks<CW>(job, dens, gp, td, (int)blockIdx.x, UNIT_BLOCKS);
+        return;
+    }
     __shared__ uint32_t s_list[2][FACE_L][128];
-    __shared__ uint2 s_stage[EDGE_Q][128];
-    __shared__ uint32_t s_wsum[2], s_base;
-    const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6, t = lane;
+    __shared__ unsigned long long s_set[PAIR_SLOTS];
+    const int tid = threadIdx.x, lane = tid & 63, q = (tid >> 6) & 1, t = lane;
+    const bool merger = tid < 128;   // waves 0 / 1 merge the face rows of sign 0 / 1; all four waves unite the distinct pairs
     const int ur = td.ur, us = td.us;
-    const int tile = blockIdx.x, ct = tile % td.ctiles, rt = (tile / td.ctiles) % td.rtiles, st = tile / (td.ctiles * td.rtiles);
+    const int tile = (int)blockIdx.x - UNIT_BLOCKS, ct = tile % td.ctiles, rt = (tile / td.ctiles) % td.rtiles, st = tile / (td.ctiles * td.rtiles);
+    for (int i = tid; i < pair_slots; i += 256) s_set[i] = 0ull;   // 0 = empty: a pair (lo << 32 | hi) has hi > lo >= 0
+    __syncthreads();
+    const uint32_t slot_mask = (uint32_t)pair_slots - 1u;
+    auto add_pair = [&](uint32_t ca, uint32_t cb) {
+        const uint32_t lo = ca < cb ? ca : cb, hi = ca < cb ? cb : ca;
+        const unsigned long long key = ((unsigned long long)lo << 32) | hi;
+        uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & slot_mask;
+        for (int probe = 0; probe < 8; ++probe, h = (h + 1u) & slot_mask) {
+            const unsigned long long old = atomicCAS(&s_set[h], 0ull, key);
+            if (old == 0ull || old == key) return;
+        }
+        uf_unite(job.parent, (int)lo, (int)hi);   // the neighbourhood of the slot is full: unite on the spot
+    };
     int rl = 0, sl = 0, dr = 0, ds = -1;
-    bool task = q < td.n_planes;
+    bool task = merger && q < td.n_planes;
     if (t < 8) { rl = 0; sl = t; dr = -1; ds = 0; }
     else if (t < 16) { rl = 0; sl = t - 8; dr = -1; }
     else if (t < 23) { rl = t - 15; sl = 0; dr = -1; }
@@ -837,18 +899,17 @@ __global__ void __launch_bounds__(128) k_face_merge(Job job, TileDims td) {
         if (na == 0 || nb == 0) task = false;
     }
     const uint32_t *ga = job.face_runs + (size_t)tile * RCAP + fa, *gb = job.face_runs + (size_t)tile_b * RCAP + fb;
+    const int col = tid & 127;
     if (task) {
 #pragma unroll
         for (int k = 0; k < FACE_L; ++k) {
-            s_list[0][k][tid] = (uint32_t)k < na ? ga[k] : 0u;
-            s_list[1][k][tid] = (uint32_t)k < nb ? gb[k] : 0u;
+            s_list[0][k][col] = (uint32_t)k < na ? ga[k] : 0u;
+            s_list[1][k][col] = (uint32_t)k < nb ? gb[k] : 0u;
         }
     }
-    const uint32_t cap = (uint32_t)(job.edge_cap / ESHARDS);
-    uint32_t n = 0;
     if (task) {   // (only own LDS entries are read back: no barrier)
-        auto ea = [&](uint32_t i) { return i < (uint32_t)FACE_L ? s_list[0][i][tid] : ga[i]; };
-        auto eb = [&](uint32_t j) { return j < (uint32_t)FACE_L ? s_list[1][j][tid] : gb[j]; };
+        auto ea = [&](uint32_t i) { return i < (uint32_t)FACE_L ? s_list[0][i][col] : ga[i]; };
+        auto eb = [&](uint32_t j) { return j < (uint32_t)FACE_L ? s_list[1][j][col] : gb[j]; };
         uint32_t i = 0, j = 0, va = ea(0), vb = eb(0), last_a = ~0u, last_b = ~0u;
         while (true) {
             const int as = va & 0xff, ae = (va >> 8) & 0xff, bs = vb & 0xff, be = (vb >> 8) & 0xff;
@@ -858,9 +919,7 @@ __global__ void __launch_bounds__(128) k_face_merge(Job job, TileDims td) {
             else {
                 const uint32_t ca = (uint32_t)tile * CCAP + (va >> 16), cb = tile_b * CCAP + (vb >> 16);
                 if (ca != last_a || cb != last_b) {   // the runs of a blob cross a face in a row: repeats are the rule
-                    if (n < (uint32_t)EDGE_Q) s_stage[n][tid] = make_uint2(ca, cb);
-                    else uf_unite(job.parent, (int)ca, (int)cb);
-                    ++n;
+                    add_pair(ca, cb);
                     last_a = ca; last_b = cb;
                 }
                 adv_a = ae < be;
@@ -871,7 +930,7 @@ __global__ void __launch_bounds__(128) k_face_merge(Job job, TileDims td) {
     }
     // c faces (grids wider than one tile): row `lane` of this tile starts with a run at position 0; the rows around it
     // (9 offsets, itself included) in the tile to the LEFT may end with a run at that tile's last position -- they touch.
-    if (ct > 0 && q < td.n_planes) {
+    if (merger && ct > 0 && q < td.n_planes) {
         const int crl = lane & 7, csl = lane >> 3;
         const int cr = rt * TILE_R + crl, cs = st * TILE_S + csl;
         const uint32_t mine = (cr < ur && cs < us) ? job.face_rows[((size_t)tile * 2 + q) * 64 + lane] : 0u;
@@ -896,128 +955,29 @@ __global__ void __launch_bounds__(128) k_face_merge(Job job, TileDims td) {
                 for (int k = 0; k < 9; ++k) {
                     if ((rows9[k] >> 16) != 0u && ((last9[k] >> 8) & 0xffu) == (uint32_t)(td.cw * 64 - 1)) {
                         const uint32_t cb = tiles9[k] * CCAP + (last9[k] >> 16);
-                        if (cb != last_b) {
-                            if (n < (uint32_t)EDGE_Q) s_stage[n][tid] = make_uint2(ca, cb);
-                            else uf_unite(job.parent, (int)ca, (int)cb);
-                            ++n;
-                            last_b = cb;
-                        }
+                        if (cb != last_b) { add_pair(ca, cb); last_b = cb; }
                     }
                 }
             }
         }
     }
-    if (n > (uint32_t)EDGE_Q) n = EDGE_Q;
-    uint32_t x = n;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d);
-        if (lane >= d) x += y;
-    }
-    if (lane == 63) s_wsum[q] = x;
     __syncthreads();
-    const uint32_t tot = s_wsum[0] + s_wsum[1];
-    if (tot == 0) return;   // block-uniform
-    const int shard = tile % ESHARDS;
-    if (tid == 0) s_base = atomicAdd(&job.edge_fill[shard], tot);
-    __syncthreads();
-    uint32_t at = s_base + (q ? s_wsum[0] : 0u) + x - n;
-    uint2 *dst = job.edges + (size_t)shard * cap;
-    for (uint32_t e = 0; e < n; ++e, ++at) {
-        const uint2 pr = s_stage[e][tid];
-        if (at < cap) dst[at] = pr;   // (a slot below the capacity never stays unwritten: k_union_edges reads min(fill, cap))
-        else uf_unite(job.parent, (int)pr.x, (int)pr.y);
-    }
-}
-
-// One mask word of the unit-tile companion of k_face_merge: it owns EVERY pair that has a unit tile on either side
-// (all rows), and unites on the spot.
-__device__ void unit_edges_word(const Job &job, const TileDims &td, const VolDesc &v0, int plane, int sl, int r, int wq) {
-    const int rw = v0.row_words;
-    const int64_t w = (int64_t)plane * rw * v0.dim[1] * v0.dim[2] + ((int64_t)sl * v0.dim[1] + r) * rw + wq;
-    const uint64_t m = job.mask[w];
-    if (m == 0ull) return;
-    NbWords nw;
-    uint32_t my_base;
-    if (!load_cross_tile(job, td, w, m, nw, my_base, true)) return;
-    cross_tile_pairs(m, my_base, nw, [&](uint32_t a, uint32_t b) { uf_unite(job.parent, (int)job.comp_of_run[a], (int)job.comp_of_run[b]); });
-}
-
-// The two unit-tile kernels behind ONE launch (the k_face_merge path): normally no tile overflowed and the kernel
-// exits on the epoch flag -- one launch floor instead of two.  Otherwise: label the unit tiles, grid barrier (the grid
-// is small enough to be co-resident many times over: 128 workgroups, so concurrent streams cannot deadlock each other), then unite every pair that has a unit tile on
-// either side.
-template <int CW>
-__global__ void __launch_bounds__(256) k_unit_fallback(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td) {
-    if (*job.unit_flag != job.epoch) return;
-    const int n_qt = td.ctiles * td.rtiles * td.stiles * 4;
-    for (int qt = blockIdx.x; qt < n_qt; qt += gridDim.x) {   // block-uniform trip count
-        unit_quarter_tile<CW>(job, dens, gp, td, qt);
-        __syncthreads();
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();   // publish run bases / records / run -> component ids
-        atomicAdd(&job.ctr->barrier, 1u);
-        while (__hip_atomic_load(&job.ctr->barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) __builtin_amdgcn_s_sleep(8);
-        __threadfence();
-    }
-    __syncthreads();
-    const VolDesc v0 = job.vols[0];
-    const int64_t per_plane = (int64_t)v0.row_words * v0.dim[1] * v0.dim[2], total = per_plane * td.n_planes;
-    for (int64_t L = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; L < total; L += (int64_t)gridDim.x * blockDim.x) {
-        const int plane = (int)(L / per_plane);
-        const int64_t rem = L % per_plane;
-        const int wq = (int)(rem % v0.row_words);
-        const int64_t row = rem / v0.row_words;
-        unit_edges_word(job, td, v0, plane, (int)(row / v0.dim[1]), (int)(row % v0.dim[1]), wq);
-    }
-}
-
-// Thread per parked run pair: map to tile components, global union-find with device-scope atomics.
-// Consecutive pairs of a word mostly name the same two components: a lane whose pair equals its
-// left neighbour's is dropped (wave shuffle), as are pairs already inside one component.
-constexpr int DEDUP_WINDOW = 16;   // lanes a k_union_edges thread looks back for a repeat of its component pair
-__global__ void __launch_bounds__(256) k_union_edges(Job job) {
-    const uint32_t shard_cap = (uint32_t)(job.edge_cap / ESHARDS);
-    const int lane = lane_id();
-    for (int sh = blockIdx.y; sh < ESHARDS; sh += gridDim.y) {
-        const uint32_t fill = job.edge_fill[sh];
-        const uint32_t n = fill < shard_cap ? fill : shard_cap;
-        const uint2 *src = job.edges + (size_t)sh * shard_cap;
-        const uint32_t stride = gridDim.x * blockDim.x;
-        for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n; i0 += stride) {   // block-uniform trip count: shuffles are safe
-            const uint32_t i = i0 + threadIdx.x;
-            int a = -1, b = -1;
-            if (i < n) {
-                const uint2 e = src[i];
-                a = job.edges_hold_comps ? (int)e.x : (int)job.comp_of_run[e.x];
-                b = job.edges_hold_comps ? (int)e.y : (int)job.comp_of_run[e.y];
-            }
-            if (a > b) { const int t = a; a = b; b = t; }   // unordered pair
-            bool dup = false;
-#pragma unroll
-            for (int d = 1; d <= DEDUP_WINDOW; ++d) {   // the same two components a few lanes back (pairs of one tile face interleave)
-                const int pa = __shfl_up(a, d), pb = __shfl_up(b, d);
-                dup = dup || (lane >= d && pa == a && pb == b);
-            }
-            if (i < n && a != b && !dup) {
-                // the same two components meet on many rows / sections of a tile face, in other workgroups: a lossy global
-                // set (one CAS) keeps all but the first of them away from the union-find, where repeats only contend
-                const unsigned long long key = ((unsigned long long)(uint32_t)a << 32) | (uint32_t)b;
-                const uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & job.pair_filter_mask;
-                if (atomicCAS(&job.pair_filter[h], 0ull, key) != key)
-                    uf_unite(job.parent, a, b);
-            }
-        }
+    // the distinct pairs of this tile, about one per thread: global union-find (parents start as the identity, so most unions
+    // are two loads and one atomic min)
+    for (int i = tid; i < pair_slots; i += 256) {
+        const unsigned long long key = s_set[i];
+        if (key != 0ull) uf_unite(job.parent, (int)(key >> 32), (int)(uint32_t)key);
     }
 }
 
 // Whole-map k_resolve: one workgroup per tile (its CCAP component ids).  Every component finds its root; the
-// non-root components of a tile that share a root are first summed in LDS (leader = lowest such thread), then ONE
+// non-root components of a tile that share a root are first summed in LDS (a small hash table keyed by the root), then ONE
 // set of global atomics per (tile, root) folds them into the root record.  A blob that spans the map (the chain of a
 // protein at 1.5 sigma: tens of thousands of tile components) would otherwise pile 9 same-address atomics per
-// component on one record.  Workgroups beyond the tiles handle the components of unit tiles one by one.
+// component on one record.  All loads of a component's record are issued up front, beside the first step of the find
+// (the kernel is a chain of dependent memory round trips, not bandwidth).  Workgroups beyond the tiles handle the
+// components of unit tiles one by one.
+constexpr int RSLOTS = 512;   // LDS slots for the distinct roots the members of one tile fold into (<= 256 members)
 __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
     static_assert(CCAP == 256, "one thread per component id of a tile");
     const int tid = threadIdx.x;
@@ -1044,45 +1004,50 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
         }
         return;
     }
-    __shared__ int s_root[256];
-    __shared__ double s_f[4][256];
-    __shared__ unsigned long long s_i[3][256], s_key[256];
-    __shared__ uint32_t s_cnt[256];
+    __shared__ int s_root[RSLOTS];
+    __shared__ double s_f[4][RSLOTS];
+    __shared__ unsigned long long s_i[3][RSLOTS], s_key[RSLOTS];
+    __shared__ uint32_t s_cnt[RSLOTS];
     const uint32_t i = (uint32_t)blockIdx.x * CCAP + tid;
+    // everything this thread may need, in flight at once (unused ids hold stale bytes: loaded, never used)
     const uint32_t n_i = job.r_n[i];
-    int root = -1 - tid;   // unused ids and roots: a value no other thread holds
-    bool member = false;   // non-root component with voxels
-    if (n_i > 0u) {
-        const int r = uf_find(job.parent, (int)i);
-        if (r != (int)i) { root = r; member = true; job.parent[i] = r; }
+    const int p0 = uf_load(job.parent, (int)i);
+    const double v_rho = job.r_rho[i], v_rc = job.r_rho_c[i], v_rr = job.r_rho_r[i], v_rs = job.r_rho_s[i];
+    const unsigned long long v_c = (unsigned long long)job.r_c[i], v_r = (unsigned long long)job.r_r[i], v_s = (unsigned long long)job.r_s[i], v_key = job.r_key[i];
+    for (int k = tid; k < RSLOTS; k += 256) {
+        s_root[k] = -1;
+        s_f[0][k] = 0.0; s_f[1][k] = 0.0; s_f[2][k] = 0.0; s_f[3][k] = 0.0;
+        s_i[0][k] = 0ull; s_i[1][k] = 0ull; s_i[2][k] = 0ull; s_key[k] = ~0ull; s_cnt[k] = 0u;
     }
-    s_root[tid] = root;
-    s_f[0][tid] = 0.0; s_f[1][tid] = 0.0; s_f[2][tid] = 0.0; s_f[3][tid] = 0.0;
-    s_i[0][tid] = 0ull; s_i[1][tid] = 0ull; s_i[2][tid] = 0ull; s_key[tid] = ~0ull; s_cnt[tid] = 0u;
+    int root = -1;
+    bool member = false;   // non-root component with voxels
+    if (n_i > 0u && p0 != (int)i) {
+        root = uf_find(job.parent, p0);
+        member = true;
+        job.parent[i] = root;
+    }
     __syncthreads();
     if (__syncthreads_or(member ? 1 : 0) == 0) return;   // nothing to fold in this tile
-    const int used = __syncthreads_count(n_i > 0u);       // a tile's components are the ids [0, used)
-    int leader = tid;
-    if (__ballot(member) != 0ull) {   // wave-uniform: only waves with something to fold look for leaders
-        for (int j = 0; j < used; ++j) {   // uniform loop, broadcast reads: the lowest thread that holds my root
-            const int rj = s_root[j];
-            if (rj == root && j < leader) leader = j;
-        }
-    }
     if (member) {
-        atomicAdd(&s_cnt[leader], n_i);
-        unsafeAtomicAdd(&s_f[0][leader], job.r_rho[i]);
-        unsafeAtomicAdd(&s_f[1][leader], job.r_rho_c[i]);
-        unsafeAtomicAdd(&s_f[2][leader], job.r_rho_r[i]);
-        unsafeAtomicAdd(&s_f[3][leader], job.r_rho_s[i]);
-        atomicAdd(&s_i[0][leader], (unsigned long long)job.r_c[i]);
-        atomicAdd(&s_i[1][leader], (unsigned long long)job.r_r[i]);
-        atomicAdd(&s_i[2][leader], (unsigned long long)job.r_s[i]);
-        atomicMin(&s_key[leader], job.r_key[i]);
+        uint32_t h = ((uint32_t)root * 2654435761u) >> 23;   // 9 bits
+        while (true) {                                         // (<= 256 members, 512 slots: a free slot always turns up)
+            const int old = atomicCAS(&s_root[h], -1, root);
+            if (old == -1 || old == root) break;
+            h = (h + 1u) & (RSLOTS - 1);
+        }
+        atomicAdd(&s_cnt[h], n_i);
+        unsafeAtomicAdd(&s_f[0][h], v_rho);
+        unsafeAtomicAdd(&s_f[1][h], v_rc);
+        unsafeAtomicAdd(&s_f[2][h], v_rr);
+        unsafeAtomicAdd(&s_f[3][h], v_rs);
+        atomicAdd(&s_i[0][h], v_c);
+        atomicAdd(&s_i[1][h], v_r);
+        atomicAdd(&s_i[2][h], v_s);
+        atomicMin(&s_key[h], v_key);
     }
     __syncthreads();
-    if (member && leader == tid)
-        fold((uint32_t)root, s_cnt[tid], s_f[0][tid], s_f[1][tid], s_f[2][tid], s_f[3][tid], s_i[0][tid], s_i[1][tid], s_i[2][tid], s_key[tid]);
+    for (int k = tid; k < RSLOTS; k += 256)
+        if (s_root[k] >= 0) fold((uint32_t)s_root[k], s_cnt[k], s_f[0][k], s_f[1][k], s_f[2][k], s_f[3][k], s_i[0][k], s_i[1][k], s_i[2][k], s_key[k]);
 }
 
 // Signed labels, one workgroup per tile, all look-ups in LDS: the tile's label-of-component table
@@ -1127,7 +1092,7 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS) k_labels_tiles(Job j
             }
         }
         if (fast) {
-            if (tid < CCAP) s_lab[tid] = job.label_of_comp[cb + tid];
+            if (tid < CCAP) s_lab[tid] = job.label_of_comp[job.parent[cb + tid]];   // (the root of a component carries its label)
             for (uint32_t i = tid; i < n_runs; i += NTL) s_comp8[i] = (uint8_t)(job.comp_of_run[rb + i] - cb);
         }
     }
@@ -1160,7 +1125,7 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS) k_labels_tiles(Job j
             for (int q = 0; q < 4; ++q) {
                 if ((nib >> q) & 1u) {
                     const uint32_t run = base + below + (uint32_t)__popc(snib & ((2u << q) - 1u)) - 1u;
-                    out[q] = fast ? s_lab[s_comp8[run - rb]] : job.label_of_comp[job.comp_of_run[run]];
+                    out[q] = fast ? s_lab[s_comp8[run - rb]] : job.label_of_comp[job.parent[job.comp_of_run[run]]];
                 }
             }
         }
