@@ -223,6 +223,26 @@ __device__ inline int uf_find(int32_t *p, int x) {
     }
     return x;
 }
+// The same with the two finds walking in step: their loads share the memory round trips (a union is a chain of dependent
+// trips: two parallel finds + one atomic min instead of three in a row).
+__device__ inline void uf_unite2(int32_t *p, int a, int b) {
+    while (true) {
+        int qa = uf_load(p, a), qb = uf_load(p, b);
+        while (qa != a || qb != b) {
+            const int ga = qa != a ? uf_load(p, qa) : qa, gb = qb != b ? uf_load(p, qb) : qb;
+            if (qa != a && ga != qa) atomicMin(p + a, ga);
+            if (qb != b && gb != qb) atomicMin(p + b, gb);
+            a = ga; b = gb;
+            qa = uf_load(p, a); qb = uf_load(p, b);
+        }
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(p + a, b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
 __device__ inline void uf_unite(int32_t *p, int a, int b) {
     while (true) {
         a = uf_find(p, a);
@@ -343,32 +363,52 @@ __global__ void __launch_bounds__(256) k_paint_keys(Job job) {
 }
 
 // Exclusive prefix table over groups of fine_per_group counters, built by the calling block in LDS; returns the total.
-// (fine_count is padded to whole groups by the allocation and cleared with the bitmap.)
+// A thread owns KEY_GROUPS / 256 = 8 consecutive groups: all its loads are in flight at once (the table is one memory
+// round trip + one block scan, not a loop of dependent trips).  fine_count is padded to whole groups and cleared with the bitmap.
 __device__ inline uint32_t rank_table_lds(const Job &job, uint32_t *s_pre /* [KEY_GROUPS] */, uint32_t *s_wave /* [4] */) {
+    constexpr int PER = KEY_GROUPS / 256;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int G = job.fine_per_group, n_groups = (job.n_fine + G - 1) / G;
     const uint4 *fine4 = reinterpret_cast<const uint4 *>(job.fine_count);
-    uint32_t carry = 0;
-    for (int base = 0; base < n_groups; base += 256) {   // block-uniform
-        const int e = base + tid;
-        uint32_t v = 0;
-        if (e < n_groups)
-            for (int k = 0; k < G / 4; ++k) { const uint4 q = fine4[(size_t)e * (G / 4) + k]; v += (q.x + q.y) + (q.z + q.w); }
-        uint32_t x = v;
+    uint32_t v[PER];
+    if (G == 8) {   // (maps up to 2^25 keys: 256^3 fused) two 16-B loads per group, 16 in flight per thread
+        uint4 q[2 * PER];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t y = __shfl_up(x, d);
-            if (lane >= d) x += y;
+        for (int k = 0; k < PER; ++k) {
+            const int e = tid * PER + k;
+            q[2 * k] = e < n_groups ? fine4[(size_t)e * 2] : make_uint4(0, 0, 0, 0);
+            q[2 * k + 1] = e < n_groups ? fine4[(size_t)e * 2 + 1] : make_uint4(0, 0, 0, 0);
         }
-        if (lane == 63) s_wave[wv] = x;
-        __syncthreads();
-        uint32_t pre = carry;
-        for (int k = 0; k < wv; ++k) pre += s_wave[k];
-        if (e < n_groups) s_pre[e] = pre + x - v;
-        carry += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; ++k) v[k] = ((q[2 * k].x + q[2 * k].y) + (q[2 * k].z + q[2 * k].w)) + ((q[2 * k + 1].x + q[2 * k + 1].y) + (q[2 * k + 1].z + q[2 * k + 1].w));
+    } else {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int e = tid * PER + k;
+            uint32_t acc = 0;
+            if (e < n_groups)
+                for (int j = 0; j < G / 4; ++j) { const uint4 q = fine4[(size_t)e * (G / 4) + j]; acc += (q.x + q.y) + (q.z + q.w); }
+            v[k] = acc;
+        }
     }
-    return carry;
+    uint32_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) mine += v[k];
+    uint32_t x = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) s_wave[wv] = x;
+    __syncthreads();
+    uint32_t pre = x - mine;
+    for (int k = 0; k < wv; ++k) pre += s_wave[k];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { s_pre[tid * PER + k] = pre; pre += v[k]; }
+    const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+    return total;
 }
 
 // Number of painted keys below `key` (s_pre: this block's rank_table_lds).

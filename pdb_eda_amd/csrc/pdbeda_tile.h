@@ -860,7 +860,7 @@ __global__ void __launch_bounds__(256) k_face_merge(Job job, const float *__rest
         unit_fallback_blocks<CW>(job, dens, gp, td, (int)blockIdx.x, UNIT_BLOCKS);
         return;
     }
-    __shared__ uint32_t s_list[2][FACE_L][128];
+    __shared__ __attribute__((aligned(16))) uint32_t s_list[2][FACE_L][128];
     __shared__ unsigned long long s_set[PAIR_SLOTS];
     const int tid = threadIdx.x, lane = tid & 63, q = (tid >> 6) & 1, t = lane;
     const bool merger = tid < 128;   // waves 0 / 1 merge the face rows of sign 0 / 1; all four waves unite the distinct pairs
@@ -877,7 +877,7 @@ __global__ void __launch_bounds__(256) k_face_merge(Job job, const float *__rest
             const unsigned long long old = atomicCAS(&s_set[h], 0ull, key);
             if (old == 0ull || old == key) return;
         }
-        uf_unite(job.parent, (int)lo, (int)hi);   // the neighbourhood of the slot is full: unite on the spot
+        uf_unite2(job.parent, (int)lo, (int)hi);   // the neighbourhood of the slot is full: unite on the spot
     };
     int rl = 0, sl = 0, dr = 0, ds = -1;
     bool task = merger && q < td.n_planes;
@@ -962,11 +962,40 @@ __global__ void __launch_bounds__(256) k_face_merge(Job job, const float *__rest
         }
     }
     __syncthreads();
-    // the distinct pairs of this tile, about one per thread: global union-find (parents start as the identity, so most unions
-    // are two loads and one atomic min)
-    for (int i = tid; i < pair_slots; i += 256) {
-        const unsigned long long key = s_set[i];
-        if (key != 0ull) uf_unite(job.parent, (int)(key >> 32), (int)(uint32_t)key);
+    // the distinct pairs of this tile: compacted (block prefix over the slots) so that thread k unites pair k, k + 256, ... --
+    // a union is a chain of dependent memory round trips, and nobody should walk two chains while others walk none
+    // (parents start as the identity, so most unions are two parallel loads and one atomic min)
+    __shared__ uint32_t s_wsum[4];
+    unsigned long long *s_pairs = reinterpret_cast<unsigned long long *>(&s_list[0][0][0]);   // (the run lists are done: 16 KiB = 2048 pairs)
+    {
+        const int per = pair_slots / 256 > 0 ? pair_slots / 256 : 1;   // consecutive slots per thread (pair_slots is a power of two)
+        unsigned long long mine[PAIR_SLOTS / 256];
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int k = 0; k < PAIR_SLOTS / 256; ++k) {
+            const int slot = tid * per + k;
+            mine[k] = (k < per && slot < pair_slots) ? s_set[slot] : 0ull;
+            cnt += mine[k] != 0ull ? 1u : 0u;
+        }
+        uint32_t x = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) s_wsum[tid >> 6] = x;
+        __syncthreads();   // (also: every thread is done with s_list)
+        uint32_t at = x - cnt;
+        for (int k = 0; k < (tid >> 6); ++k) at += s_wsum[k];
+#pragma unroll
+        for (int k = 0; k < PAIR_SLOTS / 256; ++k)
+            if (mine[k] != 0ull) s_pairs[at++] = mine[k];
+        __syncthreads();
+    }
+    const uint32_t n_pairs = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    for (uint32_t k = tid; k < n_pairs; k += 256) {
+        const unsigned long long key = s_pairs[k];
+        uf_unite2(job.parent, (int)(key >> 32), (int)(uint32_t)key);
     }
 }
 
@@ -977,7 +1006,7 @@ __global__ void __launch_bounds__(256) k_face_merge(Job job, const float *__rest
 // component on one record.  All loads of a component's record are issued up front, beside the first step of the find
 // (the kernel is a chain of dependent memory round trips, not bandwidth).  Workgroups beyond the tiles handle the
 // components of unit tiles one by one.
-constexpr int RSLOTS = 512;   // LDS slots for the distinct roots the members of one tile fold into (<= 256 members)
+constexpr int RSLOTS = 256;   // LDS slots for the distinct roots the members of one tile fold into (<= 256 members: always enough)
 __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
     static_assert(CCAP == 256, "one thread per component id of a tile");
     const int tid = threadIdx.x;
@@ -1029,8 +1058,8 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
     __syncthreads();
     if (__syncthreads_or(member ? 1 : 0) == 0) return;   // nothing to fold in this tile
     if (member) {
-        uint32_t h = ((uint32_t)root * 2654435761u) >> 23;   // 9 bits
-        while (true) {                                         // (<= 256 members, 512 slots: a free slot always turns up)
+        uint32_t h = ((uint32_t)root * 2654435761u) >> 24;   // 8 bits
+        while (true) {                                         // (<= 256 members, 256 slots: a slot always turns up)
             const int old = atomicCAS(&s_root[h], -1, root);
             if (old == -1 || old == root) break;
             h = (h + 1u) & (RSLOTS - 1);
@@ -1075,6 +1104,13 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS) k_labels_tiles(Job j
     const int w0 = ct * CW, r0 = rt * TILE_R, s0 = st * TILE_S;
     const int64_t plane_words = (int64_t)row_words * ur * us;
     const uint32_t rb = (uint32_t)blockIdx.x * (uint32_t)(NU * 32), cb = (uint32_t)blockIdx.x * CCAP;
+    // every load of the prologue is issued before anything depends on one: the tile's first 2048 run -> component ids and its
+    // label table do not wait for tile_mode / tile_runs (ids beyond the tile's run count hold stale bytes: stored, never used)
+    static_assert(NTL == 512 && LCAP == 4096, "four unconditional comp loads per thread cover the first 2048 runs");
+    uint32_t c_pre[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c_pre[k] = job.comp_of_run[rb + tid + NTL * k];
+    const int32_t lab_pre = tid < CCAP ? job.label_of_comp[job.parent[cb + tid]] : 0;   // (the root of a component carries its label)
     const bool unit = job.tile_mode[tile_index(td, 0, w0, r0, s0)] != 0;
     const uint32_t n_runs = unit ? 0u : job.tile_runs[blockIdx.x];
     const bool fast = !unit && n_runs <= (uint32_t)LCAP;   // block-uniform
@@ -1091,10 +1127,11 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS) k_labels_tiles(Job j
                 s_rb[p][tid] = has ? job.run_base[w + p * plane_words] : 0u;
             }
         }
-        if (fast) {
-            if (tid < CCAP) s_lab[tid] = job.label_of_comp[job.parent[cb + tid]];   // (the root of a component carries its label)
-            for (uint32_t i = tid; i < n_runs; i += NTL) s_comp8[i] = (uint8_t)(job.comp_of_run[rb + i] - cb);
-        }
+        if (tid < CCAP) s_lab[tid] = lab_pre;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_comp8[tid + NTL * k] = (uint8_t)(c_pre[k] - cb);
+        if (fast)
+            for (uint32_t i = tid + 4 * NTL; i < n_runs; i += NTL) s_comp8[i] = (uint8_t)(job.comp_of_run[rb + i] - cb);
     }
     __syncthreads();
     // wave wv writes RPW rows of the tile; a lane owns 4 consecutive voxels of a 256-voxel row (16 waves per tile: the
