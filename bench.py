@@ -40,7 +40,23 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-analysis", action="store_true", help="skip the informational densityAnalysis leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the bounded CPU-baseline sample")
+    ap.add_argument("--windows", type=int, default=5, help="extra timed windows of --steps steps each (dispersion of ms_per_step)")
+    ap.add_argument("--entries", type=int, default=125, help="multiple-structure leg (BASELINE configs[3]): entries per rank (1000 / 8 GPUs); 0 = skip")
+    ap.add_argument("--workers", type=int, default=4, help="multiple-structure leg: worker processes (= streams) per GPU")
+    ap.add_argument("--entry-size", type=int, default=200, help="multiple-structure leg: grid edge of an entry (configs[3]: 200)")
+    ap.add_argument("--entry-residues", type=int, default=100, help="multiple-structure leg: poly-ALA residues per entry (~500 atoms)")
     return ap.parse_args()
+
+
+def csrc_sha16():
+    """Hash of the kernel sources: ties a committed counter profile to the code it was collected on."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "pdb_eda_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        with open(os.path.join(csrc, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def algorithmic_bytes(kernel, n_vox, n_planes):
@@ -50,7 +66,6 @@ def algorithmic_bytes(kernel, n_vox, n_planes):
         "k_tile_label": 4 * n_vox + (8 + 4) * words,      # read the f32 grid once; write bit masks + run bases
         "k_labels_tiles": 4 * n_vox + (8 + 4) * words,    # write ONE signed int32 label volume; read masks + run bases
         "k_face_merge": 0,                                 # run lists of the rows on tile faces: KB per tile
-        "k_union_edges": 0,                                # sparse (pairs << voxels): no per-voxel bytes
     }
     return table.get(kernel)
 
@@ -118,6 +133,58 @@ def analysis_leg(ctx, n_res=400, edge=128, reps=5):
                     "reaches the same density_electron_ratio: profiles/r01_reference_analysis_cpu.json"}
 
 
+def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
+    import shutil
+    import tempfile
+    from pdb_eda_amd import synthetic, multipleStructures, densityAnalysis
+    densityAnalysis.setGlobals(synthetic.synthetic_params())
+    tmp = tempfile.mkdtemp(prefix="pdbeda_bench_%d_" % rank)
+    try:
+        t0 = time.perf_counter()
+        distinct = 4                 # distinct synthetic entries on disk (generating 125 different 200^3 maps would take minutes of CPU)
+        loaders = [synthetic.write_entry_files(tmp, "e%d" % k, args.entry_size, args.entry_residues, 1000 * rank + k) for k in range(distinct)]
+        gen_s = time.perf_counter() - t0
+        entries = [multipleStructures.Entry("r%de%04d" % (rank, i), loaders[i % distinct], cost_hint=0.0) for i in range(args.entries)]
+        pool.warm()
+        pool.map(entries[:2 * args.workers])                          # untimed: first-use costs of every worker (imports, arenas, file cache)
+        barrier()
+        t0 = time.perf_counter()
+        records = pool.map(entries)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        ok = sum(1 for r in records if r)
+        # single worker in THIS process for comparison (one stream, one host thread), on a short sample
+        sample = entries[:min(12, len(entries))]
+        ctx1 = _import_native().Context(local_rank)
+        multipleStructures.analyzeEntry(sample[0], ctx1, silent=True)
+        t1 = time.perf_counter()
+        for e in sample:
+            multipleStructures.analyzeEntry(e, ctx1, silent=True)
+        single = (time.perf_counter() - t1) / len(sample)
+        if dist is not None:
+            t = torch.tensor([elapsed, single], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, single = float(t[0].item()), float(t[1].item())
+            c = torch.tensor([ok], dtype=torch.int64, device="cuda")
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            ok = int(c.item())
+        n_atoms = len(list(loaders[0].structure()[0].get_atoms()))
+        return {"workload": "configs[3]: %d entries per rank (%d distinct on disk), each two CCP4 files of a %d^3 grid + a %d-atom model: read, parse, upload, "
+                            "aggregateCloud + the per-entry record of `pdb_eda multiple`" % (args.entries, distinct, args.entry_size, n_atoms),
+                "entries": args.entries * world, "entries_ok": ok, "workers_per_gpu": args.workers, "seconds": elapsed,
+                "entries_per_min": 60.0 * args.entries * world / elapsed, "entries_per_min_per_gpu": 60.0 * args.entries / elapsed,
+                "single_stream_ms_per_entry": 1e3 * single, "single_stream_entries_per_min": 60.0 / single,
+                "pool_vs_single_stream": (args.entries / elapsed) * single, "generation_s": gen_s,
+                "note": "worker processes (spawn), one HIP stream each, sharing the GPU of the rank; sharding over ranks is one entry list per rank, no collective"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _import_native():
+    from pdb_eda_amd import _native
+    return _native
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -126,6 +193,25 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
 
+    # Build (rank 0 of the node compiles if anything is stale; the others wait for the file) BEFORE this process touches the GPU:
+    # hipcc / make must not be spawned from a process that already holds the device.
+    import __graft_entry__ as entry
+    if local_rank == 0:
+        entry.build()
+    else:
+        csrc = os.path.join(ROOT, "pdb_eda_amd", "csrc")
+        newest = max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc))
+        deadline = time.time() + 600
+        while (not os.path.exists(entry.HIP_SO) or os.path.getmtime(entry.HIP_SO) < newest) and time.time() < deadline:
+            time.sleep(0.5)
+        entry.build()
+    from pdb_eda_amd import _native, ccp4, synthetic, multipleStructures
+
+    # multiple-structure leg: its worker processes are spawned now, before the GPU is initialised here
+    pool = None
+    if args.entries > 0:
+        pool = multipleStructures.ProcessPool(local_rank, args.workers, params=synthetic.synthetic_params(), silent=True)
+
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -133,14 +219,6 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
-    import __graft_entry__ as entry
-    if world > 1:                 # one rank compiles (if anything is stale), the others wait and then only load
-        if rank == 0:
-            entry.build()
-        dist.barrier()
-    entry.build()
-    from pdb_eda_amd import _native, ccp4, synthetic
 
     # ---- synthetic entry: smooth noise, orthogonal cell, resident in HBM ----
     n = args.size
@@ -178,6 +256,14 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    windows = []                      # dispersion: further windows of K steps each (never `value`)
+    for _ in range(max(0, args.windows)):
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            keep = step()
+        barrier()
+        windows.append(1e3 * (time.perf_counter() - t1) / args.steps)
     green, red = keep
     n_green, n_red = len(green), len(red)
     sig_vox = int(green.stats()["n"].sum() + red.stats()["n"].sum())
@@ -235,21 +321,29 @@ def main():
     for _ in range(args.steps):
         keep = step()
     prof = ctx.profile_end()
-    per_kernel = {k: {"calls": c, "avg_us": 1e3 * ms / c} for k, (c, ms) in prof.items()}
-    dominant = max((k for k in prof if algorithmic_bytes(k, n_vox, 2)), key=lambda k: prof[k][1])
-    dom_calls, dom_ms = prof[dominant]
-    dom_avg_s = dom_ms / dom_calls / 1e3
+    # ONE clock for the roofline: HIP events on the launch stream.  An event pair around a launch also times the launch gap
+    # (~2 us): the gap is calibrated in this same run as (sum of the event times of a step - host-timed step) / launches and
+    # taken off every kernel, so the corrected kernel times add up to ms_per_step by construction (the rocprofv3 averages
+    # under profiles/ are the cross-check).
+    n_launch = sum(c for c, _ in prof.values()) / args.steps
+    step_events_us = 1e3 * sum(ms for _, ms in prof.values()) / args.steps
+    step_wall_us = 1e6 * elapsed / args.steps
+    gap_us = max(0.0, (step_events_us - step_wall_us) / n_launch)
+    per_kernel = {k: {"calls": c, "event_us": 1e3 * ms / c, "avg_us": max(1e3 * ms / c - gap_us, 0.0)} for k, (c, ms) in prof.items()}
+    dominant = max((k for k in prof if algorithmic_bytes(k, n_vox, 2)), key=lambda k: per_kernel[k]["avg_us"])
+    dom_avg_s = per_kernel[dominant]["avg_us"] * 1e-6
     dom_bytes = algorithmic_bytes(dominant, n_vox, 2)
     achieved = dom_bytes / dom_avg_s / 1e9
-    step_kernel_s = sum(ms for _, ms in prof.values()) / 1e3 / args.steps
+    step_kernel_s = sum(v["avg_us"] * v["calls"] for v in per_kernel.values()) / args.steps * 1e-6
 
-    # measured HBM traffic of the dominant kernel (rocprofv3 PMC passes, committed under profiles/; gfx950 corrections applied there)
+    # measured HBM traffic of the dominant kernel: the PMC passes committed under profiles/ count -- but only if they were
+    # taken on THESE kernel sources (the file carries the hash of pdb_eda_amd/csrc at collection time); otherwise null
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-            pmc = json.load(fh)["kernels"]
-        if dominant in pmc and n == 256 and labels and args.nsd == 1.5:
-            traffic = pmc[dominant]["hbm_bytes_per_launch_corrected"]
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
+            pmc = json.load(fh)
+        if pmc.get("csrc_sha16") == csrc_sha16() and dominant in pmc["kernels"] and n == 256 and labels and args.nsd == 1.5:
+            traffic = pmc["kernels"][dominant]["hbm_bytes_per_launch_corrected"]
     except Exception:
         traffic = None
 
@@ -272,6 +366,15 @@ def main():
     analysis = None
     if rank == 0 and not args.no_analysis:
         analysis = analysis_leg(ctx)
+
+    # ---- BASELINE configs[3]: multiple-structure mode.  Every rank analyses ITS shard of the entries (no data-path collective):
+    # `entries` synthetic entries per rank -- each = two CCP4 files of a 200^3 grid + a ~500-atom model -- read from files, parsed,
+    # uploaded and analysed (aggregateCloud -> the record `pdb_eda multiple` keeps, plus atom region discrepancies) by a pool of
+    # worker processes, one HIP stream each.  entries/min = entries of all ranks / max-over-ranks time. ----
+    multiple = None
+    if pool is not None:
+        multiple = multiple_leg(args, pool, rank, local_rank, world, barrier, dist if world > 1 else None, torch)
+        pool.close()
 
     # host -> HBM upload of one entry (the boundary hands over a host buffer); never part of `value`
     t1 = time.perf_counter()
@@ -301,10 +404,13 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": 1e6 * dom_avg_s,
                      "d2d_copy_ceiling_GBs": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs,
-                     "timing": "HIP events on the launch stream, separate %d-step pass" % args.steps,
+                     "timing": "HIP events on the launch stream (separate %d-step pass), minus the per-launch event gap calibrated in this run: "
+                               "%.2f us = (sum of event times %.1f us - host-timed step %.1f us) / %.0f launches" % (args.steps, gap_us, step_events_us, step_wall_us, n_launch),
                      "pass_8B_per_voxel": {"bytes": 8 * n_vox, "kernel_sum_us": 1e6 * step_kernel_s,
                                            "achieved": 8 * n_vox / step_kernel_s / 1e9, "frac": 8 * n_vox / step_kernel_s / 1e9 / HBM_PEAK_GBS}},
         "kernels_us": {k: round(v["avg_us"] * v["calls"] / args.steps, 2) for k, v in sorted(per_kernel.items())},
+        "windows_ms_per_step": {"windows": [round(w, 5) for w in windows], "min": min(windows) if windows else None,
+                                "median": float(np.median(windows)) if windows else None, "steps_per_window": args.steps},
         "h2d": {"upload_ms": 1e3 * h2d_s, "pcie_inclusive_Mvoxels_per_s": n_vox / (h2d_s + elapsed / args.steps) / 1e6,
                 "note": "pageable host buffer -> HBM through pdbeda_map_upload; reported for information, never part of value"},
         "fallback_tiles": green.counters(),
@@ -313,6 +419,8 @@ def main():
         out["multi_stream"] = multi
     if analysis:
         out["analysis_entry"] = analysis
+    if multiple:
+        out["multiple_structures"] = multiple
 
     # ---- CPU baseline: the oracle (CPU restatement, O(N) clustering) on the same entry, 1 core ----
     if rank == 0 and not args.no_cpu_baseline:

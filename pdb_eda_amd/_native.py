@@ -449,7 +449,11 @@ class DeviceMap(object):
         st = bl.stats()
         n = st["n"].astype(np.float64)
         tot = float(st["totalDensity"].sum())
-        cen = (st["centroid"] * st["totalDensity"][:, None]).sum(axis=0) / tot if len(n) else np.full(3, np.nan)
+        # a component whose own total density is 0 has no density-weighted centroid (0 / 0 on the device): it contributes
+        # nothing to the weighted sum -- leaving it in would poison the whole centroid with NaN * 0
+        w = st["totalDensity"]
+        has = w != 0
+        cen = (st["centroid"][has] * w[has, None]).sum(axis=0) / tot if (len(n) and tot != 0) else np.full(3, np.nan)
         cc = (st["coordCenter"] * n[:, None]).sum(axis=0) / n.sum() if len(n) else np.full(3, np.nan)
         return {"totalDensity": tot, "centroid": cen, "coordCenter": cc, "volume": float(st["volume"].sum()), "n": int(n.sum())}
 

@@ -18,12 +18,12 @@ from . import _native
 __all__ = ["read", "parse", "read_grid", "DensityHeader", "DensityMatrix", "DensityBlob"]
 
 
-def read(ccp4Filename, pdbid=None, verbose=False):
-    """``ccp4.read`` (ref ccp4.py:58-74)."""
+def read(ccp4Filename, pdbid=None, verbose=False, ctx=None):
+    """``ccp4.read`` (ref ccp4.py:58-74); ``ctx``: the context (= stream) the map becomes resident on."""
     if not pdbid:
         pdbid = ccp4Filename
     with open(ccp4Filename, "rb") as fileHandle:
-        return parse(fileHandle, pdbid, verbose)
+        return parse(fileHandle, pdbid, verbose, ctx=ctx)
 
 
 def read_grid(handle):

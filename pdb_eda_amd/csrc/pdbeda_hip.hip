@@ -630,14 +630,14 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.total_words = total_words;
     job.key_words = (total_keys + 63) / 64;
     job.n_fine = (int32_t)((job.key_words + KEY_FINE - 1) / KEY_FINE);
-    job.fine_per_group = std::max(8, ((job.n_fine + KEY_GROUPS - 1) / KEY_GROUPS + 3) / 4 * 4);
+    job.fine_per_group = std::max(16, ((job.n_fine + KEY_GROUPS - 1) / KEY_GROUPS + 7) / 8 * 8);
     job.ctr = cv.take<Counters>(1);
     job.vols = cv.take<VolDesc>(std::max(n_vols, 1));
     job.mask = cv.take<uint64_t>(total_words);
-    job.key_bits = cv.take<uint64_t>(job.key_words);
+    job.key_bits = cv.take<uint64_t>((size_t)(job.key_words + KEY_FINE - 1) / KEY_FINE * KEY_FINE);   // whole fine buckets (rank_of_key loads a bucket whole)
     // the rank counters sit right behind the bitmap (ONE clear covers both), padded to whole groups
     job.n_fine_alloc = (int32_t)((job.n_fine + job.fine_per_group - 1) / job.fine_per_group * job.fine_per_group);
-    job.fine_count = cv.take<uint32_t>((size_t)std::max(job.n_fine_alloc, 4));
+    job.fine_count = cv.take<uint32_t>((size_t)std::max(job.n_fine_alloc / 2, 8));   // 16-bit counters, two per word
     job.run_base = cv.take<uint32_t>(total_words);
     job.comps_are_runs = n_tiles ? 0 : 1;
     job.comp_of_run = n_tiles ? cv.take<uint32_t>(max_runs) : nullptr;
@@ -709,12 +709,14 @@ static void launch_tile_label(pdbeda_ctx *ctx, unsigned n_tiles, const Job &job,
 }
 
 static void launch_labels(pdbeda_ctx *ctx, const Job &job, const TileDims &td, int32_t *labels_dev) {
-    const unsigned n_tiles = (unsigned)(td.ctiles * td.rtiles * td.stiles);
+    const int n_tiles = td.ctiles * td.rtiles * td.stiles;
+    const int per = n_tiles > 512 ? 2 : 1;   // big grids: two tiles per workgroup (the second prologue hides under the first tile's stores)
+    const unsigned grid = (unsigned)((n_tiles + per - 1) / per);
     switch (td.cw) {
-        case 1: hipLaunchKernelGGL((k_labels_tiles<1>), dim3(n_tiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev); break;
-        case 2: hipLaunchKernelGGL((k_labels_tiles<2>), dim3(n_tiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev); break;
-        case 3: hipLaunchKernelGGL((k_labels_tiles<3>), dim3(n_tiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev); break;
-        default: hipLaunchKernelGGL((k_labels_tiles<4>), dim3(n_tiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev); break;
+        case 1: hipLaunchKernelGGL((k_labels_tiles<1>), dim3(grid), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev, n_tiles, per); break;
+        case 2: hipLaunchKernelGGL((k_labels_tiles<2>), dim3(grid), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev, n_tiles, per); break;
+        case 3: hipLaunchKernelGGL((k_labels_tiles<3>), dim3(grid), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev, n_tiles, per); break;
+        default: hipLaunchKernelGGL((k_labels_tiles<4>), dim3(grid), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev, n_tiles, per); break;
     }
 }
 
@@ -741,6 +743,7 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
     td.stiles = (us + TILE_S - 1) / TILE_S;
     td.n_planes = n_planes;
     td.uc = uc; td.ur = ur; td.us = us; td.row_words = row_words;
+    td.nc = g.ncrs[0]; td.nr = g.ncrs[1];
     td.cut[0] = want_pos ? cut_pos : cut_neg;
     td.sign[0] = want_pos ? 1 : -1;
     td.cut[1] = cut_neg;
@@ -1130,7 +1133,7 @@ static int grouped_job(pdbeda_map *m, GroupSetup &gs, int64_t n_items, int64_t n
     if (n_groups > 0) e = hipMemcpyAsync(job.vols, gs.d_vols, sizeof(VolDesc) * n_groups, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess) e = hipMemsetAsync(job.ctr, 0, sizeof(Counters), st);
     if (e == hipSuccess)   // first-key bitmap + both levels of rank counters (adjacent in the arena)
-        e = hipMemsetAsync(job.key_bits, 0, (size_t)((char *)(job.fine_count + job.n_fine_alloc) - (char *)job.key_bits), st);
+        e = hipMemsetAsync(job.key_bits, 0, (size_t)((char *)(job.fine_count + job.n_fine_alloc / 2) - (char *)job.key_bits), st);
     if (e == hipSuccess && job.total_words > 0) e = hipMemsetAsync(job.mask, 0, 8 * job.total_words, st);
     if (e == hipSuccess && n_items > 0) {
         if (spheres)

@@ -45,11 +45,11 @@ struct Job {
     uint64_t *mask;
     uint32_t *run_base;
     uint64_t *key_bits;
-    // rank of a key = set bits of key_bits below it.  k_paint_keys keeps one counter per KEY_FINE key words beside the bitmap
-    // (spread over many cache lines: same-line atomics serialise); every block of k_emit turns them into a prefix table of
-    // <= KEY_GROUPS entries in LDS (fine_per_group counters per entry, a multiple of 4) -- no scan kernels
+    // rank of a key = set bits of key_bits below it.  k_paint_keys keeps one 16-bit counter per KEY_FINE key words beside the
+    // bitmap (two per 32-bit word; spread over many cache lines: same-line atomics serialise); every block of k_emit turns them
+    // into a prefix table of <= KEY_GROUPS entries in LDS (fine_per_group counters per entry, a multiple of 8) -- no scan kernels
     uint32_t *fine_count;
-    int32_t n_fine, n_fine_alloc, fine_per_group;
+    int32_t n_fine, n_fine_alloc, fine_per_group;   // counters in use / allocated (whole groups) / per table entry
     Counters *ctr;
     // union-find elements ("components"): tile-local components on the whole-map fast path,
     // single runs (comp_of_run == nullptr, identity) on the generic path
@@ -80,7 +80,7 @@ struct Job {
 };
 
 constexpr int KEY_FINE = 32;      // key words per fine counter (2048 keys)
-constexpr int KEY_GROUPS = 2048;  // entries of the prefix table a k_emit block builds in LDS
+constexpr int KEY_GROUPS = 1024;  // entries of the prefix table a k_emit block builds in LDS
 constexpr int WAVE = 64;
 
 __device__ inline int lane_id() { return threadIdx.x & 63; }
@@ -358,20 +358,35 @@ __global__ void __launch_bounds__(256) k_paint_keys(Job job) {
         if (job.parent[i] != (int32_t)i || job.r_n[i] == 0u) continue;   // not a root / unused id
         const unsigned long long key = job.r_key[i];
         atomicOr((unsigned long long *)&job.key_bits[key >> 6], 1ull << (key & 63));
-        atomicAdd(&job.fine_count[(key >> 6) / KEY_FINE], 1u);
+        const uint32_t f = (uint32_t)((key >> 6) / KEY_FINE);
+        atomicAdd(&job.fine_count[f >> 1], 1u << ((f & 1u) * 16u));   // (a fine bucket holds 2048 keys: its count fits 16 bits)
     }
 }
 
+// sum of the eight 16-bit counters of a quad, and of its first `take` (0..8) ones
+__device__ __forceinline__ uint32_t sum_u16x8(const uint4 q) {
+    const uint32_t a = (q.x & 0xffffu) + (q.x >> 16), b = (q.y & 0xffffu) + (q.y >> 16), c = (q.z & 0xffffu) + (q.z >> 16), d = (q.w & 0xffffu) + (q.w >> 16);
+    return (a + b) + (c + d);
+}
+__device__ __forceinline__ uint32_t sum_u16_first(const uint4 q, int take) {
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc += (2 * k < take ? (w[k] & 0xffffu) : 0u) + (2 * k + 1 < take ? (w[k] >> 16) : 0u);
+    return acc;
+}
+
 // Exclusive prefix table over groups of fine_per_group counters, built by the calling block in LDS; returns the total.
-// A thread owns KEY_GROUPS / 256 = 8 consecutive groups: all its loads are in flight at once (the table is one memory
-// round trip + one block scan, not a loop of dependent trips).  fine_count is padded to whole groups and cleared with the bitmap.
+// A thread owns KEY_GROUPS / 256 = 4 consecutive groups: all its loads are in flight at once (the table is one memory
+// round trip + one block scan, not a loop of dependent trips; 32 KiB per block at 256^3).  fine_count is padded to whole
+// groups and cleared with the bitmap.
 __device__ inline uint32_t rank_table_lds(const Job &job, uint32_t *s_pre /* [KEY_GROUPS] */, uint32_t *s_wave /* [4] */) {
     constexpr int PER = KEY_GROUPS / 256;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int G = job.fine_per_group, n_groups = (job.n_fine + G - 1) / G;
+    const int G = job.fine_per_group, n_groups = (job.n_fine + G - 1) / G, Q = G / 8;   // quads (8 counters = 16 B) per group
     const uint4 *fine4 = reinterpret_cast<const uint4 *>(job.fine_count);
     uint32_t v[PER];
-    if (G == 8) {   // (maps up to 2^25 keys: 256^3 fused) two 16-B loads per group, 16 in flight per thread
+    if (Q == 2) {   // (maps up to 2^25 keys: 256^3 fused)
         uint4 q[2 * PER];
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
@@ -380,14 +395,14 @@ __device__ inline uint32_t rank_table_lds(const Job &job, uint32_t *s_pre /* [KE
             q[2 * k + 1] = e < n_groups ? fine4[(size_t)e * 2 + 1] : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
-        for (int k = 0; k < PER; ++k) v[k] = ((q[2 * k].x + q[2 * k].y) + (q[2 * k].z + q[2 * k].w)) + ((q[2 * k + 1].x + q[2 * k + 1].y) + (q[2 * k + 1].z + q[2 * k + 1].w));
+        for (int k = 0; k < PER; ++k) v[k] = sum_u16x8(q[2 * k]) + sum_u16x8(q[2 * k + 1]);
     } else {
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int e = tid * PER + k;
             uint32_t acc = 0;
             if (e < n_groups)
-                for (int j = 0; j < G / 4; ++j) { const uint4 q = fine4[(size_t)e * (G / 4) + j]; acc += (q.x + q.y) + (q.z + q.w); }
+                for (int j = 0; j < Q; ++j) acc += sum_u16x8(fine4[(size_t)e * Q + j]);
             v[k] = acc;
         }
     }
@@ -411,21 +426,33 @@ __device__ inline uint32_t rank_table_lds(const Job &job, uint32_t *s_pre /* [KE
     return total;
 }
 
-// Number of painted keys below `key` (s_pre: this block's rank_table_lds).
+// Number of painted keys below `key` (s_pre: this block's rank_table_lds).  Branch-free for the common group size: the two
+// counter quads of the key's group and the 16 word pairs of its fine bucket are loaded whole and masked, so all 18 loads of a
+// thread are in flight together and the lanes of a wave do not wait for each other's trip counts.
 __device__ inline uint32_t rank_of_key(const Job &job, const uint32_t *s_pre, unsigned long long key) {
     const int64_t kw = (int64_t)(key >> 6);
-    const int G = job.fine_per_group;
+    const int G = job.fine_per_group, Q = G / 8;
     const int64_t f = kw / KEY_FINE, e = f / G;
     uint32_t rank = s_pre[e];
-    const uint4 *fine4 = reinterpret_cast<const uint4 *>(job.fine_count) + e * (G / 4);
+    const uint4 *fine4 = reinterpret_cast<const uint4 *>(job.fine_count) + e * Q;
     const int nf = (int)(f - e * G);                       // counters of my group before mine: < G
-    for (int k = 0; k * 4 < nf; ++k) {
-        const uint4 q = fine4[k];
-        const int left = nf - k * 4;
-        rank += q.x + (left > 1 ? q.y : 0u) + (left > 2 ? q.z : 0u) + (left > 3 ? q.w : 0u);
+    const ulonglong2 *bits2 = reinterpret_cast<const ulonglong2 *>(job.key_bits + f * KEY_FINE);   // (32 words: 16-B aligned; the bitmap is
+    const int nw = (int)(kw - f * KEY_FINE);               // whole words of my fine bucket before mine: < 32      padded to whole buckets)
+    if (Q == 2) {
+        const uint4 q0 = fine4[0], q1 = fine4[1];
+        ulonglong2 b[KEY_FINE / 2];
+#pragma unroll
+        for (int k = 0; k < KEY_FINE / 2; ++k) b[k] = bits2[k];
+        rank += sum_u16_first(q0, nf) + sum_u16_first(q1, nf - 8);
+#pragma unroll
+        for (int k = 0; k < KEY_FINE / 2; ++k) {
+            const uint64_t lo = 2 * k < nw ? b[k].x : (2 * k == nw ? b[k].x & bits_below((int)(key & 63)) : 0ull);
+            const uint64_t hi = 2 * k + 1 < nw ? b[k].y : (2 * k + 1 == nw ? b[k].y & bits_below((int)(key & 63)) : 0ull);
+            rank += (uint32_t)popc64(lo) + (uint32_t)popc64(hi);
+        }
+        return rank;
     }
-    const ulonglong2 *bits2 = reinterpret_cast<const ulonglong2 *>(job.key_bits + f * KEY_FINE);   // (32 words: 16-B aligned)
-    const int nw = (int)(kw - f * KEY_FINE);               // whole words of my fine bucket before mine: < 32
+    for (int k = 0; k * 8 < nf; ++k) rank += sum_u16_first(fine4[k], nf - k * 8);
 #pragma unroll 4
     for (int k = 0; k * 2 < nw; ++k) {
         const ulonglong2 q = bits2[k];
@@ -435,11 +462,18 @@ __device__ inline uint32_t rank_of_key(const Job &job, const uint32_t *s_pre, un
 }
 
 // Thread per ROOT component: its rank, its final signed label (whole-map jobs; the label writer follows parent[] to it) and
-// its blob table row (DensityBlob.fromCrsList, ccp4.py:542-545).  Block 0 publishes the blob counts.
+// its blob table row (DensityBlob.fromCrsList, ccp4.py:542-545).  Block 0 publishes the blob counts.  A root's work is a
+// chain of dependent memory round trips -- (parent, n) -> (key + the whole record) -> (counters + bitmap words) -- so each
+// step issues everything the next one needs at once, and the first step is issued before the prefix table is built.
 __global__ void __launch_bounds__(256) k_emit(Job job, const Geom *__restrict__ gp) {
     __shared__ uint32_t s_pre[KEY_GROUPS];
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_below1;
+    const uint32_t n_comp = n_components(job);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    int32_t par = i < n_comp ? job.parent[i] : -1;
+    uint32_t cnt = i < n_comp ? job.r_n[i] : 0u;
     const uint32_t total = rank_table_lds(job, s_pre, s_wave);
     const bool whole_map = job.label_of_comp != nullptr;
     if (threadIdx.x == 0) {
@@ -449,37 +483,44 @@ __global__ void __launch_bounds__(256) k_emit(Job job, const Geom *__restrict__ 
         if (blockIdx.x == 0) { job.ctr->n_blobs = total; job.ctr->n_blobs_vol0 = below1; }
     }
     __syncthreads();
-    const uint32_t n_comp = n_components(job);
     const Geom &g = *gp;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_comp; i += gridDim.x * blockDim.x) {
-        if (job.parent[i] != (int32_t)i || job.r_n[i] == 0u) continue;   // not a root / unused component id
-        const unsigned long long key = job.r_key[i];
-        const uint32_t rank = rank_of_key(job, s_pre, key);
-        const int vi = whole_map ? ((job.n_vols > 1 && (int64_t)key >= job.vols[1].key_base) ? 1 : 0) : find_vol_by_key(job.vols, job.n_vols, (int64_t)key);
-        if (whole_map) {   // blob index inside its own list, signed by the list
-            const int32_t k = (int32_t)(rank - (vi ? s_below1 : 0u));
-            job.label_of_comp[i] = job.vol_sign[vi] > 0 ? 1 + k : -1 - k;
+    for (; i < n_comp; i += stride) {
+        const bool root = par == (int32_t)i && cnt != 0u;   // else: not a root / unused component id
+        const uint32_t nx = i + stride;
+        const int32_t par_next = nx < n_comp ? job.parent[nx] : -1;   // (next trip's first step rides along)
+        const uint32_t cnt_next = nx < n_comp ? job.r_n[nx] : 0u;
+        if (root) {
+            const unsigned long long key = job.r_key[i];
+            const double tot = job.r_rho[i], rc = job.r_rho_c[i], rr = job.r_rho_r[i], rs = job.r_rho_s[i];
+            const long long ic = job.r_c[i], ir = job.r_r[i], is = job.r_s[i];
+            const uint32_t rank = rank_of_key(job, s_pre, key);
+            const int vi = whole_map ? ((job.n_vols > 1 && (int64_t)key >= job.vols[1].key_base) ? 1 : 0) : find_vol_by_key(job.vols, job.n_vols, (int64_t)key);
+            if (whole_map) {   // blob index inside its own list, signed by the list
+                const int32_t k = (int32_t)(rank - (vi ? s_below1 : 0u));
+                job.label_of_comp[i] = job.vol_sign[vi] > 0 ? 1 + k : -1 - k;
+            }
+            const VolDesc vd = job.vols[vi];
+            job.r_rank[i] = rank;
+            const double n = (double)cnt;
+            double wc[3] = {rc / tot, rr / tot, rs / tot};
+            double cc[3] = {(double)ic / n, (double)ir / n, (double)is / n};
+            double xyz[3];
+            crs2xyz_frac(g, wc, xyz);
+            job.b_centroid[3 * rank + 0] = xyz[0];
+            job.b_centroid[3 * rank + 1] = xyz[1];
+            job.b_centroid[3 * rank + 2] = xyz[2];
+            crs2xyz_frac(g, cc, xyz);
+            job.b_center[3 * rank + 0] = xyz[0];
+            job.b_center[3 * rank + 1] = xyz[1];
+            job.b_center[3 * rank + 2] = xyz[2];
+            job.b_n[rank] = (int64_t)cnt;
+            job.b_total[rank] = tot;
+            job.b_volume[rank] = g.unit_volume * n;
+            job.b_key[rank] = (int64_t)key - vd.key_base;
+            job.b_group[rank] = vd.group;
         }
-        const VolDesc vd = job.vols[vi];
-        job.r_rank[i] = rank;
-        const double n = (double)job.r_n[i];
-        const double tot = job.r_rho[i];
-        double wc[3] = {job.r_rho_c[i] / tot, job.r_rho_r[i] / tot, job.r_rho_s[i] / tot};
-        double cc[3] = {(double)job.r_c[i] / n, (double)job.r_r[i] / n, (double)job.r_s[i] / n};
-        double xyz[3];
-        crs2xyz_frac(g, wc, xyz);
-        job.b_centroid[3 * rank + 0] = xyz[0];
-        job.b_centroid[3 * rank + 1] = xyz[1];
-        job.b_centroid[3 * rank + 2] = xyz[2];
-        crs2xyz_frac(g, cc, xyz);
-        job.b_center[3 * rank + 0] = xyz[0];
-        job.b_center[3 * rank + 1] = xyz[1];
-        job.b_center[3 * rank + 2] = xyz[2];
-        job.b_n[rank] = (int64_t)job.r_n[i];
-        job.b_total[rank] = tot;
-        job.b_volume[rank] = g.unit_volume * n;
-        job.b_key[rank] = (int64_t)key - vd.key_base;
-        job.b_group[rank] = vd.group;
+        par = par_next;
+        cnt = cnt_next;
     }
 }
 

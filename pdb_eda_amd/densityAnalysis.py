@@ -71,10 +71,10 @@ def fromFile(pdbFile, ccp4DensityFile=None, ccp4DiffDensityFile=None, ctx=None):
     diffDensityObj = None
     try:
         if ccp4DensityFile is not None:
-            densityObj = ccp4.read(ccp4DensityFile, pdbid) if isinstance(ccp4DensityFile, str) else ccp4.parse(ccp4DensityFile, pdbid, ctx=ctx)
+            densityObj = ccp4.read(ccp4DensityFile, pdbid, ctx=ctx) if isinstance(ccp4DensityFile, str) else ccp4.parse(ccp4DensityFile, pdbid, ctx=ctx)
             _attachCutoffs(densityObj, None)
         if ccp4DiffDensityFile is not None:
-            diffDensityObj = ccp4.read(ccp4DiffDensityFile, pdbid) if isinstance(ccp4DiffDensityFile, str) else ccp4.parse(ccp4DiffDensityFile, pdbid, ctx=ctx)
+            diffDensityObj = ccp4.read(ccp4DiffDensityFile, pdbid, ctx=ctx) if isinstance(ccp4DiffDensityFile, str) else ccp4.parse(ccp4DiffDensityFile, pdbid, ctx=ctx)
             _attachCutoffs(None, diffDensityObj)
         biopdbObj, pdbObj = _structure.read_pdb(pdbFile, pdbid)
     except Exception:
@@ -267,10 +267,6 @@ class DensityAnalysis(object):
         if self._blueBlobList is None:
             self._blueBlobList = self.densityObj.createFullBlobList(self.densityObj.densityCutoff)
         return self._blueBlobList
-
-    @property
-    def fo(self):
-        return self.densityObj
 
     # ---- aggregateCloud (ref densityAnalysis.py:571-780) --------------------------------------
     def _cloudInputs(self):

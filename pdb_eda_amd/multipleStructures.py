@@ -187,6 +187,73 @@ class StreamPool(object):
         return results
 
 
+# ---- process pool: the reference's own shape (multiprocessing.Pool, multipleStructures.py:167-168) on a GPU -----------------------
+# Threads share one interpreter: the host-side part of an entry (building Python tables) holds the GIL, so a thread pool
+# scales only the part spent inside the library.  Worker PROCESSES scale all of it: each is a fresh interpreter (spawn --
+# HIP state does not survive fork) with its own context = stream on the same GPU.
+
+_worker_state = {}
+
+
+def _worker_init(device, params, time_out, silent):
+    _worker_state.update(device=device, time_out=time_out, silent=silent)
+    if params is not None:
+        densityAnalysis.setGlobals(params)
+
+
+def _worker_context():
+    ctx = _worker_state.get("ctx")
+    if ctx is None:
+        ctx = _native.Context(_worker_state["device"])
+        if _worker_state["time_out"] > 0:
+            ctx.set_timeout(_worker_state["time_out"])
+        _worker_state["ctx"] = ctx
+    return ctx
+
+
+def _worker_entry(entry):
+    """One entry in a worker process: (record or 0, failure reason or None).  A time-out abandons the worker's context."""
+    reasons = {}
+    try:
+        record = analyzeEntry(entry, _worker_context(), reasons, _worker_state["silent"])
+    except _native.PdbedaTimeout:
+        _worker_state["ctx"] = None
+        _drop(entry.pdbid, "Timeout", reasons, _worker_state["silent"])
+        record = 0
+    return record, reasons.get(entry.pdbid)
+
+
+class ProcessPool(object):
+    """``n_workers`` worker processes on one GPU (one stream each), started with the ``spawn`` method BEFORE they are needed
+    (ideally before the parent touches the GPU) and reused across ``map`` calls.  Entries and their loaders must be picklable."""
+
+    def __init__(self, device=0, n_workers=4, params=None, time_out=0.0, silent=True):
+        import multiprocessing
+        self.n_workers = max(1, int(n_workers))
+        self._pool = multiprocessing.get_context("spawn").Pool(self.n_workers, _worker_init, (device, params, float(time_out or 0.0), silent))
+        self.failures = {}
+
+    def warm(self):
+        """Make every worker import the package, load the library and create its context (first-use costs out of the way)."""
+        self._pool.map(_worker_warm, range(4 * self.n_workers), chunksize=1)
+
+    def map(self, entries):
+        results = self._pool.map(_worker_entry, entries, chunksize=1)
+        self.failures = {e.pdbid: why for e, (rec, why) in zip(entries, results) if why}
+        return [rec for rec, _ in results]
+
+    def close(self):
+        self._pool.close()
+        self._pool.join()
+
+
+def _worker_warm(_):
+    _worker_context()
+    import time as _time
+    _time.sleep(0.05)      # (keeps the task on this worker long enough for the others to take the next ones)
+    return 1
+
+
 def processEntries(entries, device=0, n_streams=4, time_out=0.0, silent=False, failures=None):
     """The per-GPU part of ``pdb_eda multiple``: {pdbid: record} for the entries that succeed; the reasons of the ones that
     do not are collected in ``failures`` ({pdbid: reason}) when a dict is passed."""

@@ -9,7 +9,8 @@ The CCP4 byte layout written by :func:`ccp4_bytes` is the one the reference pars
 """
 import numpy as np
 
-__all__ = ["ccp4_bytes", "ccp4_header_bytes", "synthetic_params", "noise_grid", "MapSpec", "chain_structure", "gaussian_sum_grid", "smooth_noise"]
+__all__ = ["ccp4_bytes", "ccp4_header_bytes", "synthetic_params", "noise_grid", "MapSpec", "chain_structure", "gaussian_sum_grid", "smooth_noise",
+           "sweep_param_sets", "SyntheticEntryFiles", "write_entry_files"]
 
 
 class MapSpec(object):
@@ -198,3 +199,57 @@ def sweep_param_sets():
         radii[atom_type] = round(radii[atom_type] + delta, 6)
         sets.append({**prev, "radii": radii, "slopes": {**prev["slopes"], **slopes}})
     return sets
+
+
+# ---- synthetic entries on disk (BASELINE configs[3] / [4]: "1 000 synthetic 200^3 grids ... ~500 atoms each") ---------------------
+
+def write_entry_files(directory, tag, edge, n_residues, seed, spacing=0.5):
+    """Generate ONE synthetic entry -- a 2Fo-Fc-like map (sum of atomic Gaussians + noise) and an Fo-Fc-like map (filtered noise)
+    on an ``edge``^3 grid around a poly-ALA chain of ``n_residues`` -- and write its two CCP4 files.  Returns the picklable
+    loader (:class:`SyntheticEntryFiles`) the worker processes of a pool use."""
+    import os
+    from . import ccp4
+    spec = MapSpec(ncrs=(edge, edge, edge), spacing=spacing)
+    header = ccp4.DensityHeader.fromFileHeader(ccp4_header_bytes(spec))
+    lo, hi = np.array(header.crs2xyzCoord([6, 6, 6])), np.array(header.crs2xyzCoord([edge - 7] * 3))
+    st = chain_structure(n_residues, seed, lo, hi, hetero_every=9, zero_occupancy_every=37)
+    dens = gaussian_sum_grid(header, st, synthetic_params()["full_atom_name_map_electrons"], sigma=0.55, noise=0.02, seed=seed)
+    diff = (noise_grid(spec, seed + 100, 1.2) * 0.12).astype(np.float32)
+    paths = [os.path.join(directory, "%s%s.ccp4" % (tag, suffix)) for suffix in ("", "_diff")]
+    for path, grid in zip(paths, (dens, diff)):
+        with open(path, "wb") as fh:
+            fh.write(ccp4_bytes(spec, grid))
+    return SyntheticEntryFiles(paths[0], paths[1], n_residues, seed, edge, spacing)
+
+
+class SyntheticEntryFiles(object):
+    """Loader of one synthetic entry for ``multipleStructures.Entry``: reads the two CCP4 files (as a real run reads the files
+    ``fromPDBid`` downloaded) and rebuilds the model structure from its seed (cached per process: the files are the per-entry
+    cost that matters, a coordinate file parser is outside the path).  Picklable: pools hand it to worker processes."""
+    _structures = {}
+
+    def __init__(self, density_path, diff_path, n_residues, seed, edge, spacing):
+        self.density_path, self.diff_path = density_path, diff_path
+        self.n_residues, self.seed, self.edge, self.spacing = n_residues, seed, edge, spacing
+
+    def structure(self):
+        from . import ccp4, structure
+        key = (self.n_residues, self.seed, self.edge, self.spacing)
+        if key not in SyntheticEntryFiles._structures:
+            spec = MapSpec(ncrs=(self.edge,) * 3, spacing=self.spacing)
+            header = ccp4.DensityHeader.fromFileHeader(ccp4_header_bytes(spec))
+            lo, hi = np.array(header.crs2xyzCoord([6, 6, 6])), np.array(header.crs2xyzCoord([self.edge - 7] * 3))
+            st = chain_structure(self.n_residues, self.seed, lo, hi, hetero_every=9, zero_occupancy_every=37)
+            rot = [np.hstack([np.eye(3), np.zeros((3, 1))]),
+                   np.array([[-1.0, 0, 0, 0.5 * header.xlength], [0, -1.0, 0, 0], [0, 0, 1.0, 0.5 * header.zlength]])]
+            pdb = structure.PDBEntry(structure.PDBHeader(pdbid="synth%d" % self.seed, resolution=2.0, spaceGroup="P_1", rotationMats=rot))
+            SyntheticEntryFiles._structures[key] = (st, pdb)
+        return SyntheticEntryFiles._structures[key]
+
+    def __call__(self):
+        with open(self.density_path, "rb") as fh:
+            dens = fh.read()
+        with open(self.diff_path, "rb") as fh:
+            diff = fh.read()
+        st, pdb = self.structure()
+        return dens, diff, st, pdb

@@ -120,3 +120,32 @@ def test_watchdog_abandons_a_context():
         ctx.synchronize()
     ctx2 = _native.Context(0)
     assert not ctx2.test_overlap(crs, off, [0], [1])[0]
+
+
+@pytest.mark.timeout(300)
+def test_process_pool_matches_sequential(tmp_path, gpu_ctx):
+    """BASELINE configs[3] shape: entries read from CCP4 files by worker PROCESSES (spawn; one stream each) give the records of
+    sequential processing; a broken file is dropped with its reason and the pool carries on."""
+    from pdb_eda_amd import synthetic, densityAnalysis, multipleStructures
+    params = synthetic.synthetic_params()
+    densityAnalysis.setGlobals(params)
+    loaders = [synthetic.write_entry_files(str(tmp_path), "e%d" % k, 72, 24, 300 + k) for k in range(2)]
+    entries = [multipleStructures.Entry("x%02d" % i, loaders[i % 2]) for i in range(6)]
+    bad = synthetic.SyntheticEntryFiles(str(tmp_path / "missing.ccp4"), loaders[0].diff_path, 24, 300, 72, 0.5)
+    entries.insert(3, multipleStructures.Entry("gone", bad))
+    seq = [multipleStructures.analyzeEntry(e, gpu_ctx, silent=True) for e in entries]
+    pool = multipleStructures.ProcessPool(device=0, n_workers=2, params=params, silent=True)
+    try:
+        pool.warm()
+        par = pool.map(entries)
+        again = pool.map(entries[:2])            # the workers (and their contexts) are reused
+    finally:
+        pool.close()
+    assert [bool(r) for r in par] == [bool(r) for r in seq] == [True, True, True, False, True, True, True]
+    assert par[3] == 0 and set(pool.failures) == {"gone"} and "Error" in pool.failures["gone"]
+    for a, b in zip(par + again, seq + seq[:2]):
+        if not b:
+            continue
+        assert a["pdbid"] == b["pdbid"] and a["stats"]["num_voxels_aggregated"] == b["stats"]["num_voxels_aggregated"]
+        assert a["stats"]["density_electron_ratio"] == pytest.approx(b["stats"]["density_electron_ratio"], rel=1e-12)
+        assert a["diffs"] == pytest.approx(b["diffs"], rel=1e-9, abs=1e-12)
