@@ -648,6 +648,8 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.tile_mode = n_tiles ? cv.take<uint8_t>(n_tiles) : nullptr;
     job.tile_runs = n_tiles ? cv.take<uint32_t>(n_tiles) : nullptr;
     job.run_sums = n_tiles ? cv.take<double2>((size_t)n_tiles * RCAP) : nullptr;
+    job.inbox = n_tiles ? cv.take<InboxEntry>((size_t)n_tiles * INBOX_CAP) : nullptr;
+    job.inbox_count = n_tiles ? cv.take<uint32_t>(n_tiles) : nullptr;
     job.vol_sign[0] = job.vol_sign[1] = 1;
     job.parent = cv.take<int32_t>(max_runs);
     job.r_n = cv.take<uint32_t>(max_runs);
@@ -709,14 +711,12 @@ static void launch_tile_label(pdbeda_ctx *ctx, unsigned n_tiles, const Job &job,
 }
 
 static void launch_labels(pdbeda_ctx *ctx, const Job &job, const TileDims &td, int32_t *labels_dev) {
-    const int n_tiles = td.ctiles * td.rtiles * td.stiles;
-    const int per = n_tiles > 512 ? 2 : 1;   // big grids: two tiles per workgroup (the second prologue hides under the first tile's stores)
-    const unsigned grid = (unsigned)((n_tiles + per - 1) / per);
+    const unsigned n_tiles = (unsigned)(td.ctiles * td.rtiles * td.stiles);
     switch (td.cw) {
-        case 1: hipLaunchKernelGGL((k_labels_tiles<1>), dim3(grid), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev, n_tiles, per); break;
-        case 2: hipLaunchKernelGGL((k_labels_tiles<2>), dim3(grid), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev, n_tiles, per); break;
-        case 3: hipLaunchKernelGGL((k_labels_tiles<3>), dim3(grid), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev, n_tiles, per); break;
-        default: hipLaunchKernelGGL((k_labels_tiles<4>), dim3(grid), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev, n_tiles, per); break;
+        case 1: hipLaunchKernelGGL((k_labels_tiles<1>), dim3(n_tiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev); break;
+        case 2: hipLaunchKernelGGL((k_labels_tiles<2>), dim3(n_tiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev); break;
+        case 3: hipLaunchKernelGGL((k_labels_tiles<3>), dim3(n_tiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev); break;
+        default: hipLaunchKernelGGL((k_labels_tiles<4>), dim3(n_tiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev); break;
     }
 }
 
@@ -793,7 +793,7 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
     }
     const unsigned comp_grid = grid_for(max_runs, 256, 2048);
     { PROF(ctx, "k_resolve_tiles"); hipLaunchKernelGGL(k_resolve_tiles, dim3((unsigned)tiles_pp + 64u), dim3(256), 0, st, job, (int)tiles_pp); }
-    { PROF(ctx, "k_paint_keys"); hipLaunchKernelGGL(k_paint_keys, dim3(comp_grid), dim3(256), 0, st, job); }
+    { PROF(ctx, "k_paint_tiles"); hipLaunchKernelGGL(k_paint_tiles, dim3((unsigned)tiles_pp + 64u), dim3(256), 0, st, job, (int)tiles_pp); }
     { PROF(ctx, "k_emit"); hipLaunchKernelGGL(k_emit, dim3(std::min(comp_grid, 512u)), dim3(256), 0, st, job, m->geom_dev); }
     if (labels) {
         PROF(ctx, "k_labels_tiles");

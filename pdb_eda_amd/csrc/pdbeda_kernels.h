@@ -65,6 +65,12 @@ struct Job {
     uint8_t *tile_mode;       // per tile: 0 = united in LDS, 1 = unit tile
     uint32_t *tile_runs;      // per tile: number of word-runs (ids tile * runs_per_tile ...)
     double2 *run_sums;        // whole-map tiles: per run slot (sum rho, sum rho*(c - c_tile)), RCAP per tile
+    // Scattered global atomics are the scarce resource of the merge (~20 G/s chip-wide: folding 9 fields per (tile, root) pair
+    // took 12 of k_resolve_tiles' 22 us).  So a tile's members POST their summed record to the inbox of the tile that owns
+    // their root -- one returning atomic for the slot + plain stores -- and k_paint_tiles (a workgroup per tile) absorbs
+    // the inbox in LDS before it paints the final first keys.  A full inbox falls back to the atomics.
+    struct InboxEntry *inbox;     // [tile][INBOX_CAP]
+    uint32_t *inbox_count;        // [tile] (cleared by the tile's own k_tile_label workgroup)
     int32_t vol_sign[2];      // whole-map jobs: +1 / -1 list of volume p
     // per-component records
     int32_t *parent;
@@ -78,6 +84,13 @@ struct Job {
     double *b_total, *b_centroid, *b_center, *b_volume;
     int32_t *b_group;
 };
+
+struct InboxEntry {           // 80 bytes: what a (tile, root) pair folds into the root's record
+    uint32_t local, n;        // component index of the root inside its tile; voxels
+    double rho, rho_c, rho_r, rho_s;
+    unsigned long long c, r, s, key;
+};
+constexpr int INBOX_CAP = 192;   // entries per tile (a root tile of a map-spanning blob overflows: those pairs fold with atomics)
 
 constexpr int KEY_FINE = 32;      // key words per fine counter (2048 keys)
 constexpr int KEY_GROUPS = 1024;  // entries of the prefix table a k_emit block builds in LDS
@@ -355,10 +368,12 @@ __global__ void __launch_bounds__(256) k_resolve(Job job) {
 __global__ void __launch_bounds__(256) k_paint_keys(Job job) {
     const uint32_t n_runs = n_components(job);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_runs; i += gridDim.x * blockDim.x) {
-        if (job.parent[i] != (int32_t)i || job.r_n[i] == 0u) continue;   // not a root / unused id
-        const unsigned long long key = job.r_key[i];
-        atomicOr((unsigned long long *)&job.key_bits[key >> 6], 1ull << (key & 63));
+        const int32_t par = job.parent[i];
+        const uint32_t cnt = job.r_n[i];
+        const unsigned long long key = job.r_key[i];    // (loaded beside the other two, not after them: one round trip, then the atomics)
+        if (par != (int32_t)i || cnt == 0u) continue;   // not a root / unused id
         const uint32_t f = (uint32_t)((key >> 6) / KEY_FINE);
+        atomicOr((unsigned long long *)&job.key_bits[key >> 6], 1ull << (key & 63));
         atomicAdd(&job.fine_count[f >> 1], 1u << ((f & 1u) * 16u));   // (a fine bucket holds 2048 keys: its count fits 16 bits)
     }
 }
@@ -464,7 +479,8 @@ __device__ inline uint32_t rank_of_key(const Job &job, const uint32_t *s_pre, un
 // Thread per ROOT component: its rank, its final signed label (whole-map jobs; the label writer follows parent[] to it) and
 // its blob table row (DensityBlob.fromCrsList, ccp4.py:542-545).  Block 0 publishes the blob counts.  A root's work is a
 // chain of dependent memory round trips -- (parent, n) -> (key + the whole record) -> (counters + bitmap words) -- so each
-// step issues everything the next one needs at once, and the first step is issued before the prefix table is built.
+// step issues everything the next one needs at once (the key rides with the first step: unused ids hold stale keys that are
+// loaded and never used), and the first step is issued before the prefix table is built.
 __global__ void __launch_bounds__(256) k_emit(Job job, const Geom *__restrict__ gp) {
     __shared__ uint32_t s_pre[KEY_GROUPS];
     __shared__ uint32_t s_wave[4];
@@ -474,6 +490,7 @@ __global__ void __launch_bounds__(256) k_emit(Job job, const Geom *__restrict__ 
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     int32_t par = i < n_comp ? job.parent[i] : -1;
     uint32_t cnt = i < n_comp ? job.r_n[i] : 0u;
+    unsigned long long key = i < n_comp ? job.r_key[i] : 0ull;
     const uint32_t total = rank_table_lds(job, s_pre, s_wave);
     const bool whole_map = job.label_of_comp != nullptr;
     if (threadIdx.x == 0) {
@@ -489,8 +506,8 @@ __global__ void __launch_bounds__(256) k_emit(Job job, const Geom *__restrict__ 
         const uint32_t nx = i + stride;
         const int32_t par_next = nx < n_comp ? job.parent[nx] : -1;   // (next trip's first step rides along)
         const uint32_t cnt_next = nx < n_comp ? job.r_n[nx] : 0u;
+        const unsigned long long key_next = nx < n_comp ? job.r_key[nx] : 0ull;
         if (root) {
-            const unsigned long long key = job.r_key[i];
             const double tot = job.r_rho[i], rc = job.r_rho_c[i], rr = job.r_rho_r[i], rs = job.r_rho_s[i];
             const long long ic = job.r_c[i], ir = job.r_r[i], is = job.r_s[i];
             const uint32_t rank = rank_of_key(job, s_pre, key);
@@ -521,6 +538,7 @@ __global__ void __launch_bounds__(256) k_emit(Job job, const Geom *__restrict__ 
         }
         par = par_next;
         cnt = cnt_next;
+        key = key_next;
     }
 }
 

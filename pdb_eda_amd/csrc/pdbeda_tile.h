@@ -142,6 +142,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
     const int n_planes = td.n_planes;
 
     if (tid == 0) { s_over = 0; s_vover = 0; s_ncomp = 0; s_alloc[0] = 0; s_alloc[1] = 0; s_vpool = 0; }
+    if (tid == 0) job.inbox_count[blockIdx.x] = 0u;
     if (blockIdx.x == 0 && tid == 0) {   // read by the kernels that follow; nothing in this kernel touches them
         job.vols[0] = init.v[0];
         if (td.n_planes > 1) job.vols[1] = init.v[1];
@@ -1076,143 +1077,183 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
         atomicMin(&s_key[h], v_key);
     }
     __syncthreads();
-    for (int k = tid; k < RSLOTS; k += 256)
-        if (s_root[k] >= 0) fold((uint32_t)s_root[k], s_cnt[k], s_f[0][k], s_f[1][k], s_f[2][k], s_f[3][k], s_i[0][k], s_i[1][k], s_i[2][k], s_key[k]);
+    for (int k = tid; k < RSLOTS; k += 256) {
+        if (s_root[k] < 0) continue;
+        const uint32_t root = (uint32_t)s_root[k], rtile = root / CCAP;
+        uint32_t pos = INBOX_CAP;
+        if (rtile < (uint32_t)n_tiles) pos = atomicAdd(&job.inbox_count[rtile], 1u);   // (roots among the unit components have no inbox)
+        if (pos < (uint32_t)INBOX_CAP) {
+            InboxEntry e;
+            e.local = root % CCAP; e.n = s_cnt[k];
+            e.rho = s_f[0][k]; e.rho_c = s_f[1][k]; e.rho_r = s_f[2][k]; e.rho_s = s_f[3][k];
+            e.c = s_i[0][k]; e.r = s_i[1][k]; e.s = s_i[2][k]; e.key = s_key[k];
+            job.inbox[(size_t)rtile * INBOX_CAP + pos] = e;
+        } else {
+            fold(root, s_cnt[k], s_f[0][k], s_f[1][k], s_f[2][k], s_f[3][k], s_i[0][k], s_i[1][k], s_i[2][k], s_key[k]);
+        }
+    }
 }
 
-// Signed labels, a workgroup per tile (or per two), all look-ups in LDS: the tile's label-of-component table
+// Whole-map k_paint_keys, a workgroup per tile: first the tile's roots absorb what k_resolve_tiles posted to the tile's inbox
+// (summed in LDS, written back with plain stores), then every root paints its -- now final -- first key and bumps its
+// rank counter.  Workgroups beyond the tiles paint the roots among the unit components.
+__global__ void __launch_bounds__(256) k_paint_tiles(Job job, int n_tiles) {
+    const int tid = threadIdx.x;
+    auto paint = [&](unsigned long long key) {
+        const uint32_t f = (uint32_t)((key >> 6) / KEY_FINE);
+        atomicOr((unsigned long long *)&job.key_bits[key >> 6], 1ull << (key & 63));
+        atomicAdd(&job.fine_count[f >> 1], 1u << ((f & 1u) * 16u));
+    };
+    if ((int)blockIdx.x >= n_tiles) {
+        const uint32_t n_comp = n_components(job);
+        for (uint32_t i = (uint32_t)n_tiles * CCAP + (blockIdx.x - n_tiles) * 256u + tid; i < n_comp; i += (gridDim.x - n_tiles) * 256u)
+            if (job.parent[i] == (int32_t)i && job.r_n[i] != 0u) paint(job.r_key[i]);
+        return;
+    }
+    __shared__ double s_f[4][CCAP];
+    __shared__ unsigned long long s_i[3][CCAP], s_key[CCAP];
+    __shared__ uint32_t s_cnt[CCAP];
+    const uint32_t i = (uint32_t)blockIdx.x * CCAP + tid;
+    const uint32_t n_in = min(job.inbox_count[blockIdx.x], (uint32_t)INBOX_CAP);   // block-uniform
+    const int32_t par = job.parent[i];
+    const uint32_t n_i = job.r_n[i];
+    unsigned long long key = job.r_key[i];
+    const bool root = par == (int32_t)i && n_i != 0u;
+    if (n_in != 0u) {
+        InboxEntry e;
+        const bool have = (uint32_t)tid < n_in;
+        if (have) e = job.inbox[(size_t)blockIdx.x * INBOX_CAP + tid];   // (INBOX_CAP <= 256: one entry per thread, in flight with the loads above)
+        s_f[0][tid] = 0.0; s_f[1][tid] = 0.0; s_f[2][tid] = 0.0; s_f[3][tid] = 0.0;
+        s_i[0][tid] = 0ull; s_i[1][tid] = 0ull; s_i[2][tid] = 0ull; s_key[tid] = ~0ull; s_cnt[tid] = 0u;
+        __syncthreads();
+        if (have) {
+            const uint32_t l = e.local;
+            atomicAdd(&s_cnt[l], e.n);
+            unsafeAtomicAdd(&s_f[0][l], e.rho);
+            unsafeAtomicAdd(&s_f[1][l], e.rho_c);
+            unsafeAtomicAdd(&s_f[2][l], e.rho_r);
+            unsafeAtomicAdd(&s_f[3][l], e.rho_s);
+            atomicAdd(&s_i[0][l], e.c);
+            atomicAdd(&s_i[1][l], e.r);
+            atomicAdd(&s_i[2][l], e.s);
+            atomicMin(&s_key[l], e.key);
+        }
+        __syncthreads();
+        if (root && s_cnt[tid] != 0u) {   // (only roots receive: the posting side found this id as its root)
+            job.r_n[i] = n_i + s_cnt[tid];
+            job.r_rho[i] += s_f[0][tid];
+            job.r_rho_c[i] += s_f[1][tid];
+            job.r_rho_r[i] += s_f[2][tid];
+            job.r_rho_s[i] += s_f[3][tid];
+            job.r_c[i] += (long long)s_i[0][tid];
+            job.r_r[i] += (long long)s_i[1][tid];
+            job.r_s[i] += (long long)s_i[2][tid];
+            if (s_key[tid] < key) { key = s_key[tid]; job.r_key[i] = key; }
+        }
+    }
+    if (root) paint(key);
+}
+
+// Signed labels, one workgroup per tile, all look-ups in LDS: the tile's label-of-component table
 // (<= CCAP ints), its run -> local component table (bytes) and its mask / run-base words; the 64 KiB
-// of labels of a 256 x 8 x 8 tile are then streamed out with 16-B nontemporal stores (1 KiB per wave and row).
-// The kernel is a short prologue (three dependent memory round trips into the LDS tables) followed by a pure store
-// stream; a plain zero fill of the volume takes 10 us, so the prologue must not stand in front of the stores of a whole
-// round of workgroups: on grids of more than 512 tiles a workgroup writes TWO tiles and fetches the second one's tables
-// while the stores of the first are draining.  Unit tiles / tiles with too many runs take the global look-up path.
+// of labels of a 256 x 8 x 8 tile are then streamed out with 16-B stores (1 KiB per wave and row).
+// Unit tiles / tiles with too many runs take the global look-up path (same result).
+// (Measured and dropped: two tiles per workgroup with the second tile's tables fetched under the first tile's stores --
+//  27.8 us against 20.4; the store stream of a plain zero fill of the volume takes 10 us.)
 constexpr int LCAP = 4096;  // word-runs of a tile whose run -> component bytes fit the LDS table
+template <int CW>
 #ifndef PDBEDA_LABELS_NT_THREADS
 #define PDBEDA_LABELS_NT_THREADS 512
 #endif
-template <int CW>
-__global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS) k_labels_tiles(Job job, TileDims td, int32_t *__restrict__ labels, int n_tiles, int tiles_per_wg) {
+__global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS) k_labels_tiles(Job job, TileDims td, int32_t *__restrict__ labels) {
     constexpr int NU = 64 * CW;
     constexpr int NTL = PDBEDA_LABELS_NT_THREADS, RPW = 64 / (NTL / 64);   // rows of the tile per wave
-    static_assert(NTL == 512 && LCAP == 4096, "four unconditional comp loads per thread cover the first 2048 runs");
-    __shared__ int32_t s_lab[2][CCAP];
-    __shared__ uint8_t s_comp8[2][LCAP];
-    __shared__ uint64_t s_m[2][2][256];
-    __shared__ uint32_t s_rb[2][2][256];
+    __shared__ int32_t s_lab[CCAP];
+    __shared__ uint8_t s_comp8[LCAP];
+    __shared__ uint64_t s_m[2][256];
+    __shared__ uint32_t s_rb[2][256];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int uc = td.uc, ur = td.ur, us = td.us, row_words = td.row_words;
+    int t = blockIdx.x;
+    const int ct = t % td.ctiles; t /= td.ctiles;
+    const int rt = t % td.rtiles; t /= td.rtiles;
+    const int st = t;
+    const int w0 = ct * CW, r0 = rt * TILE_R, s0 = st * TILE_S;
     const int64_t plane_words = (int64_t)row_words * ur * us;
-    struct Pre {            // everything the prologue of one tile loads, issued before anything depends on a load:
-        uint32_t c[4];      // the tile's first 2048 run -> component ids and its label table do not wait for tile_mode /
-        int32_t lab;        // tile_runs (ids beyond the tile's run count hold stale bytes: stored, never used)
-        uint64_t m[2];
-        uint32_t rb[2];
-        uint32_t n_runs;
-        bool unit;
-    };
-    auto origin = [&](int tile, int &w0, int &r0, int &s0) {
-        const int ct = tile % td.ctiles, rt = (tile / td.ctiles) % td.rtiles, st = tile / (td.ctiles * td.rtiles);
-        w0 = ct * CW; r0 = rt * TILE_R; s0 = st * TILE_S;
-    };
-    auto fetch = [&](int tile) {
-        Pre p;
-        int w0, r0, s0;
-        origin(tile, w0, r0, s0);
-        const uint32_t rb = (uint32_t)tile * (uint32_t)(NU * 32), cb = (uint32_t)tile * CCAP;
+    const uint32_t rb = (uint32_t)blockIdx.x * (uint32_t)(NU * 32), cb = (uint32_t)blockIdx.x * CCAP;
+    // every load of the prologue is issued before anything depends on one: the tile's first 2048 run -> component ids and its
+    // label table do not wait for tile_mode / tile_runs (ids beyond the tile's run count hold stale bytes: stored, never used)
+    static_assert(NTL == 512 && LCAP == 4096, "four unconditional comp loads per thread cover the first 2048 runs");
+    uint32_t c_pre[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) p.c[k] = job.comp_of_run[rb + tid + NTL * k];
-        p.lab = tid < CCAP ? job.label_of_comp[job.parent[cb + tid]] : 0;   // (the root of a component carries its label)
-        p.unit = job.tile_mode[tile_index(td, 0, w0, r0, s0)] != 0;
-        p.n_runs = job.tile_runs[tile];
+    for (int k = 0; k < 4; ++k) c_pre[k] = job.comp_of_run[rb + tid + NTL * k];
+    const int32_t lab_pre = tid < CCAP ? job.label_of_comp[job.parent[cb + tid]] : 0;   // (the root of a component carries its label)
+    const bool unit = job.tile_mode[tile_index(td, 0, w0, r0, s0)] != 0;
+    const uint32_t n_runs = unit ? 0u : job.tile_runs[blockIdx.x];
+    const bool fast = !unit && n_runs <= (uint32_t)LCAP;   // block-uniform
+    {
         const int wl = tid % CW, rowl = (tid / CW) & 63;
         const int r = r0 + (rowl & 7), s = s0 + (rowl >> 3);
         const bool valid = tid < NU && r < ur && s < us && w0 + wl < row_words;
         const int64_t w = ((int64_t)s * ur + r) * row_words + (w0 + wl);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const bool has = valid && tid < 256 && q < td.n_planes;
-            p.m[q] = has ? job.mask[w + q * plane_words] : 0ull;
-            p.rb[q] = has ? job.run_base[w + q * plane_words] : 0u;
-        }
-        return p;
-    };
-    auto stage = [&](const Pre &p, int tile, int buf) -> bool {   // -> the tile's tables are complete in LDS ("fast")
-        const uint32_t rb = (uint32_t)tile * (uint32_t)(NU * 32), cb = (uint32_t)tile * CCAP;
-        const uint32_t n_runs = p.unit ? 0u : p.n_runs;
-        const bool fast = !p.unit && n_runs <= (uint32_t)LCAP;   // block-uniform
         if (tid < 256) {
-            s_m[buf][0][tid] = p.m[0]; s_m[buf][1][tid] = p.m[1];
-            s_rb[buf][0][tid] = p.rb[0]; s_rb[buf][1][tid] = p.rb[1];
-        }
-        if (tid < CCAP) s_lab[buf][tid] = p.lab;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) s_comp8[buf][tid + NTL * k] = (uint8_t)(p.c[k] - cb);
-        if (fast)
-            for (uint32_t i = tid + 4 * NTL; i < n_runs; i += NTL) s_comp8[buf][i] = (uint8_t)(job.comp_of_run[rb + i] - cb);
-        return fast;
-    };
-    // wave wv writes RPW rows of the tile; a lane owns 4 consecutive voxels of a 256-voxel row (16 waves per tile: the
-    // per-row bit arithmetic is a dependent chain, and small maps leave one workgroup per CU to hide it)
-    auto write = [&](int tile, int buf, bool fast) {
-        int w0, r0, s0;
-        origin(tile, w0, r0, s0);
-        const uint32_t rb = (uint32_t)tile * (uint32_t)(NU * 32);
-        for (int rr = 0; rr < RPW; ++rr) {
-            const int rowl = wv * RPW + rr;
-            const int r = r0 + (rowl & 7), s = s0 + (rowl >> 3);
-            if (r >= ur || s >= us) continue;   // wave-uniform
-            const int wl = lane >> 4, bit0 = (lane & 15) * 4;
-            const int c = (w0 + wl) * 64 + bit0;
-            if (wl >= CW || c >= uc) continue;
-            const int u = rowl * CW + wl;
-            int32_t out[4] = {0, 0, 0, 0};
-            const int sh = bit0 & 31;
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                const uint64_t m = s_m[buf][p][u];
-                const uint32_t half = bit0 >= 32 ? (uint32_t)(m >> 32) : (uint32_t)m;   // my 4 voxels live in one 32-bit half
-                const unsigned nib = (half >> sh) & 0xfu;
-                if (!nib) continue;
-                const uint64_t starts = run_starts(m);
-                const uint32_t base = s_rb[buf][p][u];
-                // starts below my nibble (32-bit halves), then the nibble's own starts bit by bit
-                const uint32_t slo = (uint32_t)starts, shi = (uint32_t)(starts >> 32);
-                const uint32_t below = bit0 >= 32 ? (uint32_t)__popc(slo) + (uint32_t)__popc(shi & ((1u << sh) - 1u)) : (uint32_t)__popc(slo & ((1u << sh) - 1u));
-                const unsigned snib = ((bit0 >= 32 ? shi : slo) >> sh) & 0xfu;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if ((nib >> q) & 1u) {
-                        const uint32_t run = base + below + (uint32_t)__popc(snib & ((2u << q) - 1u)) - 1u;
-                        out[q] = fast ? s_lab[buf][s_comp8[buf][run - rb]] : job.label_of_comp[job.parent[job.comp_of_run[run]]];
-                    }
-                }
-            }
-            int32_t *dst = labels + ((int64_t)s * ur + r) * uc + c;
-            if (c + 3 < uc && ((uc & 3) == 0)) {
-                // streaming store: the labels are not read again by this job, and keeping them out of L2 measured 2.4 us faster
-                typedef int v4i __attribute__((ext_vector_type(4)));
-                const v4i o4 = {out[0], out[1], out[2], out[3]};
-                __builtin_nontemporal_store(o4, reinterpret_cast<v4i *>(dst));
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (c + q < uc) dst[q] = out[q];
+                const bool has = valid && p < td.n_planes;
+                s_m[p][tid] = has ? job.mask[w + p * plane_words] : 0ull;
+                s_rb[p][tid] = has ? job.run_base[w + p * plane_words] : 0u;
             }
         }
-    };
-    const int t0 = blockIdx.x, t1 = blockIdx.x + gridDim.x;   // (neighbouring workgroups write neighbouring tiles at the same time)
-    const bool two = tiles_per_wg > 1 && t1 < n_tiles;         // block-uniform
-    const Pre p0 = fetch(t0);
-    const bool fast0 = stage(p0, t0, 0);
+        if (tid < CCAP) s_lab[tid] = lab_pre;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_comp8[tid + NTL * k] = (uint8_t)(c_pre[k] - cb);
+        if (fast)
+            for (uint32_t i = tid + 4 * NTL; i < n_runs; i += NTL) s_comp8[i] = (uint8_t)(job.comp_of_run[rb + i] - cb);
+    }
     __syncthreads();
-    Pre p1;
-    if (two) p1 = fetch(t1);    // in flight while the stores of the first tile are issued
-    write(t0, 0, fast0);
-    if (two) {
-        const bool fast1 = stage(p1, t1, 1);
-        __syncthreads();
-        write(t1, 1, fast1);
+    // wave wv writes RPW rows of the tile; a lane owns 4 consecutive voxels of a 256-voxel row (16 waves per tile: the
+    // per-row bit arithmetic is a dependent chain, and small maps leave one workgroup per CU to hide it)
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int rowl = wv * RPW + rr;
+        const int r = r0 + (rowl & 7), s = s0 + (rowl >> 3);
+        if (r >= ur || s >= us) continue;   // wave-uniform
+        const int wl = lane >> 4, bit0 = (lane & 15) * 4;
+        const int c = (w0 + wl) * 64 + bit0;
+        if (wl >= CW || c >= uc) continue;
+        const int u = rowl * CW + wl;
+        int32_t out[4] = {0, 0, 0, 0};
+        const int sh = bit0 & 31;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const uint64_t m = s_m[p][u];
+            const uint32_t half = bit0 >= 32 ? (uint32_t)(m >> 32) : (uint32_t)m;   // my 4 voxels live in one 32-bit half
+            const unsigned nib = (half >> sh) & 0xfu;
+            if (!nib) continue;
+            const uint64_t starts = run_starts(m);
+            const uint32_t base = s_rb[p][u];
+            // starts below my nibble (32-bit halves), then the nibble's own starts bit by bit
+            const uint32_t slo = (uint32_t)starts, shi = (uint32_t)(starts >> 32);
+            const uint32_t below = bit0 >= 32 ? (uint32_t)__popc(slo) + (uint32_t)__popc(shi & ((1u << sh) - 1u)) : (uint32_t)__popc(slo & ((1u << sh) - 1u));
+            const unsigned snib = ((bit0 >= 32 ? shi : slo) >> sh) & 0xfu;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if ((nib >> q) & 1u) {
+                    const uint32_t run = base + below + (uint32_t)__popc(snib & ((2u << q) - 1u)) - 1u;
+                    out[q] = fast ? s_lab[s_comp8[run - rb]] : job.label_of_comp[job.parent[job.comp_of_run[run]]];
+                }
+            }
+        }
+        int32_t *dst = labels + ((int64_t)s * ur + r) * uc + c;
+        if (c + 3 < uc && ((uc & 3) == 0)) {
+            // streaming store: the labels are not read again by this job, and keeping them out of L2 measured 2.4 us faster
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            const v4i o4 = {out[0], out[1], out[2], out[3]};
+            __builtin_nontemporal_store(o4, reinterpret_cast<v4i *>(dst));
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (c + q < uc) dst[q] = out[q];
+        }
     }
 }
 

@@ -138,11 +138,12 @@ def test_process_pool_matches_sequential(tmp_path, gpu_ctx):
     try:
         pool.warm()
         par = pool.map(entries)
+        failures = dict(pool.failures)
         again = pool.map(entries[:2])            # the workers (and their contexts) are reused
     finally:
         pool.close()
     assert [bool(r) for r in par] == [bool(r) for r in seq] == [True, True, True, False, True, True, True]
-    assert par[3] == 0 and set(pool.failures) == {"gone"} and "Error" in pool.failures["gone"]
+    assert par[3] == 0 and set(failures) == {"gone"} and "Error" in failures["gone"]
     for a, b in zip(par + again, seq + seq[:2]):
         if not b:
             continue
