@@ -649,7 +649,7 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.tile_runs = n_tiles ? cv.take<uint32_t>(n_tiles) : nullptr;
     job.run_sums = n_tiles ? cv.take<double2>((size_t)n_tiles * RCAP) : nullptr;
     job.inbox = n_tiles ? cv.take<InboxEntry>((size_t)n_tiles * INBOX_CAP) : nullptr;
-    job.inbox_count = n_tiles ? cv.take<uint32_t>(n_tiles) : nullptr;
+    job.inbox_count = n_tiles ? cv.take<uint32_t>((size_t)n_tiles * INBOX_STRIDE) : nullptr;
     job.vol_sign[0] = job.vol_sign[1] = 1;
     job.parent = cv.take<int32_t>(max_runs);
     job.r_n = cv.take<uint32_t>(max_runs);

@@ -70,7 +70,8 @@ struct Job {
     // their root -- one returning atomic for the slot + plain stores -- and k_paint_tiles (a workgroup per tile) absorbs
     // the inbox in LDS before it paints the final first keys.  A full inbox falls back to the atomics.
     struct InboxEntry *inbox;     // [tile][INBOX_CAP]
-    uint32_t *inbox_count;        // [tile] (cleared by the tile's own k_tile_label workgroup)
+    uint32_t *inbox_count;        // [tile * INBOX_STRIDE]: one counter per 128-B line (atomics on one line serialise); cleared by the
+                                  // tile's own k_tile_label workgroup
     int32_t vol_sign[2];      // whole-map jobs: +1 / -1 list of volume p
     // per-component records
     int32_t *parent;
@@ -90,6 +91,7 @@ struct InboxEntry {           // 80 bytes: what a (tile, root) pair folds into t
     double rho, rho_c, rho_r, rho_s;
     unsigned long long c, r, s, key;
 };
+constexpr int INBOX_STRIDE = 32;   // uint32 per inbox counter: a cache line each
 constexpr int INBOX_CAP = 192;   // entries per tile (a root tile of a map-spanning blob overflows: those pairs fold with atomics)
 
 constexpr int KEY_FINE = 32;      // key words per fine counter (2048 keys)

@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
     const int n_planes = td.n_planes;
 
     if (tid == 0) { s_over = 0; s_vover = 0; s_ncomp = 0; s_alloc[0] = 0; s_alloc[1] = 0; s_vpool = 0; }
-    if (tid == 0) job.inbox_count[blockIdx.x] = 0u;
+    if (tid == 0) job.inbox_count[(size_t)blockIdx.x * INBOX_STRIDE] = 0u;
     if (blockIdx.x == 0 && tid == 0) {   // read by the kernels that follow; nothing in this kernel touches them
         job.vols[0] = init.v[0];
         if (td.n_planes > 1) job.vols[1] = init.v[1];
@@ -1081,7 +1081,7 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
         if (s_root[k] < 0) continue;
         const uint32_t root = (uint32_t)s_root[k], rtile = root / CCAP;
         uint32_t pos = INBOX_CAP;
-        if (rtile < (uint32_t)n_tiles) pos = atomicAdd(&job.inbox_count[rtile], 1u);   // (roots among the unit components have no inbox)
+        if (rtile < (uint32_t)n_tiles) pos = atomicAdd(&job.inbox_count[(size_t)rtile * INBOX_STRIDE], 1u);   // (roots among the unit components have no inbox)
         if (pos < (uint32_t)INBOX_CAP) {
             InboxEntry e;
             e.local = root % CCAP; e.n = s_cnt[k];
@@ -1114,7 +1114,7 @@ __global__ void __launch_bounds__(256) k_paint_tiles(Job job, int n_tiles) {
     __shared__ unsigned long long s_i[3][CCAP], s_key[CCAP];
     __shared__ uint32_t s_cnt[CCAP];
     const uint32_t i = (uint32_t)blockIdx.x * CCAP + tid;
-    const uint32_t n_in = min(job.inbox_count[blockIdx.x], (uint32_t)INBOX_CAP);   // block-uniform
+    const uint32_t n_in = min(job.inbox_count[(size_t)blockIdx.x * INBOX_STRIDE], (uint32_t)INBOX_CAP);   // block-uniform
     const int32_t par = job.parent[i];
     const uint32_t n_i = job.r_n[i];
     unsigned long long key = job.r_key[i];
