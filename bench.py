@@ -153,14 +153,18 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
         barrier()
         elapsed = time.perf_counter() - t0
         ok = sum(1 for r in records if r)
-        # single worker in THIS process for comparison (one stream, one host thread), on a short sample
-        sample = entries[:min(12, len(entries))]
-        ctx1 = _import_native().Context(local_rank)
-        multipleStructures.analyzeEntry(sample[0], ctx1, silent=True)
-        t1 = time.perf_counter()
-        for e in sample:
-            multipleStructures.analyzeEntry(e, ctx1, silent=True)
-        single = (time.perf_counter() - t1) / len(sample)
+        # ONE worker process of the same kind for comparison (the pool is closed first: few processes may share the GPU)
+        pool.close()
+        sample = entries[:min(16, len(entries))]
+        one = multipleStructures.ProcessPool(local_rank, 1, params=synthetic.synthetic_params(), silent=True)
+        try:
+            one.warm()
+            one.map(sample[:2])
+            t1 = time.perf_counter()
+            one.map(sample)
+            single = (time.perf_counter() - t1) / len(sample)
+        finally:
+            one.close()
         if dist is not None:
             t = torch.tensor([elapsed, single], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -173,8 +177,8 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
                             "aggregateCloud + the per-entry record of `pdb_eda multiple`" % (args.entries, distinct, args.entry_size, n_atoms),
                 "entries": args.entries * world, "entries_ok": ok, "workers_per_gpu": args.workers, "seconds": elapsed,
                 "entries_per_min": 60.0 * args.entries * world / elapsed, "entries_per_min_per_gpu": 60.0 * args.entries / elapsed,
-                "single_stream_ms_per_entry": 1e3 * single, "single_stream_entries_per_min": 60.0 / single,
-                "pool_vs_single_stream": (args.entries / elapsed) * single, "generation_s": gen_s,
+                "one_worker_ms_per_entry": 1e3 * single, "one_worker_entries_per_min": 60.0 / single,
+                "pool_vs_one_worker": (args.entries / elapsed) * single, "generation_s": gen_s,
                 "note": "worker processes (spawn), one HIP stream each, sharing the GPU of the rank; sharding over ranks is one entry list per rank, no collective"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -193,6 +197,10 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
 
+    # torch is imported first (importing does not touch the GPU): it bundles its own HIP runtime, and the library must resolve
+    # libamdhip64 to THAT copy in this process -- two runtimes in one process do not see the device.
+    import torch
+    import torch.distributed as dist
     # Build (rank 0 of the node compiles if anything is stale; the others wait for the file) BEFORE this process touches the GPU:
     # hipcc / make must not be spawned from a process that already holds the device.
     import __graft_entry__ as entry
@@ -212,8 +220,6 @@ def main():
     if args.entries > 0:
         pool = multipleStructures.ProcessPool(local_rank, args.workers, params=synthetic.synthetic_params(), silent=True)
 
-    import torch
-    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -374,7 +380,6 @@ def main():
     multiple = None
     if pool is not None:
         multiple = multiple_leg(args, pool, rank, local_rank, world, barrier, dist if world > 1 else None, torch)
-        pool.close()
 
     # host -> HBM upload of one entry (the boundary hands over a host buffer); never part of `value`
     t1 = time.perf_counter()

@@ -243,8 +243,10 @@ class ProcessPool(object):
         return [rec for rec, _ in results]
 
     def close(self):
-        self._pool.close()
-        self._pool.join()
+        if self._pool is not None:
+            self._pool.close()
+            self._pool.join()
+            self._pool = None
 
 
 def _worker_warm(_):
