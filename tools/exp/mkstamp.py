@@ -25,6 +25,8 @@ body = "\n".join(out)
 # stamp 0 at kernel entry
 body = body.replace("    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;", "    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;\n    if (threadIdx.x == 0) { for (int k = 0; k < 32; ++k) job.stamps[(size_t)blockIdx.x * 32 + k] = 0ull; job.stamps[(size_t)blockIdx.x * 32] = __builtin_amdgcn_s_memrealtime(); }", 1)
 body = body.replace("    if (tid == 0) job.tile_runs[blockIdx.x] = n_wordruns;", "    if (tid == 0) job.tile_runs[blockIdx.x] = n_wordruns;\n    if (threadIdx.x == 0) job.stamps[(size_t)blockIdx.x * 32 + 16] = __builtin_amdgcn_s_memrealtime();")
+body = body.replace("                if (tid == 0) s_changed = 0;", "                if (tid == 0) { s_changed = 0; job.stamps[(size_t)blockIdx.x * 32 + 20] += 1ull; }")
+body = body.replace("            uint32_t wmax = n_edges;   // wave maximum of the pair counts", "            if (threadIdx.x == 0) job.stamps[(size_t)blockIdx.x * 32 + 21] = __builtin_amdgcn_s_memrealtime();\n            uint32_t wmax = n_edges;   // wave maximum of the pair counts")
 t = t[:a] + body + t[b:]
 open(os.path.join(dst, "pdbeda_tile.h"), "w").write(t)
 k = open(os.path.join(dst, "pdbeda_kernels.h")).read()

@@ -23,8 +23,10 @@ assert lib.pdbeda_bloblist_stamps(g._h, out.ctypes.data_as(C.c_void_p), nt) == 0
 t = out.astype(np.int64)
 t0 = t[:, 0].min()
 print("kernel span (10 ns ticks): start spread %d, last end %d" % (t[:, 0].max() - t0, t.max() - t0))
+print("hook rounds per tile: median %d  p90 %d  max %d" % (np.median(t[:, 20]), np.percentile(t[:, 20], 90), t[:, 20].max()))
+print("B1 merge of thread 0 done %d ticks after the batch-top barrier (median; stamp 21 - stamp 7)" % np.median(t[:, 21] - t[:, 7]))
 prev = t[:, 0]
-for k in range(1, 32):
+for k in range(1, 20):
     cur = t[:, k]
     ok = cur > 0
     if not ok.any():
