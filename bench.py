@@ -89,6 +89,7 @@ def analysis_leg(ctx, n_res=400, edge=128, reps=5):
 
     def once():
         t = {}
+        st.__dict__.pop("_pdbeda_columns", None)          # a fresh entry: the columnar snapshot of the structure is rebuilt inside the timed region
         t0 = time.perf_counter()
         densityObj = ccp4.parse(io.BytesIO(files[0]), "synth", ctx=ctx)
         diffObj = ccp4.parse(io.BytesIO(files[1]), "synth", ctx=ctx)

@@ -317,9 +317,11 @@ class DensityBlob(object):
         self.volume = volume
         self._crsList = None if crsList is None else {tuple(int(x) for x in crs) for crs in crsList}
         self._numVoxels = None
-        self._lazy = None
+        self._list = None                  # blobs made by the device: the list handle and the position in it (voxels on demand)
+        self._index = None
         self.densityMatrix = densityMatrix
-        self.atoms = [] if not atoms else atoms
+        if atoms:
+            self.atoms = atoms
 
     @classmethod
     def listFromDevice(cls, bl, densityMatrix):
@@ -327,20 +329,28 @@ class DensityBlob(object):
         out = []
         columns = zip(st["centroid"].tolist(), st["coordCenter"].tolist(), st["totalDensity"].tolist(), st["volume"].tolist(), st["n"].tolist(),
                       st["firstKey"].tolist())
+        new = cls.__new__
         for i, (centroid, center, total, volume, n, key) in enumerate(columns):
-            blob = cls(centroid, center, total, volume, None, densityMatrix)
-            blob._numVoxels = n
-            blob._lazy = (bl, i)
-            blob.firstKey = key
+            blob = new(cls)                                  # same fields as __init__ sets, without a call per field
+            blob.__dict__ = {"centroid": centroid, "coordCenter": center, "totalDensity": total, "volume": volume, "_crsList": None, "_numVoxels": n,
+                             "_list": bl, "_index": i, "densityMatrix": densityMatrix, "firstKey": key}
             out.append(blob)
         return out
 
     @property
     def crsList(self):
         if self._crsList is None:
-            bl, i = self._lazy
-            self._crsList = {tuple(int(x) for x in crs) for crs in bl.voxels_of(i)}
+            self._crsList = {tuple(crs) for crs in self._list.voxels_of(self._index).tolist()}
         return self._crsList
+
+    @property
+    def atoms(self):
+        """ref ccp4.py:505: the atoms a blob was built around (an empty list until somebody fills it)."""
+        return self.__dict__.setdefault("_atoms", [])
+
+    @atoms.setter
+    def atoms(self, value):
+        self.__dict__["_atoms"] = value
 
     @crsList.setter
     def crsList(self, value):
@@ -391,7 +401,7 @@ class DensityBlob(object):
         new = DensityBlob.fromCrsList(sorted(union), self.densityMatrix)
         self.centroid, self.coordCenter = new.centroid, new.coordCenter
         self.totalDensity, self.volume = new.totalDensity, new.volume
-        self._crsList, self._numVoxels, self._lazy = new._crsList, None, None
+        self._crsList, self._numVoxels, self._list, self._index = new._crsList, None, None, None
         self.atoms = atoms
 
     def clone(self):

@@ -1207,7 +1207,7 @@ extern "C" int pdbeda_region_sums(pdbeda_map *m, const double *xyz, const float 
     if (e == hipSuccess && n_atoms > 0) {
         { PROF(ctx, "k_sphere_paint"); hipLaunchKernelGGL(k_sphere_paint, dim3((unsigned)n_atoms), dim3(256), 0, st, m->geom_dev, m->dens, gs.d_xyz, gs.d_radii,
                            gs.d_item_group, gs.d_boxes, gs.d_vols, mask, 0.0f); }
-        { PROF(ctx, "k_region_reduce"); hipLaunchKernelGGL(k_region_reduce, dim3(grid_for(n_groups * 64, 256, 4096)), dim3(256), 0, st, m->geom_dev, m->dens, gs.d_vols,
+        { PROF(ctx, "k_region_reduce"); hipLaunchKernelGGL(k_region_reduce, dim3((unsigned)std::min<int64_t>(n_groups, 65536)), dim3(256), 0, st, m->geom_dev, m->dens, gs.d_vols,
                            (int)n_groups, mask, gs.total_words, cutoff, d_pos, d_neg, d_cnt, d_inv); }
         e = hipGetLastError();
     }
@@ -1269,10 +1269,11 @@ extern "C" int pdbeda_symmetry_atoms(pdbeda_ctx *ctx, const double *xyz, int64_t
     *n_out = 0;
     if (n_atoms == 0) return PDBEDA_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const int64_t total = 27ll * n_ops * n_atoms;
-    std::vector<double> h_xyz(3 * total);
-    std::vector<uint8_t> h_keep(total);
-    int rc = with_scratch(ctx, align_up(24 * n_atoms) + align_up(96 * n_ops) + align_up(72) + 2 * align_up(24) + align_up(24 * total) + align_up(total),
+    const int64_t total = 27ll * n_ops * n_atoms, n_words = (total + 63) / 64;
+    std::vector<unsigned long long> h_keep((size_t)n_words);
+    std::vector<int64_t> picked;
+    std::vector<double> h_xyz;
+    int rc = with_scratch(ctx, align_up(24 * n_atoms) + align_up(96 * n_ops) + align_up(72) + 2 * align_up(24) + align_up(8 * n_words) + align_up(8 * total) + align_up(24 * total),
                           [&](char *base) -> int {
         Carver cv(base);
         double *d_xyz = cv.take<double>(3 * n_atoms);
@@ -1280,34 +1281,39 @@ extern "C" int pdbeda_symmetry_atoms(pdbeda_ctx *ctx, const double *xyz, int64_t
         double *d_ortho = cv.take<double>(9);
         double *d_lo = cv.take<double>(3);
         double *d_hi = cv.take<double>(3);
+        unsigned long long *d_keep = cv.take<unsigned long long>(n_words);
+        int64_t *d_picked = cv.take<int64_t>(total);
         double *d_out = cv.take<double>(3 * total);
-        uint8_t *d_keep = cv.take<uint8_t>(total);
         hipStream_t st = ctx->stream;
         HIP_TRY(ctx, hipMemcpyAsync(d_xyz, xyz, 24 * n_atoms, hipMemcpyHostToDevice, st));
         HIP_TRY(ctx, hipMemcpyAsync(d_rot, rot, 96 * n_ops, hipMemcpyHostToDevice, st));
         HIP_TRY(ctx, hipMemcpyAsync(d_ortho, ortho, 72, hipMemcpyHostToDevice, st));
         HIP_TRY(ctx, hipMemcpyAsync(d_lo, bbox_lo, 24, hipMemcpyHostToDevice, st));
         HIP_TRY(ctx, hipMemcpyAsync(d_hi, bbox_hi, 24, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_symmetry_atoms, dim3(grid_for(total, 256)), dim3(256), 0, st, d_xyz, n_atoms, d_rot, (int)n_ops, d_ortho, d_lo, d_hi, d_out, d_keep);
-        HIP_TRY(ctx, d2h(ctx, h_xyz.data(), d_out, 24 * total));
-        HIP_TRY(ctx, d2h(ctx, h_keep.data(), d_keep, total));
+        { PROF(ctx, "k_symmetry_keep"); hipLaunchKernelGGL(k_symmetry_keep, dim3(grid_for(total, 256)), dim3(256), 0, st, d_xyz, n_atoms, d_rot, (int)n_ops, d_ortho, d_lo, d_hi, d_keep); }
+        HIP_TRY(ctx, d2h(ctx, h_keep.data(), d_keep, 8 * n_words));
+        HIP_TRY(ctx, ctx_sync(ctx));
+        for (int64_t w = 0; w < n_words; ++w)
+            for (unsigned long long bits = h_keep[(size_t)w]; bits; bits &= bits - 1) picked.push_back(64 * w + __builtin_ctzll(bits));
+        const int64_t n = (int64_t)picked.size();
+        if (n == 0 || n > cap || !out_xyz) return 0;
+        h_xyz.resize(3 * (size_t)n);
+        HIP_TRY(ctx, hipMemcpyAsync(d_picked, picked.data(), 8 * n, hipMemcpyHostToDevice, st));
+        { PROF(ctx, "k_symmetry_pick"); hipLaunchKernelGGL(k_symmetry_pick, dim3(grid_for(n, 256)), dim3(256), 0, st, d_xyz, n_atoms, d_rot, (int)n_ops, d_ortho, d_lo, d_hi, d_picked, n, d_out); }
+        HIP_TRY(ctx, d2h(ctx, h_xyz.data(), d_out, 24 * n));
         return 0;
     });
     if (rc) return rc;
-    int64_t n = 0;
-    for (int64_t t = 0; t < total; ++t) {
-        if (!h_keep[t]) continue;
-        if (n < cap) {
-            const int64_t a = t % n_atoms, cell_op = t / n_atoms;
-            const int op = (int)(cell_op % n_ops), cell = (int)(cell_op / n_ops);
-            if (atom_index) atom_index[n] = (int32_t)a;
-            if (symmetry) { symmetry[4 * n] = cell / 9 - 1; symmetry[4 * n + 1] = (cell / 3) % 3 - 1; symmetry[4 * n + 2] = cell % 3 - 1; symmetry[4 * n + 3] = op; }
-            if (out_xyz) for (int q = 0; q < 3; ++q) out_xyz[3 * n + q] = h_xyz[3 * t + q];
-        }
-        ++n;
-    }
+    const int64_t n = (int64_t)picked.size();
     *n_out = n;
     if (n > cap && (atom_index || symmetry || out_xyz)) return fail(ctx, PDBEDA_ERR_CAPACITY, "need capacity %lld", (long long)n);
+    for (int64_t k = 0; k < n; ++k) {
+        const int64_t t = picked[(size_t)k], a = t % n_atoms, cell_op = t / n_atoms;
+        const int op = (int)(cell_op % n_ops), cell = (int)(cell_op / n_ops);
+        if (atom_index) atom_index[k] = (int32_t)a;
+        if (symmetry) { symmetry[4 * k] = cell / 9 - 1; symmetry[4 * k + 1] = (cell / 3) % 3 - 1; symmetry[4 * k + 2] = cell % 3 - 1; symmetry[4 * k + 3] = op; }
+    }
+    if (out_xyz && n > 0) memcpy(out_xyz, h_xyz.data(), 24 * (size_t)n);
     return PDBEDA_OK;
 }
 

@@ -172,6 +172,7 @@ __device__ inline void word_run_records(const Job &job, const Geom &g, const flo
 __global__ void __launch_bounds__(256) k_run_index(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp) {
     __shared__ uint64_t s_mask[256];
     __shared__ uint32_t s_off[256];
+    __shared__ int s_vol[256];
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -198,6 +199,7 @@ __global__ void __launch_bounds__(256) k_run_index(Job job, const float *__restr
     for (int k = 0; k < wv; ++k) wpre += s_wsum[k];
     uint32_t off = s_base + wpre + x - cnt;
     s_off[tid] = off;
+    s_vol[tid] = m ? find_vol(job.vols, job.n_vols, w) : 0;      // (every thread searches for its own word: the per-word loop below is serial)
     if (w < job.total_words) job.run_base[w] = off;
     __syncthreads();
 
@@ -207,7 +209,7 @@ __global__ void __launch_bounds__(256) k_run_index(Job job, const float *__restr
         const uint64_t mw = s_mask[slot];
         if (mw == 0ull) continue;
         const int64_t word = chunk0 + slot;
-        const VolDesc vd = job.vols[find_vol(job.vols, job.n_vols, word)];
+        const VolDesc vd = job.vols[s_vol[slot]];
         const int64_t rem = word - vd.word_base;
         const int wq = (int)(rem % vd.row_words);
         const int64_t row = rem / vd.row_words;
@@ -343,22 +345,60 @@ __global__ void __launch_bounds__(256) k_union(Job job) {
 
 __device__ inline uint32_t n_components(const Job &job) { return job.comps_are_runs ? job.ctr->n_runs : job.ctr->n_comps; }
 
-// Thread per component: flatten, and fold non-root partial sums into the root record.
+// Thread per component: flatten, and fold non-root partial sums into the root record.  Runs are numbered in word order,
+// so the lanes of a wave mostly belong to a handful of components: the lanes that share a root are summed in the wave
+// first and ONE lane sends the nine atomics (a 200-run atom cloud used to send 200 x 9 to the same cache line, where they
+// serialise).
 __global__ void __launch_bounds__(256) k_resolve(Job job) {
     const uint32_t n_runs = n_components(job);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_runs; i += gridDim.x * blockDim.x) {
-    const int root = uf_find(job.parent, (int)i);
-    if (root == (int)i) continue;
-    job.parent[i] = root;
-    atomicAdd(&job.r_n[root], job.r_n[i]);
-    unsafeAtomicAdd(&job.r_rho[root], job.r_rho[i]);
-    unsafeAtomicAdd(&job.r_rho_c[root], job.r_rho_c[i]);
-    unsafeAtomicAdd(&job.r_rho_r[root], job.r_rho_r[i]);
-    unsafeAtomicAdd(&job.r_rho_s[root], job.r_rho_s[i]);
-    atomicAdd((unsigned long long *)&job.r_c[root], (unsigned long long)job.r_c[i]);
-    atomicAdd((unsigned long long *)&job.r_r[root], (unsigned long long)job.r_r[i]);
-    atomicAdd((unsigned long long *)&job.r_s[root], (unsigned long long)job.r_s[i]);
-    atomicMin(&job.r_key[root], job.r_key[i]);
+    const int lane = lane_id();
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_runs; i0 += stride) {      // (wave-uniform trip count)
+        const uint32_t i = i0 + (uint32_t)lane;
+        int root = -1;
+        if (i < n_runs) {
+            root = uf_find(job.parent, (int)i);
+            if (root == (int)i) root = -1; else job.parent[i] = root;
+        }
+        uint32_t n = 0;
+        double rho = 0.0, rc = 0.0, rr = 0.0, rs = 0.0;
+        unsigned long long c = 0, r = 0, sv = 0, key = ~0ull;
+        if (root >= 0) {
+            n = job.r_n[i]; rho = job.r_rho[i]; rc = job.r_rho_c[i]; rr = job.r_rho_r[i]; rs = job.r_rho_s[i];
+            c = (unsigned long long)job.r_c[i]; r = (unsigned long long)job.r_r[i]; sv = (unsigned long long)job.r_s[i]; key = job.r_key[i];
+        }
+        unsigned long long todo = __ballot(root >= 0);
+        while (todo) {
+            const int first = ctz64(todo);
+            const int r0 = __shfl(root, first);
+            const bool mine = root == r0;
+            const unsigned long long group = __ballot(mine);
+            todo &= ~group;
+            uint32_t gn = mine ? n : 0u;
+            double g_rho = mine ? rho : 0.0, g_rc = mine ? rc : 0.0, g_rr = mine ? rr : 0.0, g_rs = mine ? rs : 0.0;
+            unsigned long long g_c = mine ? c : 0ull, g_r = mine ? r : 0ull, g_s = mine ? sv : 0ull, g_key = mine ? key : ~0ull;
+            if (group & (group - 1)) {           // more than one lane: butterfly over the wave (lanes outside the group carry the neutral element)
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) {
+                    gn += __shfl_xor(gn, d);
+                    g_rho += __shfl_xor(g_rho, d); g_rc += __shfl_xor(g_rc, d); g_rr += __shfl_xor(g_rr, d); g_rs += __shfl_xor(g_rs, d);
+                    g_c += __shfl_xor(g_c, d); g_r += __shfl_xor(g_r, d); g_s += __shfl_xor(g_s, d);
+                    const unsigned long long k2 = __shfl_xor(g_key, d);
+                    g_key = k2 < g_key ? k2 : g_key;
+                }
+            }
+            if (lane == first) {
+                atomicAdd(&job.r_n[r0], gn);
+                unsafeAtomicAdd(&job.r_rho[r0], g_rho);
+                unsafeAtomicAdd(&job.r_rho_c[r0], g_rc);
+                unsafeAtomicAdd(&job.r_rho_r[r0], g_rr);
+                unsafeAtomicAdd(&job.r_rho_s[r0], g_rs);
+                atomicAdd((unsigned long long *)&job.r_c[r0], g_c);
+                atomicAdd((unsigned long long *)&job.r_r[r0], g_r);
+                atomicAdd((unsigned long long *)&job.r_s[r0], g_s);
+                atomicMin(&job.r_key[r0], g_key);
+            }
+        }
     }
 }
 
@@ -723,9 +763,10 @@ __global__ void __launch_bounds__(1024) k_make_vols(const int32_t *__restrict__ 
     if (tid == 0) { ctr->total_words = s_cw; ctr->total_keys = s_ck; }
 }
 
-// Block per atom, thread per box voxel: wrapped fetch, strict density filter (Q2), fp64
-// distance (cutils.pyx:205-218, 244-245); hits are OR-ed into the group's volume, which
-// deduplicates sphere unions on raw crs exactly like the reference's set (cutils.pyx:268-271).
+// Block per atom, thread per 16-voxel piece of a box row: wrapped fetch, strict density filter (Q2), fp64 distance
+// (cutils.pyx:205-218, 244-245); the hits of a piece are collected in a register and OR-ed into the group's volume with
+// one atomic per mask word (a lane per voxel sent ~1400 atomics per atom to ~256 words), which deduplicates sphere unions
+// on raw crs exactly like the reference's set (cutils.pyx:268-271).
 __global__ void __launch_bounds__(256) k_sphere_paint(const Geom *__restrict__ gp, const float *__restrict__ dens,
                                                       const double *__restrict__ xyz, const float *__restrict__ radii,
                                                       const int32_t *__restrict__ atom_group, const AtomBox *__restrict__ boxes,
@@ -738,21 +779,42 @@ __global__ void __launch_bounds__(256) k_sphere_paint(const Geom *__restrict__ g
     const VolDesc vd = vols[atom_group[a]];
     const double px = xyz[3 * a], py = xyz[3 * a + 1], pz = xyz[3 * a + 2];
     const double rad = (double)radii[a], cut = (double)cutoff;
-    const int64_t nvox = (int64_t)dc * dr * dsz;
-    for (int64_t i = threadIdx.x; i < nvox; i += blockDim.x) {
-        const int c = bx.lo[0] + (int)(i % dc);
-        const int r = bx.lo[1] + (int)((i / dc) % dr);
-        const int s = bx.lo[2] + (int)(i / ((int64_t)dc * dr));
-        const double d = (double)fetch_wrapped(g, dens, c, r, s);
-        if (!((0.0 < cut && cut < d) || (d < cut && cut < 0.0) || cut == 0.0)) continue;
-        double q[3];
-        crs2xyz(g, c, r, s, q);
-        const double dx = q[0] - px, dy = q[1] - py, dz = q[2] - pz;
-        const double dist = __dsqrt_rn((dx * dx + dy * dy) + dz * dz);
-        if (!(dist <= rad)) continue;
-        const int lc = c - vd.org[0], lr = r - vd.org[1], ls = s - vd.org[2];
-        const int64_t w = vd.word_base + ((int64_t)ls * vd.dim[1] + lr) * vd.row_words + (lc >> 6);
-        atomicOr((unsigned long long *)&mask[w], 1ull << (lc & 63));
+    const unsigned pieces = ((unsigned)dc + 15u) / 16u, udr = (unsigned)dr;
+    const int64_t n_items64 = (int64_t)pieces * dr * dsz;
+    if (n_items64 >= (1ll << 31)) return;   // (unreachable: a box that large is rejected with its radius on the host side)
+    const unsigned n_items = (unsigned)n_items64;
+    for (unsigned it = threadIdx.x; it < n_items; it += blockDim.x) {
+        const unsigned row = it / pieces, piece = it - row * pieces, sl = row / udr;
+        const int r = bx.lo[1] + (int)(row - sl * udr), s = bx.lo[2] + (int)sl;
+        const int c0 = bx.lo[0] + 16 * (int)piece;
+        const int cnt = dc - 16 * (int)piece < 16 ? dc - 16 * (int)piece : 16;
+        float dv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) dv[u] = u < cnt ? fetch_wrapped(g, dens, c0 + u, r, s) : 0.0f;
+        const int lc0 = c0 - vd.org[0];
+        const int64_t row_word = vd.word_base + ((int64_t)(s - vd.org[2]) * vd.dim[1] + (r - vd.org[1])) * vd.row_words;
+        uint64_t bits = 0;
+        int cur = lc0 >> 6;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (u < cnt) {
+                const int lc = lc0 + u;
+                if ((lc >> 6) != cur) {
+                    if (bits) atomicOr((unsigned long long *)&mask[row_word + cur], bits);
+                    bits = 0;
+                    cur = lc >> 6;
+                }
+                const double d = (double)dv[u];
+                if ((0.0 < cut && cut < d) || (d < cut && cut < 0.0) || cut == 0.0) {
+                    double q[3];
+                    crs2xyz(g, c0 + u, r, s, q);
+                    const double dx = q[0] - px, dy = q[1] - py, dz = q[2] - pz;
+                    const double dist = __dsqrt_rn((dx * dx + dy * dy) + dz * dz);
+                    if (dist <= rad) bits |= 1ull << (lc & 63);
+                }
+            }
+        }
+        if (bits) atomicOr((unsigned long long *)&mask[row_word + cur], bits);
     }
 }
 
@@ -766,37 +828,45 @@ __global__ void k_list_paint(const int32_t *__restrict__ crs, const int32_t *__r
     atomicOr((unsigned long long *)&mask[w], 1ull << (lc & 63));
 }
 
-// Wave per word of a painted (cutoff-free) sphere-union volume: regional sums
-// (densityAnalysis.py:1183-1198) + testValidXyzList (cutils.pyx:273-313).
+// Regional sums over painted (cutoff-free) sphere-union volumes (densityAnalysis.py:1183-1198) + testValidXyzList
+// (cutils.pyx:273-313).  Workgroup per VOLUME (= group: the painted box of an atom or of a residue's atoms), thread per box
+// voxel in box order: an atom box is 16 voxels wide, so a lane per mask bit of one word would idle three lanes in four and
+// walk 256 words in a row; here every lane tests its own voxel's bit, four voxels in flight per thread, partial sums in
+// registers, ONE publish per volume.  The order of the fp64 additions is fixed (thread stride, shuffle tree, wave order).
 __global__ void __launch_bounds__(256) k_region_reduce(const Geom *__restrict__ gp, const float *__restrict__ dens,
                                                        const VolDesc *__restrict__ vols, int n_vols, const uint64_t *__restrict__ mask,
                                                        int64_t total_words, float cutoff, double *__restrict__ pos,
                                                        double *__restrict__ neg, unsigned long long *__restrict__ cnt,
                                                        unsigned int *__restrict__ invalid) {
-    // A wave per VOLUME (= group: the painted box of an atom or of a residue's atoms): it walks the volume's mask words,
-    // keeps the partial sums in registers and reduces / publishes ONCE -- no volume search, shuffles or atomics per word
-    // (a 16-voxel-wide atom box has 256 words of 16 voxels each).
-    const int lane = lane_id();
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    __shared__ double s_p[4], s_q[4];
+    __shared__ unsigned int s_n[4], s_bad[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const Geom &g = *gp;
     const double cut = (double)cutoff;
-    for (int64_t v = wave; v < n_vols; v += n_waves) {
+    for (int v = blockIdx.x; v < n_vols; v += gridDim.x) {
         const VolDesc vd = vols[v];
-        const int64_t n_words = (int64_t)vd.row_words * vd.dim[1] * vd.dim[2];
+        const unsigned dc = (unsigned)vd.dim[0], dr = (unsigned)vd.dim[1];
+        const unsigned nvox = dc * dr * (unsigned)vd.dim[2];      // (a volume is one group's bounding box: far below 2^32 voxels)
         double p = 0.0, q = 0.0;
-        unsigned long long n = 0;
+        unsigned int n = 0;
         bool bad = false;
-        for (int64_t k = 0; k < n_words; ++k) {
-            const uint64_t m = mask[vd.word_base + k];   // wave-uniform
-            if (m == 0ull) continue;
-            n += (unsigned long long)popc64(m);
-            if ((m >> lane) & 1ull) {
-                const int wq = (int)(k % vd.row_words);
-                const int64_t row = k / vd.row_words;
+        for (unsigned i0 = tid; i0 < nvox; i0 += 1024) {
+            unsigned c[4], row[4];
+            uint64_t m[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned i = i0 + 256u * u;
+                row[u] = i / dc;
+                c[u] = i - row[u] * dc;
+                m[u] = i < nvox ? mask[vd.word_base + (int64_t)row[u] * vd.row_words + (c[u] >> 6)] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!((m[u] >> (c[u] & 63)) & 1ull)) continue;
+                const unsigned sl = row[u] / dr, rl = row[u] - sl * dr;
                 bool ok = true;
-                const double d = (double)fetch_wrapped(g, dens, vd.org[0] + wq * 64 + lane, vd.org[1] + (int)(row % vd.dim[1]),
-                                                       vd.org[2] + (int)(row / vd.dim[1]), &ok);
+                const double d = (double)fetch_wrapped(g, dens, vd.org[0] + (int)c[u], vd.org[1] + (int)rl, vd.org[2] + (int)sl, &ok);
+                ++n;
                 if (d > cut) p += d;
                 if (d < -cut) q += d;
                 bad = bad || !ok;
@@ -807,13 +877,19 @@ __global__ void __launch_bounds__(256) k_region_reduce(const Geom *__restrict__ 
         for (int off = 32; off > 0; off >>= 1) {
             p += __shfl_down(p, off);
             q += __shfl_down(q, off);
+            n += __shfl_down(n, off);
         }
-        if (lane == 0) {
-            if (p != 0.0) unsafeAtomicAdd(&pos[vd.group], p);
-            if (q != 0.0) unsafeAtomicAdd(&neg[vd.group], q);
-            if (n) atomicAdd(&cnt[vd.group], n);
-            if (any_bad) atomicOr(&invalid[vd.group], 1u);
+        if (lane == 0) { s_p[wv] = p; s_q[wv] = q; s_n[wv] = n; s_bad[wv] = any_bad ? 1u : 0u; }
+        __syncthreads();
+        if (tid == 0) {
+            const double tp = ((s_p[0] + s_p[1]) + s_p[2]) + s_p[3], tq = ((s_q[0] + s_q[1]) + s_q[2]) + s_q[3];
+            const unsigned int tn = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+            if (tp != 0.0) unsafeAtomicAdd(&pos[vd.group], tp);
+            if (tq != 0.0) unsafeAtomicAdd(&neg[vd.group], tq);
+            if (tn) atomicAdd(&cnt[vd.group], (unsigned long long)tn);
+            if (s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) atomicOr(&invalid[vd.group], 1u);
         }
+        __syncthreads();
     }
 }
 
@@ -1153,15 +1229,11 @@ __global__ void __launch_bounds__(256) k_test_overlap(const int32_t *__restrict_
     if (hit) atomicOr(&out[p], 1u);
 }
 
-// utils.createSymmetryAtoms (cutils.pyx:73-103): thread per (i,j,k,op,atom) candidate in
-// the reference's product order; keep flag + coordinate, compacted on the host side of the
-// C-ABI in index order.
-__global__ void k_symmetry_atoms(const double *__restrict__ xyz, int64_t n_atoms, const double *__restrict__ rot, int n_ops,
-                                 const double *__restrict__ ortho, const double *__restrict__ lo, const double *__restrict__ hi,
-                                 double *__restrict__ out_xyz, uint8_t *__restrict__ keep) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = 27ll * n_ops * n_atoms;
-    if (t >= total) return;
+// utils.createSymmetryAtoms (cutils.pyx:73-103): candidate t = ((cell * n_ops) + op) * n_atoms + atom in the reference's
+// product order.  k_symmetry_keep tests every candidate (a keep BIT each: the flags are all the host needs to number the
+// survivors in order), k_symmetry_pick evaluates the coordinates of the listed survivors with the same arithmetic.
+__device__ inline bool symmetry_candidate(int64_t t, const double *__restrict__ xyz, int64_t n_atoms, const double *__restrict__ rot, int n_ops,
+                                          const double *__restrict__ ortho, const double *__restrict__ lo, const double *__restrict__ hi, double v[3]) {
     const int64_t a = t % n_atoms;
     const int64_t cell_op = t / n_atoms;
     const int op = (int)(cell_op % n_ops);
@@ -1169,9 +1241,8 @@ __global__ void k_symmetry_atoms(const double *__restrict__ xyz, int64_t n_atoms
     const int i = cell / 9 - 1, j = (cell / 3) % 3 - 1, k = cell % 3 - 1;
     const double p[3] = {xyz[3 * a], xyz[3 * a + 1], xyz[3 * a + 2]};
     if (i == 0 && j == 0 && k == 0 && op == 0) {
-        out_xyz[3 * t] = p[0]; out_xyz[3 * t + 1] = p[1]; out_xyz[3 * t + 2] = p[2];
-        keep[t] = 1;
-        return;
+        v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+        return true;
     }
     const double ijk[3] = {(double)i, (double)j, (double)k};
     double ot[3];
@@ -1179,12 +1250,33 @@ __global__ void k_symmetry_atoms(const double *__restrict__ xyz, int64_t n_atoms
     const double *rm = rot + 12 * op;
     bool in = true;
     for (int q = 0; q < 3; ++q) {
-        double v = ((rm[4 * q] * p[0] + rm[4 * q + 1] * p[1]) + rm[4 * q + 2] * p[2]);
-        v = (v + rm[4 * q + 3]) + ot[q];
-        out_xyz[3 * t + q] = v;
-        in = in && (lo[q] - 5 <= v) && (v <= hi[q] + 5);
+        double w = ((rm[4 * q] * p[0] + rm[4 * q + 1] * p[1]) + rm[4 * q + 2] * p[2]);
+        w = (w + rm[4 * q + 3]) + ot[q];
+        v[q] = w;
+        in = in && (lo[q] - 5 <= w) && (w <= hi[q] + 5);
     }
-    keep[t] = in ? 1 : 0;
+    return in;
+}
+
+__global__ void __launch_bounds__(256) k_symmetry_keep(const double *__restrict__ xyz, int64_t n_atoms, const double *__restrict__ rot, int n_ops,
+                                                       const double *__restrict__ ortho, const double *__restrict__ lo, const double *__restrict__ hi,
+                                                       unsigned long long *__restrict__ keep_bits) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = 27ll * n_ops * n_atoms;
+    double v[3];
+    const bool keep = t < total && symmetry_candidate(t, xyz, n_atoms, rot, n_ops, ortho, lo, hi, v);
+    const unsigned long long bits = __ballot(keep);
+    if ((threadIdx.x & 63) == 0 && t < total) keep_bits[t >> 6] = bits;
+}
+
+__global__ void __launch_bounds__(256) k_symmetry_pick(const double *__restrict__ xyz, int64_t n_atoms, const double *__restrict__ rot, int n_ops,
+                                                       const double *__restrict__ ortho, const double *__restrict__ lo, const double *__restrict__ hi,
+                                                       const int64_t *__restrict__ picked, int64_t n_picked, double *__restrict__ out_xyz) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_picked) return;
+    double v[3];
+    symmetry_candidate(picked[k], xyz, n_atoms, rot, n_ops, ortho, lo, hi, v);
+    out_xyz[3 * k] = v[0]; out_xyz[3 * k + 1] = v[1]; out_xyz[3 * k + 2] = v[2];
 }
 
 // Nearest atom per centroid (scipy cdist + argmin, densityAnalysis.py:934-935): block per

@@ -128,21 +128,35 @@ class SymAtom(object):
 
 
 class _SymAtomList(object):
-    """The list of SymAtom objects createSymmetryAtoms returns (cutils.pyx:73-103), materialised item by item."""
+    """The list of SymAtom objects createSymmetryAtoms returns (cutils.pyx:73-103), materialised item by item; the tables that
+    list thousands of them read whole columns instead (``columns``)."""
 
-    def __init__(self, atoms, idx, sym, xyz, ident, rows=None):
-        self._atoms, self._idx, self._sym, self._xyz, self._ident = atoms, idx, sym, xyz, ident
+    def __init__(self, cols, idx, sym, xyz, ident, rows=None):
+        self._cols, self._idx, self._sym, self._xyz, self._ident = cols, idx, sym, xyz, ident
         self._rows = np.arange(len(idx)) if rows is None else np.asarray(rows)
         self._made = {}
 
     def subset(self, rows):
-        return _SymAtomList(self._atoms, self._idx, self._sym, self._xyz, self._ident, self._rows[rows])
+        return _SymAtomList(self._cols, self._idx, self._sym, self._xyz, self._ident, self._rows[rows])
 
     def __len__(self):
         return len(self._rows)
 
+    def columns(self, items=None, type=""):
+        """(rows of the structure columns, symmetry tuples, coordinates as the SymAtom objects would hold them) of the listed
+        items (all by default), optionally only those whose atom name is ``type``."""
+        r = self._rows if items is None else self._rows[np.asarray(items, dtype=np.int64)]
+        atom_rows = self._idx[r]
+        if type:
+            keep = np.asarray(self._cols.name)[atom_rows] == type if len(r) else np.zeros(0, dtype=bool)
+            r, atom_rows = r[keep], atom_rows[keep]
+        symmetry = [tuple(t) for t in self._sym[r].tolist()]
+        atoms = self._cols.atoms
+        coords = [atoms[a].coord if same else xyz for a, same, xyz in zip(atom_rows.tolist(), self._ident[r].tolist(), self._xyz[r])]
+        return atom_rows, symmetry, coords
+
     def _make(self, r):
-        atom = self._atoms[int(self._idx[r])]
+        atom = self._cols.atoms[int(self._idx[r])]
         return SymAtom(atom, atom.coord if self._ident[r] else self._xyz[r], tuple(int(v) for v in self._sym[r]))
 
     def __getitem__(self, i):
@@ -155,6 +169,20 @@ class _SymAtomList(object):
 
     def __iter__(self):
         return (self[k] for k in range(len(self)))
+
+
+def _segmentMeans(values, counts):
+    """``np.mean`` of consecutive segments of ``values`` (``counts`` items each), bit-equal to calling it per segment: rows of
+    equal length are reduced together along their contiguous axis, which is the summation numpy uses for a 1-D array."""
+    counts = np.asarray(counts, dtype=np.int64)
+    start = np.cumsum(counts) - counts
+    out = np.full(len(counts), np.nan)
+    for k in np.unique(counts).tolist():
+        if k == 0:
+            continue
+        which = np.nonzero(counts == k)[0]
+        out[which] = np.add.reduce(values[start[which][:, None] + np.arange(k)[None, :]], axis=1) / k
+    return out
 
 
 def _norm3(x):
@@ -214,7 +242,6 @@ class DensityAnalysis(object):
         self._atomTypeOverlapCompleteness = None
         self._atomTypeOverlapIncompleteness = None
         self._fc = None
-        self._atomTableCache = None
 
     # ---- lazy properties (ref densityAnalysis.py:326-565) ------------------------------------
     def _lazy(name, trigger):
@@ -272,41 +299,77 @@ class DensityAnalysis(object):
     def _cloudInputs(self):
         """Flatten what aggregateCloud reads from the structure (densityAnalysis.py:596-603, 617-621, 653-656) into the arrays
         of ``pdbeda_cloud_atoms``: the eligible atoms in the reference's iteration order, a key per (residue, residue_atom
-        name), the bonded-name table restricted to each residue, and the 'owners' of the completeness count."""
+        name), the bonded-name table restricted to each residue, and the 'owners' of the completeness count.  Works on the
+        columnar snapshot of the structure (``structure.columns``): no per-atom Python."""
         typeMap, electronsMap, radii = fullAtomNameMapAtomTypeGlobal, fullAtomNameMapElectronsGlobal, radiiGlobal
-        residues = [res for res in self.biopdbObj.get_residues() if res.id[0] == ' ']
-        atoms, resAtoms, residue_of, key_of = [], [], [], []
-        keys = {}                       # (residue ordinal, residue_atom name) -> key id
-        children = []                   # (residue ordinal, residue_atom name) of EVERY child atom, for the owners
-        for ri, residue in enumerate(residues):
-            for atom in residue.child_list:
-                resAtom = residueAtomName(atom)
-                children.append((ri, resAtom))
-                if resAtom not in typeMap or atom.get_occupancy() == 0:
-                    continue
-                atoms.append(atom)
-                resAtoms.append(resAtom)
-                residue_of.append(ri)
-                key_of.append(keys.setdefault((ri, resAtom), len(keys)))
-        n = len(atoms)
-        coords = np.array([a.coord for a in atoms], dtype=np.float64).reshape(n, 3)
-        last = {}
-        for i, a in enumerate(atoms):
-            last[a.coord.tobytes()] = i                       # allAtomClouds is keyed by the coordinate: the last one wins (604)
-        alias = np.fromiter((last[a.coord.tobytes()] for a in atoms), dtype=np.int32, count=n)
-        bonded_off, bonded = [0], []
-        for (ri, resAtom) in keys:                            # (dicts keep insertion order = key id order)
-            bonded.extend(keys[(ri, r2)] for r2 in bondedAtomsGlobal[resAtom] if (ri, r2) in keys)
-            bonded_off.append(len(bonded))
-        owner_key = [keys[c] for c in children if c in keys]
-        owner_type = [typeMap[c[1]] for c in children if c in keys]
-        occupancy = np.fromiter((a.get_occupancy() for a in atoms), dtype=np.float64, count=n)
-        electrons = np.fromiter((electronsMap[ra] for ra in resAtoms), dtype=np.float64, count=n)
-        return {"residues": residues, "atoms": atoms, "resAtoms": resAtoms, "xyz": coords, "occupancy": occupancy, "electrons": electrons,
-                "radius": np.fromiter((radii[typeMap[ra]] for ra in resAtoms), dtype=np.float32, count=n),
-                "residue": np.asarray(residue_of, dtype=np.int32), "alias": alias, "key": np.asarray(key_of, dtype=np.int32),
-                "bonded_off": np.asarray(bonded_off, dtype=np.int64), "bonded": np.asarray(bonded, dtype=np.int32),
-                "owner_key": np.asarray(owner_key, dtype=np.int32), "owner_type": owner_type}
+        cols = _structure.columns(self.biopdbObj)
+        names = cols.pair_names
+        n_pairs = max(len(names), 1)
+        known = np.fromiter((name in typeMap for name in names), dtype=bool, count=len(names))
+        plain = ~cols.res_het                                                      # residues with id[0] == ' ' (596)
+        ordinal = np.cumsum(plain) - 1                                             # their running number
+        child = np.nonzero(plain[cols.res_of_atom])[0]                             # EVERY child atom of those residues, in order
+        child_res = ordinal[cols.res_of_atom[child]]
+        child_pair = cols.pair_of_atom[child]
+        eligible = known[child_pair] & (cols.occupancy[child] != 0) if len(child) else np.zeros(0, dtype=bool)
+        sel = child[eligible]                                                      # rows of cols.* of the eligible atoms
+        residue_of, pair_of = child_res[eligible], child_pair[eligible]
+        n = len(sel)
+        # key per (residue, name), numbered by first appearance
+        code = residue_of * n_pairs + pair_of
+        distinct, first, inverse = np.unique(code, return_index=True, return_inverse=True)
+        by_first = np.argsort(first, kind="stable")
+        rank = np.empty(len(distinct), dtype=np.int64)
+        rank[by_first] = np.arange(len(distinct))
+        key_of = rank[inverse]
+
+        def key_lookup(codes):
+            pos = np.minimum(np.searchsorted(distinct, codes), max(len(distinct) - 1, 0))
+            found = distinct[pos] == codes if len(distinct) else np.zeros(len(codes), dtype=bool)
+            return found, rank[pos[found]]
+        # allAtomClouds is keyed by the coordinate: the last atom with the same float32 triple wins (604)
+        triple = np.ascontiguousarray(cols.coord32[sel]).view(np.dtype((np.void, 12))).ravel()
+        _, same = np.unique(triple, return_inverse=True)
+        last = np.full(int(same.max()) + 1 if n else 0, -1, dtype=np.int64)
+        np.maximum.at(last, same, np.arange(n))
+        alias = last[same]
+        # the pair tables: type, electrons, radius, and the bonded names that exist in this structure
+        used = set(np.unique(pair_of).tolist())
+        pair_id = {name: k for k, name in enumerate(names)}
+        pair_electrons = np.zeros(n_pairs)
+        pair_radius = np.zeros(n_pairs, dtype=np.float32)
+        pair_type = [None] * n_pairs
+        nb_off = np.zeros(n_pairs + 1, dtype=np.int64)
+        nb = []
+        for k in range(len(names)):
+            if known[k]:
+                pair_type[k] = typeMap[names[k]]
+        for k in used:
+            pair_electrons[k] = electronsMap[names[k]]
+            pair_radius[k] = radii[pair_type[k]]
+        for k in range(len(names)):
+            if k in used:
+                nb.extend(pair_id[other] for other in bondedAtomsGlobal[names[k]] if other in pair_id)
+            nb_off[k + 1] = len(nb)
+        nb = np.asarray(nb, dtype=np.int64)
+        # bonded keys of every key, in key order then table order
+        key_code = distinct[by_first]
+        key_res, key_pair = key_code // n_pairs, key_code % n_pairs
+        counts = nb_off[key_pair + 1] - nb_off[key_pair]
+        owner = np.repeat(np.arange(len(key_code)), counts)
+        within = np.arange(int(counts.sum())) - np.repeat(np.cumsum(counts) - counts, counts)
+        found, bonded = key_lookup(key_res[owner] * n_pairs + nb[nb_off[key_pair][owner] + within]) if len(owner) else (np.zeros(0, dtype=bool), np.zeros(0, dtype=np.int64))
+        bonded_off = np.concatenate([[0], np.cumsum(np.bincount(owner[found], minlength=len(key_code)))]).astype(np.int64)
+        # owners of the completeness count: every child atom whose (residue, name) has a key (653-656)
+        found, owner_key = key_lookup(child_res * n_pairs + child_pair)
+        type_names = sorted({t for t in pair_type if t is not None})
+        type_id = {t: k for k, t in enumerate(type_names)}
+        pair_type_id = np.asarray([type_id[t] if t is not None else -1 for t in pair_type] + [-1] * (n_pairs - len(pair_type)), dtype=np.int64)
+        return {"cols": cols, "rows": sel, "plain_residues": np.nonzero(plain)[0], "xyz": cols.coord[sel], "occupancy": cols.occupancy[sel],
+                "electrons": pair_electrons[pair_of], "radius": pair_radius[pair_of], "pair": pair_of, "pair_type": pair_type,
+                "residue": residue_of.astype(np.int32), "alias": alias.astype(np.int32), "key": key_of.astype(np.int32),
+                "bonded_off": bonded_off, "bonded": bonded.astype(np.int32), "owner_key": owner_key.astype(np.int32),
+                "owner_type_id": pair_type_id[child_pair[found]], "type_names": type_names}
 
     def aggregateCloud(self, minCloudElectrons=25.0, minTotalElectrons=400.0):
         """Aggregate the 2Fo-Fc clouds by atom, residue and domain; sets ``densityElectronRatio``,
@@ -321,7 +384,7 @@ class DensityAnalysis(object):
         unitVolume = densityObj.header.unitVolume
         typeMap = fullAtomNameMapAtomTypeGlobal
         inp = self._cloudInputs()
-        if not inp["atoms"]:
+        if not len(inp["rows"]):
             return
         res = densityObj._map.aggregate_cloud(inp["xyz"], inp["radius"], inp["electrons"] * inp["occupancy"], inp["residue"], inp["alias"], inp["key"],
                                               inp["bonded_off"], inp["bonded"], inp["owner_key"], densityObj.densityCutoff, minCloudElectrons)
@@ -329,16 +392,17 @@ class DensityAnalysis(object):
             return
         completely = collections.defaultdict(int)
         incompletely = collections.defaultdict(int)
-        for atomType, state in zip(inp["owner_type"], res["owner_state"].tolist()):
-            if state == 1:
-                completely[atomType] += 1
-            elif state == 2:
-                incompletely[atomType] += 1
-        residues = inp["residues"]
+        n_types = len(inp["type_names"])
+        for counter, state in ((completely, 1), (incompletely, 2)):
+            per_type = np.bincount(inp["owner_type_id"][res["owner_state"] == state], minlength=n_types).tolist()
+            counter.update({t: c for t, c in zip(inp["type_names"], per_type) if c})
+        cols = inp["cols"]
+        plain = inp["plain_residues"].tolist()
 
         def cloudRows(t):
-            return [[residues[ri].parent.id, residues[ri].id[1], residues[ri].resname, tot / el, int(nv), el, int(nv) * unitVolume, list(cen)]
-                    for ri, tot, nv, el, cen in zip(t["residue"].tolist(), t["total"].tolist(), t["n"].tolist(), t["electrons"].tolist(), t["centroid"].tolist())]
+            which = [plain[ri] for ri in t["residue"].tolist()]
+            return [[cols.res_chain[k], cols.res_number[k], cols.res_name[k], tot / el, nv, el, nv * unitVolume, cen]
+                    for k, tot, nv, el, cen in zip(which, t["total"].tolist(), t["n"].tolist(), t["electrons"].tolist(), t["centroid"].tolist())]
         residueList = cloudRows(res["res"])
         domainList = cloudRows(res["dom"])
         numVoxels, totalElectrons, totalDensity = res["numVoxels"], res["totalElectrons"], res["totalDensity"]
@@ -375,16 +439,17 @@ class DensityAnalysis(object):
             ('density_electron_ratio', float), ('num_voxels', int), ('electrons', int), ('bfactor', float), ('centroid_distance', float),
             ('centroid_xyz', float, (3,)), ('adj_density_electron_ratio', float), ('domain_fraction', float), ('corrected_fraction', float),
             ('corrected_density_electron_ratio', float), ('volume', float)]))
-        picked = [inp["atoms"][i] for i in idx.tolist()]
-        table['chain'] = [a.parent.parent.id for a in picked]
-        table['residue_number'] = [a.parent.id[1] for a in picked]
-        table['residue_name'] = [a.parent.resname for a in picked]
-        table['atom_name'] = [a.name for a in picked]
-        table['atom_type'] = [typeMap[inp["resAtoms"][i]] for i in idx.tolist()]
+        cols, rows = inp["cols"], inp["rows"][idx]
+        of_residue = cols.res_of_atom[rows]
+        table['chain'] = np.asarray(cols.res_chain)[of_residue]
+        table['residue_number'] = np.asarray(cols.res_number)[of_residue]
+        table['residue_name'] = np.asarray(cols.res_name)[of_residue]
+        table['atom_name'] = np.asarray(cols.name)[rows]
+        table['atom_type'] = np.asarray([t if t is not None else '' for t in inp["pair_type"]])[inp["pair"][idx]]
         table['density_electron_ratio'] = res["atom_total"] / inp["electrons"][idx] / inp["occupancy"][idx]
         table['num_voxels'] = res["atom_n"]
         table['electrons'] = inp["electrons"][idx]
-        table['bfactor'] = [a.get_bfactor() for a in picked]
+        table['bfactor'] = cols.bfactor[rows]
         table['centroid_distance'] = res["atom_distance"]
         table['centroid_xyz'] = res["atom_centroid"]
         dist = table['centroid_distance']
@@ -393,15 +458,17 @@ class DensityAnalysis(object):
         atom_types, group = np.unique(table['atom_type'], return_inverse=True)
         n_types = len(atom_types)
 
+        group16 = group.astype(np.int16 if n_types < 32768 else np.int64)       # (16-bit keys: numpy's stable sort is a radix sort)
+        start = np.searchsorted(np.sort(group), np.arange(n_types))
+
         def typeMedians(values, keep=None):
-            """np.nanmedian of ``values`` per atom type: sort once by (type, value) -- NaNs and dropped rows last -- and take
-            the middle one or the mean of the middle two of every type's run."""
+            """np.nanmedian of ``values`` per atom type: order by value, then stably by type -- NaNs and dropped rows last in every
+            type's run -- and take the middle one or the mean of the middle two of every run."""
             v = np.asarray(values, dtype=np.float64)
             if keep is not None:
                 v = np.where(keep, v, np.nan)
-            order = np.lexsort((v, group))
-            sv = v[order]
-            start = np.searchsorted(group[order], np.arange(n_types))
+            by_value = np.argsort(v)
+            sv = v[by_value[np.argsort(group16[by_value], kind="stable")]]
             count = np.bincount(group, weights=~np.isnan(v), minlength=n_types).astype(np.int64)
             lo, hi = start + np.maximum(count - 1, 0) // 2, start + count // 2
             safe = np.minimum(np.stack([lo, hi]), max(len(sv) - 1, 0))
@@ -445,14 +512,14 @@ class DensityAnalysis(object):
         corners = np.array([[c, r, s] for c in [0, ncrs[0] - 1] for r in [0, ncrs[1] - 1] for s in [0, ncrs[2] - 1]], dtype=np.int32)
         box = densityObj._map.crs2xyz(corners)
         lo, hi = box.min(axis=0), box.max(axis=0)
-        atoms = list(self.biopdbObj.get_atoms())
-        coords = np.array([a.coord for a in atoms], dtype=np.float64)
+        cols = _structure.columns(self.biopdbObj)
+        coords = cols.coord
         rot = np.array([np.asarray(m, dtype=np.float64) for m in self.pdbObj.header.rotationMats])
         idx, sym, xyz = densityObj._ctx.symmetry_atoms(coords, rot, np.asarray(header.orthoMat, dtype=np.float64), lo, hi)
         ident = ~np.any(sym != 0, axis=1)
         allCoords = np.where(ident[:, None], coords[idx], xyz)      # == np.asarray([atom.coord ...]): float32 coordinates promote exactly
         # the SymAtom objects are made on demand: a blob-statistics table touches a few hundred of the thousands there are
-        allAtoms = _SymAtomList(atoms, idx, sym, xyz, ident)
+        allAtoms = _SymAtomList(cols, idx, sym, xyz, ident)
         self._symmetryAtoms = allAtoms
         self._symmetryAtomCoords = allCoords
         self._symmetryOnlyAtoms = allAtoms.subset(np.nonzero(~ident)[0])
@@ -469,15 +536,17 @@ class DensityAnalysis(object):
         ratio = self.densityElectronRatio
         if not blobList:
             return []
-        centroids = np.array([blob.centroid for blob in blobList], dtype=np.float64)
-        idx, dist = self.densityObj._ctx.nearest_atom(centroids, np.asarray(symmetryAtomCoords, dtype=np.float64))
-        blobStats = []
-        for blob, i, d in zip(blobList, idx, dist):
-            atom = symmetryAtoms[int(i)]
-            sign = '+' if blob.totalDensity >= 0 else '-'
-            blobStats.append([d, sign, abs(blob.totalDensity / ratio), blob.numVoxels, blob.volume, atom.parent.parent.id, atom.parent.id[1], atom.parent.resname,
-                              atom.name, atom.symmetry, atom.coord, blob.centroid])
-        return blobStats
+        centroid = [blob.centroid for blob in blobList]
+        total = np.array([blob.totalDensity for blob in blobList], dtype=np.float64)
+        idx, dist = self.densityObj._ctx.nearest_atom(np.array(centroid, dtype=np.float64), np.asarray(symmetryAtomCoords, dtype=np.float64))
+        rows, symmetry, coords = symmetryAtoms.columns(idx)
+        cols = _structure.columns(self.biopdbObj)
+        rows = rows.tolist()
+        chain, number, resname = (cols.atom_lists(which) for which in ("chain", "number", "resname"))
+        sign = np.where(total >= 0, '+', '-').tolist()
+        return [list(row) for row in zip(list(dist), sign, np.abs(total / ratio).tolist(), [blob.numVoxels for blob in blobList], [blob.volume for blob in blobList],
+                                         [chain[r] for r in rows], [number[r] for r in rows], [resname[r] for r in rows], [cols.name[r] for r in rows],
+                                         symmetry, coords, centroid)]
 
     # ---- Fo / Fc maps, RSCC / RSR (ref densityAnalysis.py:426-446, 783-882) -------------------
     @property
@@ -603,115 +672,138 @@ class DensityAnalysis(object):
                  atom.get_occupancy(), atom.get_bfactor()] for atom, cc, rr in zip(atomList, rscc, rsr)]
 
     # ---- region density / discrepancy (ref densityAnalysis.py:948-1211), batched ---------------
-    def _regionBatch(self, dm, groups, radii, cutoff):
-        """groups: list of lists of coordinates; radii: per-coordinate list of lists.  One device call."""
+    @staticmethod
+    def _flatten(groups, radii):
+        """Lists of coordinate lists + per-coordinate radius lists -> (xyz[n, 3], radius[n], offsets[groups + 1])."""
         sizes = np.fromiter((len(g) for g in groups), dtype=np.int64, count=len(groups))
         xyz = np.array([c for g in groups for c in g], dtype=np.float64).reshape(-1, 3)
         rad = np.fromiter((r for g in radii for r in g), dtype=np.float32, count=int(sizes.sum()))
-        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-        return dm._map.region_sums(xyz, rad, off, cutoff)
+        return xyz, rad, np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
 
     def _needRatio(self):
         if not self.densityElectronRatio:
             raise RuntimeError("Failed to calculate densityElectronRatio, probably due to total aggregated electrons less than the minimum.")
         return self.densityElectronRatio
 
-    def _densityRows(self, groups, radii, numSD, want_valid):
+    def _densityColumns(self, xyz, rad, off, numSD):
+        """The two columns of regionDensityHeader for every group of spheres (ONE device batch), and the validity flags."""
         ratio = self._needRatio()
         dm = self.densityObj
-        cutoff = dm.meanDensity + numSD * dm.stdDensity
-        pos, neg, cnt, valid = self._regionBatch(dm, groups, radii, cutoff)
-        rows = np.stack([pos, pos / ratio], axis=1).tolist()
-        return (rows, valid) if want_valid else rows
+        pos, neg, cnt, valid = dm._map.region_sums(xyz, rad, off, dm.meanDensity + numSD * dm.stdDensity)
+        return [pos.tolist(), (pos / ratio).tolist()], valid
 
-    def _discrepancyRows(self, groups, radii, numSD, want_valid):
+    def _discrepancyColumns(self, xyz, rad, off, numSD):
         """The ten columns of regionDiscrepancyHeader for every group, computed on whole columns (densityAnalysis.py:1200-1211)."""
         ratio = self._needRatio()
         dm = self.diffDensityObj
         cutoff = dm.meanDensity + numSD * dm.stdDensity
-        pos, neg, cnt, valid = self._regionBatch(dm, groups, radii, cutoff)
+        pos, neg, cnt, valid = dm._map.region_sums(xyz, rad, off, cutoff)
         avg = dm.getTotalAbsDensity(cutoff) / dm.densityArray.size
         absd = np.abs(pos) + np.abs(neg)
         expected = avg * cnt
         net = pos + neg
-        rows = np.stack([absd, absd / ratio, expected, expected / ratio, net, net / ratio, pos, pos / ratio, neg, neg / ratio], axis=1).tolist()
-        return (rows, valid) if want_valid else rows
+        return [c.tolist() for c in (absd, absd / ratio, expected, expected / ratio, net, net / ratio, pos, pos / ratio, neg, neg / ratio)], valid
 
-    def _atomTable(self):
-        """All atoms of the structure with the leading columns of the per-atom tables (model, chain, residue number, residue name,
-        atom name, occupancy: densityAnalysis.py:966-971), built once per analysis."""
-        if self._atomTableCache is None:
-            atoms = list(self.biopdbObj.get_atoms())
-            lead = [[a.parent.parent.parent.id, a.parent.parent.id, a.parent.id[1], a.parent.resname, a.name, a.get_occupancy()] for a in atoms]
-            self._atomTableCache = (atoms, lead)
-        return self._atomTableCache
+    @staticmethod
+    def _rows(*columns):
+        return [list(row) for row in zip(*columns)]
+
+    def _atomPick(self, type):
+        """Rows of the structure columns of the atoms named ``type`` (all when empty) and their leading table columns (model,
+        chain, residue number, residue name, atom name, occupancy: densityAnalysis.py:966-971)."""
+        cols = _structure.columns(self.biopdbObj)
+        lead = [cols.atom_lists("model"), cols.atom_lists("chain"), cols.atom_lists("number"), cols.atom_lists("resname"), cols.name, cols.occupancy_raw]
+        if not type:
+            return cols, np.arange(len(cols.atoms)), lead
+        pick = np.nonzero(np.asarray(cols.name) == type)[0] if cols.atoms else np.zeros(0, dtype=np.int64)
+        rows = pick.tolist()
+        return cols, pick, [[column[r] for r in rows] for column in lead]
+
+    def _pairRadius(self, cols, radius, useOptimizedRadii):
+        """Per-atom radius of the structure columns: the optimised radius of the atom type where the name is known, else ``radius``."""
+        if not useOptimizedRadii:
+            return np.full(len(cols.atoms), radius, dtype=np.float32)
+        typeMap = fullAtomNameMapAtomTypeGlobal
+        per_pair = np.array([radiiGlobal[typeMap[name]] if name in typeMap else radius for name in cols.pair_names] + [radius], dtype=np.float32)
+        return per_pair[cols.pair_of_atom]
+
+    def _symmetryPick(self, type):
+        atom_rows, symmetry, coords = self.symmetryAtoms.columns(None, type)
+        cols = _structure.columns(self.biopdbObj)
+        rows = atom_rows.tolist()
+        lead = [[column[r] for r in rows] for column in (cols.atom_lists("model"), cols.atom_lists("chain"), cols.atom_lists("number"), cols.atom_lists("resname"), cols.name)]
+        xyz = np.array(coords, dtype=np.float64).reshape(-1, 3)
+        return cols, atom_rows, lead + [symmetry, coords], xyz
+
+    def _residuePick(self, type, keepAtom, dropEmpty):
+        """Residues (optionally only those named ``type``) with the atoms ``keepAtom(residue name, atom name)`` lets through:
+        (lead columns incl. the mean occupancy, atom rows, offsets)."""
+        cols = _structure.columns(self.biopdbObj)
+        n_res = len(cols.residues)
+        res_keep = np.ones(n_res, dtype=bool) if not type else np.asarray(cols.res_name) == type
+        atom_keep = res_keep[cols.res_of_atom] if len(cols.atoms) else np.zeros(0, dtype=bool)
+        if keepAtom is not None:
+            resname = cols.atom_lists("resname")
+            atom_keep = atom_keep & np.fromiter((keepAtom(rn, an) for rn, an in zip(resname, cols.name)), dtype=bool, count=len(cols.atoms))
+        counts = np.bincount(cols.res_of_atom[atom_keep], minlength=n_res) if len(cols.atoms) else np.zeros(n_res, dtype=np.int64)
+        if dropEmpty:
+            res_keep = res_keep & (counts > 0)
+        which = np.nonzero(res_keep)[0]
+        counts = counts[which]
+        atom_rows = np.nonzero(atom_keep)[0]
+        mean_occupancy = _segmentMeans(cols.occupancy[atom_rows], counts)
+        rows = which.tolist()
+        lead = [[column[r] for r in rows] for column in (cols.res_model, cols.res_chain, cols.res_number, cols.res_name)] + [list(mean_occupancy)]
+        return cols, lead, atom_rows, np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
 
     def calculateRegionDensity(self, xyzCoordList, radius, numSD=1.5, testValidCrs=False):
         """ref densityAnalysis.py:1037-1068."""
         rad = list(radius) if isinstance(radius, (list, tuple, np.ndarray)) else [radius] * len(xyzCoordList)
-        out = self._densityRows([list(xyzCoordList)], [rad], numSD, testValidCrs)
-        return (out[0][0], bool(out[1][0])) if testValidCrs else out[0]
+        columns, valid = self._densityColumns(*self._flatten([list(xyzCoordList)], [rad]), numSD)
+        row = [column[0] for column in columns]
+        return (row, bool(valid[0])) if testValidCrs else row
 
     def calculateRegionDiscrepancy(self, xyzCoordList, radius, numSD=3.0, testValidCrs=False):
         """ref densityAnalysis.py:1160-1211."""
         rad = list(radius) if isinstance(radius, (list, tuple, np.ndarray)) else [radius] * len(xyzCoordList)
-        out = self._discrepancyRows([list(xyzCoordList)], [rad], numSD, testValidCrs)
-        return (out[0][0], bool(out[1][0])) if testValidCrs else out[0]
-
-    def _atomRadius(self, atom, radius, useOptimizedRadii):
-        resAtom = residueAtomName(atom)
-        return radiiGlobal[fullAtomNameMapAtomTypeGlobal[resAtom]] if useOptimizedRadii and resAtom in fullAtomNameMapAtomTypeGlobal else radius
+        columns, valid = self._discrepancyColumns(*self._flatten([list(xyzCoordList)], [rad]), numSD)
+        row = [column[0] for column in columns]
+        return (row, bool(valid[0])) if testValidCrs else row
 
     def calculateAtomRegionDensity(self, radius, numSD=1.5, type="", useOptimizedRadii=False):
         """ref densityAnalysis.py:948-973 (all atoms in ONE device batch)."""
-        atoms, lead = self._atomTable()
-        pick = [i for i, a in enumerate(atoms) if not type or a.name == type]
-        rows = self._densityRows([[atoms[i].coord] for i in pick], [[self._atomRadius(atoms[i], radius, useOptimizedRadii)] for i in pick], numSD, False)
-        return [lead[i] + r for i, r in zip(pick, rows)]
+        cols, pick, lead = self._atomPick(type)
+        columns, _ = self._densityColumns(cols.coord[pick], self._pairRadius(cols, radius, useOptimizedRadii)[pick], np.arange(len(pick) + 1, dtype=np.int64), numSD)
+        return self._rows(*lead, *columns)
 
     def calculateSymmetryAtomRegionDensity(self, radius, numSD=1.5, type="", useOptimizedRadii=False):
         """ref densityAnalysis.py:975-999."""
-        atoms = [a for a in self.symmetryAtoms if not type or a.name == type]
-        rows, valid = self._densityRows([[a.coord] for a in atoms], [[self._atomRadius(a, radius, useOptimizedRadii)] for a in atoms], numSD, True)
-        return [[a.parent.parent.parent.id, a.parent.parent.id, a.parent.id[1], a.parent.resname, a.name, a.symmetry, a.coord, bool(v)] + r
-                for a, r, v in zip(atoms, rows, valid)]
+        cols, atom_rows, lead, xyz = self._symmetryPick(type)
+        columns, valid = self._densityColumns(xyz, self._pairRadius(cols, radius, useOptimizedRadii)[atom_rows], np.arange(len(atom_rows) + 1, dtype=np.int64), numSD)
+        return self._rows(*lead, valid.astype(bool).tolist(), *columns)
 
     def calculateResidueRegionDensity(self, radius, numSD=1.5, type="", atomMask=None, useOptimizedRadii=False):
-        """ref densityAnalysis.py:1001-1035."""
-        sel = []
-        for residue in self.biopdbObj.get_residues():
-            if type and residue.resname != type:
-                continue
-            atoms = [a for a in residue.get_atoms() if not atomMask or residue.resname not in atomMask or a.name in atomMask[residue.resname]]
-            if atoms:
-                sel.append((residue, atoms))
-        rows = self._densityRows([[a.coord for a in atoms] for _, atoms in sel],
-                                 [[self._atomRadius(a, radius, useOptimizedRadii) for a in atoms] for _, atoms in sel], numSD, False)
-        return [[res.parent.parent.id, res.parent.id, res.id[1], res.resname, np.mean([a.get_occupancy() for a in atoms])] + r
-                for (res, atoms), r in zip(sel, rows)]
+        """ref densityAnalysis.py:1001-1035 (residues left without atoms by the mask are skipped)."""
+        keep = None if not atomMask else (lambda resname, name: resname not in atomMask or name in atomMask[resname])
+        cols, lead, atom_rows, off = self._residuePick(type, keep, True)
+        columns, _ = self._densityColumns(cols.coord[atom_rows], self._pairRadius(cols, radius, useOptimizedRadii)[atom_rows], off, numSD)
+        return self._rows(*lead, *columns)
 
     def calculateAtomRegionDiscrepancies(self, radius, numSD=3.0, type=""):
         """ref densityAnalysis.py:1081-1104 (33 ms/atom in the reference; ONE device batch here)."""
-        atoms, lead = self._atomTable()
-        pick = [i for i, a in enumerate(atoms) if not type or a.name == type]
-        rows = self._discrepancyRows([[atoms[i].coord] for i in pick], [[radius]] * len(pick), numSD, False)
-        return [lead[i] + r for i, r in zip(pick, rows)]
+        cols, pick, lead = self._atomPick(type)
+        columns, _ = self._discrepancyColumns(cols.coord[pick], np.full(len(pick), radius, dtype=np.float32), np.arange(len(pick) + 1, dtype=np.int64), numSD)
+        return self._rows(*lead, *columns)
 
     def calculateSymmetryAtomRegionDiscrepancies(self, radius, numSD=3.0, type=""):
         """ref densityAnalysis.py:1106-1128."""
-        atoms = [a for a in self.symmetryAtoms if not type or a.name == type]
-        rows, valid = self._discrepancyRows([[a.coord] for a in atoms], [[radius] for a in atoms], numSD, True)
-        return [[a.parent.parent.parent.id, a.parent.parent.id, a.parent.id[1], a.parent.resname, a.name, a.symmetry, a.coord, bool(v)] + r
-                for a, r, v in zip(atoms, rows, valid)]
+        cols, atom_rows, lead, xyz = self._symmetryPick(type)
+        columns, valid = self._discrepancyColumns(xyz, np.full(len(atom_rows), radius, dtype=np.float32), np.arange(len(atom_rows) + 1, dtype=np.int64), numSD)
+        return self._rows(*lead, valid.astype(bool).tolist(), *columns)
 
     def calculateResidueRegionDiscrepancies(self, radius, numSD=3.0, type="", atomMask=None):
-        """ref densityAnalysis.py:1130-1158."""
-        sel = []
-        for residue in self.biopdbObj.get_residues():
-            if type and residue.resname != type:
-                continue
-            atoms = [a for a in residue.get_atoms() if not atomMask or (residue.resname in atomMask and a.name in atomMask[residue.resname])]
-            sel.append((residue, atoms))
-        rows = self._discrepancyRows([[a.coord for a in atoms] for _, atoms in sel], [[radius] * len(atoms) for _, atoms in sel], numSD, False)
-        return [[res.parent.parent.id, res.parent.id, res.id[1], res.resname, np.mean([a.get_occupancy() for a in atoms])] + r
-                for (res, atoms), r in zip(sel, rows)]
+        """ref densityAnalysis.py:1130-1158 (with a mask, only atoms the mask names; residues it empties stay in the table)."""
+        keep = None if not atomMask else (lambda resname, name: resname in atomMask and name in atomMask[resname])
+        cols, lead, atom_rows, off = self._residuePick(type, keep, False)
+        columns, _ = self._discrepancyColumns(cols.coord[atom_rows], np.full(len(atom_rows), radius, dtype=np.float32), off, numSD)
+        return self._rows(*lead, *columns)

@@ -14,7 +14,7 @@ preparation, not part of the accelerated path.
 """
 import numpy as np
 
-__all__ = ["Structure", "Model", "Chain", "Residue", "Atom", "PDBHeader", "PDBEntry", "read_pdb"]
+__all__ = ["Structure", "Model", "Chain", "Residue", "Atom", "PDBHeader", "PDBEntry", "read_pdb", "columns", "Columns"]
 
 
 class _Entity(object):
@@ -127,6 +127,80 @@ class PDBEntry(object):
     def __init__(self, header, atoms=None):
         self.header = header
         self.atoms = atoms or []
+
+
+class Columns(object):
+    """A columnar snapshot of a structure: what the analysis reads from the object tree (see the module text), gathered in
+    ONE walk so that the per-entry host work runs on arrays instead of on 10^3..10^4 Python objects.
+
+    Order is the order of ``structure.get_residues()`` / ``get_atoms()`` (the atoms of a residue are contiguous).
+    Per residue: ``residues`` (the objects), ``res_model``, ``res_chain``, ``res_number``, ``res_name`` (lists),
+    ``res_het`` (bool array: ``id[0] != ' '``), ``res_start`` (int64[n_res + 1], atom range of every residue).
+    Per atom: ``atoms`` (the objects), ``name`` (list), ``res_of_atom`` (int64), ``coord32`` (float32[n, 3], the stored
+    coordinates), ``coord`` (float64, promoted exactly), ``occupancy``, ``bfactor`` (float64; ``occupancy_raw``: the objects as read), ``pair_of_atom`` (int64 index
+    into ``pair_names``, the distinct 'RES_ATOM' names of densityAnalysis.residueAtomName).
+    The snapshot is cached on the structure object: edit the tree and call ``columns(structure, refresh=True)``."""
+
+    def __init__(self, structure):
+        residues = list(structure.get_residues())
+        chains = [residue.parent for residue in residues]
+        ids = [residue.id for residue in residues]
+        res_model = [chain.parent.id for chain in chains]
+        res_chain = [chain.id for chain in chains]
+        res_number = [rid[1] for rid in ids]
+        res_name = [residue.resname for residue in residues]
+        res_het = [rid[0] != ' ' for rid in ids]
+        children = [residue.child_list for residue in residues]
+        res_start = [0]
+        pair_of_atom = []
+        pairs = {}
+        for resname, child_list in zip(res_name, children):
+            prefix = resname.strip() + '_'
+            pair_of_atom.extend([pairs.setdefault(prefix + atom.name, len(pairs)) for atom in child_list])
+            res_start.append(len(pair_of_atom))
+        atoms = [atom for child_list in children for atom in child_list]
+        name = [atom.name for atom in atoms]
+        occupancy = [atom.get_occupancy() for atom in atoms]
+        bfactor = [atom.get_bfactor() for atom in atoms]
+        coord = [atom.coord for atom in atoms]
+        n = len(atoms)
+        self.residues, self.atoms = residues, atoms
+        self.res_model, self.res_chain, self.res_number, self.res_name = res_model, res_chain, res_number, res_name
+        self.res_het = np.asarray(res_het, dtype=bool)
+        self.res_start = np.asarray(res_start, dtype=np.int64)
+        self.res_of_atom = np.repeat(np.arange(len(residues), dtype=np.int64), np.diff(self.res_start))
+        self.name = name
+        self.occupancy_raw = occupancy
+        self.occupancy = np.asarray(occupancy, dtype=np.float64)
+        self.bfactor = np.asarray(bfactor, dtype=np.float64)
+        self.coord32 = np.asarray(coord, dtype=np.float32).reshape(n, 3)
+        self.coord = self.coord32.astype(np.float64)
+        self.pair_of_atom = np.asarray(pair_of_atom, dtype=np.int64)
+        self.pair_names = list(pairs)
+
+    def atom_lists(self, which):
+        """Per-atom Python lists of residue-level columns ('model', 'chain', 'number', 'resname'), made on first use."""
+        cache = self.__dict__.setdefault("_atom_lists", {})
+        if which not in cache:
+            source = {"model": self.res_model, "chain": self.res_chain, "number": self.res_number, "resname": self.res_name}[which]
+            counts = np.diff(self.res_start).tolist()
+            out = []
+            for value, count in zip(source, counts):
+                out.extend([value] * count)
+            cache[which] = out
+        return cache[which]
+
+
+def columns(structure, refresh=False):
+    """The :class:`Columns` snapshot of ``structure`` (ours or a Bio.PDB one), built on first use and kept on the object."""
+    cols = None if refresh else getattr(structure, "_pdbeda_columns", None)
+    if cols is None:
+        cols = Columns(structure)
+        try:
+            structure._pdbeda_columns = cols
+        except AttributeError:
+            pass
+    return cols
 
 
 def read_pdb(handle_or_path, structure_id="xxxx"):

@@ -1,0 +1,89 @@
+"""Host logic: the columnar flattening of a structure for ``pdbeda_aggregate_cloud`` against a per-atom walk that follows
+the reference's loops (densityAnalysis.py:596-604, 617-621, 653-656) statement by statement."""
+import numpy as np
+import pytest
+
+from pdb_eda_amd import densityAnalysis as da, structure, synthetic
+
+
+def walk(biopdbObj):
+    """The plain loops: eligible atoms in iteration order, key per (residue, name) by first appearance, last atom per
+    coordinate, bonded keys within the residue, owners = every child atom whose (residue, name) has a key."""
+    typeMap, electronsMap, radii, bondedMap = da.fullAtomNameMapAtomTypeGlobal, da.fullAtomNameMapElectronsGlobal, da.radiiGlobal, da.bondedAtomsGlobal
+    residues = [res for res in biopdbObj.get_residues() if res.id[0] == ' ']
+    atoms, names, residue_of, key_of, keys, children = [], [], [], [], {}, []
+    for ri, residue in enumerate(residues):
+        for atom in residue.child_list:
+            name = da.residueAtomName(atom)
+            children.append((ri, name))
+            if name not in typeMap or atom.get_occupancy() == 0:
+                continue
+            atoms.append(atom)
+            names.append(name)
+            residue_of.append(ri)
+            key_of.append(keys.setdefault((ri, name), len(keys)))
+    last = {}
+    for i, a in enumerate(atoms):
+        last[a.coord.tobytes()] = i
+    bonded_off, bonded = [0], []
+    for (ri, name) in keys:
+        bonded.extend(keys[(ri, other)] for other in bondedMap[name] if (ri, other) in keys)
+        bonded_off.append(len(bonded))
+    return {"atoms": atoms, "xyz": np.array([a.coord for a in atoms], dtype=np.float64).reshape(len(atoms), 3),
+            "occupancy": np.array([a.get_occupancy() for a in atoms], dtype=np.float64),
+            "electrons": np.array([electronsMap[n] for n in names], dtype=np.float64),
+            "radius": np.array([radii[typeMap[n]] for n in names], dtype=np.float32),
+            "residue": np.array(residue_of, dtype=np.int32), "key": np.array(key_of, dtype=np.int32),
+            "alias": np.array([last[a.coord.tobytes()] for a in atoms], dtype=np.int32),
+            "bonded_off": np.array(bonded_off, dtype=np.int64), "bonded": np.array(bonded, dtype=np.int32),
+            "owner_key": np.array([keys[c] for c in children if c in keys], dtype=np.int32),
+            "owner_type": [typeMap[c[1]] for c in children if c in keys], "residues": residues}
+
+
+def make_structure(seed, n_res):
+    rng = np.random.default_rng(seed)
+    st = synthetic.chain_structure(n_res, 3, np.array([2.0, 2.0, 2.0]), np.array([40.0, 40.0, 40.0]), hetero_every=5, zero_occupancy_every=7)
+    atoms = list(st.get_atoms())
+    for k in rng.choice(len(atoms), size=max(2, len(atoms) // 9), replace=False):          # shared coordinates (alternate models of a site)
+        atoms[int(k)].coord = atoms[int(rng.integers(len(atoms)))].coord.copy()
+    res = list(st.get_residues())
+    extra = res[min(1, len(res) - 1)]
+    structure.Atom("XX9", np.array([5.0, 5.0, 5.0]), 1.0, 10.0, "X", extra)                  # a name the tables do not know
+    structure.Atom(extra.child_list[0].name, np.array([6.0, 5.0, 5.0]), 0.5, 10.0, "C", extra)   # a repeated (residue, name)
+    return st
+
+
+@pytest.mark.parametrize("seed,n_res", [(1, 1), (2, 7), (3, 60), (4, 211)])
+def test_cloud_inputs_match_the_plain_walk(seed, n_res):
+    da.setGlobals(synthetic.synthetic_params())
+    st = make_structure(seed, n_res)
+    inp = da.DensityAnalysis("t", None, None, st, None)._cloudInputs()
+    ref = walk(st)
+    cols = inp["cols"]
+    assert [cols.atoms[i] for i in inp["rows"].tolist()] == ref["atoms"]
+    for name in ("xyz", "occupancy", "electrons", "radius", "residue", "key", "alias", "bonded_off", "bonded", "owner_key"):
+        got, want = np.asarray(inp[name]), ref[name]
+        assert got.dtype == want.dtype and got.shape == want.shape and (got == want).all(), name
+    assert [inp["type_names"][k] for k in inp["owner_type_id"].tolist()] == ref["owner_type"]
+    assert [cols.residues[k] for k in inp["plain_residues"].tolist()] == ref["residues"]
+
+
+def test_cloud_inputs_empty_structure():
+    da.setGlobals(synthetic.synthetic_params())
+    st = structure.Structure("e")
+    structure.Chain("A", structure.Model(0, st))
+    inp = da.DensityAnalysis("t", None, None, st, None)._cloudInputs()
+    assert len(inp["rows"]) == 0
+
+
+def test_columns_snapshot():
+    st = make_structure(9, 12)
+    cols = structure.columns(st)
+    assert structure.columns(st) is cols and structure.columns(st, refresh=True) is not cols
+    atoms = list(st.get_atoms())
+    assert cols.atoms == atoms and cols.residues == list(st.get_residues())
+    assert (cols.coord == np.array([a.coord for a in atoms], dtype=np.float64)).all()
+    assert [cols.pair_names[k] for k in cols.pair_of_atom.tolist()] == [da.residueAtomName(a) for a in atoms]
+    assert cols.atom_lists("chain") == [a.parent.parent.id for a in atoms]
+    assert cols.atom_lists("number") == [a.parent.id[1] for a in atoms]
+    assert [cols.residues[k] for k in cols.res_of_atom.tolist()] == [a.parent for a in atoms]
