@@ -143,7 +143,7 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
     try:
         t0 = time.perf_counter()
         distinct = 4                 # distinct synthetic entries on disk (generating 125 different 200^3 maps would take minutes of CPU)
-        loaders = [synthetic.write_entry_files(tmp, "e%d" % k, args.entry_size, args.entry_residues, 1000 * rank + k) for k in range(distinct)]
+        loaders = [synthetic.write_entry_files(tmp, "e%d" % k, args.entry_size, args.entry_residues, 1000 * rank + k, as_paths=True) for k in range(distinct)]
         gen_s = time.perf_counter() - t0
         entries = [multipleStructures.Entry("r%de%04d" % (rank, i), loaders[i % distinct], cost_hint=0.0) for i in range(args.entries)]
         pool.warm()
@@ -224,6 +224,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    pinned_cpus = _native.pin_to_device(local_rank)      # host side of this rank on the GPU's NUMA node (the workers above do the same)
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
@@ -404,7 +405,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": "configs[1]: %d^3 synthetic CCP4 grid (gaussian-filtered noise, sigma_filter 1.5 voxels), fused green/red blob "
                                "labelling at +-(mean+%.1f*std), per-blob fp64 stats%s, map resident in HBM" % (n, args.nsd, " + dense int32 labels of both signs" if labels else ""),
-                   "grid": [n, n, n], "cutoff_sigma": args.nsd, "labels": labels, "entries_per_rank": 1, "sharding": "one entry per rank, no data-path collective"},
+                   "grid": [n, n, n], "cutoff_sigma": args.nsd, "labels": labels, "entries_per_rank": 1, "sharding": "one entry per rank, no data-path collective",
+                   "host_affinity": ("%d cores of the GPU's NUMA node" % pinned_cpus) if pinned_cpus else "unchanged"},
         "entries_per_min": 60.0 * world * args.steps / elapsed,
         "blobs": {"green": n_green, "red": n_red, "significant_voxels": sig_vox, "all_ranks": [int(x) for x in totals.tolist()]},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -64,6 +64,10 @@ typedef struct pdbeda_geometry {
 /* ---- library / context ------------------------------------------------------------ */
 const char *pdbeda_version(void);
 int pdbeda_device_count(void);
+/* PCI address of a device ("0000:dc:00.0"): /sys/bus/pci/devices/<address>/local_cpulist names the host cores of the GPU's
+ * NUMA node.  The reference's multiprocessing pool (multipleStructures.py:167-168) leaves placement to the OS; a worker that
+ * feeds a GPU from the other socket reads and uploads its maps across the socket link (measured: 4x slower per entry). */
+int pdbeda_device_pci_address(int device_id, char *out, int out_len);
 int pdbeda_ctx_create(int device_id, pdbeda_ctx **out);
 /* Bind to an existing hipStream_t (e.g. torch's current stream); stream == NULL -> new stream. */
 int pdbeda_ctx_create_on_stream(int device_id, void *hip_stream, pdbeda_ctx **out);
@@ -88,6 +92,11 @@ int pdbeda_ctx_profile_end(pdbeda_ctx *ctx, char *buf, int64_t cap);
 int pdbeda_map_upload(pdbeda_ctx *ctx, const float *density, const pdbeda_geometry *geom, pdbeda_map **out);
 /* density_dev: a device pointer the caller keeps alive (zero-copy, e.g. a torch tensor). */
 int pdbeda_map_from_device(pdbeda_ctx *ctx, const float *density_dev, const pdbeda_geometry *geom, pdbeda_map **out);
+/* The grid of a CCP4 FILE straight into HBM (ccp4.read -> parse, ccp4.py:58-127): n = ncrs[0]*ncrs[1]*ncrs[2] float32 values
+ * starting at byte `offset` (1024 + the symmetry records) of `path`, read through two pinned chunks that alternate between
+ * pread() and the PCIe copy; byteswap != 0 when the file has the other endianness (swapped on the device).  No host copy
+ * of the map exists afterwards (pdbeda_map_download fetches one on demand). */
+int pdbeda_map_upload_file(pdbeda_ctx *ctx, const char *path, int64_t offset, int byteswap, const pdbeda_geometry *geom, pdbeda_map **out);
 int pdbeda_map_free(pdbeda_map *map);
 /* A new map on the geometry of `a` with density  float32( double(a) + alpha * double(b) )  per voxel -- the Fc map of
  * DensityAnalysis.fc is (2Fo-Fc) - 2 (Fo-Fc), densityAnalysis.py:426-435 (alpha = -2).  Same grid shape required. */

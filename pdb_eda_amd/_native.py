@@ -25,6 +25,7 @@ class PdbedaTimeout(PdbedaError):
 
 
 PDBEDA_ERR_TIMEOUT = -6
+PDBEDA_ERR_ARGUMENT = -2
 
 
 class Geometry(C.Structure):
@@ -69,6 +70,7 @@ _i64 = C.c_int64
 _SIGS = {
     "pdbeda_version": (C.c_char_p, []),
     "pdbeda_device_count": (C.c_int, []),
+    "pdbeda_device_pci_address": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "pdbeda_ctx_create": (C.c_int, [C.c_int, C.POINTER(_p)]),
     "pdbeda_ctx_create_on_stream": (C.c_int, [C.c_int, _p, C.POINTER(_p)]),
     "pdbeda_ctx_destroy": (C.c_int, [_p]),
@@ -79,6 +81,7 @@ _SIGS = {
     "pdbeda_ctx_profile_begin": (C.c_int, [_p]),
     "pdbeda_ctx_profile_end": (C.c_int, [_p, C.c_char_p, _i64]),
     "pdbeda_map_upload": (C.c_int, [_p, _p, C.POINTER(Geometry), C.POINTER(_p)]),
+    "pdbeda_map_upload_file": (C.c_int, [_p, C.c_char_p, _i64, C.c_int, C.POINTER(Geometry), C.POINTER(_p)]),
     "pdbeda_map_from_device": (C.c_int, [_p, _p, C.POINTER(Geometry), C.POINTER(_p)]),
     "pdbeda_map_free": (C.c_int, [_p]),
     "pdbeda_map_combine": (C.c_int, [_p, _p, C.c_double, C.POINTER(_p)]),
@@ -154,7 +157,9 @@ class Context(object):
         if rc != 0:
             msg = self._lib.pdbeda_last_error(self._h)
             cls = PdbedaTimeout if rc == PDBEDA_ERR_TIMEOUT else PdbedaError
-            raise cls("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+            error = cls("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+            error.code = rc
+            raise error
 
     def set_timeout(self, seconds):
         """Arm (seconds > 0) or disarm (0) the per-entry watchdog: see pdbeda_ctx_set_timeout in include/pdbeda.h."""
@@ -230,6 +235,43 @@ class Context(object):
 
 _default_ctx = {}
 _default_lock = threading.Lock()
+
+
+def device_local_cpus(device=0):
+    """Host cores on the NUMA node of GPU ``device`` (sysfs ``local_cpulist`` of its PCI function), or None when the
+    platform does not say (no sysfs, a single node, a container that hides it)."""
+    buf = C.create_string_buffer(64)
+    if lib().pdbeda_device_pci_address(int(device), buf, 64) != 0:
+        return None
+    address = buf.value.decode().strip().lower()
+    try:
+        with open("/sys/bus/pci/devices/%s/local_cpulist" % address) as fh:
+            text = fh.read().strip()
+    except OSError:
+        return None
+    cpus = set()
+    for part in text.split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus or None
+
+
+def pin_to_device(device=0):
+    """Restrict the calling thread (and the threads and processes it starts afterwards) to the cores of the GPU's NUMA node:
+    file reads, parsing and the pageable side of every upload then stay on the socket the GPU hangs off.  Returns the number
+    of cores kept, or 0 when nothing was changed."""
+    if not hasattr(os, "sched_setaffinity"):
+        return 0
+    local = device_local_cpus(device)
+    if not local:
+        return 0
+    keep = local & os.sched_getaffinity(0)
+    if not keep or keep == os.sched_getaffinity(0):
+        return 0
+    os.sched_setaffinity(0, keep)
+    return len(keep)
 
 
 def default_context(device=None):
@@ -329,6 +371,24 @@ class DeviceMap(object):
         ctx.check(rc, "pdbeda_map_upload")
         self._h = h
         self.unique_shape = tuple(min(geometry.ncrs[k], geometry.xyz_interval[geometry.map2crs[k]]) for k in (2, 1, 0))
+
+    @classmethod
+    def from_file(cls, ctx, path, offset, byteswap, geometry):
+        """The float32 grid stored at byte ``offset`` of ``path`` straight into HBM (pinned double buffer: file read and PCIe
+        copy overlap; no host copy of the map is kept)."""
+        self = cls.__new__(cls)
+        self._ctx, self._geom, self._keep = ctx, geometry, None
+        h = C.c_void_p()
+        try:
+            ctx.check(ctx._lib.pdbeda_map_upload_file(ctx._h, os.fsencode(path), int(offset), 1 if byteswap else 0, C.byref(geometry), C.byref(h)),
+                      "pdbeda_map_upload_file")
+        except PdbedaError as error:
+            if getattr(error, "code", 0) == PDBEDA_ERR_ARGUMENT:       # the FILE is at fault (unreadable, truncated): an entry-level condition
+                raise OSError(str(error))
+            raise
+        self._h = h
+        self.unique_shape = tuple(min(geometry.ncrs[k], geometry.xyz_interval[geometry.map2crs[k]]) for k in (2, 1, 0))
+        return self
 
     @classmethod
     def combine(cls, a, b, alpha):

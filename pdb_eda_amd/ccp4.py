@@ -11,6 +11,9 @@ the unit-cell basis to :func:`pdb_eda_amd._native.map_upload`.
 There is no CPU fallback: constructing a ``DensityMatrix`` without the HIP library /
 a GPU raises.
 """
+import os
+import sys
+
 import numpy as np
 
 from . import _native
@@ -19,11 +22,27 @@ __all__ = ["read", "parse", "read_grid", "DensityHeader", "DensityMatrix", "Dens
 
 
 def read(ccp4Filename, pdbid=None, verbose=False, ctx=None):
-    """``ccp4.read`` (ref ccp4.py:58-74); ``ctx``: the context (= stream) the map becomes resident on."""
+    """``ccp4.read`` (ref ccp4.py:58-74); ``ctx``: the context (= stream) the map becomes resident on.
+
+    An uncompressed mode-2 file goes from the page cache to HBM through the library's pinned double buffer
+    (``pdbeda_map_upload_file``): only the header is parsed here, and ``DensityMatrix.density`` is fetched back on demand."""
     if not pdbid:
         pdbid = ccp4Filename
     with open(ccp4Filename, "rb") as fileHandle:
-        return parse(fileHandle, pdbid, verbose, ctx=ctx)
+        head = fileHandle.read(1024)
+        header = DensityHeader.fromFileHeader(head) if len(head) == 1024 else None
+        n_bytes = 4 * header.ncrs[0] * header.ncrs[1] * header.ncrs[2] if header is not None else 0
+        direct = header is not None and header.mode == 2 and n_bytes > 0 and os.fstat(fileHandle.fileno()).st_size == 1024 + header.symmetryBytes + n_bytes
+        if not direct:
+            fileHandle.seek(0)
+            return parse(fileHandle, pdbid, verbose, ctx=ctx)
+        assert header.xlength != 0.0 or header.ylength != 0.0 or header.zlength != 0.0, \
+            "Error: Cell dimensions are all 0, Map file will not align with other structures"
+        header.symmetry = fileHandle.read(header.symmetryBytes)
+    ctx = ctx if ctx is not None else _native.default_context()
+    swapped = header.endian != ("<" if sys.byteorder == "little" else ">")
+    device_map = _native.DeviceMap.from_file(ctx, ccp4Filename, 1024 + header.symmetryBytes, swapped, header.geometry())
+    return DensityMatrix.fromDeviceMap(header, header.origin, device_map, pdbid, ctx)
 
 
 def read_grid(handle):
@@ -193,13 +212,14 @@ class DensityMatrix(object):
 
     @classmethod
     def fromDeviceMap(cls, header, origin, device_map, pdbid, ctx):
-        """A DensityMatrix around a map that already lives in HBM (e.g. ``DeviceMap.combine``); ``density`` is downloaded
-        once, for inspection."""
+        """A DensityMatrix around a map that already lives in HBM (``DeviceMap.combine`` / ``from_file``); ``density`` is
+        downloaded on first use, for inspection."""
         self = cls.__new__(cls)
         self.pdbid, self.header, self.origin = pdbid, header, origin
         self._ctx, self._map = ctx, device_map
-        self.density = device_map.download()
-        self.densityArray = self.density.reshape(-1)
+        self._density = None
+        self._densityArray = None
+        self._flatOf = None
         self._meanDensity = self._stdDensity = None
         self._totalAbsDensity = {}
         return self
@@ -211,13 +231,46 @@ class DensityMatrix(object):
         grid = np.asarray(density)
         if grid.dtype != np.float32 or not grid.dtype.isnative:
             grid = grid.astype(np.float32)
-        self.density = np.ascontiguousarray(grid).reshape(header.ncrs[2], header.ncrs[1], header.ncrs[0])
-        self.densityArray = self.density.reshape(-1)
+        self._density = np.ascontiguousarray(grid).reshape(header.ncrs[2], header.ncrs[1], header.ncrs[0])
+        self._densityArray = None
+        self._flatOf = None                 # another DensityMatrix whose flat array stands in for this one's (densityAnalysis.fc)
         self._ctx = ctx if ctx is not None else _native.default_context()
-        self._map = _native.DeviceMap(self._ctx, self.density, header.geometry())
+        self._map = _native.DeviceMap(self._ctx, self._density, header.geometry())
         self._meanDensity = None
         self._stdDensity = None
         self._totalAbsDensity = {}
+
+    @property
+    def density(self):
+        """The float32 grid [section][row][column] on the host (ref ccp4.py:337); fetched from HBM when the map never had a
+        host copy."""
+        if self._density is None:
+            self._density = self._map.download()
+        return self._density
+
+    @density.setter
+    def density(self, value):
+        self._density = value
+
+    @property
+    def densityArray(self):
+        """ref ccp4.py:338: the flat view of ``density`` (or whatever was assigned to it)."""
+        if self._densityArray is not None:
+            return self._densityArray
+        return self._flatOf.densityArray if self._flatOf is not None else self.density.reshape(-1)
+
+    @densityArray.setter
+    def densityArray(self, value):
+        self._densityArray = value
+
+    @property
+    def numStoredVoxels(self):
+        """``densityArray.size`` without touching the host copy."""
+        if self._densityArray is not None:
+            return self._densityArray.size
+        if self._flatOf is not None:
+            return self._flatOf.numStoredVoxels
+        return self.header.ncrs[0] * self.header.ncrs[1] * self.header.ncrs[2]
 
     # -- whole-map reductions -------------------------------------------------------
     def _stats(self):

@@ -1,6 +1,10 @@
 // pdbeda_hip.hip -- host side of libpdbeda_hip.so: contexts, device arenas, job setup and the
 // extern "C" entry points declared in include/pdbeda.h.  gfx950 only, no CPU fallback.
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <cerrno>
 
 #include <algorithm>
 #include <chrono>
@@ -44,6 +48,9 @@ struct pdbeda_ctx {
     size_t pinned_cap = 0, pinned_used = 0;
     struct Pending { void *dst; size_t off, bytes; };
     std::vector<Pending> pending;
+    // file -> device uploads (pdbeda_map_upload_file): two pinned chunks filled by pread() while the other one is in flight
+    char *ring[2] = {nullptr, nullptr};
+    hipEvent_t ring_done[2] = {nullptr, nullptr};
     int live_handles = 0;
     // optional per-kernel timing with HIP events on ctx->stream (bench.py's roofline leg)
     bool profiling = false;
@@ -269,6 +276,13 @@ extern "C" int pdbeda_device_count(void) {
     return n;
 }
 
+extern "C" int pdbeda_device_pci_address(int device_id, char *out, int out_len) {
+    if (!out || out_len < 16) return PDBEDA_ERR_ARGUMENT;
+    out[0] = 0;
+    if (hipDeviceGetPCIBusId(out, out_len, device_id) != hipSuccess) { (void)hipGetLastError(); return PDBEDA_ERR_DEVICE; }
+    return PDBEDA_OK;
+}
+
 extern "C" int pdbeda_ctx_create_on_stream(int device_id, void *hip_stream, pdbeda_ctx **out) {
     if (!out) return PDBEDA_ERR_ARGUMENT;
     *out = nullptr;
@@ -310,6 +324,10 @@ extern "C" int pdbeda_ctx_destroy(pdbeda_ctx *ctx) {
     ctx->pool.clear();
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->ring[k]) (void)hipHostFree(ctx->ring[k]);
+        if (ctx->ring_done[k]) (void)hipEventDestroy(ctx->ring_done[k]);
+    }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PDBEDA_OK;
@@ -430,6 +448,94 @@ extern "C" int pdbeda_map_upload(pdbeda_ctx *ctx, const float *density, const pd
 }
 extern "C" int pdbeda_map_from_device(pdbeda_ctx *ctx, const float *density_dev, const pdbeda_geometry *geom, pdbeda_map **out) {
     return map_create(ctx, nullptr, density_dev, geom, out);
+}
+
+// Wait for an event of the context's stream with the watchdog's rules (see ctx_wait).
+static hipError_t event_wait(pdbeda_ctx *ctx, hipEvent_t ev) {
+    if (ctx->timed_out) return hipErrorNotReady;
+    if (ctx->timeout_s <= 0.0) return hipEventSynchronize(ev);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q != hipErrorNotReady) return q;
+        if (spins > 256) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > ctx->timeout_s) {
+                ctx->timed_out = true;
+                ctx->err = "watchdog: the stream did not drain within the per-entry time-out; context abandoned";
+                return hipErrorNotReady;
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+    }
+}
+
+// The grid of a CCP4 file straight into HBM: pread() fills one pinned chunk while the previous one is on its way over PCIe,
+// so an entry costs max(page-cache copy, DMA) instead of read + copy to a staging buffer + DMA, and no host copy of the map
+// is ever made (ccp4.py:77-127 unpacks it into a Python tuple).  byteswap: the file has the other endianness.
+static const size_t FILE_CHUNK = (size_t)4 << 20;
+extern "C" int pdbeda_map_upload_file(pdbeda_ctx *ctx, const char *path, int64_t offset, int byteswap, const pdbeda_geometry *geom, pdbeda_map **out) {
+    if (!ctx || !path || !geom || !out || offset < 0) return PDBEDA_ERR_ARGUMENT;
+    *out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t n_vox = (int64_t)geom->ncrs[0] * geom->ncrs[1] * geom->ncrs[2];
+    if (n_vox <= 0 || n_vox >= (1ll << 32)) return fail(ctx, PDBEDA_ERR_ARGUMENT, "grid size out of range");
+    const size_t need = sizeof(float) * (size_t)n_vox;
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return fail(ctx, PDBEDA_ERR_ARGUMENT, "cannot open %s: %s", path, strerror(errno));
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || (int64_t)sb.st_size < offset + (int64_t)need) {
+        close(fd);
+        return fail(ctx, PDBEDA_ERR_ARGUMENT, "%s holds fewer than %lld grid bytes after offset %lld", path, (long long)need, (long long)offset);
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (!ctx->ring[k] && hipHostMalloc((void **)&ctx->ring[k], FILE_CHUNK, hipHostMallocDefault) != hipSuccess) { ctx->ring[k] = nullptr; (void)hipGetLastError(); }
+        if (!ctx->ring_done[k] && hipEventCreateWithFlags(&ctx->ring_done[k], hipEventDisableTiming) != hipSuccess) { ctx->ring_done[k] = nullptr; (void)hipGetLastError(); }
+        if (!ctx->ring[k] || !ctx->ring_done[k]) { close(fd); return fail(ctx, PDBEDA_ERR_MEMORY, "no pinned chunk for the file upload"); }
+    }
+    pdbeda_map *m = new pdbeda_map();
+    m->ctx = ctx;
+    int rc = fill_geom(ctx, geom, &m->geom);
+    if (rc == 0) rc = arena_get(ctx, align_up(sizeof(Geom)) + align_up(need), &m->arena);
+    if (rc) { close(fd); delete m; return rc; }
+    m->n_vox = n_vox;
+    Carver cv(m->arena.base);
+    m->geom_dev = cv.take<Geom>(1);
+    float *d = cv.take<float>((size_t)n_vox);
+    m->dens = d;
+    m->own_dens = true;
+    hipError_t e = hipMemcpyAsync(m->geom_dev, &m->geom, sizeof(Geom), hipMemcpyHostToDevice, ctx->stream);
+    const char *why = nullptr;
+    int64_t chunk_no = 0;
+    for (size_t pos = 0; pos < need && e == hipSuccess && !why; pos += FILE_CHUNK, ++chunk_no) {
+        const int b = (int)(chunk_no & 1);
+        if (chunk_no >= 2) e = event_wait(ctx, ctx->ring_done[b]);        // the chunk sent from this buffer two rounds ago has left it
+        if (e != hipSuccess) break;
+        const size_t len = std::min(FILE_CHUNK, need - pos);
+        for (size_t got = 0; got < len;) {
+            const ssize_t r = pread(fd, ctx->ring[b] + got, len - got, (off_t)(offset + (int64_t)pos + (int64_t)got));
+            if (r < 0 && errno == EINTR) continue;
+            if (r <= 0) { why = r < 0 ? strerror(errno) : "unexpected end of file"; break; }
+            got += (size_t)r;
+        }
+        if (why) break;
+        e = hipMemcpyAsync((char *)d + pos, ctx->ring[b], len, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ring_done[b], ctx->stream);
+    }
+    close(fd);
+    if (e == hipSuccess && !why && byteswap) {
+        hipLaunchKernelGGL(k_byteswap32, dim3(grid_for(n_vox, 256, 8192)), dim3(256), 0, ctx->stream, (uint32_t *)d, n_vox);
+        e = hipGetLastError();
+    }
+    const hipError_t e2 = ctx_sync(ctx);      // (the ring and &m->geom are free again)
+    if (e == hipSuccess) e = e2;
+    if (e != hipSuccess || why) {
+        arena_put(ctx, m->arena);
+        delete m;
+        return why ? fail(ctx, PDBEDA_ERR_ARGUMENT, "reading %s: %s", path, why) : fail(ctx, PDBEDA_ERR_DEVICE, "map upload from file: %s", hipGetErrorString(e));
+    }
+    ctx->live_handles++;
+    *out = m;
+    return PDBEDA_OK;
 }
 
 extern "C" int pdbeda_map_combine(pdbeda_map *a, pdbeda_map *b, double alpha, pdbeda_map **out) {

@@ -962,6 +962,11 @@ __global__ void __launch_bounds__(256) k_abs_select_hist(const Geom *__restrict_
 }
 
 // out = float32(double(a) + alpha * double(b)), float4 per thread (the Fc map: alpha = -2).
+// In-place 32-bit byte swap of an uploaded grid (a CCP4 file written on a machine of the other endianness).
+__global__ void __launch_bounds__(256) k_byteswap32(uint32_t *__restrict__ x, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] = __builtin_bswap32(x[i]);
+}
+
 __global__ void __launch_bounds__(256) k_map_combine(const float *__restrict__ a, const float *__restrict__ b, double alpha, int64_t n,
                                                      float *__restrict__ out) {
     const int64_t n4 = n >> 2;

@@ -567,7 +567,7 @@ class DensityAnalysis(object):
         if self._fc is None:
             d = self.densityObj
             fc = ccp4.DensityMatrix.fromDeviceMap(d.header, d.origin, type(d._map).combine(d._map, self.diffDensityObj._map, -2.0), d.pdbid, d._ctx)
-            fc.densityArray = d.densityArray
+            fc._flatOf = d                      # (== fc.densityArray = d.densityArray, without fetching a host copy)
             fc._meanDensity, fc._stdDensity = d.meanDensity, d.stdDensity
             fc._totalAbsDensity = d._totalAbsDensity
             self._fc = fc
@@ -698,7 +698,7 @@ class DensityAnalysis(object):
         dm = self.diffDensityObj
         cutoff = dm.meanDensity + numSD * dm.stdDensity
         pos, neg, cnt, valid = dm._map.region_sums(xyz, rad, off, cutoff)
-        avg = dm.getTotalAbsDensity(cutoff) / dm.densityArray.size
+        avg = dm.getTotalAbsDensity(cutoff) / dm.numStoredVoxels
         absd = np.abs(pos) + np.abs(neg)
         expected = avg * cnt
         net = pos + neg

@@ -12,6 +12,7 @@ Filters and reload: out of scope.
 import collections
 import csv
 import io
+import os
 import json
 import sys
 import queue
@@ -28,7 +29,9 @@ statsHeaders = ['density_electron_ratio', 'voxel_volume', 'f000', 'num_voxels_ag
 
 
 class Entry(object):
-    """One PDB entry: a loader returning (2Fo-Fc CCP4 bytes, Fo-Fc CCP4 bytes, structure, pdbObj)."""
+    """One PDB entry: a loader returning (2Fo-Fc map, Fo-Fc map, structure, pdbObj); a map is either the bytes of a CCP4
+    file (a download held in memory, densityAnalysis.py:96-99 of the reference) or the path of one on disk (its local-mirror
+    mode), which goes from the page cache to HBM without a host copy (``ccp4.read``)."""
 
     def __init__(self, pdbid, loader, cost_hint=0.0):
         self.pdbid = pdbid
@@ -51,6 +54,13 @@ def _drop(pdbid, reason, failures, silent):
     return 0
 
 
+def loadMap(source, pdbid, ctx=None):
+    """A resident DensityMatrix from what an entry loader hands over: CCP4 bytes, or the path of a CCP4 file."""
+    if isinstance(source, (str, os.PathLike)):
+        return ccp4.read(os.fspath(source), pdbid, ctx=ctx)
+    return ccp4.parse(io.BytesIO(source), pdbid, ctx=ctx)
+
+
 def analyzeEntry(entry, ctx=None, failures=None, silent=False):
     """ref multipleStructures.py:320-356: one entry -> result record, or 0 when the ENTRY fails (its files do not load or
     parse, the analysis raises, or there is no density-electron ratio: Q7); the reason goes to ``failures[pdbid]`` and to
@@ -58,9 +68,9 @@ def analyzeEntry(entry, ctx=None, failures=None, silent=False):
     a HIP fault, a missing library, the watchdog) are NOT entry failures: they propagate."""
     startTime = time.thread_time()
     try:
-        dens_bytes, diff_bytes, biopdbObj, pdbObj = entry.loader()
-        densityObj = ccp4.parse(io.BytesIO(dens_bytes), entry.pdbid, ctx=ctx)
-        diffDensityObj = ccp4.parse(io.BytesIO(diff_bytes), entry.pdbid, ctx=ctx)
+        dens, diff, biopdbObj, pdbObj = entry.loader()
+        densityObj = loadMap(dens, entry.pdbid, ctx)
+        diffDensityObj = loadMap(diff, entry.pdbid, ctx)
         densityAnalysis._attachCutoffs(densityObj, diffDensityObj)
         analyzer = densityAnalysis.DensityAnalysis(entry.pdbid, densityObj, diffDensityObj, biopdbObj, pdbObj)
         ratio = analyzer.densityElectronRatio
@@ -197,6 +207,7 @@ _worker_state = {}
 
 def _worker_init(device, params, time_out, silent):
     _worker_state.update(device=device, time_out=time_out, silent=silent)
+    _native.pin_to_device(device)          # the worker's reads, parsing and uploads stay on the GPU's socket
     if params is not None:
         densityAnalysis.setGlobals(params)
 

@@ -12,22 +12,21 @@ and stays with the caller: ``sweep`` takes the parameter tables to evaluate.
 Entries keep their parsed maps resident in HBM between iterations (``ResidentEntry``): an iteration changes radii and
 slopes, never the maps, so only the analysis is repeated.
 """
-import io
 import time
 
 import numpy as np
 
-from . import _native, ccp4, densityAnalysis, multipleStructures, optimizeStats
+from . import _native, densityAnalysis, multipleStructures, optimizeStats
 
 
 class ResidentEntry(object):
     """An entry whose two maps were parsed and uploaded once (by the worker thread that owns ``ctx``)."""
 
     def __init__(self, entry, ctx):
-        dens_bytes, diff_bytes, self.biopdbObj, self.pdbObj = entry.loader()
+        dens, diff, self.biopdbObj, self.pdbObj = entry.loader()
         self.pdbid = entry.pdbid
-        self.densityObj = ccp4.parse(io.BytesIO(dens_bytes), entry.pdbid, ctx=ctx)
-        self.diffDensityObj = ccp4.parse(io.BytesIO(diff_bytes), entry.pdbid, ctx=ctx)
+        self.densityObj = multipleStructures.loadMap(dens, entry.pdbid, ctx)
+        self.diffDensityObj = multipleStructures.loadMap(diff, entry.pdbid, ctx)
         densityAnalysis._attachCutoffs(self.densityObj, self.diffDensityObj)
 
 

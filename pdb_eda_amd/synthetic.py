@@ -203,7 +203,7 @@ def sweep_param_sets():
 
 # ---- synthetic entries on disk (BASELINE configs[3] / [4]: "1 000 synthetic 200^3 grids ... ~500 atoms each") ---------------------
 
-def write_entry_files(directory, tag, edge, n_residues, seed, spacing=0.5):
+def write_entry_files(directory, tag, edge, n_residues, seed, spacing=0.5, as_paths=False):
     """Generate ONE synthetic entry -- a 2Fo-Fc-like map (sum of atomic Gaussians + noise) and an Fo-Fc-like map (filtered noise)
     on an ``edge``^3 grid around a poly-ALA chain of ``n_residues`` -- and write its two CCP4 files.  Returns the picklable
     loader (:class:`SyntheticEntryFiles`) the worker processes of a pool use."""
@@ -219,7 +219,7 @@ def write_entry_files(directory, tag, edge, n_residues, seed, spacing=0.5):
     for path, grid in zip(paths, (dens, diff)):
         with open(path, "wb") as fh:
             fh.write(ccp4_bytes(spec, grid))
-    return SyntheticEntryFiles(paths[0], paths[1], n_residues, seed, edge, spacing)
+    return SyntheticEntryFiles(paths[0], paths[1], n_residues, seed, edge, spacing, as_paths)
 
 
 class SyntheticEntryFiles(object):
@@ -228,9 +228,10 @@ class SyntheticEntryFiles(object):
     cost that matters, a coordinate file parser is outside the path).  Picklable: pools hand it to worker processes."""
     _structures = {}
 
-    def __init__(self, density_path, diff_path, n_residues, seed, edge, spacing):
+    def __init__(self, density_path, diff_path, n_residues, seed, edge, spacing, as_paths=False):
         self.density_path, self.diff_path = density_path, diff_path
         self.n_residues, self.seed, self.edge, self.spacing = n_residues, seed, edge, spacing
+        self.as_paths = as_paths          # hand the file PATHS to the analysis (local-mirror mode) instead of their bytes
 
     def structure(self):
         from . import ccp4, structure
@@ -247,9 +248,14 @@ class SyntheticEntryFiles(object):
         return SyntheticEntryFiles._structures[key]
 
     def __call__(self):
+        if self.as_paths:
+            st, pdb = self.structure()
+            st.__dict__.pop("_pdbeda_columns", None)
+            return self.density_path, self.diff_path, st, pdb
         with open(self.density_path, "rb") as fh:
             dens = fh.read()
         with open(self.diff_path, "rb") as fh:
             diff = fh.read()
         st, pdb = self.structure()
+        st.__dict__.pop("_pdbeda_columns", None)        # (a real entry arrives with a fresh structure: no snapshot carried over)
         return dens, diff, st, pdb

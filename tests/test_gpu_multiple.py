@@ -133,6 +133,8 @@ def test_process_pool_matches_sequential(tmp_path, gpu_ctx):
     entries = [multipleStructures.Entry("x%02d" % i, loaders[i % 2]) for i in range(6)]
     bad = synthetic.SyntheticEntryFiles(str(tmp_path / "missing.ccp4"), loaders[0].diff_path, 24, 300, 72, 0.5)
     entries.insert(3, multipleStructures.Entry("gone", bad))
+    by_path = synthetic.SyntheticEntryFiles(loaders[1].density_path, loaders[1].diff_path, 24, 301, 72, 0.5, as_paths=True)
+    entries[5] = multipleStructures.Entry("x04", by_path)        # the same entry handed over as file paths (page cache -> HBM)
     seq = [multipleStructures.analyzeEntry(e, gpu_ctx, silent=True) for e in entries]
     pool = multipleStructures.ProcessPool(device=0, n_workers=2, params=params, silent=True)
     try:
@@ -150,3 +152,40 @@ def test_process_pool_matches_sequential(tmp_path, gpu_ctx):
         assert a["pdbid"] == b["pdbid"] and a["stats"]["num_voxels_aggregated"] == b["stats"]["num_voxels_aggregated"]
         assert a["stats"]["density_electron_ratio"] == pytest.approx(b["stats"]["density_electron_ratio"], rel=1e-12)
         assert a["diffs"] == pytest.approx(b["diffs"], rel=1e-9, abs=1e-12)
+
+
+def test_ccp4_file_goes_straight_to_the_device(tmp_path, gpu_ctx):
+    """``ccp4.read`` of a mode-2 file: header parsed on the host, grid from the file to HBM through the library's pinned double
+    buffer -- the same resident map as parsing the bytes (both endiannesses, symmetry records skipped, more than two chunks),
+    the host copy only on demand; a truncated file is an entry-level error (OSError), not a device failure."""
+    import numpy as np
+    from pdb_eda_amd import _native, ccp4, synthetic
+    spec = synthetic.MapSpec(ncrs=(160, 130, 150), spacing=0.45)          # 12.5 MB grid: four 4 MiB chunks, the last one partial
+    grid = synthetic.smooth_noise((150, 130, 160), seed=11, sigma_voxels=1.2)
+    raw = synthetic.ccp4_bytes(spec, grid, symmetry_bytes=b"X" * 160)
+    big = synthetic.ccp4_bytes(spec, grid, big_endian=True)
+    for name, payload in (("little.ccp4", raw), ("big.ccp4", bytes(big))):
+        path = tmp_path / name
+        path.write_bytes(payload)
+        want = ccp4.parse(__import__("io").BytesIO(payload), "ref", ctx=gpu_ctx)
+        got = ccp4.read(str(path), "file", ctx=gpu_ctx)
+        assert got._density is None                                        # no host copy was made
+        assert got.header.ncrs == want.header.ncrs and got.header.endian == want.header.endian
+        assert (got.meanDensity, got.stdDensity) == (want.meanDensity, want.stdDensity)
+        assert got.numStoredVoxels == want.densityArray.size
+        cut = want.meanDensity + 2.0 * want.stdDensity
+        a, b = got.createFullBlobList(cut), want.createFullBlobList(cut)
+        assert len(a) == len(b) > 10 and all(x.numVoxels == y.numVoxels and x.totalDensity == y.totalDensity for x, y in zip(a, b))
+        assert np.array_equal(got.density, want.density) and got.densityArray.shape == want.densityArray.shape
+    short = tmp_path / "short.ccp4"
+    short.write_bytes(raw[:len(raw) - 4096])
+    with pytest.raises(Exception) as err:                                  # the size check sends it down the parsing path, which fails on the count
+        ccp4.read(str(short), "short", ctx=gpu_ctx)
+    assert not isinstance(err.value, _native.PdbedaError)
+    from pdb_eda_amd._native import DeviceMap
+    hdr = ccp4.DensityHeader.fromFileHeader(raw[:1024])
+    with pytest.raises(OSError):                                           # the library's own check of the file length
+        DeviceMap.from_file(gpu_ctx, str(short), 1024 + 160, False, hdr.geometry())
+    with pytest.raises(OSError):
+        DeviceMap.from_file(gpu_ctx, str(tmp_path / "absent.ccp4"), 1024, False, hdr.geometry())
+    assert len(ccp4.read(str(tmp_path / "little.ccp4"), ctx=gpu_ctx).createFullBlobList(cut)) == len(b)      # the context is still good
