@@ -43,3 +43,17 @@ def test_no_cpu_fallback():
             if f.endswith((".py", ".h", ".hip")):
                 src += open(os.path.join(dirpath, f)).read()
     assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) and "libpdbeda_oracle" not in src
+
+
+def test_numa_helpers_degrade_without_a_device():
+    """``device_local_cpus`` / ``pin_to_device`` never raise: no GPU, no sysfs or a single node leave the affinity alone."""
+    import os
+    before = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    cpus = _native.device_local_cpus(0)
+    assert cpus is None or (isinstance(cpus, set) and cpus)
+    kept = _native.pin_to_device(0)
+    assert isinstance(kept, int) and kept >= 0
+    if before is not None:
+        if kept == 0:
+            assert os.sched_getaffinity(0) == before
+        os.sched_setaffinity(0, before)
