@@ -47,7 +47,7 @@ def test_no_cpu_fallback():
 
 def test_numa_helpers_degrade_without_a_device():
     """``device_local_cpus`` / ``pin_to_device`` never raise: no GPU, no sysfs or a single node leave the affinity alone."""
-    import os
+    from pdb_eda_amd import _native
     before = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
     cpus = _native.device_local_cpus(0)
     assert cpus is None or (isinstance(cpus, set) and cpus)
