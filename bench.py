@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--workers", type=int, default=4, help="multiple-structure leg: worker processes (= streams) per GPU")
     ap.add_argument("--entry-size", type=int, default=200, help="multiple-structure leg: grid edge of an entry (configs[3]: 200)")
     ap.add_argument("--entry-residues", type=int, default=100, help="multiple-structure leg: poly-ALA residues per entry (~500 atoms)")
+    ap.add_argument("--sweep-entries", type=int, default=32, help="optimise-mode leg (BASELINE configs[4]): resident entries per rank; 0 = skip")
+    ap.add_argument("--sweep-iterations", type=int, default=3, help="optimise-mode leg: parameter tables evaluated (one changed radius each)")
     return ap.parse_args()
 
 
@@ -182,6 +184,50 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
                 "pool_vs_one_worker": (args.entries / elapsed) * single, "generation_s": gen_s,
                 "note": "worker processes (spawn), one HIP stream each, sharing the GPU of the rank; sharding over ranks is one entry list per rank, no collective"}
     finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def sweep_leg(args, rank, local_rank, world, barrier, dist, torch):
+    """BASELINE configs[4]: one iteration of the radius optimisation = every resident entry re-analysed under a candidate
+    parameter table + the statistics reduction (all-gather of rows, all-reduce of counters: RCCL when world > 1)."""
+    import shutil
+    import tempfile
+    from pdb_eda_amd import synthetic, multipleStructures, optimizeSweep
+    tmp = tempfile.mkdtemp(prefix="pdbeda_sweep_%d_" % rank)
+    sw = None
+    try:
+        distinct = 4
+        loaders = [synthetic.write_entry_files(tmp, "s%d" % k, args.entry_size, args.entry_residues, 5000 + 1000 * rank + k, as_paths=True) for k in range(distinct)]
+        entries = [multipleStructures.Entry("r%ds%04d" % (rank, i), loaders[i % distinct], cost_hint=0.0) for i in range(args.sweep_entries)]
+        t0 = time.perf_counter()
+        sw = optimizeSweep.ProcessSweep(entries, local_rank, args.workers)
+        load_s = time.perf_counter() - t0
+        sets = synthetic.sweep_param_sets()
+        sets = [sets[k % len(sets)] for k in range(1, args.sweep_iterations + 1)]
+        sw.iteration(sets[0])                                   # untimed: first-use costs of the workers
+        barrier()
+        t0 = time.perf_counter()
+        for params in sets:
+            reduction, records = sw.iteration(params)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        ok = sum(1 for r in records if r)
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        per = elapsed / (len(sets) * max(1, args.sweep_entries))
+        return {"workload": "configs[4]: %d resident entries per rank (%d^3 maps, ~%d atoms), %d parameter tables of a radius sweep: per table every entry is "
+                            "re-analysed (aggregateCloud -> diffs / slopes / overlap counters) and the records are reduced over all ranks" %
+                            (args.sweep_entries, args.entry_size, 5 * args.entry_residues, len(sets)),
+                "entries": args.sweep_entries * world, "iterations": len(sets), "workers_per_gpu": args.workers, "seconds": elapsed,
+                "ms_per_entry_iteration_per_gpu": 1e3 * per, "entry_iterations_per_s": world / per, "entries_ok_last_iteration": ok,
+                "reduced_types": len(reduction[0]), "load_s": load_s,
+                "reduction": "optimizeStats: all_gather of per-entry rows + all_reduce of counters (%s)" % ("RCCL" if dist is not None else "single process: no group"),
+                "note": "worker processes keep their lane of entries resident in HBM between iterations; load_s includes spawning them"}
+    finally:
+        if sw is not None:
+            sw.close()
         shutil.rmtree(tmp, ignore_errors=True)
 
 
@@ -383,6 +429,11 @@ def main():
     if pool is not None:
         multiple = multiple_leg(args, pool, rank, local_rank, world, barrier, dist if world > 1 else None, torch)
 
+    # ---- BASELINE configs[4]: optimise-mode iterations over resident entries + the statistics reduction (informational) ----
+    sweep = None
+    if args.sweep_entries > 0 and args.sweep_iterations > 0:
+        sweep = sweep_leg(args, rank, local_rank, world, barrier, dist if world > 1 else None, torch)
+
     # host -> HBM upload of one entry (the boundary hands over a host buffer); never part of `value`
     t1 = time.perf_counter()
     tmp = _native.DeviceMap(ctx, grid, header.geometry())
@@ -429,6 +480,8 @@ def main():
         out["analysis_entry"] = analysis
     if multiple:
         out["multiple_structures"] = multiple
+    if sweep:
+        out["radius_sweep"] = sweep
 
     # ---- CPU baseline: the oracle (CPU restatement, O(N) clustering) on the same entry, 1 core ----
     if rank == 0 and not args.no_cpu_baseline:

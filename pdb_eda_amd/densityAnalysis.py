@@ -297,12 +297,30 @@ class DensityAnalysis(object):
 
     # ---- aggregateCloud (ref densityAnalysis.py:571-780) --------------------------------------
     def _cloudInputs(self):
+        """The arrays of ``pdbeda_cloud_atoms`` for the current parameter tables.  Everything but the radius column depends on
+        the structure and on the name -> type / electrons / bonded tables only, so it is kept on the structure's snapshot
+        while those tables are the same objects: the iterations of optimise mode (optimizeParams.py:232-243 passes
+        ``{**params, "radii": ..., "slopes": ...}``) change radii and slopes, nothing else."""
+        cols = _structure.columns(self.biopdbObj)
+        tables = (fullAtomNameMapAtomTypeGlobal, fullAtomNameMapElectronsGlobal, bondedAtomsGlobal)
+        cached = cols.__dict__.get("_cloud_inputs")
+        if cached is None or any(a is not b for a, b in zip(cached[0], tables)):
+            cached = (tables, self._cloudInputsFixed(cols))            # (holding the tables keeps their identity meaningful)
+            cols._cloud_inputs = cached
+        inp = dict(cached[1])
+        pair_radius = np.zeros(len(inp["pair_type"]), dtype=np.float32)
+        for k in inp["used_pairs"]:
+            pair_radius[k] = radiiGlobal[inp["pair_type"][k]]
+        inp["radius"] = pair_radius[inp["pair"]]
+        return inp
+
+    @staticmethod
+    def _cloudInputsFixed(cols):
         """Flatten what aggregateCloud reads from the structure (densityAnalysis.py:596-603, 617-621, 653-656) into the arrays
         of ``pdbeda_cloud_atoms``: the eligible atoms in the reference's iteration order, a key per (residue, residue_atom
         name), the bonded-name table restricted to each residue, and the 'owners' of the completeness count.  Works on the
         columnar snapshot of the structure (``structure.columns``): no per-atom Python."""
-        typeMap, electronsMap, radii = fullAtomNameMapAtomTypeGlobal, fullAtomNameMapElectronsGlobal, radiiGlobal
-        cols = _structure.columns(self.biopdbObj)
+        typeMap, electronsMap = fullAtomNameMapAtomTypeGlobal, fullAtomNameMapElectronsGlobal
         names = cols.pair_names
         n_pairs = max(len(names), 1)
         known = np.fromiter((name in typeMap for name in names), dtype=bool, count=len(names))
@@ -337,7 +355,6 @@ class DensityAnalysis(object):
         used = set(np.unique(pair_of).tolist())
         pair_id = {name: k for k, name in enumerate(names)}
         pair_electrons = np.zeros(n_pairs)
-        pair_radius = np.zeros(n_pairs, dtype=np.float32)
         pair_type = [None] * n_pairs
         nb_off = np.zeros(n_pairs + 1, dtype=np.int64)
         nb = []
@@ -346,7 +363,6 @@ class DensityAnalysis(object):
                 pair_type[k] = typeMap[names[k]]
         for k in used:
             pair_electrons[k] = electronsMap[names[k]]
-            pair_radius[k] = radii[pair_type[k]]
         for k in range(len(names)):
             if k in used:
                 nb.extend(pair_id[other] for other in bondedAtomsGlobal[names[k]] if other in pair_id)
@@ -366,7 +382,7 @@ class DensityAnalysis(object):
         type_id = {t: k for k, t in enumerate(type_names)}
         pair_type_id = np.asarray([type_id[t] if t is not None else -1 for t in pair_type] + [-1] * (n_pairs - len(pair_type)), dtype=np.int64)
         return {"cols": cols, "rows": sel, "plain_residues": np.nonzero(plain)[0], "xyz": cols.coord[sel], "occupancy": cols.occupancy[sel],
-                "electrons": pair_electrons[pair_of], "radius": pair_radius[pair_of], "pair": pair_of, "pair_type": pair_type,
+                "electrons": pair_electrons[pair_of], "used_pairs": sorted(used), "pair": pair_of, "pair_type": pair_type,
                 "residue": residue_of.astype(np.int32), "alias": alias.astype(np.int32), "key": key_of.astype(np.int32),
                 "bonded_off": bonded_off, "bonded": bonded.astype(np.int32), "owner_key": owner_key.astype(np.int32),
                 "owner_type_id": pair_type_id[child_pair[found]], "type_names": type_names}

@@ -95,11 +95,111 @@ class Sweep(object):
         self._pool.close()
 
 
-def sweep(entries, paramSets, device=0, n_streams=4, rank=0, world_size=1, silent=True):
+def _sweep_worker(conn, device, lane, silent):
+    """A worker process of ProcessSweep: owns one context and the resident maps of its lane of entries; serves iterations."""
+    try:
+        _native.pin_to_device(device)
+        ctx = _native.Context(device)
+        failures, resident = {}, []
+        for i, entry in lane:
+            try:
+                resident.append((i, ResidentEntry(entry, ctx)))
+            except _native.PdbedaError:
+                raise
+            except Exception as exception:
+                multipleStructures._drop(entry.pdbid, "%s: %s" % (type(exception).__name__, exception), failures, silent)
+        conn.send(("ready", failures))
+        while True:
+            params = conn.recv()
+            if params is None:
+                return
+            densityAnalysis.setGlobals(params)
+            records, failures = {}, {}
+            for i, res in resident:
+                t0 = time.thread_time()
+                analyzer = densityAnalysis.DensityAnalysis(res.pdbid, res.densityObj, res.diffDensityObj, res.biopdbObj, res.pdbObj)
+                try:
+                    records[i] = processRecord(analyzer, params, t0)
+                except _native.PdbedaError:
+                    raise
+                except Exception as exception:
+                    multipleStructures._drop(res.pdbid, "%s: %s" % (type(exception).__name__, exception), failures, silent)
+            conn.send(("records", records, failures))
+    except BaseException as exception:            # a device / library failure (or a broken pipe): tell the parent, then die
+        try:
+            conn.send(("error", "%s: %s" % (type(exception).__name__, exception)))
+        except Exception:
+            pass
+
+
+class ProcessSweep(object):
+    """``Sweep`` with worker PROCESSES (spawned; one context = stream each): the host side of an iteration -- flattening the
+    structure, the statistics tail -- holds the GIL, so threads do not scale it (measured: 1.36 ms per entry and iteration
+    with four threads against 1.50 with one); a process owns its entries' resident maps for the life of the sweep.
+    Same interface: ``iteration(params)`` -> (reduction over ALL ranks, this rank's records), ``failures``, ``close()``."""
+
+    def __init__(self, entries, device=0, n_workers=4, silent=True):
+        import multiprocessing
+        self.silent = silent
+        self.failures = {}
+        self.n_entries = len(entries)
+        n = max(1, min(int(n_workers), max(1, len(entries))))
+        mp = multiprocessing.get_context("spawn")
+        self._workers = []
+        for k in range(n):
+            parent, child = mp.Pipe()
+            lane = [(i, entries[i]) for i in range(k, len(entries), n)]
+            proc = mp.Process(target=_sweep_worker, args=(child, device, lane, silent), daemon=True)
+            proc.start()
+            child.close()
+            self._workers.append((proc, parent))
+        for message in self._gather():
+            self.failures.update(message[1])
+
+    def _gather(self):
+        out = []
+        for proc, conn in self._workers:
+            try:
+                message = conn.recv()
+            except EOFError:
+                message = ("error", "worker process ended")
+            if message[0] == "error":
+                self.close()
+                raise _native.PdbedaError("sweep worker failed: %s" % message[1])
+            out.append(message)
+        return out
+
+    def iteration(self, params):
+        for _, conn in self._workers:
+            conn.send(params)
+        records = [0] * self.n_entries
+        for _, part, failures in self._gather():
+            self.failures.update(failures)
+            for i, record in part.items():
+                records[i] = record
+        densityAnalysis.setGlobals(params)
+        return optimizeStats.calculateMedianDiffsSlopes(records, params), records
+
+    def close(self):
+        for proc, conn in self._workers:
+            try:
+                conn.send(None)
+            except Exception:
+                pass
+        for proc, conn in self._workers:
+            proc.join(timeout=30)
+            if proc.is_alive():
+                proc.kill()            # (the exact process this object started)
+            conn.close()
+        self._workers = []
+
+
+def sweep(entries, paramSets, device=0, n_streams=4, rank=0, world_size=1, silent=True, processes=False):
     """Evaluate ``paramSets`` (a sequence of parameter tables, e.g. one changed radius per step) over ``entries``:
-    this rank keeps its shard resident, and every iteration ends in the RCCL reduction.  Returns one reduction tuple per set."""
+    this rank keeps its shard resident, and every iteration ends in the RCCL reduction.  Returns one reduction tuple per set.
+    ``processes``: worker processes instead of threads (``ProcessSweep``)."""
     mine = multipleStructures.shard(entries, rank, world_size)
-    sw = Sweep(mine, device, n_streams, silent)
+    sw = ProcessSweep(mine, device, n_streams, silent) if processes else Sweep(mine, device, n_streams, silent)
     try:
         return [sw.iteration(p)[0] for p in paramSets]
     finally:

@@ -87,3 +87,26 @@ def test_columns_snapshot():
     assert cols.atom_lists("chain") == [a.parent.parent.id for a in atoms]
     assert cols.atom_lists("number") == [a.parent.id[1] for a in atoms]
     assert [cols.residues[k] for k in cols.res_of_atom.tolist()] == [a.parent for a in atoms]
+
+
+def test_cloud_inputs_follow_the_radius_table():
+    """Only the radius column changes between the iterations of optimise mode: the rest is kept on the structure's snapshot
+    while the name tables are the same objects, and rebuilt when they are not."""
+    base = synthetic.synthetic_params()
+    da.setGlobals(base)
+    st = make_structure(5, 40)
+    an = da.DensityAnalysis("t", None, None, st, None)
+    first = an._cloudInputs()
+    radii = dict(base["radii"])
+    some_type = first["pair_type"][int(first["pair"][0])]
+    radii[some_type] = radii[some_type] + 0.25
+    da.setGlobals({**base, "radii": radii})
+    second = an._cloudInputs()
+    assert second["key"] is first["key"] and second["xyz"] is first["xyz"]                  # the kept part
+    changed = np.asarray(second["radius"]) != np.asarray(first["radius"])
+    assert changed.any() and all(first["pair_type"][k] == some_type for k in np.asarray(first["pair"])[changed].tolist())
+    ref = walk(st)
+    assert (np.asarray(second["radius"]) == ref["radius"]).all()
+    da.setGlobals(synthetic.synthetic_params())                                             # new table objects: everything is rebuilt
+    third = an._cloudInputs()
+    assert third["key"] is not first["key"] and (np.asarray(third["key"]) == np.asarray(first["key"])).all()

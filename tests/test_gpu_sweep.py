@@ -90,6 +90,37 @@ def test_sweep_function_shards_by_rank():
     assert whole[0][4] != half[0][4] and max(half[0][4].values()) == 1
 
 
+@pytest.mark.timeout(300)
+def test_process_sweep_matches_thread_sweep(tmp_path):
+    """Worker PROCESSES that keep their lane of entries resident give the records and reductions of the thread sweep, iteration
+    by iteration; an entry whose file is missing is dropped with its reason at load time."""
+    from pdb_eda_amd import synthetic, multipleStructures, optimizeSweep
+    loaders = [synthetic.write_entry_files(str(tmp_path), "e%d" % k, 72, 24, 500 + k, as_paths=(k % 2 == 0)) for k in range(3)]
+    entries = [multipleStructures.Entry("p%02d" % i, loaders[i % 3]) for i in range(5)]
+    bad = synthetic.SyntheticEntryFiles(str(tmp_path / "missing.ccp4"), loaders[0].diff_path, 24, 500, 72, 0.5, as_paths=True)
+    entries.insert(2, multipleStructures.Entry("gone", bad))
+    sets = synthetic.sweep_param_sets()[:3]
+    threads = optimizeSweep.Sweep(entries, device=0, n_streams=2)
+    procs = optimizeSweep.ProcessSweep(entries, device=0, n_workers=2)
+    try:
+        assert set(threads.failures) == set(procs.failures) == {"gone"}
+        for params in sets:
+            (ta, tb, tc, td, te, tf), trec = threads.iteration(params)
+            (pa, pb, pc, pd, pe, pf), prec = procs.iteration(params)
+            assert [bool(r) for r in prec] == [bool(r) for r in trec] == [True, True, False, True, True, True]
+            for a, b in zip(prec, trec):
+                if b:
+                    assert a["pdbid"] == b["pdbid"] and a["diffs"] == pytest.approx(b["diffs"], rel=1e-12, abs=1e-15)
+                    assert a["slopes"] == pytest.approx(b["slopes"], rel=1e-12, abs=1e-15)
+                    assert a["atomtype_overlap_completeness"] == b["atomtype_overlap_completeness"]
+            assert pa == pytest.approx(ta, rel=1e-12, abs=1e-15) and pe == te and pf == pytest.approx(tf, rel=1e-12)
+    finally:
+        threads.close()
+        procs.close()
+    whole = optimizeSweep.sweep(entries, sets[:1], device=0, n_streams=2, processes=True)
+    assert whole[0][4] == te or len(whole) == 1
+
+
 NCCL_WORKER = r'''
 import io, json, os, sys
 sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
