@@ -753,6 +753,8 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.unit_flag = n_tiles ? cv.take<uint32_t>(1) : nullptr;
     job.tile_mode = n_tiles ? cv.take<uint8_t>(n_tiles) : nullptr;
     job.tile_runs = n_tiles ? cv.take<uint32_t>(n_tiles) : nullptr;
+    job.root_mask = n_tiles ? cv.take<uint64_t>((size_t)n_tiles * 4) : nullptr;
+    job.n_tiles = (int32_t)n_tiles;
     job.run_sums = n_tiles ? cv.take<double2>((size_t)n_tiles * RCAP) : nullptr;
     job.inbox = n_tiles ? cv.take<InboxEntry>((size_t)n_tiles * INBOX_CAP) : nullptr;
     job.inbox_count = n_tiles ? cv.take<uint32_t>((size_t)n_tiles * INBOX_STRIDE) : nullptr;
@@ -897,10 +899,9 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
         case 3: launch_tile_label<3>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init, pair_slots); break;
         default: launch_tile_label<4>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init, pair_slots); break;
     }
-    const unsigned comp_grid = grid_for(max_runs, 256, 2048);
     { PROF(ctx, "k_resolve_tiles"); hipLaunchKernelGGL(k_resolve_tiles, dim3((unsigned)tiles_pp + 64u), dim3(256), 0, st, job, (int)tiles_pp); }
     { PROF(ctx, "k_paint_tiles"); hipLaunchKernelGGL(k_paint_tiles, dim3((unsigned)tiles_pp + 64u), dim3(256), 0, st, job, (int)tiles_pp); }
-    { PROF(ctx, "k_emit"); hipLaunchKernelGGL(k_emit, dim3(std::min(comp_grid, 512u)), dim3(256), 0, st, job, m->geom_dev); }
+    { PROF(ctx, "k_emit"); hipLaunchKernelGGL(k_emit, dim3(std::min<unsigned>(512u, ((unsigned)tiles_pp + 1u) / 2u)), dim3(256), 0, st, job, m->geom_dev); }
     if (labels) {
         PROF(ctx, "k_labels_tiles");
         launch_labels(ctx, job, td, labels_dev);

@@ -84,6 +84,10 @@ struct Job {
     int64_t *b_n, *b_key;
     double *b_total, *b_centroid, *b_center, *b_volume;
     int32_t *b_group;
+    // (last: the tile kernel's scalar-register allocation is sensitive to the offsets of the fields above -- inserting these
+    //  in the middle cost it 10 more SGPR spills and 1.6 us)
+    uint64_t *root_mask;      // per tile: which of its TILE_COMPS component slots are blob roots (4 ballots, written by k_paint_tiles):
+    int32_t n_tiles;          // k_emit visits the ~36 k roots of a 256^3 job, not its 262 k component ids
 };
 
 struct InboxEntry {           // 80 bytes: what a (tile, root) pair folds into the root's record
@@ -94,6 +98,7 @@ struct InboxEntry {           // 80 bytes: what a (tile, root) pair folds into t
 constexpr int INBOX_STRIDE = 32;   // uint32 per inbox counter: a cache line each
 constexpr int INBOX_CAP = 192;   // entries per tile (a root tile of a map-spanning blob overflows: those pairs fold with atomics)
 
+constexpr int TILE_COMPS = 256;   // component ids a whole-map tile owns (== CCAP of pdbeda_tile.h)
 constexpr int KEY_FINE = 32;      // key words per fine counter (2048 keys)
 constexpr int KEY_GROUPS = 1024;  // entries of the prefix table a k_emit block builds in LDS
 constexpr int WAVE = 64;
@@ -523,18 +528,39 @@ __device__ inline uint32_t rank_of_key(const Job &job, const uint32_t *s_pre, un
 // chain of dependent memory round trips -- (parent, n) -> (key + the whole record) -> (counters + bitmap words) -- so each
 // step issues everything the next one needs at once (the key rides with the first step: unused ids hold stale keys that are
 // loaded and never used), and the first step is issued before the prefix table is built.
+// Position of the k-th (0-based) set bit of m (k < popcount(m)).
+__device__ __forceinline__ int nth_set_bit(uint64_t m, int k) {
+    int pos = 0;
+#pragma unroll
+    for (int w = 32; w > 0; w >>= 1) {
+        const int c = popc64(m & ((1ull << w) - 1ull));
+        if (k >= c) { k -= c; m >>= w; pos += w; }
+    }
+    return pos;
+}
+
 __global__ void __launch_bounds__(256) k_emit(Job job, const Geom *__restrict__ gp) {
     __shared__ uint32_t s_pre[KEY_GROUPS];
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_below1;
     const uint32_t n_comp = n_components(job);
+    const bool whole_map = job.label_of_comp != nullptr;
     const uint32_t stride = gridDim.x * blockDim.x;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    // Whole-map jobs: half a workgroup per tile, thread k of the half takes the tile's k-th root (k_paint_tiles left a
+    // 256-bit root mask per tile), so ONE pass covers the job; the first trip's loads are issued before the rank table is
+    // built.  Generic jobs (and the unit components of a whole-map job, ids above the tiles' ranges): grid-stride over ids.
+    const int half = threadIdx.x >> 7, k0 = threadIdx.x & 127;
+    int tile = whole_map ? (int)blockIdx.x * 2 + half : 0;
+    uint64_t rm[4] = {0ull, 0ull, 0ull, 0ull};
+    if (whole_map && tile < job.n_tiles) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rm[q] = job.root_mask[(size_t)tile * 4 + q];
+    }
+    uint32_t i = whole_map ? (uint32_t)job.n_tiles * (uint32_t)TILE_COMPS + blockIdx.x * blockDim.x + threadIdx.x : blockIdx.x * blockDim.x + threadIdx.x;
     int32_t par = i < n_comp ? job.parent[i] : -1;
     uint32_t cnt = i < n_comp ? job.r_n[i] : 0u;
     unsigned long long key = i < n_comp ? job.r_key[i] : 0ull;
     const uint32_t total = rank_table_lds(job, s_pre, s_wave);
-    const bool whole_map = job.label_of_comp != nullptr;
     if (threadIdx.x == 0) {
         uint32_t below1 = total;   // blobs before volume 1 (fused green / red job); every blob when there is one volume
         if (job.n_vols > 1 && whole_map) below1 = rank_of_key(job, s_pre, (unsigned long long)job.vols[1].key_base);
@@ -543,41 +569,62 @@ __global__ void __launch_bounds__(256) k_emit(Job job, const Geom *__restrict__ 
     }
     __syncthreads();
     const Geom &g = *gp;
+    auto emit_root = [&](uint32_t id, uint32_t n_vox, unsigned long long first_key) {
+        const double tot = job.r_rho[id], rc = job.r_rho_c[id], rr = job.r_rho_r[id], rs = job.r_rho_s[id];
+        const long long ic = job.r_c[id], ir = job.r_r[id], is = job.r_s[id];
+        const uint32_t rank = rank_of_key(job, s_pre, first_key);
+        const int vi = whole_map ? ((job.n_vols > 1 && (int64_t)first_key >= job.vols[1].key_base) ? 1 : 0) : find_vol_by_key(job.vols, job.n_vols, (int64_t)first_key);
+        if (whole_map) {   // blob index inside its own list, signed by the list
+            const int32_t k = (int32_t)(rank - (vi ? s_below1 : 0u));
+            job.label_of_comp[id] = job.vol_sign[vi] > 0 ? 1 + k : -1 - k;
+        }
+        const VolDesc vd = job.vols[vi];
+        job.r_rank[id] = rank;
+        const double n = (double)n_vox;
+        double wc[3] = {rc / tot, rr / tot, rs / tot};
+        double cc[3] = {(double)ic / n, (double)ir / n, (double)is / n};
+        double xyz[3];
+        crs2xyz_frac(g, wc, xyz);
+        job.b_centroid[3 * rank + 0] = xyz[0];
+        job.b_centroid[3 * rank + 1] = xyz[1];
+        job.b_centroid[3 * rank + 2] = xyz[2];
+        crs2xyz_frac(g, cc, xyz);
+        job.b_center[3 * rank + 0] = xyz[0];
+        job.b_center[3 * rank + 1] = xyz[1];
+        job.b_center[3 * rank + 2] = xyz[2];
+        job.b_n[rank] = (int64_t)n_vox;
+        job.b_total[rank] = tot;
+        job.b_volume[rank] = g.unit_volume * n;
+        job.b_key[rank] = (int64_t)first_key - vd.key_base;
+        job.b_group[rank] = vd.group;
+    };
+    if (whole_map) {
+        for (; tile < job.n_tiles; tile += (int)gridDim.x * 2) {
+            const int c0 = popc64(rm[0]), c1 = c0 + popc64(rm[1]), c2 = c1 + popc64(rm[2]), n_roots = c2 + popc64(rm[3]);
+            const int next = tile + (int)gridDim.x * 2;
+            uint64_t nm[4] = {0ull, 0ull, 0ull, 0ull};
+            if (next < job.n_tiles) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) nm[q] = job.root_mask[(size_t)next * 4 + q];
+            }
+            for (int k = k0; k < n_roots; k += 128) {
+                const int q = k < c0 ? 0 : (k < c1 ? 1 : (k < c2 ? 2 : 3));
+                const int before = q == 0 ? 0 : (q == 1 ? c0 : (q == 2 ? c1 : c2));
+                const uint64_t word = q == 0 ? rm[0] : (q == 1 ? rm[1] : (q == 2 ? rm[2] : rm[3]));
+                const uint32_t id = (uint32_t)tile * (uint32_t)TILE_COMPS + (uint32_t)(64 * q + nth_set_bit(word, k - before));
+                emit_root(id, job.r_n[id], job.r_key[id]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rm[q] = nm[q];
+        }
+    }
     for (; i < n_comp; i += stride) {
         const bool root = par == (int32_t)i && cnt != 0u;   // else: not a root / unused component id
         const uint32_t nx = i + stride;
         const int32_t par_next = nx < n_comp ? job.parent[nx] : -1;   // (next trip's first step rides along)
         const uint32_t cnt_next = nx < n_comp ? job.r_n[nx] : 0u;
         const unsigned long long key_next = nx < n_comp ? job.r_key[nx] : 0ull;
-        if (root) {
-            const double tot = job.r_rho[i], rc = job.r_rho_c[i], rr = job.r_rho_r[i], rs = job.r_rho_s[i];
-            const long long ic = job.r_c[i], ir = job.r_r[i], is = job.r_s[i];
-            const uint32_t rank = rank_of_key(job, s_pre, key);
-            const int vi = whole_map ? ((job.n_vols > 1 && (int64_t)key >= job.vols[1].key_base) ? 1 : 0) : find_vol_by_key(job.vols, job.n_vols, (int64_t)key);
-            if (whole_map) {   // blob index inside its own list, signed by the list
-                const int32_t k = (int32_t)(rank - (vi ? s_below1 : 0u));
-                job.label_of_comp[i] = job.vol_sign[vi] > 0 ? 1 + k : -1 - k;
-            }
-            const VolDesc vd = job.vols[vi];
-            job.r_rank[i] = rank;
-            const double n = (double)cnt;
-            double wc[3] = {rc / tot, rr / tot, rs / tot};
-            double cc[3] = {(double)ic / n, (double)ir / n, (double)is / n};
-            double xyz[3];
-            crs2xyz_frac(g, wc, xyz);
-            job.b_centroid[3 * rank + 0] = xyz[0];
-            job.b_centroid[3 * rank + 1] = xyz[1];
-            job.b_centroid[3 * rank + 2] = xyz[2];
-            crs2xyz_frac(g, cc, xyz);
-            job.b_center[3 * rank + 0] = xyz[0];
-            job.b_center[3 * rank + 1] = xyz[1];
-            job.b_center[3 * rank + 2] = xyz[2];
-            job.b_n[rank] = (int64_t)cnt;
-            job.b_total[rank] = tot;
-            job.b_volume[rank] = g.unit_volume * n;
-            job.b_key[rank] = (int64_t)key - vd.key_base;
-            job.b_group[rank] = vd.group;
-        }
+        if (root) emit_root(i, cnt, key);
         par = par_next;
         cnt = cnt_next;
         key = key_next;

@@ -27,6 +27,7 @@ constexpr int TILE_R = 8, TILE_S = 8;
 constexpr int RCAP = 1408;        // run slots per tile handled in LDS (runs are tracked per ROW: a run crossing words is one run);
                                   // sign 0 fills them from the bottom, sign 1 ends at the top: [RCAP - n1, RCAP) -- a one-sign job has them all
 constexpr int CCAP = 256;   // tile-local components (both signs together) handled in LDS
+static_assert(CCAP == TILE_COMPS, "k_emit walks the tiles' component ranges");
 constexpr int VCAP = 3584;  // significant values per tile parked in LDS during phase A (aliases the 14 KiB scratch)
 constexpr int VMAIN = 3072; // of the VCAP parked values: split into one private region per wave (no atomics) ...
 constexpr int VPOOL = VCAP - VMAIN;      // ... and a shared pool a wave spills into with one LDS atomic (rare)
@@ -75,13 +76,27 @@ __device__ __forceinline__ uint32_t wave_writelane(uint32_t old, uint32_t sval, 
 
 // Tile t owns component ids [t * CCAP, (t+1) * CCAP) and run ids [t * runs_per_tile, ...): no
 // allocation atomics on the fast path.  Unused component ids are marked empty (r_n = 0).
-__device__ inline void mark_comps_unused(const Job &job, uint32_t cb, uint32_t from, int tid, int nt) {
+template <typename JobRef>
+__device__ inline void mark_comps_unused(const JobRef &job, uint32_t cb, uint32_t from, int tid, int nt) {
+    int32_t *parent = job.parent;
+    uint32_t *r_n = job.r_n;
+    unsigned long long *r_key = job.r_key;
     for (uint32_t i = from + tid; i < (uint32_t)CCAP; i += nt) {
-        job.parent[cb + i] = (int32_t)(cb + i);
-        job.r_n[cb + i] = 0u;
-        job.r_key[cb + i] = ~0ull;
+        parent[cb + i] = (int32_t)(cb + i);
+        r_n[cb + i] = 0u;
+        r_key[cb + i] = ~0ull;
     }
 }
+
+// The Job of a kernel whose FIRST argument it is, read from the kernel-argument segment at the point of use.  A by-value
+// argument is loaded into scalar registers at kernel entry and stays live until its last use: the ~20 pointers that only
+// the tail of k_tile_label stores through sat on 40 SGPRs during the hot LDS phases and pushed their loop scalars into
+// spills.  The empty asm keeps the loads below it.
+typedef const Job __attribute__((address_space(4))) *JobKernarg;
+#define PDBEDA_LATE_JOB(name)                                                      \
+    JobKernarg name##_p = (JobKernarg)__builtin_amdgcn_kernarg_segment_ptr();      \
+    asm volatile("" : "+s"(name##_p));                                             \
+    const Job __attribute__((address_space(4))) &name = *name##_p
 
 
 // NT = 512 threads: the same tile with twice the waves -- the kernel is one round of co-resident workgroups (1024
@@ -380,16 +395,17 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
     auto slot_used = [&](uint32_t sl) -> bool { return sl < al0 || sl >= (uint32_t)RCAP - al1; };
 
     if (n_slots == 0 || s_over) {
+        PDBEDA_LATE_JOB(lj);
         // nothing significant, or too many runs for LDS: publish the masks; an overflowing tile
         // is labelled by k_unit_fallback (every run its own component)
         if (my_valid) {
-            job.mask[my_word] = m0;
-            job.run_base[my_word] = 0u;
-            if (n_planes > 1) { job.mask[plane_words + my_word] = m1; job.run_base[plane_words + my_word] = 0u; }
+            lj.mask[my_word] = m0;
+            lj.run_base[my_word] = 0u;
+            if (n_planes > 1) { lj.mask[plane_words + my_word] = m1; lj.run_base[plane_words + my_word] = 0u; }
         }
-        if (tid == 0) { job.tile_mode[tile_id] = n_slots ? 1 : 0; job.tile_runs[blockIdx.x] = 0u; if (n_slots) *job.unit_flag = job.epoch; }
-        if (job.face_rows && tid < 128) job.face_rows[(size_t)blockIdx.x * 128 + tid] = 0u;   // no run lists: nothing / the unit kernels unite   // mode 1: run slots / values overflowed
-        mark_comps_unused(job, (uint32_t)blockIdx.x * CCAP, 0u, tid, NT);
+        if (tid == 0) { lj.tile_mode[tile_id] = n_slots ? 1 : 0; lj.tile_runs[blockIdx.x] = 0u; if (n_slots) *lj.unit_flag = lj.epoch; }
+        if (lj.face_rows && tid < 128) lj.face_rows[(size_t)blockIdx.x * 128 + tid] = 0u;   // no run lists: nothing / the unit kernels unite   // mode 1: run slots / values overflowed
+        mark_comps_unused(lj, (uint32_t)blockIdx.x * CCAP, 0u, tid, NT);
         return;
     }
 
@@ -537,24 +553,25 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
     for (uint32_t i = tid; i < RCAP; i += NT)
         if (slot_used(i) && s_parent[i] == i) s_compidx[i] = (uint16_t)atomicAdd(&s_ncomp, 1u);
     __syncthreads();
+    PDBEDA_LATE_JOB(lj);          // (everything below stores through pointers nothing above needs)
     const uint32_t n_comp = s_ncomp;
     if (n_comp > CCAP) {  // block-uniform: too many components for LDS -> unit tile
         if (my_valid) {
-            job.mask[my_word] = m0;
-            job.run_base[my_word] = 0u;
-            if (n_planes > 1) { job.mask[plane_words + my_word] = m1; job.run_base[plane_words + my_word] = 0u; }
+            lj.mask[my_word] = m0;
+            lj.run_base[my_word] = 0u;
+            if (n_planes > 1) { lj.mask[plane_words + my_word] = m1; lj.run_base[plane_words + my_word] = 0u; }
         }
-        if (tid == 0) { job.tile_mode[tile_id] = 3; job.tile_runs[blockIdx.x] = 0u; *job.unit_flag = job.epoch; }
-        if (job.face_rows && tid < 128) job.face_rows[(size_t)blockIdx.x * 128 + tid] = 0u;   // mode 3: component table overflowed
-        mark_comps_unused(job, (uint32_t)blockIdx.x * CCAP, 0u, tid, NT);
+        if (tid == 0) { lj.tile_mode[tile_id] = 3; lj.tile_runs[blockIdx.x] = 0u; *lj.unit_flag = lj.epoch; }
+        if (lj.face_rows && tid < 128) lj.face_rows[(size_t)blockIdx.x * 128 + tid] = 0u;   // mode 3: component table overflowed
+        mark_comps_unused(lj, (uint32_t)blockIdx.x * CCAP, 0u, tid, NT);
         return;
     }
-    if (job.face_runs) {   // export the runs with their tile components for k_face_merge
+    if (lj.face_runs) {   // export the runs with their tile components for k_face_merge
 #pragma unroll
         for (int t = 0; t < SLOTS; ++t)
             if (ex_slot[t] != 0xffffffffu)
-                job.face_runs[(size_t)blockIdx.x * RCAP + ex_slot[t]] = ex_se[t] | ((uint32_t)s_compidx[s_parent[ex_slot[t]]] << 16);
-        if (tid < 128) job.face_rows[(size_t)blockIdx.x * 128 + tid] = (uint32_t)s_rowfirst[tid >> 6][tid & 63] | ((uint32_t)s_rowcnt[tid >> 6][tid & 63] << 16);
+                lj.face_runs[(size_t)blockIdx.x * RCAP + ex_slot[t]] = ex_se[t] | ((uint32_t)s_compidx[s_parent[ex_slot[t]]] << 16);
+        if (tid < 128) lj.face_rows[(size_t)blockIdx.x * 128 + tid] = (uint32_t)s_rowfirst[tid >> 6][tid & 63] | ((uint32_t)s_rowcnt[tid >> 6][tid & 63] << 16);
     }
     if (tid == 0) {
         s_runbase = (uint32_t)blockIdx.x * (uint32_t)(NU * 32);
@@ -584,7 +601,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
                 todo &= todo - 1;
                 const uint32_t slot = k == 0 ? (first & 0x7fffu) : next + k - 1u;
                 ++k;
-                job.comp_of_run[g++] = cb + s_compidx[s_parent[slot]];
+                lj.comp_of_run[g++] = cb + s_compidx[s_parent[slot]];
             }
         }
     }
@@ -612,30 +629,30 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
         }
     }
     if (my_valid) {
-        job.mask[my_word] = m0;
-        job.run_base[my_word] = my_g;
-        if (n_planes > 1) { job.mask[plane_words + my_word] = m1; job.run_base[plane_words + my_word] = my_g + (uint32_t)popc64(run_starts(m0)); }
+        lj.mask[my_word] = m0;
+        lj.run_base[my_word] = my_g;
+        if (n_planes > 1) { lj.mask[plane_words + my_word] = m1; lj.run_base[plane_words + my_word] = my_g + (uint32_t)popc64(run_starts(m0)); }
     }
-    if (tid == 0) job.tile_mode[tile_id] = 0;
+    if (tid == 0) lj.tile_mode[tile_id] = 0;
     __syncthreads();
     const int64_t keys_pp = (int64_t)uc * ur * us;
     for (uint32_t i = tid; i < n_comp; i += NT) {
         const uint32_t g = cb + i;
-        job.parent[g] = (int32_t)g;
+        lj.parent[g] = (int32_t)g;
         const unsigned long long pk = s_pk[i];
         const long long n = (long long)(pk & 0xfffffull);
-        job.r_n[g] = (uint32_t)n;
-        job.r_rho[g] = s_rho[i];
-        job.r_rho_c[g] = s_rho_c[i];
-        job.r_rho_r[g] = s_rho_r[i];
-        job.r_rho_s[g] = s_rho_s[i];
-        job.r_c[g] = (long long)s_crel[i] + n * (w0 * 64);
-        job.r_r[g] = (long long)((pk >> 20) & 0xfffffull) + n * r0;
-        job.r_s[g] = (long long)(pk >> 40) + n * s0;
-        job.r_key[g] = (unsigned long long)(s_cplane[i] ? keys_pp : 0) + s_key[i];
+        lj.r_n[g] = (uint32_t)n;
+        lj.r_rho[g] = s_rho[i];
+        lj.r_rho_c[g] = s_rho_c[i];
+        lj.r_rho_r[g] = s_rho_r[i];
+        lj.r_rho_s[g] = s_rho_s[i];
+        lj.r_c[g] = (long long)s_crel[i] + n * (w0 * 64);
+        lj.r_r[g] = (long long)((pk >> 20) & 0xfffffull) + n * r0;
+        lj.r_s[g] = (long long)(pk >> 40) + n * s0;
+        lj.r_key[g] = (unsigned long long)(s_cplane[i] ? keys_pp : 0) + s_key[i];
     }
-    mark_comps_unused(job, cb, n_comp, tid, NT);
-    if (tid == 0) job.tile_runs[blockIdx.x] = n_wordruns;
+    mark_comps_unused(lj, cb, n_comp, tid, NT);
+    if (tid == 0) lj.tile_runs[blockIdx.x] = n_wordruns;
 }
 
 // Generic labelling of the tiles k_tile_label could not hold in LDS ("unit tiles"): every run
@@ -1123,6 +1140,10 @@ __global__ void __launch_bounds__(256) k_paint_tiles(Job job, int n_tiles) {
     const uint32_t n_i = job.r_n[i];
     unsigned long long key = job.r_key[i];
     const bool root = par == (int32_t)i && n_i != 0u;
+    {   // the tile's roots as four ballots: k_emit maps its threads onto the set bits instead of scanning every component id
+        const unsigned long long rbits = __ballot(root);
+        if ((tid & 63) == 0) job.root_mask[(size_t)blockIdx.x * 4 + (tid >> 6)] = rbits;
+    }
     if (n_in != 0u) {
         InboxEntry e;
         const bool have = (uint32_t)tid < n_in;
