@@ -542,7 +542,6 @@ __device__ __forceinline__ int nth_set_bit(uint64_t m, int k) {
 __global__ void __launch_bounds__(256) k_emit(Job job, const Geom *__restrict__ gp) {
     __shared__ uint32_t s_pre[KEY_GROUPS];
     __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_below1;
     const uint32_t n_comp = n_components(job);
     const bool whole_map = job.label_of_comp != nullptr;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -560,24 +559,18 @@ __global__ void __launch_bounds__(256) k_emit(Job job, const Geom *__restrict__ 
     int32_t par = i < n_comp ? job.parent[i] : -1;
     uint32_t cnt = i < n_comp ? job.r_n[i] : 0u;
     unsigned long long key = i < n_comp ? job.r_key[i] : 0ull;
+    // first key of volume 1 (fused green / red job); loaded before the table so that nothing below waits for it
+    const int64_t key_base1 = (whole_map && job.n_vols > 1) ? job.vols[1].key_base : INT64_MAX;
     const uint32_t total = rank_table_lds(job, s_pre, s_wave);
-    if (threadIdx.x == 0) {
-        uint32_t below1 = total;   // blobs before volume 1 (fused green / red job); every blob when there is one volume
-        if (job.n_vols > 1 && whole_map) below1 = rank_of_key(job, s_pre, (unsigned long long)job.vols[1].key_base);
-        s_below1 = below1;
-        if (blockIdx.x == 0) { job.ctr->n_blobs = total; job.ctr->n_blobs_vol0 = below1; }
-    }
-    __syncthreads();
     const Geom &g = *gp;
     auto emit_root = [&](uint32_t id, uint32_t n_vox, unsigned long long first_key) {
         const double tot = job.r_rho[id], rc = job.r_rho_c[id], rr = job.r_rho_r[id], rs = job.r_rho_s[id];
         const long long ic = job.r_c[id], ir = job.r_r[id], is = job.r_s[id];
         const uint32_t rank = rank_of_key(job, s_pre, first_key);
-        const int vi = whole_map ? ((job.n_vols > 1 && (int64_t)first_key >= job.vols[1].key_base) ? 1 : 0) : find_vol_by_key(job.vols, job.n_vols, (int64_t)first_key);
-        if (whole_map) {   // blob index inside its own list, signed by the list
-            const int32_t k = (int32_t)(rank - (vi ? s_below1 : 0u));
-            job.label_of_comp[id] = job.vol_sign[vi] > 0 ? 1 + k : -1 - k;
-        }
+        const int vi = whole_map ? ((int64_t)first_key >= key_base1 ? 1 : 0) : find_vol_by_key(job.vols, job.n_vols, (int64_t)first_key);
+        // signed by its list, numbered by its rank in the WHOLE table: k_labels_tiles takes the blobs of volume 0 off the
+        // labels of volume 1 (ctr->n_blobs_vol0) -- here that count would be a second dependent round trip before any root
+        if (whole_map) job.label_of_comp[id] = job.vol_sign[vi] > 0 ? 1 + (int32_t)rank : -1 - (int32_t)rank;
         const VolDesc vd = job.vols[vi];
         job.r_rank[id] = rank;
         const double n = (double)n_vox;
@@ -628,6 +621,12 @@ __global__ void __launch_bounds__(256) k_emit(Job job, const Geom *__restrict__ 
         par = par_next;
         cnt = cnt_next;
         key = key_next;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {   // the table's totals, for the host and for k_labels_tiles
+        uint32_t below1 = total;                 // blobs before volume 1; every blob when there is one volume
+        if (key_base1 != INT64_MAX) below1 = rank_of_key(job, s_pre, (unsigned long long)key_base1);
+        job.ctr->n_blobs = total;
+        job.ctr->n_blobs_vol0 = below1;
     }
 }
 

@@ -1214,6 +1214,10 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS) k_labels_tiles(Job j
 #pragma unroll
     for (int k = 0; k < 4; ++k) c_pre[k] = job.comp_of_run[rb + tid + NTL * k];
     const int32_t lab_pre = tid < CCAP ? job.label_of_comp[job.parent[cb + tid]] : 0;   // (the root of a component carries its label)
+    // k_emit numbers the blobs of volume 1 by their rank in the whole table: their labels are -1 - rank, and the blobs of
+    // volume 0 come off here (one scalar load beside the others)
+    const int32_t vol0 = job.n_vols > 1 ? (int32_t)job.ctr->n_blobs_vol0 : 0;
+    auto own_list = [&](int32_t lab) { return lab < 0 ? lab + vol0 : lab; };
     const bool unit = job.tile_mode[tile_index(td, 0, w0, r0, s0)] != 0;
     const uint32_t n_runs = unit ? 0u : job.tile_runs[blockIdx.x];
     const bool fast = !unit && n_runs <= (uint32_t)LCAP;   // block-uniform
@@ -1230,7 +1234,7 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS) k_labels_tiles(Job j
                 s_rb[p][tid] = has ? job.run_base[w + p * plane_words] : 0u;
             }
         }
-        if (tid < CCAP) s_lab[tid] = lab_pre;
+        if (tid < CCAP) s_lab[tid] = own_list(lab_pre);
 #pragma unroll
         for (int k = 0; k < 4; ++k) s_comp8[tid + NTL * k] = (uint8_t)(c_pre[k] - cb);
         if (fast)
@@ -1265,7 +1269,7 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS) k_labels_tiles(Job j
             for (int q = 0; q < 4; ++q) {
                 if ((nib >> q) & 1u) {
                     const uint32_t run = base + below + (uint32_t)__popc(snib & ((2u << q) - 1u)) - 1u;
-                    out[q] = fast ? s_lab[s_comp8[run - rb]] : job.label_of_comp[job.parent[job.comp_of_run[run]]];
+                    out[q] = fast ? s_lab[s_comp8[run - rb]] : own_list(job.label_of_comp[job.parent[job.comp_of_run[run]]]);
                 }
             }
         }
