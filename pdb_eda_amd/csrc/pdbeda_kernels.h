@@ -265,6 +265,17 @@ __device__ inline void uf_unite2(int32_t *p, int a, int b) {
     }
 }
 
+// Optimistic union for the cross-tile merge, where most elements are still roots: hook the larger id under the smaller with
+// ONE atomic min and no find; if the larger one already had a parent, that parent and the smaller id are what is left to
+// unite (the min keeps parent[x] <= x and never undoes a link).  A chain of atomics only where a chain exists.
+__device__ inline void uf_hook(int32_t *p, int a, int b) {
+    if (a == b) return;
+    if (a < b) { const int t = a; a = b; b = t; }
+    const int old = atomicMin(p + a, b);
+    if (old == a || old == b) return;
+    uf_unite2(p, old, b);      // a already hung under `old`: unite the two smaller ids root to root (keeps the trees shallow)
+}
+
 __device__ inline void uf_unite(int32_t *p, int a, int b) {
     while (true) {
         a = uf_find(p, a);

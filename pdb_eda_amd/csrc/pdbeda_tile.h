@@ -900,7 +900,7 @@ __global__ void __launch_bounds__(256) k_face_merge(Job job, const float *__rest
             const unsigned long long old = atomicCAS(&s_set[h], 0ull, key);
             if (old == 0ull || old == key) return;
         }
-        uf_unite2(job.parent, (int)lo, (int)hi);   // the neighbourhood of the slot is full: unite on the spot
+        uf_hook(job.parent, (int)lo, (int)hi);   // the neighbourhood of the slot is full: unite on the spot
     };
     int rl = 0, sl = 0, dr = 0, ds = -1;
     bool task = merger && q < td.n_planes;
@@ -1018,7 +1018,7 @@ __global__ void __launch_bounds__(256) k_face_merge(Job job, const float *__rest
     const uint32_t n_pairs = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
     for (uint32_t k = tid; k < n_pairs; k += 256) {
         const unsigned long long key = s_pairs[k];
-        uf_unite2(job.parent, (int)(key >> 32), (int)(uint32_t)key);
+        uf_hook(job.parent, (int)(key >> 32), (int)(uint32_t)key);
     }
 }
 
