@@ -496,3 +496,13 @@ def test_full_size_repeating_map(gpu_ctx):
     from pdb_eda_amd import synthetic
     g = synthetic.smooth_noise((200, 256, 256), 13, 1.5)
     _full_size_case(g, gpu_ctx, 1.5, interval=(232, 256, 180), cell=(92.8, 102.4, 72.0))
+
+
+@pytest.mark.timeout(600)
+def test_six_times_full_size(gpu_ctx):
+    """A 512 x 384 x 512 map (6x BASELINE configs[1]; two c tiles per row, 6144 tiles: more than one round of resident
+    workgroups, the tile faces along c in play): the same properties + oracle equality of both lists."""
+    from pdb_eda_amd import synthetic
+    g = synthetic.smooth_noise((512, 384, 512), 21, 1.5)
+    n_green, n_red = _full_size_case(g, gpu_ctx, 1.5, spacing=0.4)
+    assert n_green > 50000 and n_red > 50000
