@@ -235,29 +235,47 @@ def _worker_entry(entry):
 
 
 class ProcessPool(object):
-    """``n_workers`` worker processes on one GPU (one stream each), started with the ``spawn`` method BEFORE they are needed
-    (ideally before the parent touches the GPU) and reused across ``map`` calls.  Entries and their loaders must be picklable."""
+    """``n_workers`` worker processes on one GPU (one stream each), started with the ``spawn`` method when the pool is made
+    (ideally before the parent touches the GPU) and reused across ``map`` calls.  Entries and their loaders must be picklable.
+    A worker that DIES (killed for memory, a fault that takes the process down) does not hang the pool: the call in flight
+    raises ``PdbedaError`` -- like any other device failure it is not an entry-level condition."""
 
     def __init__(self, device=0, n_workers=4, params=None, time_out=0.0, silent=True):
+        import concurrent.futures
         import multiprocessing
         self.n_workers = max(1, int(n_workers))
-        self._pool = multiprocessing.get_context("spawn").Pool(self.n_workers, _worker_init, (device, params, float(time_out or 0.0), silent))
+        self._pool = concurrent.futures.ProcessPoolExecutor(self.n_workers, mp_context=multiprocessing.get_context("spawn"),
+                                                            initializer=_worker_init, initargs=(device, params, float(time_out or 0.0), silent))
         self.failures = {}
+        self.run(_worker_hold, range(self.n_workers))       # the executor starts a process per task it cannot hand to an idle one
+
+    def run(self, fn, items):
+        """``fn(item)`` for every item on the workers (results in order); a dead worker raises ``PdbedaError``."""
+        from concurrent.futures.process import BrokenProcessPool
+        try:
+            return list(self._pool.map(fn, items, chunksize=1))
+        except BrokenProcessPool as broken:
+            raise _native.PdbedaError("a worker process of the pool died (%s): its GPU context is gone, the entries in flight are lost" % broken)
 
     def warm(self):
         """Make every worker import the package, load the library and create its context (first-use costs out of the way)."""
-        self._pool.map(_worker_warm, range(4 * self.n_workers), chunksize=1)
+        self.run(_worker_warm, range(4 * self.n_workers))
 
     def map(self, entries):
-        results = self._pool.map(_worker_entry, entries, chunksize=1)
+        results = self.run(_worker_entry, entries)
         self.failures = {e.pdbid: why for e, (rec, why) in zip(entries, results) if why}
         return [rec for rec, _ in results]
 
     def close(self):
         if self._pool is not None:
-            self._pool.close()
-            self._pool.join()
+            self._pool.shutdown(wait=True)
             self._pool = None
+
+
+def _worker_hold(_):
+    import time as _time
+    _time.sleep(0.2)       # (long enough that the next task finds no idle worker and a new process is started for it)
+    return 1
 
 
 def _worker_warm(_):

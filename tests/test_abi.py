@@ -57,3 +57,24 @@ def test_numa_helpers_degrade_without_a_device():
         if kept == 0:
             assert os.sched_getaffinity(0) == before
         os.sched_setaffinity(0, before)
+
+
+def _die(_):
+    os._exit(3)
+
+
+def _double(x):
+    return 2 * x
+
+
+def test_process_pool_survives_nothing_silently():
+    """The worker pool without a GPU: plain functions run on the spawned workers; a worker that dies raises PdbedaError in the
+    parent instead of hanging the map (multiprocessing.Pool would wait for the lost task for ever)."""
+    from pdb_eda_amd import _native, multipleStructures
+    pool = multipleStructures.ProcessPool(device=0, n_workers=2)
+    try:
+        assert pool.run(_double, range(5)) == [0, 2, 4, 6, 8]
+        with pytest.raises(_native.PdbedaError):
+            pool.run(_die, range(2))
+    finally:
+        pool.close()
