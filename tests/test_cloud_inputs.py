@@ -110,3 +110,21 @@ def test_cloud_inputs_follow_the_radius_table():
     da.setGlobals(synthetic.synthetic_params())                                             # new table objects: everything is rebuilt
     third = an._cloudInputs()
     assert third["key"] is not first["key"] and (np.asarray(third["key"]) == np.asarray(first["key"])).all()
+
+
+def test_segment_means_are_numpy_means():
+    """``_segmentMeans`` (rows of equal length reduced along their contiguous axis) is bit-equal to ``np.mean`` per segment:
+    the per-residue mean occupancy of the region tables (densityAnalysis.py:1033, 1156), also for long residues where numpy
+    switches to its unrolled pairwise summation."""
+    rng = np.random.default_rng(3)
+    for trial in range(50):
+        counts = rng.integers(0, 45, size=60)
+        values = rng.random(int(counts.sum())) * rng.choice([1.0, 0.5, 0.37, 0.01], size=int(counts.sum()))
+        got = da._segmentMeans(values, counts)
+        start = np.concatenate([[0], np.cumsum(counts)])
+        for k in range(len(counts)):
+            seg = values[start[k]:start[k + 1]]
+            if len(seg) == 0:
+                assert np.isnan(got[k])
+            else:
+                assert got[k] == np.mean(list(seg))
