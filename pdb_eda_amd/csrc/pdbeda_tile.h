@@ -346,10 +346,19 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
                         const int u = row * CW + wlc;
                         const int ca = wlc == (p0 >> 6) ? (p0 & 63) : 0, ce = wlc == (p1 >> 6) ? (p1 & 63) : 63;
                         const uint32_t off = s_vbase[u] + (uint32_t)popc64((s_mask[0][u] | s_mask[1][u]) & bits_below(ca));
-                        for (int i = 0; i <= ce - ca; ++i) {
+                        const int nv = ce - ca + 1, cpos = wlc * 64 + ca;
+                        int i = 0;
+                        for (; i + 4 <= nv; i += 4) {   // four parked values in flight (the longest run of the tile sets the pace of this phase);
+                            const float v0 = s_val[off + i], v1 = s_val[off + i + 1], v2 = s_val[off + i + 2], v3 = s_val[off + i + 3];   // the additions keep their order
+                            sum += (double)v0; sumc += (double)v0 * (double)(cpos + i);
+                            sum += (double)v1; sumc += (double)v1 * (double)(cpos + i + 1);
+                            sum += (double)v2; sumc += (double)v2 * (double)(cpos + i + 2);
+                            sum += (double)v3; sumc += (double)v3 * (double)(cpos + i + 3);
+                        }
+                        for (; i < nv; ++i) {
                             const double val = (double)s_val[off + i];
                             sum += val;
-                            sumc += val * (double)(wlc * 64 + ca + i);
+                            sumc += val * (double)(cpos + i);
                         }
                     }
                 } else {   // dense tile: the values were not parked; re-read from L2, 4 loads in flight per trip (clamped inside the run)
