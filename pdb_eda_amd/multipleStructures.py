@@ -61,17 +61,27 @@ def loadMap(source, pdbid, ctx=None):
     return ccp4.parse(io.BytesIO(source), pdbid, ctx=ctx)
 
 
-def analyzeEntry(entry, ctx=None, failures=None, silent=False):
+def loadEntry(entry, ctx=None):
+    """The first half of an entry: its loader, both maps resident on ``ctx`` (file or bytes -> HBM), mean / std and the default
+    cutoffs.  Returns (densityObj, diffDensityObj, biopdbObj, pdbObj); raises what the loader / parser raise."""
+    dens, diff, biopdbObj, pdbObj = entry.loader()
+    densityObj = loadMap(dens, entry.pdbid, ctx)
+    diffDensityObj = loadMap(diff, entry.pdbid, ctx)
+    densityAnalysis._attachCutoffs(densityObj, diffDensityObj)
+    return densityObj, diffDensityObj, biopdbObj, pdbObj
+
+
+def analyzeEntry(entry, ctx=None, failures=None, silent=False, loaded=None):
     """ref multipleStructures.py:320-356: one entry -> result record, or 0 when the ENTRY fails (its files do not load or
     parse, the analysis raises, or there is no density-electron ratio: Q7); the reason goes to ``failures[pdbid]`` and to
     stderr like the reference's processFunction (277-282).  Device / library failures (``_native.PdbedaError``: no memory,
-    a HIP fault, a missing library, the watchdog) are NOT entry failures: they propagate."""
+    a HIP fault, a missing library, the watchdog) are NOT entry failures: they propagate.
+    ``loaded``: the result of ``loadEntry`` (or the exception it raised) when the maps were brought in ahead of time."""
     startTime = time.thread_time()
     try:
-        dens, diff, biopdbObj, pdbObj = entry.loader()
-        densityObj = loadMap(dens, entry.pdbid, ctx)
-        diffDensityObj = loadMap(diff, entry.pdbid, ctx)
-        densityAnalysis._attachCutoffs(densityObj, diffDensityObj)
+        if isinstance(loaded, BaseException):
+            raise loaded
+        densityObj, diffDensityObj, biopdbObj, pdbObj = loaded if loaded is not None else loadEntry(entry, ctx)
         analyzer = densityAnalysis.DensityAnalysis(entry.pdbid, densityObj, diffDensityObj, biopdbObj, pdbObj)
         ratio = analyzer.densityElectronRatio
     except _native.PdbedaError:
@@ -212,26 +222,59 @@ def _worker_init(device, params, time_out, silent):
         densityAnalysis.setGlobals(params)
 
 
-def _worker_context():
-    ctx = _worker_state.get("ctx")
-    if ctx is None:
-        ctx = _native.Context(_worker_state["device"])
+def _worker_context(k=0):
+    ctxs = _worker_state.setdefault("ctxs", [None, None])
+    if ctxs[k] is None:
+        ctxs[k] = _native.Context(_worker_state["device"])
         if _worker_state["time_out"] > 0:
-            ctx.set_timeout(_worker_state["time_out"])
-        _worker_state["ctx"] = ctx
-    return ctx
+            ctxs[k].set_timeout(_worker_state["time_out"])
+    return ctxs[k]
 
 
 def _worker_entry(entry):
     """One entry in a worker process: (record or 0, failure reason or None).  A time-out abandons the worker's context."""
-    reasons = {}
-    try:
-        record = analyzeEntry(entry, _worker_context(), reasons, _worker_state["silent"])
-    except _native.PdbedaTimeout:
-        _worker_state["ctx"] = None
-        _drop(entry.pdbid, "Timeout", reasons, _worker_state["silent"])
-        record = 0
-    return record, reasons.get(entry.pdbid)
+    return _worker_chunk([entry])[0]
+
+
+def _worker_chunk(entries):
+    """A few entries in a worker process, as a two-stage pipeline: while entry i is analysed (host-side table building: holds
+    the GIL) a helper thread brings the maps of entry i + 1 into HBM on the worker's OTHER context (file reads and PCIe copies
+    happen inside the library, GIL released) -- a worker used to alternate between feeding the PCIe link and feeding the
+    interpreter, and four of them left the link idle 40 % of the time.  Entry i lives on context i % 2 from its upload to its
+    record.  Returns [(record or 0, failure reason or None)]; a time-out abandons the context it happened on."""
+    silent = _worker_state["silent"]
+
+    def load(i, box):
+        try:
+            box.append(loadEntry(entries[i], _worker_context(i % 2)))
+        except BaseException as exception:           # handed to the analysing side, which sorts entry errors from device errors
+            box.append(exception)
+
+    def start(i):
+        box = []
+        thread = threading.Thread(target=load, args=(i, box), daemon=True)
+        thread.start()
+        return thread, box
+
+    out = []
+    pending = start(0) if entries else None
+    for i, entry in enumerate(entries):
+        thread, box = pending
+        thread.join()
+        pending = start(i + 1) if i + 1 < len(entries) else None
+        reasons = {}
+        try:
+            record = analyzeEntry(entry, _worker_context(i % 2), reasons, silent, loaded=box[0])
+        except _native.PdbedaTimeout:
+            _worker_state["ctxs"][i % 2] = None
+            _drop(entry.pdbid, "Timeout", reasons, silent)
+            record = 0
+        except BaseException:
+            if pending is not None:
+                pending[0].join()                    # (do not leave the helper running into a dying call)
+            raise
+        out.append((record, reasons.get(entry.pdbid)))
+    return out
 
 
 class ProcessPool(object):
@@ -261,8 +304,15 @@ class ProcessPool(object):
         """Make every worker import the package, load the library and create its context (first-use costs out of the way)."""
         self.run(_worker_warm, range(4 * self.n_workers))
 
-    def map(self, entries):
-        results = self.run(_worker_entry, entries)
+    def map(self, entries, chunk=None):
+        """Records of ``entries`` in order (0 for a failed entry, its reason in ``self.failures``).  The entries go to the
+        workers in chunks (default: about four chunks per worker, at most 8 entries each) so that a worker can bring the
+        next entry's maps in while it analyses the current one (``_worker_chunk``)."""
+        entries = list(entries)
+        if chunk is None:
+            chunk = max(1, min(8, len(entries) // (4 * self.n_workers)))
+        chunks = [entries[k:k + chunk] for k in range(0, len(entries), chunk)]
+        results = [pair for part in self.run(_worker_chunk, chunks) for pair in part]
         self.failures = {e.pdbid: why for e, (rec, why) in zip(entries, results) if why}
         return [rec for rec, _ in results]
 
@@ -279,7 +329,8 @@ def _worker_hold(_):
 
 
 def _worker_warm(_):
-    _worker_context()
+    _worker_context(0)
+    _worker_context(1)
     import time as _time
     _time.sleep(0.05)      # (keeps the task on this worker long enough for the others to take the next ones)
     return 1
