@@ -164,7 +164,7 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
             one.warm()
             one.map(sample[:2])
             t1 = time.perf_counter()
-            one.map(sample)
+            one.map(sample, chunk=8)                # (the chunk size the big pool works with: the worker pipelines inside a chunk)
             single = (time.perf_counter() - t1) / len(sample)
         finally:
             one.close()
