@@ -231,6 +231,17 @@ def sweep_leg(args, rank, local_rank, world, barrier, dist, torch):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def guarded(name, leg):
+    """An informational leg must not take the headline line down with it: its failure is reported in its place."""
+    try:
+        return leg()
+    except BaseException as exception:
+        if isinstance(exception, (KeyboardInterrupt, SystemExit)):
+            raise
+        print("bench.py: leg %s failed: %s: %s" % (name, type(exception).__name__, exception), file=sys.stderr)
+        return {"error": "%s: %s" % (type(exception).__name__, exception)}
+
+
 def _import_native():
     from pdb_eda_amd import _native
     return _native
@@ -419,7 +430,7 @@ def main():
     # region discrepancies + blob statistics, maps uploaded from host buffers -> entries/min of the whole per-entry pipeline
     analysis = None
     if rank == 0 and not args.no_analysis:
-        analysis = analysis_leg(ctx)
+        analysis = guarded("analysis_entry", lambda: analysis_leg(ctx))
 
     # ---- BASELINE configs[3]: multiple-structure mode.  Every rank analyses ITS shard of the entries (no data-path collective):
     # `entries` synthetic entries per rank -- each = two CCP4 files of a 200^3 grid + a ~500-atom model -- read from files, parsed,
@@ -427,12 +438,12 @@ def main():
     # worker processes, one HIP stream each.  entries/min = entries of all ranks / max-over-ranks time. ----
     multiple = None
     if pool is not None:
-        multiple = multiple_leg(args, pool, rank, local_rank, world, barrier, dist if world > 1 else None, torch)
+        multiple = guarded("multiple_structures", lambda: multiple_leg(args, pool, rank, local_rank, world, barrier, dist if world > 1 else None, torch))
 
     # ---- BASELINE configs[4]: optimise-mode iterations over resident entries + the statistics reduction (informational) ----
     sweep = None
     if args.sweep_entries > 0 and args.sweep_iterations > 0:
-        sweep = sweep_leg(args, rank, local_rank, world, barrier, dist if world > 1 else None, torch)
+        sweep = guarded("radius_sweep", lambda: sweep_leg(args, rank, local_rank, world, barrier, dist if world > 1 else None, torch))
 
     # host -> HBM upload of one entry (the boundary hands over a host buffer); never part of `value`
     t1 = time.perf_counter()
