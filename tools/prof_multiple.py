@@ -8,7 +8,7 @@ from pdb_eda_amd import _native, synthetic, multipleStructures, densityAnalysis
 densityAnalysis.setGlobals(synthetic.synthetic_params())
 tmp = tempfile.mkdtemp(prefix="pdbeda_prof_")
 try:
-    loaders = [synthetic.write_entry_files(tmp, "e%d" % k, 200, 100, k) for k in range(2)]
+    loaders = [synthetic.write_entry_files(tmp, "e%d" % k, 200, 100, k, as_paths=True) for k in range(2)]
     entries = [multipleStructures.Entry("e%04d" % i, loaders[i % 2], cost_hint=0.0) for i in range(24)]
     ctx = _native.Context(0)
     failures = {}
@@ -24,6 +24,6 @@ try:
     for e in entries[:8]:
         multipleStructures.analyzeEntry(e, ctx, failures, True)
     pr.disable()
-    pstats.Stats(pr).sort_stats("tottime").print_stats(18)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(30)
 finally:
     shutil.rmtree(tmp, ignore_errors=True)
