@@ -96,6 +96,13 @@ def test_full_map_fused_and_labels(case):
     # lazily computed labels of a non-fused list agree too
     single = dm._map.full_blobs(cp)
     assert np.array_equal(single.labels(dm._map.unique_shape), green.labels(dm._map.unique_shape))
+    # ... and those of a NEGATIVE list on its own (one volume, signed -1: its labels must not lose the volume-0 count that the
+    # red list of a fused job sheds), eager and lazy
+    red_labels = red.labels(dm._map.unique_shape)
+    for with_labels in (True, False):
+        lone = dm._map.full_blobs(cn, labels=with_labels)
+        assert np.array_equal(lone.labels(dm._map.unique_shape), red_labels)
+        assert np.array_equal(lone.stats()["n"], red.stats()["n"])
     assert dm.createFullBlobList(0.0) is None
 
 
