@@ -755,7 +755,6 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.tile_runs = n_tiles ? cv.take<uint32_t>(n_tiles) : nullptr;
     job.root_mask = n_tiles ? cv.take<uint64_t>((size_t)n_tiles * 4) : nullptr;
     job.n_tiles = (int32_t)n_tiles;
-    job.run_sums = n_tiles ? cv.take<double2>((size_t)n_tiles * RCAP) : nullptr;
     job.inbox = n_tiles ? cv.take<InboxEntry>((size_t)n_tiles * INBOX_CAP) : nullptr;
     job.inbox_count = n_tiles ? cv.take<uint32_t>((size_t)n_tiles * INBOX_STRIDE) : nullptr;
     job.vol_sign[0] = job.vol_sign[1] = 1;
@@ -807,13 +806,10 @@ static pdbeda_bloblist *new_list(pdbeda_ctx *ctx, pdbeda_map *m) {
     return bl;
 }
 
-#ifndef PDBEDA_TILE_NT
-#define PDBEDA_TILE_NT 512   // threads per tile workgroup (256 or 512; see k_tile_label)
-#endif
 template <int CW>
 static void launch_tile_label(pdbeda_ctx *ctx, unsigned n_tiles, const Job &job, const float *dens, const Geom *geom_dev, const TileDims &td,
                               const JobInit &init, int pair_slots) {
-    { PROF(ctx, "k_tile_label"); hipLaunchKernelGGL((k_tile_label<CW, PDBEDA_TILE_NT>), dim3(n_tiles), dim3(PDBEDA_TILE_NT), 0, ctx->stream, job, dens, geom_dev, td, init); }
+    { PROF(ctx, "k_tile_label"); hipLaunchKernelGGL((k_tile_label<CW>), dim3(n_tiles), dim3(512), 0, ctx->stream, job, dens, geom_dev, td, init); }
     // cross-tile unions; the first UNIT_BLOCKS workgroups are the fallback for tiles that overflowed LDS (rare: they exit at once)
     { PROF(ctx, "k_face_merge"); hipLaunchKernelGGL((k_face_merge<CW>), dim3(n_tiles + UNIT_BLOCKS), dim3(256), 0, ctx->stream, job, dens, geom_dev, td, pair_slots); }
 }
@@ -857,7 +853,7 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
     td.cut[1] = cut_neg;
     td.sign[1] = -1;
     const int64_t tiles_pp = (int64_t)td.ctiles * td.rtiles * td.stiles;
-    if (tiles_pp >= (1ll << 31)) return fail(ctx, PDBEDA_ERR_ARGUMENT, "grid too large");
+    if (tiles_pp >= (1ll << 31) || keys_pp >= (1ll << 31)) return fail(ctx, PDBEDA_ERR_ARGUMENT, "grid too large");   // (first keys inside a plane are 31-bit)
     // run / component ids: a fixed range per tile (no allocation atomics) + worst case of the unit tiles above them
     const int64_t max_runs = tiles_pp * td.cw * 64 * 32 + (int64_t)((uc + 1) / 2) * ur * us * n_planes + 1;
     if (max_runs >= (1ll << 31))

@@ -64,7 +64,6 @@ struct Job {
     uint32_t epoch;           // job number of the context (never 0)
     uint8_t *tile_mode;       // per tile: 0 = united in LDS, 1 = unit tile
     uint32_t *tile_runs;      // per tile: number of word-runs (ids tile * runs_per_tile ...)
-    double2 *run_sums;        // whole-map tiles: per run slot (sum rho, sum rho*(c - c_tile)), RCAP per tile
     // Scattered global atomics are the scarce resource of the merge (~20 G/s chip-wide: folding 9 fields per (tile, root) pair
     // took 12 of k_resolve_tiles' 22 us).  So a tile's members POST their summed record to the inbox of the tile that owns
     // their root -- one returning atomic for the slot + plain stores -- and k_paint_tiles (a workgroup per tile) absorbs

@@ -1,18 +1,24 @@
 // pdbeda_tile.h -- the whole-map fast path (pdbeda_full_blobs / pdbeda_full_blobs_pm).
 //
-// k_tile_label<CW, 512> (one 512-thread workgroup per tile of CW words x 8 rows x 8 sections,
-// i.e. up to 256 c x 8 r x 8 s = 16 Ki voxels):
-//   A1 stream the tile's density once from HBM (coalesced 256-B wave loads), compare -> the compare
-//      masks ARE the wave ballots -> bit masks of both signs (fused green/red); the significant values
-//      are compacted into LDS
-//   A2 runs of every word (bit tricks), one block scan -> per-row run slots
-//   A3 run extents by the thread of the run's first word, then exact fp64 (sum rho, sum rho*c) of every run,
-//      sequentially by a thread per RUN (a thread owns the same <= 3 run slots from here to the end)
-//   B  26-connected components INSIDE the tile: one two-pointer merge per (sign, row, earlier neighbour
-//      row) lists the touching run pairs; hook-and-jump rounds in LDS unite them (no returning atomics)
-//   C  a thread per run folds it into its component (fp64 sums, packed integer sums, c-major first key); one
-//      record per tile component is flushed to HBM, run -> component ids are published for the label writer,
-//      the runs (start, end, component) are exported for the face merge.
+// k_tile_label<CW> (one 512-thread workgroup per tile of CW words x 8 rows x 8 sections, i.e. up to
+// 256 c x 8 r x 8 s = 16 Ki voxels; WAVE w owns SECTION w of the tile from the first load to the last fold):
+//   A1 the wave streams its section once from HBM (coalesced 256-B wave loads); the compare masks ARE the wave
+//      ballots -> bit masks of both signs (fused green / red); the significant values are parked in the wave's
+//      own slice of LDS, compacted in lane order
+//   -- barrier 1 (the masks of all sections are in LDS) --
+//   A2 lane = (sign, row, word) of the section: the lane counts the word-runs of its mask word; ONE packed
+//      32-lane DPP scan numbers them (ids follow wave, sign, row, word: the runs of a row are consecutive), numbers
+//      the words of the section below as that wave does (so nobody waits for anybody's ids) and places the parked values
+//   B  26-connected components inside the tile, without a run list and without rounds: the touching pairs between
+//      my word and an earlier neighbour row are the set bits of two bit expressions (a pair is charged to the
+//      later of its two run starts, which makes it unique), and every pair is united on the spot in a lock-free
+//      union-find in LDS (atomic min on the larger root).  Waves do not wait for each other.
+//   -- barrier 2 (all unions done) --  C1 roots take component numbers  -- barrier 3 --
+//   C2 the lane walks the runs of its word: exact fp64 (sum rho, sum rho * c) over the parked values, folded into
+//      the component's accumulators (LDS atomics); run -> component ids are published for the label writer and
+//      the runs (start, end, component) exported for the face merge
+//   -- barrier 4 --  one record per tile component is flushed to HBM.
+// Four barriers on a tile's path (round 2: 24); per-run sums never leave the chip.
 // Only component pairs that touch across a tile face are united globally (k_face_merge, after an LDS
 // de-duplication per tile), and only non-root tile components cost global atomics (k_resolve_tiles, after an
 // LDS pre-reduction per tile).  A tile whose run or component count exceeds the LDS capacity falls
@@ -24,20 +30,11 @@
 namespace pdbeda {
 
 constexpr int TILE_R = 8, TILE_S = 8;
-constexpr int RCAP = 1408;        // run slots per tile handled in LDS (runs are tracked per ROW: a run crossing words is one run);
-                                  // sign 0 fills them from the bottom, sign 1 ends at the top: [RCAP - n1, RCAP) -- a one-sign job has them all
+constexpr int RCAP = 1408;  // word-runs of a tile (both signs) handled in LDS
 constexpr int CCAP = 256;   // tile-local components (both signs together) handled in LDS
 static_assert(CCAP == TILE_COMPS, "k_emit walks the tiles' component ranges");
-constexpr int VCAP = 3584;  // significant values per tile parked in LDS during phase A (aliases the 14 KiB scratch)
-constexpr int VMAIN = 3072; // of the VCAP parked values: split into one private region per wave (no atomics) ...
-constexpr int VPOOL = VCAP - VMAIN;      // ... and a shared pool a wave spills into with one LDS atomic (rare)
-// touching run pairs a (row, neighbour row) task parks per batch, 16 bits each (both run numbers relative to their
-// rows): EQ * NT * 2 B + the 16-bit proposal table (RCAP * 2 B) share the scratch during phase B
-constexpr int tile_eq(int) { return 16; }
-constexpr int tile_scratch_bytes(int nt) {
-    return tile_eq(nt) * nt * 2 + RCAP * 2 > 4 * CCAP * 8 + 6 * CCAP * 4 ? tile_eq(nt) * nt * 2 + RCAP * 2 : 4 * CCAP * 8 + 6 * CCAP * 4;
-}
-
+constexpr int VCAP = 3584;  // significant values of a tile parked in LDS: one private region of VCAP / 8 per wave (= section)
+constexpr int ECAPW = 384;  // touching run pairs a wave lists before it unites them (the list lives where the component sums go later)
 
 struct TileDims {
     int cw;                       // words per tile along c (1..4)
@@ -66,12 +63,46 @@ __device__ inline uint32_t mbcnt_lt(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+__device__ inline uint32_t mbcnt_lt_add(uint64_t mask, uint32_t add) {   // ... + add (the instruction has an accumulator operand)
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, add));
+}
+
 // lane `sel` of `old` <- the wave-uniform value `sval` (v_writelane_b32; this clang has no builtin for it).
 // A select on `lane == sel` would do, but its 64-bit masks are loop invariant: hoisted, 16 of them spill the SGPRs.
 // (`sel` must fold to a constant 0..63 -- an inline constant: a second SGPR would break the constant-bus limit.)
 __device__ __forceinline__ uint32_t wave_writelane(uint32_t old, uint32_t sval, int sel) {
     asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(__builtin_amdgcn_readfirstlane((int)sval)), "n"(sel));
     return old;
+}
+
+// x of another lane through the DPP network (no LDS crossbar trip); lanes without a source read 0
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp0(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, true);
+}
+constexpr int DPP_ROW_SHR = 0x110, DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+// inclusive prefix sums inside each HALF of the wave (lanes 0..31 and 32..63 separately): five DPP adds
+__device__ __forceinline__ uint32_t half_scan(uint32_t x) {
+    x += dpp0<DPP_ROW_SHR + 1>(x);
+    x += dpp0<DPP_ROW_SHR + 2>(x);
+    x += dpp0<DPP_ROW_SHR + 4>(x);
+    x += dpp0<DPP_ROW_SHR + 8>(x);
+    x += dpp0<DPP_ROW_BCAST15, 0xa>(x);   // rows 1 and 3 add the totals of rows 0 and 2
+    return x;
+}
+
+// inclusive prefix sums over the whole wave: six DPP adds
+__device__ __forceinline__ uint32_t wave_scan(uint32_t x) {
+    x = half_scan(x);
+    x += dpp0<DPP_ROW_BCAST31, 0xc>(x);   // rows 2 and 3 add the total of rows 0 and 1
+    return x;
+}
+// orders this wave's LDS accesses for its own lanes (LDS executes a wave's instructions in order: nothing to wait for,
+// the fences only pin the compiler)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // Tile t owns component ids [t * CCAP, (t+1) * CCAP) and run ids [t * runs_per_tile, ...): no
@@ -90,62 +121,68 @@ __device__ inline void mark_comps_unused(const JobRef &job, uint32_t cb, uint32_
 
 // The Job of a kernel whose FIRST argument it is, read from the kernel-argument segment at the point of use.  A by-value
 // argument is loaded into scalar registers at kernel entry and stays live until its last use: the ~20 pointers that only
-// the tail of k_tile_label stores through sat on 40 SGPRs during the hot LDS phases and pushed their loop scalars into
-// spills.  The empty asm keeps the loads below it.
+// the tail of k_tile_label stores through would sit on 40 SGPRs during the hot phases.  The empty asm keeps the loads below it.
 typedef const Job __attribute__((address_space(4))) *JobKernarg;
 #define PDBEDA_LATE_JOB(name)                                                      \
     JobKernarg name##_p = (JobKernarg)__builtin_amdgcn_kernarg_segment_ptr();      \
     asm volatile("" : "+s"(name##_p));                                             \
     const Job __attribute__((address_space(4))) &name = *name##_p
 
+// Lock-free union in an LDS parent table (parent[x] <= x, roots point at themselves): find both roots, hang the larger
+// under the smaller with an atomic min; if the larger was no root any more, carry on with its new parent.
+// (find splits the path it walks: every node on it is re-pointed at its grandparent with a plain store.  A store that
+//  overwrites a concurrent hook of a NON-root loses nothing: whoever hooks a non-root goes on to unite its old parent.)
+__device__ __forceinline__ uint32_t lds_find(uint32_t *parent, uint32_t x) {
+    uint32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (p != x) {
+        const uint32_t gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        x = p;
+        p = gp;
+    }
+    return x;
+}
+__device__ __forceinline__ void lds_unite(uint32_t *parent, uint32_t a, uint32_t b) {
+    while (true) {
+        a = lds_find(parent, a);
+        b = lds_find(parent, b);
+        if (a == b) return;
+        const uint32_t hi = a > b ? a : b, lo = a > b ? b : a;
+        const uint32_t old = atomicMin(&parent[hi], lo);
+        if (old == hi) return;
+        a = old;
+        b = lo;
+    }
+}
 
-// NT = 512 threads: the same tile with twice the waves -- the kernel is one round of co-resident workgroups (1024
-// tiles at 256^3, 4 per CU), so its duration is the critical path of ONE tile; 8 waves halve the serial word loop of
-// A1, split A3 / C2 by sign (threads 256.. own the "<= cutoff" plane) and halve the pair tasks per thread.
-template <int CW, int NT>
-__global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td,
-                                                                       JobInit init) {
-    constexpr int NW = NT / 64;   // waves
-    constexpr int NU = 64 * CW;   // (row, word) units of the tile = threads that own a word
-    constexpr int UPW = NU / NW;  // units per wave (whole rows)
-    constexpr int CHU = UPW < 16 ? UPW : ((CW == 3) ? 12 : 16);  // units per chunk: whole rows
-    constexpr int VREG = VMAIN / NW;
-    constexpr int EQ = tile_eq(NT);
-    constexpr int SLOTS = (RCAP + NT - 1) / NT;   // run slots a thread owns in phase B
-    static_assert(UPW % CHU == 0 && CHU % CW == 0, "chunks are whole rows");
-    static_assert(NT == 512, "phase B maps one (sign, row, neighbour row) merge task to each of 2 x 64 x 4 threads");
-    __shared__ uint64_t s_mask[2][256];
-    __shared__ uint16_t s_first[2][256];  // LDS slot of the word's first run (may continue from the previous word)
-    // (the word's second run has slot (first & 0x7fff) + 1, the others follow)
-    __shared__ uint16_t s_gword[256];     // ordinal of the word's first word-run among the wave's word-runs
-    __shared__ uint16_t s_rowfirst[2][64];
-    __shared__ uint16_t s_rowcnt[2][64];
-    // per row-run sums sum(rho), sum(rho * (c - c_tile)) live in HBM/L2 (job.run_sums, 2 doubles per slot of this
-    // tile): written in A3b and read back in C2 by the SAME thread (it owns the same <= 3 run slots in both), so they cost
-    // no LDS (occupancy) and no atomics.  (Holding them in registers instead spills: the kernel sits at 64 VGPRs.)
-    double2 *g_run = job.run_sums + (size_t)blockIdx.x * RCAP;
-    __shared__ uint16_t s_parent[RCAP];   // hook-and-jump parents (plain stores only, so 16 bits suffice)
-    __shared__ uint16_t s_rse16[RCAP];    // run start | end << 8: positions inside the tile row (0..255); later: component index
-    __shared__ uint8_t s_rowof[RCAP];     // tile row (0..63) of every run slot
-    // 14 KiB scratch: per-thread edge buffers in phase B, per-component accumulators in phase C
-    __shared__ double s_scratch[tile_scratch_bytes(NT) / 8];
-    double *s_rho = s_scratch, *s_rho_c = s_scratch + CCAP, *s_rho_r = s_scratch + 2 * CCAP, *s_rho_s = s_scratch + 3 * CCAP;
-    uint32_t *s_n = reinterpret_cast<uint32_t *>(s_scratch + 4 * CCAP), *s_r = s_n + 2 * CCAP, *s_key = s_n + 4 * CCAP, *s_cplane = s_n + 5 * CCAP;
-    // (phase C: s_n .. +2 CCAP holds the packed 64-bit integer sums, s_r the c sums; see s_pk / s_crel)
-    uint16_t *s_edges = reinterpret_cast<uint16_t *>(s_scratch);
-    uint16_t *s_cand = s_edges + EQ * NT;   // phase B: hook proposals (0xffff = none)
-    static_assert(EQ * NT * 2 + RCAP * 2 <= tile_scratch_bytes(NT) && VCAP * 4 <= tile_scratch_bytes(NT), "phase-A/B tables must fit the scratch");
-    uint16_t *s_compidx = s_rse16;        // reused after phase B
-    float *s_val = reinterpret_cast<float *>(s_scratch);  // phase A: significant values, compacted per word (4 wave regions)
-    __shared__ uint16_t s_vbase[256];
-    __shared__ uint32_t s_alloc[2];       // slots handed out per sign
-    __shared__ uint32_t s_wsx[4], s_wsy[4];   // the word-owning threads are the first 256 (= 4 waves) also when NT = 512
-    __shared__ uint32_t s_gcnt[4];        // word-runs per wave
-    __shared__ uint32_t s_over, s_vover, s_changed, s_more, s_ncomp, s_runbase, s_compbase, s_vpool;
-
+template <int CW>
+__global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td, JobInit init) {
+    constexpr int NT = 512, NW = 8;
+    constexpr int NU = 64 * CW;     // (row, word) units of the tile
+    constexpr int USEC = 8 * CW;    // units of a section = of a wave
+    constexpr int CHU = USEC < 16 ? USEC : ((CW == 3) ? 12 : 16);  // units per chunk of the stream: whole rows
+    constexpr int VREG = VCAP / NW;
+    constexpr uint32_t ROOT16 = 0x8000u;   // C1: the low half of parent[root] = ROOT16 | component number
+    static_assert(USEC % CHU == 0 && CHU % CW == 0, "chunks are whole rows");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wt = tid & 255;     // the word this thread owns in the thread-per-word phases ...
-    const int half = tid >> 8;    // ... and (NT = 512) the sign plane it works on there; threads 256.. mirror 0..255 in A2
+    const int wvs = __builtin_amdgcn_readfirstlane(wv);
+    const int wvs_edge_base = wvs * ECAPW;
+    __shared__ uint64_t s_mask[2][256];
+    __shared__ float s_val[VCAP];
+    __shared__ uint32_t s_parent[RCAP];
+    // phase B: the waves' edge lists; phase C: the component accumulators (sums relative to the tile origin)
+    __shared__ __attribute__((aligned(16))) unsigned char s_blob[CCAP * 48];
+    static_assert(NW * ECAPW * 4 <= CCAP * 48, "the edge lists fit the accumulator block");
+    double *s_rho = reinterpret_cast<double *>(s_blob), *s_rho_c = s_rho + CCAP, *s_rho_r = s_rho + 2 * CCAP, *s_rho_s = s_rho + 3 * CCAP;
+    // integer sums of a component, relative to the tile origin, packed so that a run costs two LDS atomics, not four:
+    // s_pk = voxels (20 bits) | sum (r - r0) << 20 (20 bits) | sum (s - s0) << 40;  s_crel = sum (c - c_tile)
+    unsigned long long *s_pk = reinterpret_cast<unsigned long long *>(s_rho + 4 * CCAP);
+    uint32_t *s_crel = reinterpret_cast<uint32_t *>(s_pk + CCAP), *s_key = s_crel + CCAP;   // s_key: plane << 31 | c-major key inside the plane (min = first voxel)
+    uint32_t *s_edge = reinterpret_cast<uint32_t *>(s_blob) + wvs_edge_base;
+    __shared__ __attribute__((aligned(16))) uint32_t s_wtot[NW];   // word-runs of section w (both signs); bit 31: it could not park all its values
+    __shared__ uint16_t s_vb16[256];   // first parked value of every unit
+    __shared__ uint32_t s_ncomp;
+
     const int uc = td.uc, ur = td.ur, us = td.us;   // (kernel arguments: no dependent load through gp before the stream can start)
     const int nc = td.nc, nr = td.nr;
     int t = blockIdx.x;
@@ -156,51 +193,50 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
     const int row_words = (uc + 63) >> 6;
     const int n_planes = td.n_planes;
 
-    if (tid == 0) { s_over = 0; s_vover = 0; s_ncomp = 0; s_alloc[0] = 0; s_alloc[1] = 0; s_vpool = 0; }
-    if (tid == 0) job.inbox_count[(size_t)blockIdx.x * INBOX_STRIDE] = 0u;
-    if (blockIdx.x == 0 && tid == 0) {   // read by the kernels that follow; nothing in this kernel touches them
-        job.vols[0] = init.v[0];
-        if (td.n_planes > 1) job.vols[1] = init.v[1];
-        Counters c;
-        memset(&c, 0, sizeof c);
-        c.n_runs = init.runs0;
-        c.n_comps = init.comps0;
-        *job.ctr = c;
-    }
-    {   // every tile clears its slice of the first-key bitmap (saves a memset launch; it is painted two kernels later)
-        const int64_t per = (job.key_words + gridDim.x - 1) / gridDim.x;
-        const int64_t lo = per * blockIdx.x, hi = lo + per < job.key_words ? lo + per : job.key_words;
-        for (int64_t i = lo + tid; i < hi; i += NT) job.key_bits[i] = 0ull;
-        const int64_t nfc = job.n_fine_alloc / 2;   // ... and of the rank counters (16-bit, two per word)
+    {
+        PDBEDA_LATE_JOB(pj);
+        if (tid == 0) { s_ncomp = 0; pj.inbox_count[(size_t)blockIdx.x * INBOX_STRIDE] = 0u; }
+        if (blockIdx.x == 0 && tid == 0) {   // read by the kernels that follow; nothing in this kernel touches them
+            pj.vols[0] = init.v[0];
+            if (td.n_planes > 1) pj.vols[1] = init.v[1];
+            Counters c;
+            memset(&c, 0, sizeof c);
+            c.n_runs = init.runs0;
+            c.n_comps = init.comps0;
+            *pj.ctr = c;
+        }
+        // every tile clears its slice of the first-key bitmap (saves a memset launch; it is painted two kernels later)
+        const int64_t key_words = pj.key_words;
+        const int64_t per = (key_words + gridDim.x - 1) / gridDim.x;
+        const int64_t lo = per * blockIdx.x, hi = lo + per < key_words ? lo + per : key_words;
+        uint64_t *key_bits = pj.key_bits;
+        for (int64_t i = lo + tid; i < hi; i += NT) key_bits[i] = 0ull;
+        const int64_t nfc = pj.n_fine_alloc / 2;   // ... and of the rank counters (16-bit, two per word)
         const int64_t perc = (nfc + gridDim.x - 1) / gridDim.x, clo = perc * blockIdx.x, chi = clo + perc < nfc ? clo + perc : nfc;
-        for (int64_t i = clo + tid; i < chi; i += NT) job.fine_count[i] = 0u;
+        uint32_t *fine_count = pj.fine_count;
+        for (int64_t i = clo + tid; i < chi; i += NT) fine_count[i] = 0u;
     }
-    for (int i = tid; i < RCAP; i += NT) s_parent[i] = (uint16_t)i;
-    __syncthreads();
+    for (int i = tid; i < RCAP; i += NT) s_parent[i] = (uint32_t)i;
 
     // the streaming phase runs at raised wave priority: a tile whose data arrives late shares its CU with tiles that are already
-    // in their LDS phases, and it is the late tile that ends the kernel (measured: 56.4 -> 54.3 us)
+    // in their LDS phases, and it is the late tile that ends the kernel
     __builtin_amdgcn_s_setprio(3);
-    // ---- A1: stream the tile once from HBM: compare, ballot, store the masks; the significant
-    //      values of every word are compacted into LDS (lane order) with one conflict-free write.
-    //      A tile that lies wholly inside the grid (all but the last ones along each axis) takes the
-    //      unguarded path: scalar row bases + immediate offsets, no per-load address arithmetic or
-    //      exec juggling (this phase is scalar-/vector-issue bound next to the HBM stream).
+    // ---- A1: the wave streams its section: compare, ballot, park the significant values (lane order) in its LDS region.
+    //      A tile that lies wholly inside the grid (all but the last ones along each axis) takes the unguarded path:
+    //      scalar row bases + immediate offsets, no per-load address arithmetic or exec juggling.  Eleven vector
+    //      instructions per 64 voxels: this phase is issue bound next to the HBM stream.
     {
-        const int wvs = __builtin_amdgcn_readfirstlane(wv);
         const bool interior = (r0 + TILE_R <= ur) && (s0 + TILE_S <= us) && ((w0 + CW) * 64 <= uc);   // block-uniform
-        uint32_t vcnt = 0;  // wave-uniform: values parked so far in this wave's region
+        uint32_t vcnt = 0;      // wave-uniform: significant values so far (> VREG: the region overflowed)
+        uint32_t rtot = 0;      // lanes < CHU: word-runs of the units they collected
         const uint32_t vreg = (uint32_t)wvs * VREG;
-        // plane 0 is ">= cut" or "<= cut": x * sg >= cut * sg with sg = +-1 (exact) is one multiply + one compare whose
-        // mask IS the ballot; plane 1 ("<= cut[1]") is masked off as a whole for one-plane jobs
-        const float sg0 = td.sign[0] > 0 ? 1.0f : -1.0f, cs0 = td.cut[0] * sg0, c1 = td.cut[1];
-        const uint64_t pm1 = n_planes > 1 ? ~0ull : 0ull;
-        auto stream = [&](auto interior_tag) {
-            constexpr bool INTERIOR = decltype(interior_tag)::value;
+        const float c0 = td.cut[0], c1 = td.cut[1];
+        auto stream = [&](auto interior_tag, auto pos_tag, auto two_tag) {
+            constexpr bool INTERIOR = decltype(interior_tag)::value, POS = decltype(pos_tag)::value, TWO = decltype(two_tag)::value;
 #pragma unroll 1
-            for (int chunk = 0; chunk < UPW / CHU; ++chunk) {
-                const int u0 = wvs * UPW + chunk * CHU;   // first unit of the chunk (scalar; a multiple of CW)
-                const int rowl0 = u0 / CW;                // its CHU / CW rows lie in one section
+            for (int chunk = 0; chunk < USEC / CHU; ++chunk) {
+                const int u0 = wvs * USEC + chunk * CHU;   // first unit of the chunk (scalar; a multiple of CW)
+                const int rowl0 = u0 / CW;                 // its CHU / CW rows lie in one section
                 const float *cbase = dens + ((int64_t)(s0 + (rowl0 >> 3)) * nr + (r0 + (rowl0 & 7))) * nc + w0 * 64 + lane;
                 float v[CHU];
 #pragma unroll
@@ -214,454 +250,288 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 8 : 1) k_tile_label(Job job, c
                         v[jj] = in ? *ptr : 0.0f;
                     }
                 }
-                // lane jj of the chunk collects the masks / value base of unit jj (v_writelane from the scalar
-                // ballots); one 16-lane LDS write per array and chunk instead of three lane-0 writes per unit
-                uint32_t k0lo = 0, k0hi = 0, k1lo = 0, k1hi = 0, kvb = 0;
+                // lane jj of the chunk collects the masks of unit jj (v_writelane from the scalar ballots)
+                uint32_t k0lo = 0, k0hi = 0, k1lo = 0, k1hi = 0;
 #pragma unroll
                 for (int jj = 0; jj < CHU; ++jj) {
                     const int u = u0 + jj;
                     const int wl = u % CW, rowl = u / CW;
                     const float x = v[jj];
-                    bool hit0 = x * sg0 >= cs0;
-                    bool hit1 = x <= c1;
+                    bool hit0 = POS ? x >= c0 : x <= c0;
+                    bool hit1 = TWO && x <= c1;
                     if (!INTERIOR) {
                         const bool in = (r0 + (rowl & 7) < ur) && (s0 + (rowl >> 3) < us) && ((w0 + wl) * 64 + lane < uc);
                         hit0 = hit0 && in;
                         hit1 = hit1 && in;
                     }
                     const uint64_t b0 = __ballot(hit0);
-                    const uint64_t b1 = __ballot(hit1) & pm1;
+                    const uint64_t b1 = __ballot(hit1);
                     const uint64_t bb = b0 | b1;
                     const uint32_t nv = (uint32_t)popc64(bb);
-                    uint32_t base = vreg + vcnt;
-                    if (vcnt + nv <= (uint32_t)VREG) {   // wave-uniform: the common case costs no LDS round trip
-                        vcnt += nv;
-                    } else {
-                        uint32_t got = 0;
-                        if (lane == 0) got = atomicAdd(&s_vpool, nv);
-                        base = VMAIN + (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-                        if (base + nv > (uint32_t)VCAP) { base = 0xffffu; if (lane == 0) s_vover = 1; }   // tile too dense to park its values:
-                    }                                                                                      // A3 re-reads them from global memory (L2)
+                    // branch-free: a value beyond the region lands on its last slot, and vcnt > VREG at the end says that the
+                    // section was too dense to park (C2 then re-reads the tile's values from global memory / L2)
+                    if (hit0 || hit1) s_val[vreg + min(mbcnt_lt_add(bb, vcnt), (uint32_t)(VREG - 1))] = x;
+                    vcnt += nv;
                     k0lo = wave_writelane(k0lo, (uint32_t)b0, jj);
                     k0hi = wave_writelane(k0hi, (uint32_t)(b0 >> 32), jj);
                     k1lo = wave_writelane(k1lo, (uint32_t)b1, jj);
                     k1hi = wave_writelane(k1hi, (uint32_t)(b1 >> 32), jj);
-                    kvb = wave_writelane(kvb, base, jj);
-                    if (((bb >> lane) & 1ull) && base != 0xffffu) s_val[base + mbcnt_lt(bb)] = x;
                 }
                 if (lane < CHU) {
-                    s_mask[0][u0 + lane] = ((uint64_t)k0hi << 32) | k0lo;
-                    s_mask[1][u0 + lane] = ((uint64_t)k1hi << 32) | k1lo;
-                    s_vbase[u0 + lane] = (uint16_t)kvb;
+                    const uint64_t k0 = ((uint64_t)k0hi << 32) | k0lo, k1 = ((uint64_t)k1hi << 32) | k1lo;
+                    s_mask[0][u0 + lane] = k0;
+                    s_mask[1][u0 + lane] = k1;
+                    rtot += (uint32_t)popc64(run_starts(k0)) + (uint32_t)popc64(run_starts(k1));
                 }
             }
         };
-        if (interior) stream(std::true_type{}); else stream(std::false_type{});
+        const bool pos = td.sign[0] > 0;
+        if (n_planes > 1) {   // (a fused job: plane 0 is the ">= cut" plane)
+            if (interior) stream(std::true_type{}, std::true_type{}, std::true_type{}); else stream(std::false_type{}, std::true_type{}, std::true_type{});
+        } else if (interior) {
+            if (pos) stream(std::true_type{}, std::true_type{}, std::false_type{}); else stream(std::true_type{}, std::false_type{}, std::false_type{});
+        } else {
+            if (pos) stream(std::false_type{}, std::true_type{}, std::false_type{}); else stream(std::false_type{}, std::false_type{}, std::false_type{});
+        }
+        // word-runs of the section: the units sat on lanes < 16 (one DPP row)
+        rtot += dpp0<DPP_ROW_SHR + 1>(rtot);
+        rtot += dpp0<DPP_ROW_SHR + 2>(rtot);
+        rtot += dpp0<DPP_ROW_SHR + 4>(rtot);
+        rtot += dpp0<DPP_ROW_SHR + 8>(rtot);
+        if (lane == 15) s_wtot[wvs] = rtot | (vcnt > (uint32_t)VREG ? 0x80000000u : 0u);
     }
-    __syncthreads();
-
+    __syncthreads();   // ---- barrier 1 ----
     __builtin_amdgcn_s_setprio(0);
-    // ---- A2 (thread per word): run counts, row continuation, ONE block scan -> run slots ---------
-    // Runs are tracked per ROW: a run that continues from the previous word keeps that word's last
-    // slot.  Sign 0 uses slots [0, n0), sign 1 [RCAP - n1, RCAP); slots follow word order, so the
-    // runs of a row are contiguous and sorted by position.
+
+    // ---- A2: lane = (sign q, row rl, word wl) of section wvs --------------------------------------------------------
+    const int q = lane >> 5, usec = lane & 31;
+    const bool act = usec < USEC;
+    const int rl = usec / CW, wl = usec % CW;
+    const int u = wvs * USEC + (act ? usec : 0);
+    uint32_t wbase = 0, n_runs = 0, wprev = 0;
+    bool from_global = false;
     {
-        const uint64_t a0 = (wt < NU) ? s_mask[0][wt] : 0ull, a1 = (wt < NU) ? s_mask[1][wt] : 0ull;
-        const int wl = wt % CW;
-        const bool k0 = (wt < NU) && wl > 0 && (a0 & 1ull) && (s_mask[0][wt - 1] >> 63);
-        const bool k1 = (wt < NU) && wl > 0 && (a1 & 1ull) && (s_mask[1][wt - 1] >> 63);
-        const uint32_t n0 = (uint32_t)popc64(run_starts(a0)), n1 = (uint32_t)popc64(run_starts(a1));
-        const uint32_t vx = (n0 - (k0 ? 1u : 0u)) | ((n1 - (k1 ? 1u : 0u)) << 16);  // new slots of sign 0 | sign 1
-        const uint32_t vy = n0 + n1;                                                // word-runs
-        uint32_t x = vx, y = vy;
+        const uint4 t0 = *reinterpret_cast<const uint4 *>(&s_wtot[0]), t1 = *reinterpret_cast<const uint4 *>(&s_wtot[4]);
+        const uint32_t wt[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t tx = __shfl_up(x, d), ty = __shfl_up(y, d);
-            if (lane >= d) { x += tx; y += ty; }
-        }
-        if (lane == 63) { s_wsx[wv & 3] = x; s_wsy[wv & 3] = y; }   // (mirror waves store the same numbers)
-        __syncthreads();
-        uint32_t px = 0, py = 0;
-        for (int k = 0; k < (wv & 3); ++k) { px += s_wsx[k]; py += s_wsy[k]; }
-        const uint32_t ex = px + x - vx, ey = py + y - vy;
-        const uint32_t e0 = ex & 0xffffu, e1 = ex >> 16;
-        const uint32_t tx = s_wsx[0] + s_wsx[1] + s_wsx[2] + s_wsx[3];
-        const bool over_slots = (tx & 0xffffu) + (tx >> 16) > (uint32_t)RCAP;  // block-uniform
-        const uint32_t base1 = (uint32_t)RCAP - (tx >> 16);                    // first slot of sign 1
-        const uint32_t first0 = k0 ? e0 - 1u : e0, next0 = k0 ? e0 : e0 + 1u;
-        const uint32_t first1 = base1 + (k1 ? e1 - 1u : e1), next1 = base1 + (k1 ? e1 : e1 + 1u);
-        if (tid < NU) {
-            s_first[0][tid] = (uint16_t)(first0 | (k0 ? 0x8000u : 0u));
-            s_first[1][tid] = (uint16_t)(first1 | (k1 ? 0x8000u : 0u));
-            s_gword[tid] = (uint16_t)ey;
-            if (wl == 0) { s_rowfirst[0][tid / CW] = (uint16_t)e0; s_rowfirst[1][tid / CW] = (uint16_t)(base1 + e1); }
-        }
-        if (tid == 255) {
-            s_alloc[0] = tx & 0xffffu;
-            s_alloc[1] = tx >> 16;
-            s_gcnt[0] = s_wsy[0] + s_wsy[1] + s_wsy[2] + s_wsy[3];
-            if (over_slots) s_over = 1;
-        }
-        // ---- A3a (same thread per word and sign): extent of each run that STARTS in my word -- a run that continues into
-        // the following word(s) of the row is followed by its owner, so every run slot has one writer.
-        const bool from_global = s_vover != 0;   // block-uniform (set before the barrier that ended A1)
-        if (wt < NU && (a0 | a1) && !over_slots && s_over == 0) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const uint64_t m = q ? a1 : a0;
-                if (!m || (NT == 512 && q != half)) continue;
-                const bool kq = q ? k1 : k0;
-                const uint32_t fr = q ? first1 : first0, nx = q ? next1 : next0;
-                uint64_t todo = run_starts(m);
-                uint32_t k = 0;
-                while (todo) {
-                    const int a = ctz64(todo);
-                    todo &= todo - 1;
-                    const uint32_t slot = k == 0 ? fr : nx + k - 1u;
-                    ++k;
-                    if (a == 0 && kq) continue;   // continues a run of the previous word: its owner handles it
-                    int cur = wt, wlc = wl, e = run_end_of(m, a);
-                    while (e == 63 && wlc < CW - 1 && (s_mask[q][cur + 1] & 1ull)) { ++cur; ++wlc; e = run_end_of(s_mask[q][cur], 0); }
-                    s_rse16[slot] = (uint16_t)((wl * 64 + a) | ((wlc * 64 + e) << 8));
-                    s_rowof[slot] = (uint8_t)(wt / CW);
-                }
-            }
-        }
-        __syncthreads();
-        // ---- A3b (thread per RUN): exact fp64 (sum rho, sum rho * position), sequentially over the run's parked values.
-        // Per word this loop diverged badly (0 .. 6 runs of 1 .. 60 voxels per word: 13 % of the lane slots did work);
-        // per run a wave waits only for its longest run.
-        if (!over_slots && s_over == 0) {
-            const uint32_t n0 = s_alloc[0], n1 = s_alloc[1];
-#pragma unroll
-            for (int t = 0; t < SLOTS; ++t) {
-                const uint32_t lin = tid + (uint32_t)NT * t;
-                if (lin >= n0 + n1) continue;
-                const uint32_t slot = lin < n0 ? lin : (uint32_t)RCAP - n1 + (lin - n0);
-                const int q = lin < n0 ? 0 : 1;
-                const int row = s_rowof[slot], p0 = s_rse16[slot] & 0xff, p1 = s_rse16[slot] >> 8;
-                double sum = 0.0, sumc = 0.0;
-                if (!from_global) {
-                    for (int wlc = p0 >> 6; wlc <= (p1 >> 6); ++wlc) {   // the piece of the run in word wlc (almost always one piece)
-                        const int u = row * CW + wlc;
-                        const int ca = wlc == (p0 >> 6) ? (p0 & 63) : 0, ce = wlc == (p1 >> 6) ? (p1 & 63) : 63;
-                        const uint32_t off = s_vbase[u] + (uint32_t)popc64((s_mask[0][u] | s_mask[1][u]) & bits_below(ca));
-                        const int nv = ce - ca + 1, cpos = wlc * 64 + ca;
-                        int i = 0;
-                        for (; i + 4 <= nv; i += 4) {   // four parked values in flight (the longest run of the tile sets the pace of this phase);
-                            const float v0 = s_val[off + i], v1 = s_val[off + i + 1], v2 = s_val[off + i + 2], v3 = s_val[off + i + 3];   // the additions keep their order
-                            sum += (double)v0; sumc += (double)v0 * (double)(cpos + i);
-                            sum += (double)v1; sumc += (double)v1 * (double)(cpos + i + 1);
-                            sum += (double)v2; sumc += (double)v2 * (double)(cpos + i + 2);
-                            sum += (double)v3; sumc += (double)v3 * (double)(cpos + i + 3);
-                        }
-                        for (; i < nv; ++i) {
-                            const double val = (double)s_val[off + i];
-                            sum += val;
-                            sumc += val * (double)(cpos + i);
-                        }
-                    }
-                } else {   // dense tile: the values were not parked; re-read from L2, 4 loads in flight per trip (clamped inside the run)
-                    const float *rowptr = dens + ((int64_t)(s0 + (row >> 3)) * nr + (r0 + (row & 7))) * nc + w0 * 64;
-                    for (int pp = p0; pp <= p1; pp += 4) {
-                        float v4[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) v4[k] = rowptr[pp + k <= p1 ? pp + k : p1];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            if (pp + k <= p1) {
-                                const double val = (double)v4[k];
-                                sum += val;
-                                sumc += val * (double)(pp + k);
-                            }
-                        }
-                    }
-                }
-                (void)q;
-                g_run[slot] = make_double2(sum, sumc);
-            }
-        }
-        __syncthreads();
-        if (tid < 128) {
-            const int q = tid >> 6, row = tid & 63;
-            const uint32_t end = row < 63 ? s_rowfirst[q][row + 1] : (q ? (uint32_t)RCAP : s_alloc[0]);
-            s_rowcnt[q][row] = (uint16_t)(end - s_rowfirst[q][row]);
+        for (int k = 0; k < NW; ++k) {
+            const uint32_t vw = (uint32_t)__builtin_amdgcn_readfirstlane((int)wt[k]), v = vw & 0x7fffffffu;
+            if (k < wvs) wbase += v;
+            if (k == wvs - 1) wprev = v;
+            n_runs += v;
+            from_global = from_global || (vw >> 31) != 0u;
         }
     }
-    __syncthreads();
-
-    // my word (threads tid < NU own unit tid)
-    const int my_wl = wt % CW, my_rowl = (wt / CW) & 63;
-    const int my_rl = my_rowl & 7, my_sl = my_rowl >> 3;
-    const bool my_valid = (tid < NU) && (r0 + my_rl < ur) && (s0 + my_sl < us) && (w0 + my_wl < row_words);
-    const int64_t my_word = ((int64_t)(s0 + my_sl) * ur + (r0 + my_rl)) * row_words + (w0 + my_wl);  // inside a plane
+    const uint64_t m = act ? s_mask[q][u] : 0ull, mo = act ? s_mask[q ^ 1][u] : 0ull;
+    // my word
+    const bool my_valid = act && q < n_planes && (r0 + rl < ur) && (s0 + wvs < us) && (w0 + wl < row_words);
     const int64_t plane_words = (int64_t)row_words * ur * us;
+    const int64_t my_word = (int64_t)q * plane_words + ((int64_t)(s0 + wvs) * ur + (r0 + rl)) * row_words + (w0 + wl);
     const int64_t tile_id = tile_index(td, 0, w0, r0, s0);
-    const uint32_t al0 = s_alloc[0], al1 = s_alloc[1];
-    const uint32_t n_slots = al0 + al1;
-    const uint32_t n_wordruns = s_gcnt[0];
-    const uint64_t m0 = (wt < NU) ? s_mask[0][wt] : 0ull, m1 = (wt < NU) ? s_mask[1][wt] : 0ull;
-    auto slot_used = [&](uint32_t sl) -> bool { return sl < al0 || sl >= (uint32_t)RCAP - al1; };
 
-    if (n_slots == 0 || s_over) {
+    if (n_runs == 0 || n_runs > (uint32_t)RCAP) {   // block-uniform
         PDBEDA_LATE_JOB(lj);
         // nothing significant, or too many runs for LDS: publish the masks; an overflowing tile
         // is labelled by k_unit_fallback (every run its own component)
-        if (my_valid) {
-            lj.mask[my_word] = m0;
-            lj.run_base[my_word] = 0u;
-            if (n_planes > 1) { lj.mask[plane_words + my_word] = m1; lj.run_base[plane_words + my_word] = 0u; }
-        }
-        if (tid == 0) { lj.tile_mode[tile_id] = n_slots ? 1 : 0; lj.tile_runs[blockIdx.x] = 0u; if (n_slots) *lj.unit_flag = lj.epoch; }
-        if (lj.face_rows && tid < 128) lj.face_rows[(size_t)blockIdx.x * 128 + tid] = 0u;   // no run lists: nothing / the unit kernels unite   // mode 1: run slots / values overflowed
+        if (my_valid) { lj.mask[my_word] = m; lj.run_base[my_word] = 0u; }
+        if (tid == 0) { lj.tile_mode[tile_id] = n_runs ? 1 : 0; lj.tile_runs[blockIdx.x] = 0u; if (n_runs) *lj.unit_flag = lj.epoch; }
+        if (lj.face_rows && tid < 128) lj.face_rows[(size_t)blockIdx.x * 128 + tid] = 0u;   // no run lists: nothing / the unit kernels unite
         mark_comps_unused(lj, (uint32_t)blockIdx.x * CCAP, 0u, tid, NT);
         return;
     }
 
-    // ---- B: tile-local 26-connected components ---------------------------------------------------
-    // B1: thread (row, earlier neighbour row) merges the two sorted run lists (bytes, 32-bit math)
-    //     and parks the touching pairs in a private buffer.
-    // B2: hook (fire-and-forget atomic min on the larger parent) and jump (pointer jumping) rounds
-    //     until no pair disagrees -- no returning atomic, no divergent retry loop.
+    // the same word one section below (wave wvs - 1 owns it), and its three neighbours in my own numbering of that section:
+    // every wave numbers the section below exactly as its owner does, so ids never travel between waves
+    const bool sec = wvs > 0;
+    const uint64_t B2 = (act && sec) ? s_mask[q][u - USEC] : 0ull;
+    const uint64_t B0 = (act && rl > 0) ? s_mask[q][u - CW] : 0ull;
+    const uint64_t B1 = (act && sec && rl > 0) ? s_mask[q][u - USEC - CW] : 0ull;
+    const uint64_t B3 = (act && sec && rl < 7) ? s_mask[q][u - USEC + CW] : 0ull;
+    const uint64_t SA = run_starts(m);
+    const uint32_t cnt = (uint32_t)popc64(SA), cnt2 = (uint32_t)popc64(run_starts(B2));
+    // one packed scan per half wave: word-runs of my section [0, 11), of the section below [11, 22), parked values [22, 32)
+    const uint32_t packed = cnt | (cnt2 << 11) | ((uint32_t)popc64(m | mo) << 22);
+    const uint32_t incl = half_scan(packed), excl = incl - packed;
+    const uint32_t half0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);   // totals of the sign-0 lanes
+    const uint32_t my_base = wbase + (q ? (half0 & 0x7ffu) : 0u) + (excl & 0x7ffu);                         // id of my first run
+    const uint32_t base2 = wbase - wprev + (q ? ((half0 >> 11) & 0x7ffu) : 0u) + ((excl >> 11) & 0x7ffu);   // ... of B2's first run
+    const uint32_t vb = (uint32_t)wvs * VREG + (excl >> 22);   // my unit's first parked value (both sign lanes of a unit agree)
+    const uint32_t base0 = (uint32_t)__shfl((int)my_base, lane - CW), base1 = (uint32_t)__shfl((int)base2, lane - CW),
+                   base3 = (uint32_t)__shfl((int)base2, lane + CW);
+
+    // ---- B: touching pairs -> unions.  Between my word A and a neighbour row's word B (same word index; the bit
+    // below bit 0 comes from the words to the left), a pair of runs is charged to the later of its two starts:
+    //   EA = starts(A) & (B | B << 1): my run starts at p and B covers p or p - 1 (that run started no later than p)
+    //   EB = starts(B) & (A << 1):     B's run starts at p and my row covers p - 1 (my run started earlier)
+    // -- every touching pair of ROW runs appears exactly once; word-runs that continue across a word boundary add
+    // harmless repeats.  Ids of a row are consecutive, so "the run to the left of bit 0" is simply base - 1.
     {
-        // Slot ownership for the apply / flatten passes: a thread owns the slots tid, tid + NT, ... (sign-0 first).
-        uint32_t ji[SLOTS];
-#pragma unroll
-        for (int t = 0; t < SLOTS; ++t) {
-            const uint32_t lin = tid + (uint32_t)NT * t;
-            ji[t] = lin < al0 ? lin : (lin - al0 < al1 ? (uint32_t)RCAP - al1 + (lin - al0) : 0xffffffffu);
-            if (ji[t] != 0xffffffffu) s_cand[ji[t]] = 0xffffu;
-        }
-        // B1 task of this thread: (sign q, row A, earlier neighbour row B) -- 2 x 64 x 4 = NT tasks.  The runs of a
-        // row are contiguous slots sorted by position, so the touching pairs of two rows come out of ONE two-pointer
-        // merge of two short byte lists (~6 runs each): no searching, a dozen instructions per step.  A pair is
-        // parked as (run number in A) << 8 | (run number in B): 16 bits.
-        const int tq = tid >> 8, trow = (tid >> 2) & 63, tnb = tid & 3;
-        const int tr2 = (trow & 7) + (tnb == 2 ? 0 : (tnb == 3 ? 1 : -1)), ts2 = (trow >> 3) + (tnb == 0 ? 0 : -1);
-        const bool ttask = tr2 >= 0 && tr2 < TILE_R && ts2 >= 0 && (tq == 0 || n_planes > 1);
-        const int trowb = ttask ? ts2 * TILE_R + tr2 : 0;
-        const uint32_t a_first = s_rowfirst[tq][trow], b_first = s_rowfirst[tq][trowb];
-        const uint32_t na = ttask ? s_rowcnt[tq][trow] : 0u, nb = ttask ? s_rowcnt[tq][trowb] : 0u;
-        uint32_t mi = 0, mj = 0;   // merge state (kept across batches)
-        bool first_batch = true;   // parents are still the identity: B1 itself is the first hook pass
-        while (true) {  // batches of at most EQ parked pairs per thread (almost always one batch)
-            if (tid == 0) s_more = 0;
-            __syncthreads();
-            uint32_t n_edges = 0;
-            if (mi < na && mj < nb) {
-                // one 16-bit read per run (start | end << 8); the step is branch-light: compare, maybe park, advance ONE list
-                uint32_t va = s_rse16[a_first + mi], vb = s_rse16[b_first + mj];
-                while (true) {
-                    const int as = (int)(va & 0xffu), ae = (int)(va >> 8), bs = (int)(vb & 0xffu), be = (int)(vb >> 8);
-                    const bool a_before = ae + 1 < bs, b_before = be + 1 < as;   // entirely before the other run
-                    const bool touch = !(a_before || b_before);                   // Chebyshev distance <= 1 along c
-                    if (touch) {
-                        if (n_edges == (uint32_t)EQ) break;           // buffer full: resume here in the next batch
-                        s_edges[n_edges * NT + tid] = (uint16_t)((mi << 8) | mj);
-                        const uint32_t i = a_first + mi, j = b_first + mj;
-                        if (first_batch) s_cand[i > j ? i : j] = (uint16_t)(i > j ? j : i);
-                        ++n_edges;
-                    }
-                    const bool adv_a = a_before || (touch && ae < be);   // the run that ends first cannot touch anything further
-                    mi += adv_a ? 1u : 0u;
-                    mj += adv_a ? 0u : 1u;
-                    if (mi == na || mj == nb) break;
-                    va = s_rse16[a_first + mi];
-                    vb = s_rse16[b_first + mj];
+        // (cross-lane reads sit outside every conditional: a masked-off source lane would read as zero)
+        const uint32_t upA = dpp0<DPP_WAVE_SHR1>((uint32_t)(m >> 32));
+        const uint32_t cA = wl > 0 ? upA >> 31 : 0u;   // bit 63 of the word to my left
+        const uint64_t A1s = (m << 1) | cA;
+        const uint32_t up0 = dpp0<DPP_WAVE_SHR1>((uint32_t)(B0 >> 32)), up1 = dpp0<DPP_WAVE_SHR1>((uint32_t)(B1 >> 32)),
+                       up2 = dpp0<DPP_WAVE_SHR1>((uint32_t)(B2 >> 32)), up3 = dpp0<DPP_WAVE_SHR1>((uint32_t)(B3 >> 32));
+        const uint64_t SB0 = run_starts(B0), SB1 = run_starts(B1), SB2 = run_starts(B2), SB3 = run_starts(B3);
+        auto pairs = [&](uint64_t B, uint64_t SB, uint32_t up) { return (SA & (B | (B << 1) | (wl > 0 ? up >> 31 : 0u))) | (SB & A1s); };   // EA and EB are disjoint
+        const uint64_t E0 = pairs(B0, SB0, up0), E1 = pairs(B1, SB1, up1), E2 = pairs(B2, SB2, up2), E3 = pairs(B3, SB3, up3);
+        const bool same_row = (m & 1ull) && cA;   // my row continues across the word boundary
+        // The lanes list their pairs (mine << 16 | earlier: ids of earlier rows are smaller), then lane k unites pair k, k + 64, ...:
+        // a union is a chain of dependent LDS trips, and a lane with six pairs must not keep 63 others waiting -- instruction issue,
+        // not LDS, bounds this kernel, and a divergent loop issues for its slowest lane.
+        const uint32_t ecount = (uint32_t)popc64(E0) + (uint32_t)popc64(E1) + (uint32_t)popc64(E2) + (uint32_t)popc64(E3) + (same_row ? 1u : 0u);
+        const uint32_t eincl = wave_scan(ecount);
+        const uint32_t etot = (uint32_t)__builtin_amdgcn_readlane((int)eincl, 63);
+        const uint32_t mb1 = my_base - 1u;
+        if (etot <= (uint32_t)ECAPW) {   // wave-uniform
+            uint32_t epos = eincl - ecount;
+            if (same_row) s_edge[epos++] = (my_base << 16) | mb1;
+            // bit p of E: my run is the one that covers p or p - 1 (the last start <= p), and so is the neighbour's
+            auto list = [&](uint64_t E, uint64_t SB, uint32_t baseB) {
+                const uint32_t bb1 = baseB - 1u;
+                while (E) {
+                    const uint64_t below = E - 1, upto = E ^ below;   // bits <= p
+                    E &= below;
+                    s_edge[epos++] = ((mb1 + (uint32_t)popc64(SA & upto)) << 16) | (bb1 + (uint32_t)popc64(SB & upto));
                 }
+            };
+            list(E0, SB0, base0);
+            list(E1, SB1, base1);
+            list(E2, SB2, base2);
+            list(E3, SB3, base3);
+            wave_lds_sync();
+            for (uint32_t e = lane; e < etot; e += 64) {
+                const uint32_t pk = s_edge[e], a = pk >> 16, b = pk & 0xffffu;
+                const uint32_t old = atomicMin(&s_parent[a], b);   // optimistic: most runs are still roots when their first pair arrives
+                if (old != a) lds_unite(s_parent, old, b);         // a hung under `old` already: unite that tree with b's
             }
-            if (mi < na && mj < nb) s_more = 1;
-            uint32_t wmax = n_edges;   // wave maximum of the pair counts
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(wmax, d); wmax = o > wmax ? o : wmax; }
-            wmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wmax);
-            bool hooked = first_batch;   // the proposals of this round are already in the table
-            first_batch = false;
-            while (true) {
-                if (tid == 0) s_changed = 0;
-                __syncthreads();
-                // hook: a pair whose two roots differ proposes "larger root -> smaller root".  ANY proposal that
-                // reaches the table is good enough (hook-and-jump needs a smaller neighbour, not the smallest), so
-                // a plain racy 16-bit store replaces the same-address atomic that serialised this phase.
-                // A pair whose ends share a root stays satisfied for ever: it is dropped from the thread's list.
-                bool ch = false;
-                if (hooked) {
-                    ch = n_edges != 0;
-                    hooked = false;
-                } else {
-                    uint32_t keep = 0;
-                    for (uint32_t e0 = 0; e0 < wmax; e0 += 4) {   // wave-uniform bound; 4 independent pairs per trip
-                        uint32_t pr[4], pa[4], pb[4];
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const bool valid = e0 + t < n_edges;
-                            pr[t] = valid ? s_edges[(e0 + t) * NT + tid] : 0u;
-                            pa[t] = valid ? s_parent[a_first + (pr[t] >> 8)] : 0u;
-                            pb[t] = valid ? s_parent[b_first + (pr[t] & 0xffu)] : 0u;
-                        }
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            if (pa[t] != pb[t]) {
-                                s_cand[pa[t] > pb[t] ? pa[t] : pb[t]] = (uint16_t)(pa[t] > pb[t] ? pb[t] : pa[t]);
-                                s_edges[keep * NT + tid] = (uint16_t)pr[t];   // keep <= e0 + t: never ahead of the reads
-                                ++keep;
-                            }
-                        }
-                    }
-                    ch = keep != 0;
-                    n_edges = keep;
-                    wmax = keep;
-#pragma unroll
-                    for (int d = 32; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(wmax, d); wmax = o > wmax ? o : wmax; }
-                    wmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wmax);
+        } else {   // a very dense section: unite on the spot
+            if (same_row) lds_unite(s_parent, my_base, mb1);
+            auto direct = [&](uint64_t E, uint64_t SB, uint32_t baseB) {
+                const uint32_t bb1 = baseB - 1u;
+                while (E) {
+                    const uint64_t below = E - 1, upto = E ^ below;
+                    E &= below;
+                    lds_unite(s_parent, mb1 + (uint32_t)popc64(SA & upto), bb1 + (uint32_t)popc64(SB & upto));
                 }
-                if (ch) s_changed = 1;
-                __syncthreads();
-                if (s_changed == 0) break;   // block-uniform: every pair is satisfied (no proposal was made)
-                // apply: the owner of a slot attaches it (roots only) to its proposal
-#pragma unroll
-                for (int t = 0; t < SLOTS; ++t) {
-                    if (ji[t] != 0xffffffffu) {
-                        const uint32_t c = s_cand[ji[t]];
-                        if (c != 0xffffu) {
-                            if (s_parent[ji[t]] == ji[t]) s_parent[ji[t]] = (uint16_t)c;
-                            s_cand[ji[t]] = 0xffffu;
-                        }
-                    }
-                }
-                __syncthreads();
-                // flatten: every used slot points at its root again (chains are as long as the hooks of this round)
-                auto flatten = [&](uint32_t slot) {
-                    if (slot == 0xffffffffu) return;
-                    uint32_t x = s_parent[slot], y = s_parent[x];
-                    if (x != y) {
-                        while (x != y) { x = y; y = s_parent[x]; }
-                        s_parent[slot] = (uint16_t)x;
-                    }
-                };
-                static_assert(SLOTS == 3, "three run slots per thread");
-                flatten(ji[0]); flatten(ji[1]); flatten(ji[2]);
-                // (the barrier at the top of the loop orders these writes before the next round's reads, and the
-                //  s_changed reset after everybody's read above)
-            }
-            const bool more = s_more != 0;
-            __syncthreads();
-            if (!more) break;
+            };
+            direct(E0, SB0, base0);
+            direct(E1, SB1, base1);
+            direct(E2, SB2, base2);
+            direct(E3, SB3, base3);
         }
     }
-    // the run extents of my slots, for the face export below (C1 reuses their LDS bytes)
-    uint32_t ex_slot[SLOTS], ex_se[SLOTS];
-#pragma unroll
-    for (int t = 0; t < SLOTS; ++t) {
-        const uint32_t lin = tid + (uint32_t)NT * t;
-        ex_slot[t] = lin < al0 ? lin : (lin - al0 < al1 ? (uint32_t)RCAP - al1 + (lin - al0) : 0xffffffffu);
-        ex_se[t] = ex_slot[t] != 0xffffffffu ? (uint32_t)s_rse16[ex_slot[t]] : 0u;
+    __syncthreads();   // ---- barrier 2: all unions done ----
+    // ---- C1: the accumulators take the place of the edge lists; roots take component numbers; every lane describes the
+    //      runs of its word (unit | sign << 8 | first bit << 9) in the idle upper halves of the parent table, so that C2 can
+    //      hand ONE RUN to each thread: a lane-per-word loop issues for the word with the most runs and the longest run ----
+    for (uint32_t i = tid; i < (uint32_t)CCAP; i += NT) {
+        s_rho[i] = 0.0; s_rho_c[i] = 0.0; s_rho_r[i] = 0.0; s_rho_s[i] = 0.0;
+        s_pk[i] = 0ull; s_crel[i] = 0u; s_key[i] = 0xffffffffu;
     }
-    // ---- C1: number the tile-local components (the run extents are free now: reuse as u16 table) -----
-    __syncthreads();
-    for (uint32_t i = tid; i < RCAP; i += NT)
-        if (slot_used(i) && s_parent[i] == i) s_compidx[i] = (uint16_t)atomicAdd(&s_ncomp, 1u);
-    __syncthreads();
+    uint16_t *s_half = reinterpret_cast<uint16_t *>(s_parent);   // [2 i]: parent / ROOT16 | component, [2 i + 1]: descriptor of run i
+    for (uint32_t i = tid; i < n_runs; i += NT)   // (one LDS atomic per wave: the compiler aggregates)
+        if (s_half[2 * i] == i) s_half[2 * i] = (uint16_t)(ROOT16 | atomicAdd(&s_ncomp, 1u));
+    {
+        const uint32_t dw = (uint32_t)u | ((uint32_t)q << 8);
+        uint64_t todo = SA;
+        uint32_t id = my_base;
+        while (todo) {
+            s_half[2 * id + 1] = (uint16_t)(dw | ((uint32_t)ctz64(todo) << 9));
+            todo &= todo - 1;
+            ++id;
+        }
+        if (act && q == 0) s_vb16[u] = (uint16_t)vb;
+    }
     PDBEDA_LATE_JOB(lj);          // (everything below stores through pointers nothing above needs)
+    const uint32_t cb = (uint32_t)blockIdx.x * CCAP, rb = (uint32_t)blockIdx.x * (uint32_t)(NU * 32);
+    {   // what the later kernels read per word and per row (run bases are wrong for a tile that turns out to be a unit tile
+        // below: that path writes them again)
+        if (my_valid) { lj.mask[my_word] = m; lj.run_base[my_word] = rb + my_base; }
+        if (lj.face_rows) {   // per sign and row: first run | count << 16 (the first lane of the row adds up its CW words)
+            uint32_t rc = cnt;
+            if (CW > 1) rc += (uint32_t)__shfl_down((int)cnt, 1);
+            if (CW > 2) rc += (uint32_t)__shfl_down((int)cnt, 2);
+            if (CW > 3) rc += (uint32_t)__shfl_down((int)cnt, 3);
+            if (act && wl == 0) lj.face_rows[((size_t)blockIdx.x * 2 + q) * 64 + wvs * TILE_R + rl] = my_base | (rc << 16);
+        }
+    }
+    __syncthreads();   // ---- barrier 3 ----
     const uint32_t n_comp = s_ncomp;
     if (n_comp > CCAP) {  // block-uniform: too many components for LDS -> unit tile
-        if (my_valid) {
-            lj.mask[my_word] = m0;
-            lj.run_base[my_word] = 0u;
-            if (n_planes > 1) { lj.mask[plane_words + my_word] = m1; lj.run_base[plane_words + my_word] = 0u; }
-        }
+        if (my_valid) lj.run_base[my_word] = 0u;
         if (tid == 0) { lj.tile_mode[tile_id] = 3; lj.tile_runs[blockIdx.x] = 0u; *lj.unit_flag = lj.epoch; }
         if (lj.face_rows && tid < 128) lj.face_rows[(size_t)blockIdx.x * 128 + tid] = 0u;   // mode 3: component table overflowed
         mark_comps_unused(lj, (uint32_t)blockIdx.x * CCAP, 0u, tid, NT);
         return;
     }
-    if (lj.face_runs) {   // export the runs with their tile components for k_face_merge
-#pragma unroll
-        for (int t = 0; t < SLOTS; ++t)
-            if (ex_slot[t] != 0xffffffffu)
-                lj.face_runs[(size_t)blockIdx.x * RCAP + ex_slot[t]] = ex_se[t] | ((uint32_t)s_compidx[s_parent[ex_slot[t]]] << 16);
-        if (tid < 128) lj.face_rows[(size_t)blockIdx.x * 128 + tid] = (uint32_t)s_rowfirst[tid >> 6][tid & 63] | ((uint32_t)s_rowcnt[tid >> 6][tid & 63] << 16);
-    }
-    if (tid == 0) {
-        s_runbase = (uint32_t)blockIdx.x * (uint32_t)(NU * 32);
-        s_compbase = (uint32_t)blockIdx.x * CCAP;
-    }
-    // integer sums of a component, relative to the tile origin, packed so that a run costs two LDS atomics, not four:
-    // s_pk = voxels (20 bits) | sum (r - r0) << 20 (20 bits) | sum (s - s0) << 40;  s_crel = sum (c - c_tile)
-    unsigned long long *s_pk = reinterpret_cast<unsigned long long *>(s_n);   // (spans s_n and s_c)
-    uint32_t *s_crel = s_r;
-    for (uint32_t i = tid; i < n_comp; i += NT) {
-        s_rho[i] = 0.0; s_rho_c[i] = 0.0; s_rho_r[i] = 0.0; s_rho_s[i] = 0.0;
-        s_pk[i] = 0ull; s_crel[i] = 0u; s_key[i] = 0xffffffffu; s_cplane[i] = 0u;
-    }
-    __syncthreads();
-    // ---- C2 (a) thread per word: publish run -> component for the label writer ----
-    const uint32_t cb = s_compbase, rb = s_runbase;
-    const uint32_t my_g = rb + ((wt < NU) ? s_gword[wt] : 0u);
-    if (wt < NU && (m0 | m1)) {
-        for (int q = 0; q < n_planes; ++q) {
-            if (NT == 512 && q != half) continue;
-            const uint64_t m = q ? m1 : m0;
-            uint32_t g = my_g + (q ? (uint32_t)popc64(run_starts(m0)) : 0u);
-            uint64_t todo = run_starts(m);
-            const uint32_t first = s_first[q][wt], next = (first & 0x7fffu) + 1u;
-            uint32_t k = 0;
-            while (todo) {
-                todo &= todo - 1;
-                const uint32_t slot = k == 0 ? (first & 0x7fffu) : next + k - 1u;
-                ++k;
-                lj.comp_of_run[g++] = cb + s_compidx[s_parent[slot]];
-            }
-        }
-    }
-    // ---- C2 (b) thread per RUN (the thread that summed it in A3b): fold the run into its component ----
+    // ---- C2: a thread per run: sums over the parked values, fold into the component ----
     {
+        uint32_t *comp_of_run = lj.comp_of_run + rb;
+        uint32_t *face_runs = lj.face_runs ? lj.face_runs + (size_t)blockIdx.x * RCAP : nullptr;
         const int ctile = w0 * 64;
-#pragma unroll
-        for (int t = 0; t < SLOTS; ++t) {
-            const uint32_t slot = ex_slot[t];
-            if (slot == 0xffffffffu) continue;
-            const uint32_t comp = s_compidx[s_parent[slot]];
-            const int p0 = (int)(ex_se[t] & 0xffu), p1 = (int)((ex_se[t] >> 8) & 0xffu), row = s_rowof[slot];
-            const int rl = row & 7, sl = row >> 3, r = r0 + rl, sabs = s0 + sl;
-            const uint32_t len = (uint32_t)(p1 - p0 + 1);
-            const double2 rs2 = g_run[slot];
-            const double rho = rs2.x;
-            unsafeAtomicAdd(&s_rho[comp], rho);
-            unsafeAtomicAdd(&s_rho_c[comp], (double)ctile * rho + rs2.y);
-            unsafeAtomicAdd(&s_rho_r[comp], (double)r * rho);
-            unsafeAtomicAdd(&s_rho_s[comp], (double)sabs * rho);
-            atomicMin(&s_key[comp], (uint32_t)(((int64_t)(ctile + p0) * ur + r) * us + sabs));
-            if (slot >= (uint32_t)RCAP - al1) s_cplane[comp] = 1u;
-            atomicAdd(&s_pk[comp], (unsigned long long)len | ((unsigned long long)(len * (uint32_t)rl) << 20) | ((unsigned long long)(len * (uint32_t)sl) << 40));
-            atomicAdd(&s_crel[comp], len * (uint32_t)p0 + len * (len - 1u) / 2u);
+        const uint32_t urus = (uint32_t)ur * (uint32_t)us;
+        for (uint32_t i = tid; i < n_runs; i += NT) {
+            const uint32_t pd = s_parent[i], desc = pd >> 16;
+            uint32_t x = pd & 0xffffu;
+            while (!(x & ROOT16)) x = s_half[2 * x];
+            const uint32_t comp = x & 0x7fffu;
+            const int ru = (int)(desc & 0xffu), rq = (int)((desc >> 8) & 1u), a = (int)(desc >> 9);
+            const int rsl = ru / USEC, rrl = (ru % USEC) / CW, rwl = ru % CW;
+            const uint64_t rm = s_mask[rq][ru];
+            const uint64_t inv = ~(rm >> a);
+            const int len = inv ? ctz64(inv) : 64;   // (a run that fills bits a..63: rm >> a has 64 - a ones and zeros above)
+            // exact sequential fp64 sums: S = sum v_i, T = sum of the running S = sum (len - i) v_i, so sum i v_i = len S - T
+            double S = 0.0, T = 0.0;
+            if (!from_global) {
+                const uint32_t off = (uint32_t)s_vb16[ru] + (uint32_t)popc64((rm | s_mask[rq ^ 1][ru]) & bits_below(a));
+                int k = 0;
+                for (; k + 2 <= len; k += 2) {   // two parked values in flight
+                    const float v0 = s_val[off + k], v1 = s_val[off + k + 1];
+                    S += (double)v0; T += S;
+                    S += (double)v1; T += S;
+                }
+                if (k < len) { S += (double)s_val[off + k]; T += S; }
+            } else {   // dense tile: the values were not parked; re-read from L2
+                const float *rowptr = dens + ((int64_t)(s0 + rsl) * nr + (r0 + rrl)) * nc + ctile + rwl * 64;
+                for (int k = 0; k < len; ++k) { S += (double)rowptr[a + k]; T += S; }
+            }
+            const int p0 = rwl * 64 + a;
+            unsafeAtomicAdd(&s_rho[comp], S);
+            unsafeAtomicAdd(&s_rho_c[comp], (double)p0 * S + ((double)len * S - T));
+            unsafeAtomicAdd(&s_rho_r[comp], (double)rrl * S);
+            unsafeAtomicAdd(&s_rho_s[comp], (double)rsl * S);
+            // (keys of a plane are below 2^31: the host checks)
+            atomicMin(&s_key[comp], ((uint32_t)rq << 31) | ((uint32_t)(ctile + p0) * urus + (uint32_t)(r0 + rrl) * (uint32_t)us + (uint32_t)(s0 + rsl)));
+            const uint32_t ulen = (uint32_t)len;
+            atomicAdd(&s_pk[comp], (unsigned long long)ulen | ((unsigned long long)(ulen * (uint32_t)rrl) << 20) | ((unsigned long long)(ulen * (uint32_t)rsl) << 40));
+            atomicAdd(&s_crel[comp], ulen * (uint32_t)p0 + ulen * (ulen - 1u) / 2u);
+            comp_of_run[i] = cb + comp;
+            if (face_runs) face_runs[i] = (uint32_t)p0 | ((uint32_t)(p0 + len - 1) << 8) | (comp << 16);
         }
+        if (tid == 0) lj.tile_mode[tile_id] = 0;
     }
-    if (my_valid) {
-        lj.mask[my_word] = m0;
-        lj.run_base[my_word] = my_g;
-        if (n_planes > 1) { lj.mask[plane_words + my_word] = m1; lj.run_base[plane_words + my_word] = my_g + (uint32_t)popc64(run_starts(m0)); }
-    }
-    if (tid == 0) lj.tile_mode[tile_id] = 0;
-    __syncthreads();
+    __syncthreads();   // ---- barrier 4 ----
     const int64_t keys_pp = (int64_t)uc * ur * us;
     for (uint32_t i = tid; i < n_comp; i += NT) {
         const uint32_t g = cb + i;
         lj.parent[g] = (int32_t)g;
         const unsigned long long pk = s_pk[i];
         const long long n = (long long)(pk & 0xfffffull);
+        const double rho = s_rho[i];
         lj.r_n[g] = (uint32_t)n;
-        lj.r_rho[g] = s_rho[i];
-        lj.r_rho_c[g] = s_rho_c[i];
-        lj.r_rho_r[g] = s_rho_r[i];
-        lj.r_rho_s[g] = s_rho_s[i];
+        lj.r_rho[g] = rho;
+        lj.r_rho_c[g] = (double)(w0 * 64) * rho + s_rho_c[i];
+        lj.r_rho_r[g] = (double)r0 * rho + s_rho_r[i];
+        lj.r_rho_s[g] = (double)s0 * rho + s_rho_s[i];
         lj.r_c[g] = (long long)s_crel[i] + n * (w0 * 64);
         lj.r_r[g] = (long long)((pk >> 20) & 0xfffffull) + n * r0;
         lj.r_s[g] = (long long)(pk >> 40) + n * s0;
-        lj.r_key[g] = (unsigned long long)(s_cplane[i] ? keys_pp : 0) + s_key[i];
+        const uint32_t key = s_key[i];
+        lj.r_key[g] = (unsigned long long)((key >> 31) ? keys_pp : 0) + (key & 0x7fffffffu);
     }
     mark_comps_unused(lj, cb, n_comp, tid, NT);
-    if (tid == 0) lj.tile_runs[blockIdx.x] = n_wordruns;
+    if (tid == 0) lj.tile_runs[blockIdx.x] = n_runs;
 }
 
 // Generic labelling of the tiles k_tile_label could not hold in LDS ("unit tiles"): every run
