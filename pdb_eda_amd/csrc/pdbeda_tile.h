@@ -374,7 +374,10 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
                        up2 = dpp0<DPP_WAVE_SHR1>((uint32_t)(B2 >> 32)), up3 = dpp0<DPP_WAVE_SHR1>((uint32_t)(B3 >> 32));
         const uint64_t SB0 = run_starts(B0), SB1 = run_starts(B1), SB2 = run_starts(B2), SB3 = run_starts(B3);
         auto pairs = [&](uint64_t B, uint64_t SB, uint32_t up) { return (SA & (B | (B << 1) | (wl > 0 ? up >> 31 : 0u))) | (SB & A1s); };   // EA and EB are disjoint
-        const uint64_t E0 = pairs(B0, SB0, up0), E1 = pairs(B1, SB1, up1), E2 = pairs(B2, SB2, up2), E3 = pairs(B3, SB3, up3);
+        // A pair with the row diagonally below (B1, B3) is implied wherever the row straight below (B2) has a voxel at p or p - 1:
+        // that voxel touches both runs of the pair, and its own pairs with them are of the kinds that are never dropped.
+        const uint64_t keep = ~(B2 | (B2 << 1) | (wl > 0 ? up2 >> 31 : 0u));
+        const uint64_t E0 = pairs(B0, SB0, up0), E1 = pairs(B1, SB1, up1) & keep, E2 = pairs(B2, SB2, up2), E3 = pairs(B3, SB3, up3) & keep;
         const bool same_row = (m & 1ull) && cA;   // my row continues across the word boundary
         // The lanes list their pairs (mine << 16 | earlier: ids of earlier rows are smaller), then lane k unites pair k, k + 64, ...:
         // a union is a chain of dependent LDS trips, and a lane with six pairs must not keep 63 others waiting -- instruction issue,
