@@ -42,6 +42,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the bounded CPU-baseline sample")
     ap.add_argument("--windows", type=int, default=5, help="extra timed windows of --steps steps each (dispersion of ms_per_step)")
     ap.add_argument("--entries", type=int, default=125, help="multiple-structure leg (BASELINE configs[3]): entries per rank (1000 / 8 GPUs); 0 = skip")
+    ap.add_argument("--entry-files", type=int, default=16, help="multiple-structure leg: distinct entries on disk per rank (the entry list cycles through them)")
+    ap.add_argument("--entry-seconds", type=float, default=2.0, help="multiple-structure leg: repeat the entry list until the timed region is at least this long")
     ap.add_argument("--workers", type=int, default=4, help="multiple-structure leg: worker processes (= streams) per GPU")
     ap.add_argument("--entry-size", type=int, default=200, help="multiple-structure leg: grid edge of an entry (configs[3]: 200)")
     ap.add_argument("--entry-residues", type=int, default=100, help="multiple-structure leg: poly-ALA residues per entry (~500 atoms)")
@@ -144,18 +146,24 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
     tmp = tempfile.mkdtemp(prefix="pdbeda_bench_%d_" % rank)
     try:
         t0 = time.perf_counter()
-        distinct = 4                 # distinct synthetic entries on disk (generating 125 different 200^3 maps would take minutes of CPU)
+        distinct = max(1, args.entry_files)   # distinct synthetic entries on disk (each = 2 x 32 MB of CCP4 files at 200^3; generating one costs ~0.3 s)
         loaders = [synthetic.write_entry_files(tmp, "e%d" % k, args.entry_size, args.entry_residues, 1000 * rank + k, as_paths=True) for k in range(distinct)]
         gen_s = time.perf_counter() - t0
         entries = [multipleStructures.Entry("r%de%04d" % (rank, i), loaders[i % distinct], cost_hint=0.0) for i in range(args.entries)]
         pool.warm()
-        pool.map(entries[:2 * args.workers])                          # untimed: first-use costs of every worker (imports, arenas, file cache)
+        pool.map(entries[:2 * args.workers])                          # untimed: first-use costs of every worker (imports, arenas)
         barrier()
-        t0 = time.perf_counter()
-        records = pool.map(entries)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        ok = sum(1 for r in records if r)
+        # the timed region is the WHOLE entry list, repeated until it has run for at least --entry-seconds (a 0.2 s region says little)
+        elapsed, passes, ok = 0.0, 0, 0
+        while passes == 0 or (elapsed < args.entry_seconds and passes < 64):
+            t0 = time.perf_counter()
+            records = pool.map(entries)
+            barrier()
+            elapsed += time.perf_counter() - t0
+            ok += sum(1 for r in records if r)
+            passes += 1
+        n_done = passes * args.entries
+        own_rate = 60.0 * n_done / elapsed
         # ONE worker process of the same kind for comparison (the pool is closed first: few processes may share the GPU)
         pool.close()
         sample = entries[:min(16, len(entries))]
@@ -168,20 +176,30 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
             single = (time.perf_counter() - t1) / len(sample)
         finally:
             one.close()
+        per_rank = [own_rate]
+        total_done = n_done
         if dist is not None:
             t = torch.tensor([elapsed, single], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed, single = float(t[0].item()), float(t[1].item())
-            c = torch.tensor([ok], dtype=torch.int64, device="cuda")
+            c = torch.tensor([ok, n_done], dtype=torch.int64, device="cuda")
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
-            ok = int(c.item())
+            ok, total_done = int(c[0].item()), int(c[1].item())
+            rates = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+            dist.all_gather(rates, torch.tensor([own_rate], dtype=torch.float64, device="cuda"))
+            per_rank = [float(r.item()) for r in rates]
         n_atoms = len(list(loaders[0].structure()[0].get_atoms()))
-        return {"workload": "configs[3]: %d entries per rank (%d distinct on disk), each two CCP4 files of a %d^3 grid + a %d-atom model: read, parse, upload, "
-                            "aggregateCloud + the per-entry record of `pdb_eda multiple`" % (args.entries, distinct, args.entry_size, n_atoms),
-                "entries": args.entries * world, "entries_ok": ok, "workers_per_gpu": args.workers, "seconds": elapsed,
-                "entries_per_min": 60.0 * args.entries * world / elapsed, "entries_per_min_per_gpu": 60.0 * args.entries / elapsed,
+        file_mb = 2 * 4 * args.entry_size ** 3 / 1e6
+        return {"workload": "configs[3]: %d entries per rank and pass (%d distinct on disk = %.0f MB of CCP4 files per rank), each two CCP4 files of a %d^3 grid + a "
+                            "%d-atom model: read, parse, upload, aggregateCloud + the per-entry record of `pdb_eda multiple`"
+                            % (args.entries, distinct, distinct * file_mb, args.entry_size, n_atoms),
+                "entries": total_done, "entries_ok": ok, "passes": passes, "workers_per_gpu": args.workers, "seconds": elapsed,
+                "entries_per_min": 60.0 * total_done / elapsed, "entries_per_min_per_gpu": 60.0 * total_done / world / elapsed,
+                "entries_per_min_per_rank": [round(v, 1) for v in per_rank],
                 "one_worker_ms_per_entry": 1e3 * single, "one_worker_entries_per_min": 60.0 / single,
-                "pool_vs_one_worker": (args.entries / elapsed) * single, "generation_s": gen_s,
+                "pool_vs_one_worker": (total_done / world / elapsed) * single, "generation_s": gen_s,
+                "page_cache": "warm: the files were written by this process moments earlier and every one is read again on each pass (no O_DIRECT, no cache drop: "
+                              "an ordinary user cannot drop caches on the box); a cold first read of a 64 MB entry costs its disk time on top",
                 "note": "worker processes (spawn), one HIP stream each, sharing the GPU of the rank; sharding over ranks is one entry list per rank, no collective"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -247,12 +265,37 @@ def _import_native():
     return _native
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nproc-per-node N bench.py <same args>`
+    as a CHILD process (this process has not touched the GPU and never will), relay its output and return its exit code.
+    Fewer than N visible devices is an error, not a one-GPU measurement."""
+    import socket
+    import subprocess
+    import torch                                   # (import only; device_count() does not initialise the GPU on this image)
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        print("bench.py: --gpus %d but only %d device(s) are visible: refusing to measure fewer GPUs than asked for" % (args.gpus, n_dev), file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
 
     # torch is imported first (importing does not touch the GPU): it bundles its own HIP runtime, and the library must resolve
@@ -282,8 +325,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     pinned_cpus = _native.pin_to_device(local_rank)      # host side of this rank on the GPU's NUMA node (the workers above do the same)
+    rccl_ranks = 1
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        rccl_ranks = dist.get_world_size()
 
     # ---- synthetic entry: smooth noise, orthogonal cell, resident in HBM ----
     n = args.size
@@ -457,6 +502,7 @@ def main():
         "value": value,
         "unit": "Mvoxels/s",
         "n_gpus": world,
+        "rccl_ranks": rccl_ranks,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,

@@ -12,6 +12,8 @@ nothing else; a real ``Bio.PDB`` structure can be passed to ``DensityAnalysis`` 
 fields ``pdbParser.py:67-95`` and Bio.PDB feed into the path); it is host-side input
 preparation, not part of the accelerated path.
 """
+import re
+
 import numpy as np
 
 __all__ = ["Structure", "Model", "Chain", "Residue", "Atom", "PDBHeader", "PDBEntry", "read_pdb", "columns", "Columns"]
@@ -222,28 +224,51 @@ def read_pdb(handle_or_path, structure_id="xxxx"):
     chains = {}
     residues = {}
     atom_slots = {}
+    # Header fields exactly as the reference's pdbParser.parse reads them in its 'lite' mode (pdbParser.py:24-98; pinned by
+    # tests/golden/pdbheader.json): every field starts as 0, the date is the two characters at columns 58-59, blanks inside
+    # names become '_', header records count only up to the first record that starts with 'ATOM', and a file without
+    # REMARK 290 has NO operators (an empty list, so no symmetry atoms -- not an identity).
     rot = []
-    resolution = 0
-    space_group = 0
-    pdbid = ""
+    pdbid = date = method = resolution = r_value = r_free = program = space_group = 0
+    header_open = True
     n_models = 0
     for rec in lines:
         tag = rec[:6]
-        if tag == "HEADER":
-            pdbid = rec[62:66].strip()
-        elif rec.startswith("REMARK   2 RESOLUTION"):
-            body = rec.split("RESOLUTION.", 1)[-1]
-            if "ANGSTROMS" in body:
-                resolution = body.split("ANGSTROMS")[0].strip()
-        elif rec.startswith("REMARK 290 SYMMETRY OPERATORS FOR SPACE GROUP:"):
-            space_group = rec.split(":", 1)[1].strip().replace(" ", "_")
-        elif rec.startswith("REMARK 290   SMTRY"):
-            items = rec[18:].split()
-            row, op = int(items[0]) - 1, int(items[1]) - 1
-            while len(rot) <= op:
-                rot.append(np.zeros((3, 4)))
-            rot[op][row] = [float(x) for x in items[2:6]]
-        elif tag == "MODEL ":
+        if rec.startswith("ATOM"):
+            header_open = False
+        if header_open and tag != "HETATM":
+            if tag == "HEADER":
+                date = rec[57:59].strip()
+                pdbid = rec[62:66].strip()
+            elif tag == "EXPDTA":
+                method = rec[6:36].strip().replace(" ", "_")
+            elif rec.startswith("REMARK   2 RESOLUTION"):
+                m = re.search("RESOLUTION.(.+)ANGSTROMS", rec)
+                if m:
+                    resolution = m.group(1).strip()
+            elif rec.startswith("REMARK   3   R VALUE"):
+                m = re.search(r"^REMARK   3   R VALUE            \(WORKING SET\) : (.+)$", rec)
+                if m:
+                    r_value = m.group(1).strip()
+            elif rec.startswith("REMARK   3   FREE R VALUE"):
+                m = re.search(r"^REMARK   3   FREE R VALUE                     : (.+)$", rec)
+                if m:
+                    r_free = m.group(1).strip()
+            elif rec.startswith("REMARK   3   PROGRAM"):
+                m = re.search(r"^REMARK   3   PROGRAM     : (.+)$", rec)
+                if m:
+                    program = m.group(1).strip().replace(" ", "_")
+            elif rec.startswith("REMARK 290 SYMMETRY OPERATORS FOR SPACE GROUP:"):
+                m = re.search(r"^REMARK 290 SYMMETRY OPERATORS FOR SPACE GROUP: (.+)$", rec)
+                if m:
+                    space_group = m.group(1).strip().replace(" ", "_")
+            elif rec.startswith("REMARK 290   SMTRY"):
+                items = rec[18:].split()
+                row, op = int(items[0]) - 1, int(items[1]) - 1
+                while len(rot) <= op:
+                    rot.append(np.zeros((3, 4)))
+                rot[op][row] = [float(x) for x in items[2:6]]
+        if tag == "MODEL ":
             n_models += 1
             if n_models > 1:
                 break
@@ -276,5 +301,6 @@ def read_pdb(handle_or_path, structure_id="xxxx"):
             elif occ > prev.occupancy:
                 prev.coord, prev.occupancy, prev.bfactor, prev.altloc = xyz, occ, bfac, altloc
     st.header = {"resolution": float(resolution) if resolution not in (0, "") else None}
-    hdr = PDBHeader(pdbid=pdbid, resolution=resolution, spaceGroup=space_group, rotationMats=rot or None)
+    hdr = PDBHeader(pdbid=pdbid, resolution=resolution, spaceGroup=space_group, rotationMats=rot, date=date, method=method, rValue=r_value, rFree=r_free,
+                    program=program)
     return st, PDBEntry(hdr)

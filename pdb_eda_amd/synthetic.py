@@ -201,6 +201,31 @@ def sweep_param_sets():
     return sets
 
 
+# ---- one synthetic entry in memory: the generator behind bench.py's analysis leg, the entry files of the multiple-structure leg and
+#      the reference goldens at the BASELINE sizes (tests/golden/make_golden_big.py keeps only seeds + the reference's numbers) ----
+BIG_CASES = {
+    # name: (ncrs, residues of the poly-ALA chain (5 atoms each), seed, grid spacing in Angstrom) -- SURVEY.md 8d
+    "c0_1stp_like": ((100, 108, 96), 200, 31, 0.45),     # BASELINE configs[0] stand-in: ~100^3, ~1 k atoms
+    "c2_bench_entry": ((128, 128, 128), 400, 5, 0.5),    # bench.py's analysis_entry: 128^3, 2 000 atoms ("~2 A entry")
+    "c3_multiple_entry": ((200, 200, 200), 100, 0, 0.5),  # one entry of configs[3]: 200^3, 500 atoms
+}
+
+
+def cube_entry(ncrs, n_residues, seed, spacing=0.5):
+    """(spec, header, structure, params, 2Fo-Fc grid, Fo-Fc grid, rotation matrices) of one synthetic entry."""
+    from . import ccp4
+    spec = MapSpec(ncrs=tuple(ncrs), spacing=spacing)
+    header = ccp4.DensityHeader.fromFileHeader(ccp4_header_bytes(spec))
+    lo, hi = np.array(header.crs2xyzCoord([6, 6, 6])), np.array(header.crs2xyzCoord([n - 7 for n in ncrs]))
+    st = chain_structure(n_residues, seed, lo, hi, hetero_every=9, zero_occupancy_every=37)
+    params = synthetic_params()
+    dens = gaussian_sum_grid(header, st, params["full_atom_name_map_electrons"], sigma=0.55, noise=0.02, seed=seed)
+    diff = (noise_grid(spec, seed + 100, 1.2) * 0.12).astype(np.float32)
+    rot = [np.hstack([np.eye(3), np.zeros((3, 1))]),
+           np.array([[-1.0, 0, 0, 0.5 * header.xlength], [0, -1.0, 0, 0], [0, 0, 1.0, 0.5 * header.zlength]])]
+    return spec, header, st, params, dens, diff, rot
+
+
 # ---- synthetic entries on disk (BASELINE configs[3] / [4]: "1 000 synthetic 200^3 grids ... ~500 atoms each") ---------------------
 
 def write_entry_files(directory, tag, edge, n_residues, seed, spacing=0.5, as_paths=False):

@@ -101,3 +101,38 @@ def test_from_file_and_from_pdbid(tmp_path, monkeypatch, gpu_ctx):
     assert len(an2.greenBlobList) == len(an.greenBlobList)
     assert densityAnalysis.fromPDBid("0000") == 0
     assert densityAnalysis.fromFile(str(tmp_path / "nope.pdb")) == 0
+
+
+def test_read_pdb_header_equals_reference_pdbparser():
+    """SURVEY 8f.2, header half: every field of the reference's pdbParser.parse (lite mode) on five synthetic header texts
+    (tests/golden/make_golden_pdbheader.py ran the reference).  The ATOM / HETATM half stays unpinned (Bio.PDB is not installed)."""
+    import json
+    from pdb_eda_amd import structure
+    with open(os.path.join(os.path.dirname(__file__), "golden", "pdbheader.json")) as fh:
+        cases = json.load(fh)
+    assert len(cases) >= 5
+    for name, case in cases.items():
+        _, pdb = structure.read_pdb(io.StringIO(case["text"]), name)
+        h, want = pdb.header, case["header"]
+        for field in ("pdbid", "date", "method", "resolution", "rValue", "rFree", "program", "spaceGroup"):
+            assert getattr(h, field) == want[field], (name, field, getattr(h, field), want[field])
+            assert type(getattr(h, field)) is type(want[field]), (name, field)       # 0 stays the integer 0, text stays text
+        assert len(h.rotationMats) == len(want["rotationMats"]), name
+        for got, ref in zip(h.rotationMats, want["rotationMats"]):
+            assert np.array_equal(np.asarray(got), np.asarray(ref)), name
+
+
+def test_bench_gpus_flag_refuses_to_measure_fewer_devices():
+    """`python bench.py --gpus N` starts N ranks itself (torch.distributed.run as a child) -- and with fewer than N devices visible
+    it exits non-zero instead of measuring one GPU."""
+    import subprocess
+    import sys
+    import torch
+    n = torch.cuda.device_count() + 2
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n)], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode != 0 and "device(s) are visible" in p.stderr, (p.returncode, p.stderr[-500:])
+    env["WORLD_SIZE"] = "3"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode != 0 and "does not match WORLD_SIZE" in p.stderr, (p.returncode, p.stderr[-500:])
