@@ -74,21 +74,17 @@ def algorithmic_bytes(kernel, n_vox, n_planes):
     return table.get(kernel)
 
 
-def analysis_leg(ctx, n_res=400, edge=128, reps=5):
+def analysis_leg(ctx, case="c2_bench_entry", reps=5):
     """Whole per-entry pipeline on a synthetic entry: parse + upload of both maps, aggregateCloud, atom and residue region
-    discrepancies, green/red blob statistics (the record `pdb_eda multiple` keeps per entry)."""
+    discrepancies, green/red blob statistics (the record `pdb_eda multiple` keeps per entry).  The entry is one of the cases the
+    REFERENCE was run on (tests/golden/analysis_big_<case>.npz): the leg checks its result against the reference's."""
     import io
     from pdb_eda_amd import ccp4, synthetic, structure, densityAnalysis as da
-    spec = synthetic.MapSpec(ncrs=(edge, edge, edge), spacing=0.5)
-    header = ccp4.DensityHeader.fromFileHeader(synthetic.ccp4_header_bytes(spec))
-    lo, hi = np.array(header.crs2xyzCoord([6, 6, 6])), np.array(header.crs2xyzCoord([edge - 7] * 3))
-    st = synthetic.chain_structure(n_res, 5, lo, hi, hetero_every=9, zero_occupancy_every=37)
-    params = synthetic.synthetic_params()
+    ncrs, n_res, seed, spacing = synthetic.BIG_CASES[case]
+    edge = ncrs[0]
+    spec, header, st, params, dens, diff, rot = synthetic.cube_entry(ncrs, n_res, seed, spacing)
     da.setGlobals(params)
-    dens = synthetic.gaussian_sum_grid(header, st, params["full_atom_name_map_electrons"], sigma=0.55, noise=0.02, seed=5)
-    diff = (synthetic.noise_grid(spec, 105, 1.2) * 0.12).astype(np.float32)
     files = synthetic.ccp4_bytes(spec, dens), synthetic.ccp4_bytes(spec, diff)
-    rot = [np.hstack([np.eye(3), np.zeros((3, 1))]), np.array([[-1.0, 0, 0, 0.5 * header.xlength], [0, -1.0, 0, 0], [0, 0, 1.0, 0.5 * header.zlength]])]
     pdbObj = structure.PDBEntry(structure.PDBHeader(pdbid="synth", resolution=2.0, spaceGroup="P_1", rotationMats=rot))
 
     def once():
@@ -130,12 +126,19 @@ def analysis_leg(ctx, n_res=400, edge=128, reps=5):
     dev_ms = sum(ms for _, ms in prof.values())
     sphere = {"atoms": len(atoms), "radius_A": 3.5, "voxels_tested": box * len(atoms), "device_ms": dev_ms,
               "voxels_tested_per_s": box * len(atoms) / (dev_ms * 1e-3) if dev_ms > 0 else None, "kernels_ms": {k: round(ms, 4) for k, (_, ms) in sorted(prof.items())}}
+    # the reference's own result on this entry (seeds + numbers only are kept: tests/golden/make_golden_big.py)
+    golden = np.load(os.path.join(ROOT, "tests", "golden", "analysis_big_%s.npz" % case), allow_pickle=False)
+    want = float(golden["ratio"])
+    rel = abs(an.densityElectronRatio - want) / abs(want)
+    assert rel < 1e-8 and an.numVoxelsAggregated == int(golden["num_voxels"]), "analysis leg differs from the reference: %r vs %r" % (an.densityElectronRatio, want)
+    ref_s = json.loads(str(golden["reference_seconds"]))
     return {"sphere_region_sums": sphere, "workload": "synthetic ~2 A entry: %d^3 grid at 0.5 A, %d atoms (%d with clouds), 2Fo-Fc + Fo-Fc maps parsed from CCP4 bytes" %
                         (edge, len(list(st.get_atoms())), len(an.atomCloudDescriptions)),
             "ms": {k: round(1e3 * v, 2) for k, v in best.items()}, "ms_per_entry": 1e3 * total, "entries_per_min": 60.0 / total,
             "density_electron_ratio": an.densityElectronRatio,
-            "note": "single host thread + one stream; the reference (Cython path, one core, build container) needs 158 s for this same entry and "
-                    "reaches the same density_electron_ratio: profiles/r01_reference_analysis_cpu.json"}
+            "reference": {"density_electron_ratio": want, "relative_difference": rel, "num_voxels_aggregated_equal": True,
+                          "seconds_one_core_build_container": ref_s, "total_s": round(sum(ref_s.values()), 1)},
+            "note": "single host thread + one stream; checked here against the reference's result on the same entry (Cython path, one core, build container)"}
 
 
 def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):

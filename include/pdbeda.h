@@ -76,10 +76,18 @@ int pdbeda_ctx_synchronize(pdbeda_ctx *ctx);
 void *pdbeda_ctx_stream(pdbeda_ctx *ctx); /* the hipStream_t the kernels are launched on */
 /* Per-entry watchdog: the reference wraps every entry of `pdb_eda multiple` in a SIGALRM time-out
  * (multipleStructures.py:297-304, 359-377), which threads cannot use.  With seconds > 0 every wait of this context on its
- * stream is a timed hipStreamQuery loop; when it expires the call returns PDBEDA_ERR_TIMEOUT, the context is marked
- * abandoned (every later call on it or its handles fails at once with the same status) and pdbeda_ctx_destroy releases the
- * host object without waiting for the stream.  seconds == 0 disarms it (plain hipStreamSynchronize). */
+ * stream is a timed hipStreamQuery loop against ONE deadline, now + seconds, shared by all waits until the next call of this
+ * function: the caller re-arms it when an entry starts (an entry makes dozens of waits; a clock per wait would let it run for
+ * many multiples of the time-out).  When the deadline passes the call returns PDBEDA_ERR_TIMEOUT, the context is marked
+ * abandoned (every later call on it or its handles fails at once with the same status) and pdbeda_ctx_destroy does not wait
+ * for the stream: the context is parked and its device memory -- pool, buffers, and the arenas of the maps / jobs the entry
+ * left behind -- is released by pdbeda_reap_abandoned once the stream has drained.  seconds == 0 disarms the watchdog (plain
+ * hipStreamSynchronize).  Host-side phases of an entry are outside the library: the caller checks its own clock. */
 int pdbeda_ctx_set_timeout(pdbeda_ctx *ctx, double seconds);
+/* Destroy the abandoned contexts of this process whose streams have drained (hipStreamQuery, no waiting); returns how many are
+ * still parked.  Called by the library itself at every context creation and before an allocation is reported as failed (then
+ * the parked arenas of the sibling contexts on the device go back to the driver too); exposed for callers and tests. */
+int64_t pdbeda_reap_abandoned(void);
 const char *pdbeda_last_error(pdbeda_ctx *ctx);
 /* Per-kernel timing with HIP events recorded on the context's stream (measurement aid for
  * bench.py; no reference counterpart).  profile_end synchronises and writes one

@@ -77,6 +77,7 @@ _SIGS = {
     "pdbeda_ctx_synchronize": (C.c_int, [_p]),
     "pdbeda_ctx_stream": (_p, [_p]),
     "pdbeda_ctx_set_timeout": (C.c_int, [_p, C.c_double]),
+    "pdbeda_reap_abandoned": (C.c_int64, []),
     "pdbeda_last_error": (C.c_char_p, [_p]),
     "pdbeda_ctx_profile_begin": (C.c_int, [_p]),
     "pdbeda_ctx_profile_end": (C.c_int, [_p, C.c_char_p, _i64]),
@@ -162,7 +163,8 @@ class Context(object):
             raise error
 
     def set_timeout(self, seconds):
-        """Arm (seconds > 0) or disarm (0) the per-entry watchdog: see pdbeda_ctx_set_timeout in include/pdbeda.h."""
+        """Arm (seconds > 0: ONE deadline, now + seconds, for every wait until the next call -- re-arm it when an entry starts) or
+        disarm (0) the per-entry watchdog: see pdbeda_ctx_set_timeout in include/pdbeda.h."""
         self.check(self._lib.pdbeda_ctx_set_timeout(self._h, C.c_double(float(seconds))), "pdbeda_ctx_set_timeout")
 
     def synchronize(self):

@@ -66,8 +66,65 @@ struct pdbeda_ctx {
     // timeout_s > 0 every wait on the stream is a timed hipStreamQuery loop; a wait that expires marks the context
     // abandoned: every later call fails at once with PDBEDA_ERR_TIMEOUT and destroy does not wait for the stream.
     double timeout_s = 0.0;
+    std::chrono::steady_clock::time_point deadline;   // ONE deadline for every wait of the entry: set when the watchdog is (re-)armed
     bool timed_out = false;
+    // the pool is touched by its own context's thread, and -- when another context of the process runs out of device memory --
+    // by that context's thread, which trims its siblings' pools before it gives up
+    std::mutex pool_mu;
+    std::map<char *, size_t> lent;      // arenas handed out and not yet returned (maps, jobs): an abandoned context frees them too
 };
+
+// Contexts of this process: live ones (a context short of memory trims the arena pools of its siblings) and the ones the
+// watchdog abandoned.  An abandoned context cannot be destroyed at once -- its stream may still run, hipFree would hang with
+// it -- but leaking its arenas for the life of the process is not an option either: the entries that time out are the large
+// ones.  So it is parked here and REAPED (normal destroy path, including the arenas its lost handles still hold) as soon as a
+// query finds its stream drained: at every context creation and whenever an allocation fails.
+static std::mutex g_ctx_mu;
+static std::vector<pdbeda_ctx *> g_live, g_abandoned;
+
+static void ctx_release_device(pdbeda_ctx *ctx, bool lent_too) {
+    for (auto &kv : ctx->pool) (void)hipFree(kv.second.base);
+    ctx->pool.clear();
+    ctx->pool_bytes = 0;
+    if (lent_too) {
+        for (auto &kv : ctx->lent) (void)hipFree(kv.first);
+        ctx->lent.clear();
+    }
+    if (ctx->partials) (void)hipFree(ctx->partials);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->ring[k]) (void)hipHostFree(ctx->ring[k]);
+        if (ctx->ring_done[k]) (void)hipEventDestroy(ctx->ring_done[k]);
+    }
+    for (auto &r : ctx->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+}
+
+// Destroy the abandoned contexts whose stream has drained meanwhile; returns how many are still parked.
+static size_t reap_abandoned() {
+    std::lock_guard<std::mutex> g(g_ctx_mu);
+    for (size_t i = 0; i < g_abandoned.size();) {
+        pdbeda_ctx *ctx = g_abandoned[i];
+        (void)hipSetDevice(ctx->device);
+        if (hipStreamQuery(ctx->stream) == hipErrorNotReady) { ++i; continue; }   // still running (or hung): try again later
+        ctx_release_device(ctx, true);
+        delete ctx;
+        g_abandoned.erase(g_abandoned.begin() + i);
+    }
+    return g_abandoned.size();
+}
+
+// Give the parked arenas of the OTHER live contexts of this device back to the driver (the caller is out of device memory).
+static void trim_sibling_pools(pdbeda_ctx *self) {
+    std::lock_guard<std::mutex> g(g_ctx_mu);
+    for (pdbeda_ctx *other : g_live) {
+        if (other == self || other->device != self->device) continue;
+        std::lock_guard<std::mutex> p(other->pool_mu);
+        for (auto &kv : other->pool) (void)hipFree(kv.second.base);
+        other->pool.clear();
+        other->pool_bytes = 0;
+    }
+}
 
 struct ProfScope {
     pdbeda_ctx *ctx;
@@ -145,12 +202,11 @@ static int fail(pdbeda_ctx *ctx, int code, const char *fmt, ...) {
 static hipError_t ctx_wait(pdbeda_ctx *ctx) {
     if (ctx->timed_out) return hipErrorNotReady;
     if (ctx->timeout_s <= 0.0) return hipStreamSynchronize(ctx->stream);
-    const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0;; ++spins) {
         const hipError_t q = hipStreamQuery(ctx->stream);
         if (q != hipErrorNotReady) return q;
         if (spins > 256) {   // first ~0.3 ms: busy poll (the usual wait is tens of microseconds), then back off
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > ctx->timeout_s) {
+            if (std::chrono::steady_clock::now() > ctx->deadline) {   // the entry's ONE deadline: an entry makes dozens of waits
                 ctx->timed_out = true;
                 ctx->err = "watchdog: the stream did not drain within the per-entry time-out; context abandoned";
                 return hipErrorNotReady;
@@ -197,30 +253,44 @@ static int arena_get(pdbeda_ctx *ctx, size_t bytes, Arena *out) {
 static int arena_get_raw(pdbeda_ctx *ctx, size_t bytes, Arena *out) {
     if (ctx->timed_out) return PDBEDA_ERR_TIMEOUT;
     bytes = align_up(std::max<size_t>(bytes, 256));
-    auto it = ctx->pool.lower_bound(bytes);
-    if (it != ctx->pool.end() && it->first <= bytes * 2 + (1u << 20)) {
-        *out = it->second;
-        ctx->pool_bytes -= it->second.cap;
-        ctx->pool.erase(it);
-        return 0;
+    {
+        std::lock_guard<std::mutex> g(ctx->pool_mu);
+        auto it = ctx->pool.lower_bound(bytes);
+        if (it != ctx->pool.end() && it->first <= bytes * 2 + (1u << 20)) {
+            *out = it->second;
+            ctx->pool_bytes -= it->second.cap;
+            ctx->pool.erase(it);
+            ctx->lent[out->base] = out->cap;
+            return 0;
+        }
     }
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {
-        // drop the cache and retry once
-        for (auto &kv : ctx->pool) (void)hipFree(kv.second.base);
-        ctx->pool.clear();
-        ctx->pool_bytes = 0;
+        {   // drop the cache and retry
+            std::lock_guard<std::mutex> g(ctx->pool_mu);
+            for (auto &kv : ctx->pool) (void)hipFree(kv.second.base);
+            ctx->pool.clear();
+            ctx->pool_bytes = 0;
+        }
         e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {   // then what abandoned contexts still hold, then what the sibling contexts have parked
+            reap_abandoned();
+            trim_sibling_pools(ctx);
+            e = hipMalloc(&p, bytes);
+        }
         if (e != hipSuccess) return fail(ctx, PDBEDA_ERR_MEMORY, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     }
     out->base = (char *)p;
     out->cap = bytes;
+    std::lock_guard<std::mutex> g(ctx->pool_mu);
+    ctx->lent[out->base] = out->cap;
     return 0;
 }
 
 static void arena_put(pdbeda_ctx *ctx, Arena &a) {
-    if (a.base) { ctx->pool.emplace(a.cap, a); ctx->pool_bytes += a.cap; }
+    std::lock_guard<std::mutex> g(ctx->pool_mu);
+    if (a.base) { ctx->lent.erase(a.base); ctx->pool.emplace(a.cap, a); ctx->pool_bytes += a.cap; }
     a.base = nullptr;
     a.cap = 0;
     while (ctx->pool_bytes > ctx->pool_cap && !ctx->pool.empty() && !ctx->timed_out) {   // trim: the largest parked arena goes back to the
@@ -306,6 +376,11 @@ extern "C" int pdbeda_ctx_create_on_stream(int device_id, void *hip_stream, pdbe
     if (const char *v = getenv("PDBEDA_DEBUG_POISON")) ctx->debug_poison = v[0] && v[0] != '0';
     if (const char *v = getenv("PDBEDA_DEBUG_EDGE_CAP")) ctx->debug_edge_cap = atoll(v);
     if (const char *v = getenv("PDBEDA_POOL_CAP_MB")) ctx->pool_cap = (size_t)std::max<long long>(atoll(v), 0) << 20;
+    reap_abandoned();   // (what the watchdog left behind earlier may have drained by now)
+    {
+        std::lock_guard<std::mutex> g(g_ctx_mu);
+        g_live.push_back(ctx);
+    }
     *out = ctx;
     return PDBEDA_OK;
 }
@@ -315,20 +390,19 @@ extern "C" int pdbeda_ctx_create(int device_id, pdbeda_ctx **out) { return pdbed
 extern "C" int pdbeda_ctx_destroy(pdbeda_ctx *ctx) {
     if (!ctx) return PDBEDA_ERR_ARGUMENT;
     (void)hipSetDevice(ctx->device);
-    if (ctx->timed_out) {   // abandoned by the watchdog: its stream may never drain -- leak the device memory rather than hang in hipFree
-        delete ctx;
+    {
+        std::lock_guard<std::mutex> g(g_ctx_mu);
+        g_live.erase(std::remove(g_live.begin(), g_live.end(), ctx), g_live.end());
+        // abandoned by the watchdog: its stream may never drain, and hipFree would hang with it -- parked, and reaped (with the
+        // arenas of the maps / jobs its entry left behind) once a query finds the stream empty; leaked only if it never drains
+        if (ctx->timed_out) g_abandoned.push_back(ctx);
+    }
+    if (ctx->timed_out) {
+        reap_abandoned();
         return PDBEDA_OK;
     }
     (void)ctx_sync(ctx);
-    for (auto &kv : ctx->pool) (void)hipFree(kv.second.base);
-    ctx->pool.clear();
-    if (ctx->partials) (void)hipFree(ctx->partials);
-    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-    for (int k = 0; k < 2; ++k) {
-        if (ctx->ring[k]) (void)hipHostFree(ctx->ring[k]);
-        if (ctx->ring_done[k]) (void)hipEventDestroy(ctx->ring_done[k]);
-    }
-    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    ctx_release_device(ctx, false);   // (arenas still lent belong to live handles of the caller)
     delete ctx;
     return PDBEDA_OK;
 }
@@ -374,8 +448,11 @@ extern "C" int pdbeda_ctx_profile_end(pdbeda_ctx *ctx, char *buf, int64_t cap) {
 extern "C" int pdbeda_ctx_set_timeout(pdbeda_ctx *ctx, double seconds) {
     if (!ctx || !(seconds >= 0.0)) return PDBEDA_ERR_ARGUMENT;
     ctx->timeout_s = seconds;
+    ctx->deadline = std::chrono::steady_clock::now() + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(seconds));
     return PDBEDA_OK;
 }
+
+extern "C" int64_t pdbeda_reap_abandoned(void) { return (int64_t)reap_abandoned(); }
 
 extern "C" void *pdbeda_ctx_stream(pdbeda_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 

@@ -121,9 +121,12 @@ class StreamPool(object):
     ``each(fn)`` calls ``fn(k, ctx_k)`` once on every worker k (work pinned to a stream).  Per item:
       * an ordinary exception drops the item (result 0) with its reason in ``self.failures[index]`` and on stderr
         (multipleStructures.py:297-304);
-      * ``time_out`` seconds (the reference's --time-out, 359-377) arm the library's watchdog: a stream that does not
-        drain fails the item with reason "Timeout", the worker ABANDONS that context (never waits on it again, never
-        re-execs the process) and carries on with a fresh one;
+      * ``time_out`` seconds (the reference's --time-out, 359-377: a SIGALRM around the whole of analyzePDBID) arm the
+        library's watchdog with ONE deadline per item (re-armed when the item starts): a stream that does not drain by
+        then fails the item with reason "Timeout", the worker ABANDONS that context (never waits on it again, never
+        re-execs the process; the library reaps its memory when its stream has drained) and carries on with a fresh
+        one.  Host-side phases cannot be interrupted from a thread: an item whose wall time exceeded ``time_out`` is
+        dropped as "Timeout" when it returns (weaker than the reference's signal, same outcome for the result set);
       * any other ``PdbedaError`` is a device failure: the pool stops handing out work, joins its threads and re-raises it.
     """
 
@@ -172,7 +175,14 @@ class StreamPool(object):
 
     def _call(self, fn, k, index, item, results):
         try:
-            results[index] = fn(item, self.context(k))
+            ctx = self.context(k)
+            t0 = time.monotonic()
+            if self.time_out > 0:
+                ctx.set_timeout(self.time_out)      # the item's deadline starts now
+            result = fn(item, ctx)
+            if self.time_out > 0 and time.monotonic() - t0 > self.time_out:
+                raise _native.PdbedaTimeout("the item took %.3f s (host phases included)" % (time.monotonic() - t0))
+            results[index] = result
         except _native.PdbedaTimeout:
             self.failures[index] = "Timeout"
             _drop(getattr(item, "pdbid", index), "Timeout", None, self.silent)
@@ -244,9 +254,16 @@ def _worker_chunk(entries):
     record.  Returns [(record or 0, failure reason or None)]; a time-out abandons the context it happened on."""
     silent = _worker_state["silent"]
 
+    time_out = _worker_state["time_out"]
+    started = {}
+
     def load(i, box):
         try:
-            box.append(loadEntry(entries[i], _worker_context(i % 2)))
+            ctx = _worker_context(i % 2)
+            started[i] = time.monotonic()
+            if time_out > 0:
+                ctx.set_timeout(time_out)            # the entry's ONE deadline starts with its upload
+            box.append(loadEntry(entries[i], ctx))
         except BaseException as exception:           # handed to the analysing side, which sorts entry errors from device errors
             box.append(exception)
 
@@ -265,6 +282,9 @@ def _worker_chunk(entries):
         reasons = {}
         try:
             record = analyzeEntry(entry, _worker_context(i % 2), reasons, silent, loaded=box[0])
+            if time_out > 0 and record and time.monotonic() - started.get(i, time.monotonic()) > time_out:
+                _drop(entry.pdbid, "Timeout", reasons, silent)     # (host phases cannot be interrupted: judged when the entry returns)
+                record = 0
         except _native.PdbedaTimeout:
             _worker_state["ctxs"][i % 2] = None
             _drop(entry.pdbid, "Timeout", reasons, silent)

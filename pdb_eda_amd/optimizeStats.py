@@ -49,6 +49,24 @@ def reduce_counts(local_counts):
     return t.cpu().numpy()
 
 
+def all_ranks_ok(error=None):
+    """Every rank calls this between its local work and the reduction: a rank whose device or worker failed must not simply
+    leave -- the others would wait in the all-gather for ever.  All-reduce (min) of one 'ok' flag; if any rank reports a failure,
+    EVERY rank raises (the failing one with its own error), so the job ends instead of hanging."""
+    torch, dist = _dist()
+    if not (dist.is_available() and dist.is_initialized()):
+        if error is not None:
+            raise error
+        return
+    device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    flag = torch.tensor([0 if error is not None else 1], dtype=torch.int64, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if error is not None:
+        raise error
+    if int(flag.item()) == 0:
+        raise RuntimeError("another rank failed during this iteration: the statistics reduction is abandoned on every rank")
+
+
 def calculateMedianDiffsSlopes(local_records, params):
     """ref optimizeParams.py:341-408 over the records of ALL ranks.
 

@@ -87,12 +87,31 @@ class Sweep(object):
                 except Exception as exception:
                     multipleStructures._drop(res.pdbid, "%s: %s" % (type(exception).__name__, exception), self.failures, self.silent)
             return 1
-        self._pool.each(run)
+        error = None
+        try:
+            self._pool.each(run)
+        except Exception as exception:          # (a device failure of this rank: the other ranks must hear of it before the reduction)
+            error = exception
+        optimizeStats.all_ranks_ok(error)
         return optimizeStats.calculateMedianDiffsSlopes(records, params), records
 
     def close(self):
         self.lanes = []
         self._pool.close()
+
+
+_FIXED_TABLES = ("full_atom_name_map_atom_type", "full_atom_name_map_electrons", "bonded_atoms")
+
+
+def _splice_fixed_tables(params, kept):
+    """Replace the name tables of ``params`` by the objects kept from an earlier, equal table (and keep new ones)."""
+    for name in _FIXED_TABLES:
+        if name in params:
+            if name in kept and kept[name] == params[name]:
+                params[name] = kept[name]
+            else:
+                kept[name] = params[name]
+    return params
 
 
 def _sweep_worker(conn, device, lane, silent):
@@ -109,10 +128,15 @@ def _sweep_worker(conn, device, lane, silent):
             except Exception as exception:
                 multipleStructures._drop(entry.pdbid, "%s: %s" % (type(exception).__name__, exception), failures, silent)
         conn.send(("ready", failures))
+        kept = {}
         while True:
             params = conn.recv()
             if params is None:
                 return
+            # Every iteration arrives as a freshly unpickled dict: equal tables, new objects.  The per-structure flattening is
+            # cached on the IDENTITY of the three name tables (densityAnalysis._cloudInputs), so the first objects are kept and
+            # spliced into later tables that compare equal: only radii / slopes change between the iterations of a sweep.
+            _splice_fixed_tables(params, kept)
             densityAnalysis.setGlobals(params)
             records, failures = {}, {}
             for i, res in resident:
@@ -170,13 +194,18 @@ class ProcessSweep(object):
         return out
 
     def iteration(self, params):
-        for _, conn in self._workers:
-            conn.send(params)
         records = [0] * self.n_entries
-        for _, part, failures in self._gather():
-            self.failures.update(failures)
-            for i, record in part.items():
-                records[i] = record
+        error = None
+        try:
+            for _, conn in self._workers:
+                conn.send(params)
+            for _, part, failures in self._gather():
+                self.failures.update(failures)
+                for i, record in part.items():
+                    records[i] = record
+        except Exception as exception:          # (a worker of this rank failed: tell the other ranks before they enter the reduction)
+            error = exception
+        optimizeStats.all_ranks_ok(error)
         densityAnalysis.setGlobals(params)
         return optimizeStats.calculateMedianDiffsSlopes(records, params), records
 

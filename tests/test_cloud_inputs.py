@@ -128,3 +128,28 @@ def test_segment_means_are_numpy_means():
                 assert np.isnan(got[k])
             else:
                 assert got[k] == np.mean(list(seg))
+
+
+def test_sweep_worker_keeps_the_flattened_structure_between_iterations():
+    """ProcessSweep sends every iteration's parameter table through a pipe: equal tables, NEW objects.  The worker splices the
+    first objects back in, so the per-structure cache of densityAnalysis._cloudInputs (keyed on the identity of the name tables)
+    hits from the second iteration on: only the radius column is rebuilt."""
+    import pickle
+    from pdb_eda_amd import densityAnalysis, optimizeSweep, structure, synthetic
+    sets = synthetic.sweep_param_sets()
+    spec, header, st, params, dens, diff, rot = synthetic.cube_entry((40, 40, 40), 12, 3, 0.5)
+    kept = {}
+    flattened = []
+    for p in sets[:3]:
+        p = optimizeSweep._splice_fixed_tables(pickle.loads(pickle.dumps(p)), kept)     # what a worker receives, then does
+        densityAnalysis.setGlobals(p)
+        an = densityAnalysis.DensityAnalysis.__new__(densityAnalysis.DensityAnalysis)
+        an.biopdbObj = st
+        inp = an._cloudInputs()
+        flattened.append(structure.columns(st)._cloud_inputs[1])
+        assert np.array_equal(inp["radius"], np.array([p["radii"][t] for t in np.asarray(inp["pair_type"], dtype=object)[inp["pair"]]], dtype=np.float32))
+    assert flattened[0] is flattened[1] is flattened[2]
+    # without the splice the cache would miss: the unpickled tables are equal but not identical
+    densityAnalysis.setGlobals(pickle.loads(pickle.dumps(sets[0])))
+    an._cloudInputs()
+    assert structure.columns(st)._cloud_inputs[1] is not flattened[0]

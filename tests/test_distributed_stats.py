@@ -114,3 +114,38 @@ def test_single_process_matches_serial():
     assert got[0] == {t: (float(v) if not isinstance(v, int) else v) for t, v in want[0].items()} or all(abs(got[0][t] - want[0][t]) < 1e-15 for t in want[0])
     assert abs(got[2] - want[2]) < 1e-12
     assert got[4] == want[4]
+
+
+OK_WORKER = """
+import sys, os, json
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+rank = int(sys.argv[1])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="%(port)d")
+dist.init_process_group("gloo", rank=rank, world_size=2)
+from pdb_eda_amd import optimizeStats
+optimizeStats.all_ranks_ok(None)                       # everybody fine: returns on both ranks
+try:
+    optimizeStats.all_ranks_ok(ValueError("device lost") if rank == 1 else None)
+    outcome = "returned"
+except ValueError as e:
+    outcome = "own:" + str(e)
+except RuntimeError as e:
+    outcome = "other:" + str(e)[:20]
+open(%(out)r + str(rank), "w").write(outcome)
+dist.destroy_process_group()
+"""
+
+
+def test_a_failing_rank_ends_the_iteration_on_every_rank(tmp_path):
+    """A rank whose device / worker failed does not leave the others waiting in the all-gather: the 'ok' flag is all-reduced
+    first and every rank raises (world_size 2, gloo)."""
+    port = 31500 + os.getpid() % 2000
+    script = tmp_path / "ok_worker.py"
+    out = str(tmp_path / "outcome")
+    script.write_text(OK_WORKER % dict(root=ROOT, port=port, out=out))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=240) == 0
+    assert open(out + "0").read().startswith("other:another rank failed")
+    assert open(out + "1").read() == "own:device lost"

@@ -120,6 +120,41 @@ def test_watchdog_abandons_a_context():
         ctx.synchronize()
     ctx2 = _native.Context(0)
     assert not ctx2.test_overlap(crs, off, [0], [1])[0]
+    # abandoned contexts are parked, not leaked: once their streams have drained the library reaps them (every context
+    # creation tries; so does an allocation that is about to fail) -- with the arenas their lost handles held
+    ctx.close()
+    import time
+    lib = _native.lib()
+    deadline = time.time() + 30
+    while lib.pdbeda_reap_abandoned() != 0 and time.time() < deadline:
+        time.sleep(0.05)
+    assert lib.pdbeda_reap_abandoned() == 0
+
+
+@pytest.mark.timeout(120)
+def test_watchdog_deadline_is_per_entry_not_per_wait():
+    """One deadline for ALL waits of an entry (the reference's SIGALRM is around the whole of analyzePDBID): many short waits
+    that each stay below the time-out still time out together once their sum passes it; re-arming starts a new entry."""
+    import time
+    from pdb_eda_amd import _native
+    n = 20000
+    a = np.stack([np.arange(n), np.zeros(n), np.zeros(n)], axis=1).astype(np.int32)
+    crs, off = np.concatenate([a, a + np.array([0, 50, 50], dtype=np.int32)]), np.array([0, n, 2 * n], dtype=np.int64)
+    ctx = _native.Context(0)
+    ctx.test_overlap(crs, off, [0], [1])                     # warm
+    t0 = time.perf_counter()
+    ctx.test_overlap(crs, off, [0], [1])
+    one = time.perf_counter() - t0                           # one call = one wait of ~20 ms of work on one compute unit
+    ctx.set_timeout(max(4 * one, 0.02))
+    with pytest.raises(_native.PdbedaTimeout):
+        for _ in range(40):                                  # 40 waits, each well below the time-out: the ENTRY is over time
+            ctx.test_overlap(crs, off, [0], [1])
+    ctx.close()
+    ctx = _native.Context(0)
+    for _ in range(6):                                       # re-armed per entry: never expires
+        ctx.set_timeout(max(4 * one, 0.02))
+        ctx.test_overlap(crs, off, [0], [1])
+        ctx.test_overlap(crs, off, [0], [1])
 
 
 @pytest.mark.timeout(300)
