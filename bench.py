@@ -193,6 +193,19 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
             per_rank = [float(r.item()) for r in rates]
         n_atoms = len(list(loaders[0].structure()[0].get_atoms()))
         file_mb = 2 * 4 * args.entry_size ** 3 / 1e6
+        # the same entries on the host cores of this box (rank 0, N = 1 only): the CPU restatement ("port": the product's host code over
+        # oracle/pdbeda_oracle.c) in a multiprocessing.Pool on ALL cores -- the reference's own shape (multipleStructures.py:167-168)
+        cpu_pool = None
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            from oracle import cpu_entry
+            cores = len(os.sched_getaffinity(0))
+            tasks = [(l.density_path, l.n_residues, l.seed, l.edge, l.spacing) for l in loaders]
+            tasks = [tasks[i % len(tasks)] for i in range(max(len(tasks), 2 * cores))]
+            cpu_pool = cpu_entry.multiple_baseline(tasks, cores, seconds=args.cpu_seconds)
+            cpu_pool.update({"cores": cores, "kind": "port", "unit": "entries/min", "value": cpu_pool["entries_per_min"],
+                             "sample": "%d x %d^3 entries (%d atoms) per pass, repeated for %.0f s: read the 2Fo-Fc CCP4 file, numpy-tree mean / std, aggregateCloud "
+                                       "(flattening + oracle composite + statistics tail), the entry's diffs -- multiprocessing.Pool(%d), one entry per task"
+                                       % (len(tasks), args.entry_size, n_atoms, cpu_pool["seconds"], cores)})
         return {"workload": "configs[3]: %d entries per rank and pass (%d distinct on disk = %.0f MB of CCP4 files per rank), each two CCP4 files of a %d^3 grid + a "
                             "%d-atom model: read, parse, upload, aggregateCloud + the per-entry record of `pdb_eda multiple`"
                             % (args.entries, distinct, distinct * file_mb, args.entry_size, n_atoms),
@@ -201,6 +214,7 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
                 "entries_per_min_per_rank": [round(v, 1) for v in per_rank],
                 "one_worker_ms_per_entry": 1e3 * single, "one_worker_entries_per_min": 60.0 / single,
                 "pool_vs_one_worker": (total_done / world / elapsed) * single, "generation_s": gen_s,
+                "cpu_baseline": cpu_pool,
                 "page_cache": "warm: the files were written by this process moments earlier and every one is read again on each pass (no O_DIRECT, no cache drop: "
                               "an ordinary user cannot drop caches on the box); a cold first read of a 64 MB entry costs its disk time on top",
                 "note": "worker processes (spawn), one HIP stream each, sharing the GPU of the rank; sharding over ranks is one entry list per rank, no collective"}
@@ -558,6 +572,8 @@ def main():
         out["cpu_baseline"] = {"value": done * n_vox / spent / 1e6, "unit": "Mvoxels/s", "cores": 1, "kind": "port",
                                "sample": "%d x the same %d^3 entry, green+red, oracle/pdbeda_oracle.c ora_full_blobs (single thread); "
                                          "the reference's own O(N^2) clustering cannot run this size (SURVEY.md 6)" % (done, n)}
+        if multiple and isinstance(multiple.get("cpu_baseline"), dict):      # the all-core baseline of the entries/min leg rides along
+            out["cpu_baseline"]["multiple_structures"] = multiple["cpu_baseline"]
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -68,6 +68,12 @@ def lib():
         _lib.ora_symmetry_atoms.argtypes = [p, i64, p, C.c_int32, p, p, p, p, p, p, i64]
         _lib.ora_full_blobs.restype = i64
         _lib.ora_full_blobs.argtypes = [mp, C.c_float, p, p, p, i64, p]
+        _lib.ora_cloud_begin.restype = C.c_void_p
+        _lib.ora_cloud_begin.argtypes = [mp, i64, p, p, p, p, p, p, i64, p, p, i64, p, C.c_float, p]
+        _lib.ora_cloud_finish.restype = C.c_int
+        _lib.ora_cloud_finish.argtypes = [C.c_void_p, C.c_double, C.c_double, i64] + [p] * 16 + [p, p]
+        _lib.ora_cloud_end.restype = None
+        _lib.ora_cloud_end.argtypes = [C.c_void_p]
     return _lib
 
 
@@ -173,6 +179,49 @@ class Oracle(object):
         else:
             crs = self.sphere_crs(x[0], np.asarray(radii, dtype=np.float32).reshape(-1)[0], cutoff)
         return self.blob_list(crs)
+
+    def aggregate_cloud(self, xyz, radius, weight, residue, alias, key, bonded_off, bonded, owner_key, cutoff, min_cloud_electrons):
+        """The composite behind DensityAnalysis.aggregateCloud (densityAnalysis.py:571-731) on the flattened structure: same
+        arguments and same result dict as the product's DeviceMap.aggregate_cloud, so it can stand in for the device in the
+        host-side table code.  The centroid-distance cut-off between the two phases is numpy's own (607)."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+        a = {"radius": np.ascontiguousarray(radius, dtype=np.float32), "weight": np.ascontiguousarray(weight, dtype=np.float64),
+             "residue": np.ascontiguousarray(residue, dtype=np.int32), "alias": np.ascontiguousarray(alias, dtype=np.int32),
+             "key": np.ascontiguousarray(key, dtype=np.int32), "bonded_off": np.ascontiguousarray(bonded_off, dtype=np.int64),
+             "bonded": np.ascontiguousarray(bonded, dtype=np.int32), "owner_key": np.ascontiguousarray(owner_key, dtype=np.int32)}
+        n, no = len(xyz), len(a["owner_key"])
+        dist = np.zeros(max(n, 1))
+        st = self.L.ora_cloud_begin(C.byref(self.m), n, _ptr(xyz), _ptr(a["radius"]), _ptr(a["weight"]), _ptr(a["residue"]), _ptr(a["alias"]), _ptr(a["key"]),
+                                    len(a["bonded_off"]) - 1, _ptr(a["bonded_off"]), _ptr(a["bonded"]), no, _ptr(a["owner_key"]), C.c_float(cutoff), _ptr(dist))
+        if not st:
+            raise ValueError("the oracle composite does not model atoms that share a coordinate")
+        try:
+            d = dist[:n][~np.isnan(dist[:n])]
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                cut = float(np.nanmedian(d) + 2.5 * np.nanstd(d)) if len(d) else float("nan")     # densityAnalysis.py:607
+            cap = max(4 * n, 16)
+            at = {"atom": np.zeros(cap, np.int32), "atom_total": np.zeros(cap), "atom_n": np.zeros(cap, np.int64), "atom_centroid": np.zeros((cap, 3)),
+                  "atom_distance": np.zeros(cap)}
+            tabs = {tag: {"residue": np.zeros(cap, np.int32), "total": np.zeros(cap), "n": np.zeros(cap, np.int64), "electrons": np.zeros(cap),
+                          "centroid": np.zeros((cap, 3))} for tag in ("res", "dom")}
+            owner = np.zeros(max(no, 1), np.uint8)
+            counts, totals = np.zeros(3, np.int64), np.zeros(3)
+            rc = self.L.ora_cloud_finish(st, cut, float(min_cloud_electrons), cap,
+                                         _ptr(at["atom"]), _ptr(at["atom_total"]), _ptr(at["atom_n"]), _ptr(at["atom_centroid"]), _ptr(at["atom_distance"]),
+                                         *[_ptr(tabs[tag][f]) for tag in ("res", "dom") for f in ("residue", "total", "n", "electrons", "centroid")],
+                                         _ptr(owner), _ptr(counts), _ptr(totals))
+            assert rc == 0, rc
+        finally:
+            self.L.ora_cloud_end(st)
+        na, nr, nd = (int(v) for v in counts)
+        out = {"numVoxels": int(totals[0]), "totalElectrons": float(totals[1]), "totalDensity": float(totals[2]), "centroidDistanceCutoff": cut,
+               "owner_state": owner[:no].copy()}
+        out.update({k: v[:na].copy() for k, v in at.items()})
+        out["res"] = {k: v[:nr].copy() for k, v in tabs["res"].items()}
+        out["dom"] = {k: v[:nd].copy() for k, v in tabs["dom"].items()}
+        return out
 
     def valid_xyz(self, xyz, radius):
         x = np.asarray(xyz, dtype=np.float64)

@@ -503,3 +503,289 @@ int64_t ora_full_blobs(const ora_map *m, float cutoff, int64_t *out_n, double *o
     free(par); free(slot); free(kr); free(acc); free(cnt); free(rank);
     return nroot;
 }
+
+/* ---------------------------------------------------------------------------------
+ * Composite: DensityAnalysis.aggregateCloud up to its statistics tail (densityAnalysis.py:571-731), on the flattened
+ * structure the product hands to pdbeda_aggregate_cloud (include/pdbeda.h: pdbeda_cloud_atoms; the flattening itself is
+ * checked against a statement-by-statement walk of the reference's loops in tests/test_cloud_inputs.py).  Checker for
+ * entries of thousands of atoms, where the reference itself takes minutes; pinned on the reference's analysis goldens by
+ * tests/test_oracle_cloud.py.  Two phases, because the cut-off between them is numpy's (np.nanmedian + 2.5 np.nanstd, 607):
+ * the caller computes it with numpy itself from the distances of phase 1.
+ * Not modelled: atoms that share a coordinate (allAtomClouds is keyed by the coordinate, 604: the later atom's clouds
+ * replace the earlier one's) -- ora_cloud_begin refuses them (alias[i] != i).
+ * --------------------------------------------------------------------------------- */
+typedef struct ora_cloud1 {      /* one cloud: sorted distinct voxels + fromCrsList statistics */
+    int32_t *crs;
+    int64_t n;
+    double total, centroid[3];
+    int32_t lo[3], hi[3];
+    int32_t *atoms;              /* indices of the eligible atoms behind it (cloud.atoms), distinct */
+    int64_t n_atoms;
+} ora_cloud1;
+
+typedef struct ora_cloud_state {
+    const ora_map *m;
+    int64_t n;
+    const double *xyz, *weight;
+    const int32_t *residue, *key;
+    int64_t n_keys;
+    const int64_t *bonded_off;
+    const int32_t *bonded;
+    int64_t n_owners;
+    const int32_t *owner_key;
+    ora_cloud1 **clouds;         /* per atom: its clouds, in createBlobList order */
+    int64_t *n_clouds;
+} ora_cloud_state;
+
+static void cloud_finish(const ora_map *m, ora_cloud1 *c) {
+    double st[8];
+    ora_blob_stats(m, c->crs, c->n, st);
+    c->total = st[0];
+    for (int k = 0; k < 3; ++k) { c->centroid[k] = st[1 + k]; c->lo[k] = c->hi[k] = c->crs[k]; }
+    for (int64_t i = 1; i < c->n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            if (c->crs[3 * i + k] < c->lo[k]) c->lo[k] = c->crs[3 * i + k];
+            if (c->crs[3 * i + k] > c->hi[k]) c->hi[k] = c->crs[3 * i + k];
+        }
+}
+
+static void cloud_free1(ora_cloud1 *c) { free(c->crs); free(c->atoms); c->crs = NULL; c->atoms = NULL; }
+
+/* utils.testOverlap (cutils.pyx:8-25) behind a bounding-box rejection */
+static int cloud_overlap(const ora_cloud1 *a, const ora_cloud1 *b) {
+    for (int k = 0; k < 3; ++k)
+        if (a->lo[k] > b->hi[k] + 1 || b->lo[k] > a->hi[k] + 1) return 0;
+    return ora_test_overlap(a->crs, a->n, b->crs, b->n);
+}
+
+/* DensityBlob.clone + merge (ccp4.py:575-594) of the clouds pool[idx[0..k)]: set union of the voxels, union of the atoms,
+ * statistics recomputed over the union (fromCrsList). */
+static int cloud_union(const ora_map *m, ora_cloud1 *const *pool, const int64_t *idx, int64_t k, ora_cloud1 *out) {
+    int64_t nv = 0, na = 0;
+    for (int64_t i = 0; i < k; ++i) { nv += pool[idx[i]]->n; na += pool[idx[i]]->n_atoms; }
+    out->crs = (int32_t *)malloc(sizeof(int32_t) * 3 * (size_t)(nv > 0 ? nv : 1));
+    out->atoms = (int32_t *)malloc(sizeof(int32_t) * (size_t)(na > 0 ? na : 1));
+    if (!out->crs || !out->atoms) return -1;
+    nv = 0; na = 0;
+    for (int64_t i = 0; i < k; ++i) {
+        memcpy(out->crs + 3 * nv, pool[idx[i]]->crs, sizeof(int32_t) * 3 * (size_t)pool[idx[i]]->n);
+        nv += pool[idx[i]]->n;
+        for (int64_t j = 0; j < pool[idx[i]]->n_atoms; ++j) {
+            int seen = 0;
+            for (int64_t q = 0; q < na; ++q) seen |= out->atoms[q] == pool[idx[i]]->atoms[j];
+            if (!seen) out->atoms[na++] = pool[idx[i]]->atoms[j];
+        }
+    }
+    qsort(out->crs, (size_t)nv, sizeof(int32_t) * 3, cmp_crs);
+    int64_t u = 0;
+    for (int64_t i = 0; i < nv; ++i)
+        if (i == 0 || cmp_crs(out->crs + 3 * i, out->crs + 3 * (i - 1)) != 0) { if (u != i) memcpy(out->crs + 3 * u, out->crs + 3 * i, sizeof(int32_t) * 3); ++u; }
+    out->n = u;
+    out->n_atoms = na;
+    cloud_finish(m, out);
+    return 0;
+}
+
+void ora_cloud_end(ora_cloud_state *s) {
+    if (!s) return;
+    if (s->clouds)
+        for (int64_t i = 0; i < s->n; ++i) {
+            for (int64_t j = 0; s->clouds[i] && j < s->n_clouds[i]; ++j) cloud_free1(&s->clouds[i][j]);
+            free(s->clouds[i]);
+        }
+    free(s->clouds); free(s->n_clouds); free(s);
+}
+
+/* Phase 1 (596-606): the clouds of every eligible atom (findAberrantBlobs with the atom's own radius); min_distance[i] = the
+ * distance from the atom to the nearest of its clouds' centroids (np.linalg.norm), NaN for an atom without clouds. */
+ora_cloud_state *ora_cloud_begin(const ora_map *m, int64_t n, const double *xyz, const float *radius, const double *weight, const int32_t *residue,
+                                 const int32_t *alias, const int32_t *key, int64_t n_keys, const int64_t *bonded_off, const int32_t *bonded,
+                                 int64_t n_owners, const int32_t *owner_key, float density_cutoff, double *min_distance) {
+    for (int64_t i = 0; i < n; ++i) if (alias[i] != (int32_t)i) return NULL;   /* shared coordinates: not modelled */
+    ora_cloud_state *s = (ora_cloud_state *)calloc(1, sizeof *s);
+    if (!s) return NULL;
+    s->m = m; s->n = n; s->xyz = xyz; s->weight = weight; s->residue = residue; s->key = key; s->n_keys = n_keys;
+    s->bonded_off = bonded_off; s->bonded = bonded; s->n_owners = n_owners; s->owner_key = owner_key;
+    s->clouds = (ora_cloud1 **)calloc((size_t)(n > 0 ? n : 1), sizeof *s->clouds);
+    s->n_clouds = (int64_t *)calloc((size_t)(n > 0 ? n : 1), sizeof *s->n_clouds);
+    if (!s->clouds || !s->n_clouds) { ora_cloud_end(s); return NULL; }
+    for (int64_t i = 0; i < n; ++i) {
+        min_distance[i] = NAN;
+        const int64_t nv = ora_sphere_crs(m, xyz + 3 * i, radius[i], density_cutoff, NULL, 0);
+        if (nv == 0) continue;
+        int32_t *crs = (int32_t *)malloc(sizeof(int32_t) * 3 * (size_t)nv), *lab = (int32_t *)malloc(sizeof(int32_t) * (size_t)nv);
+        if (!crs || !lab) { free(crs); free(lab); ora_cloud_end(s); return NULL; }
+        ora_sphere_crs(m, xyz + 3 * i, radius[i], density_cutoff, crs, nv);
+        const int64_t nc = ora_cluster(crs, nv, lab);
+        s->clouds[i] = (ora_cloud1 *)calloc((size_t)nc, sizeof(ora_cloud1));
+        s->n_clouds[i] = nc;
+        for (int64_t c = 0; c < nc; ++c) {
+            ora_cloud1 *cl = &s->clouds[i][c];
+            int64_t cnt = 0;
+            for (int64_t v = 0; v < nv; ++v) cnt += lab[v] == c;
+            cl->crs = (int32_t *)malloc(sizeof(int32_t) * 3 * (size_t)cnt);
+            cl->atoms = (int32_t *)malloc(sizeof(int32_t));
+            cl->atoms[0] = (int32_t)i; cl->n_atoms = 1;           /* aCloud.atoms = [atom] (639) */
+            cl->n = 0;
+            for (int64_t v = 0; v < nv; ++v)
+                if (lab[v] == c) { memcpy(cl->crs + 3 * cl->n, crs + 3 * v, sizeof(int32_t) * 3); ++cl->n; }
+            cloud_finish(m, cl);                                   /* (list order: the sphere's iteration order, as the reference sums) */
+            double d2 = 0;
+            for (int k = 0; k < 3; ++k) { const double d = xyz[3 * i + k] - cl->centroid[k]; d2 += d * d; }
+            const double d = sqrt(d2);
+            if (!(min_distance[i] <= d)) min_distance[i] = d;
+        }
+        free(crs); free(lab);
+    }
+    return s;
+}
+
+/* connected components of the overlap graph over pool[0..n): comp[i] = component number in order of lowest member */
+static int64_t overlap_components(ora_cloud1 *const *pool, int64_t n, int64_t *comp) {
+    int64_t *par = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+    for (int64_t i = 0; i < n; ++i) par[i] = i;
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = i + 1; j < n; ++j)
+            if (uf_find(par, i) != uf_find(par, j) && cloud_overlap(pool[i], pool[j])) uf_union(par, i, j);
+    int64_t nc = 0;
+    for (int64_t i = 0; i < n; ++i) comp[i] = -1;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t r = uf_find(par, i);
+        if (comp[r] < 0) comp[r] = nc++;
+        comp[i] = comp[r];
+    }
+    free(par);
+    return nc;
+}
+
+/* Phase 2 (609-726).  Row buffers are caller-allocated: atom rows <= n, residue / domain rows <= total clouds (cap_rows each).
+ * counts[3] = atom rows, residue rows, domain rows; totals[3] = numVoxels, totalElectrons, totalDensity (718-721).
+ * Residue rows in the reference's emission order up to the set order inside a cluster (lowest pooled index first). */
+int ora_cloud_finish(ora_cloud_state *s, double centroid_cutoff, double min_cloud_electrons, int64_t cap_rows,
+                     int32_t *atom_idx, double *atom_total, int64_t *atom_n, double *atom_centroid, double *atom_distance,
+                     int32_t *res_residue, double *res_total, int64_t *res_n, double *res_electrons, double *res_centroid,
+                     int32_t *dom_residue, double *dom_total, int64_t *dom_n, double *dom_electrons, double *dom_centroid,
+                     uint8_t *owner_state, int64_t counts[3], double totals[3]) {
+    const ora_map *m = s->m;
+    int64_t total_clouds = 0;
+    for (int64_t i = 0; i < s->n; ++i) total_clouds += s->n_clouds[i];
+    ora_cloud1 *dom_pool = (ora_cloud1 *)calloc((size_t)(total_clouds > 0 ? total_clouds : 1), sizeof(ora_cloud1));
+    int32_t *dom_res = (int32_t *)malloc(sizeof(int32_t) * (size_t)(total_clouds > 0 ? total_clouds : 1));
+    ora_cloud1 **pool = (ora_cloud1 **)malloc(sizeof(ora_cloud1 *) * (size_t)(total_clouds > 0 ? total_clouds : 1));
+    int64_t *comp = (int64_t *)malloc(sizeof(int64_t) * (size_t)(total_clouds > 0 ? total_clouds : 1));
+    int64_t *members = (int64_t *)malloc(sizeof(int64_t) * (size_t)(total_clouds > 0 ? total_clouds : 1));
+    int64_t *first_of_key = (int64_t *)malloc(sizeof(int64_t) * (size_t)(s->n_keys > 0 ? s->n_keys : 1));
+    int64_t *count_of_key = (int64_t *)malloc(sizeof(int64_t) * (size_t)(s->n_keys > 0 ? s->n_keys : 1));
+    if (!dom_pool || !dom_res || !pool || !comp || !members || !first_of_key || !count_of_key) return -1;
+    for (int64_t k = 0; k < s->n_keys; ++k) { first_of_key[k] = -1; count_of_key[k] = 0; }
+    for (int64_t o = 0; o < s->n_owners; ++o) owner_state[o] = 0;
+    int64_t n_atom_rows = 0, n_res_rows = 0, n_dom_pool = 0, owner_cursor = 0;
+    int64_t a0 = 0;
+    while (a0 < s->n) {                                  /* one residue: atoms [a0, a1) */
+        int64_t a1 = a0;
+        while (a1 < s->n && s->residue[a1] == s->residue[a0]) ++a1;
+        int64_t n_pool = 0;
+        for (int64_t i = a0; i < a1; ++i) {
+            const int64_t nc = s->n_clouds[i];
+            if (nc == 0) continue;
+            int64_t best = 0;
+            double best_d = 0;
+            {
+                double dmin = INFINITY;
+                for (int64_t c = 0; c < nc; ++c) {
+                    double d2 = 0;
+                    for (int k = 0; k < 3; ++k) { const double d = s->xyz[3 * i + k] - s->clouds[i][c].centroid[k]; d2 += d * d; }
+                    const double d = sqrt(d2);
+                    if (d < dmin) { dmin = d; best = c; }          /* distances.index(min): first */
+                }
+                best_d = dmin;
+                if (nc > 1 && dmin > centroid_cutoff) continue;     /* (627-629; a single cloud is never tested, 622-623) */
+            }
+            first_of_key[s->key[i]] = n_pool;                       /* atomCloudIndeces[resAtom]: the LAST atom of that name wins (640) */
+            count_of_key[s->key[i]] = nc;
+            for (int64_t c = 0; c < nc; ++c) pool[n_pool++] = &s->clouds[i][c];
+            if (n_atom_rows < cap_rows) {
+                const ora_cloud1 *b = &s->clouds[i][best];
+                atom_idx[n_atom_rows] = (int32_t)i; atom_total[n_atom_rows] = b->total; atom_n[n_atom_rows] = b->n;
+                for (int k = 0; k < 3; ++k) atom_centroid[3 * n_atom_rows + k] = b->centroid[k];
+                atom_distance[n_atom_rows] = best_d;
+            }
+            ++n_atom_rows;
+        }
+        /* bonded-atom overlap completeness (652-659): the owners of this residue are the next ones whose key belongs to it */
+        const int32_t res_id = s->residue[a0];
+        (void)res_id;
+        /* keys of this residue: those of its atoms; owners are listed residue by residue, so consume while the key is one of them */
+        while (owner_cursor < s->n_owners) {
+            const int32_t k = s->owner_key[owner_cursor];
+            int mine = 0;
+            for (int64_t i = a0; i < a1 && !mine; ++i) mine = s->key[i] == k;
+            if (!mine) break;
+            if (first_of_key[k] >= 0) {
+                int all_ok = 1;
+                for (int64_t b = s->bonded_off[k]; b < s->bonded_off[k + 1] && all_ok; ++b) {
+                    const int32_t k2 = s->bonded[b];
+                    if (first_of_key[k2] < 0) continue;              /* "if resAtom2 in atomCloudIndeces" */
+                    int any = 0;
+                    for (int64_t i1 = first_of_key[k]; i1 < first_of_key[k] + count_of_key[k] && !any; ++i1)
+                        for (int64_t i2 = first_of_key[k2]; i2 < first_of_key[k2] + count_of_key[k2] && !any; ++i2)
+                            any = i1 != i2 && cloud_overlap(pool[i1], pool[i2]);   /* (overlap[i][i] stays 0, 645-648) */
+                    all_ok = any;
+                }
+                owner_state[owner_cursor] = all_ok ? 1 : 2;
+            }
+            ++owner_cursor;
+        }
+        /* residue clouds = clusters of the pool under testOverlap, merged (661-683) */
+        const int64_t nc = overlap_components(pool, n_pool, comp);
+        for (int64_t c = 0; c < nc; ++c) {
+            int64_t k = 0;
+            for (int64_t i = 0; i < n_pool; ++i) if (comp[i] == c) members[k++] = i;
+            ora_cloud1 *rc = &dom_pool[n_dom_pool];
+            if (cloud_union(m, pool, members, k, rc)) return -1;
+            dom_res[n_dom_pool++] = s->residue[a0];
+            double el = 0;
+            for (int64_t j = 0; j < rc->n_atoms; ++j) el += s->weight[rc->atoms[j]];
+            if (el >= min_cloud_electrons) {
+                if (n_res_rows < cap_rows) {
+                    res_residue[n_res_rows] = s->residue[a0]; res_total[n_res_rows] = rc->total; res_n[n_res_rows] = rc->n; res_electrons[n_res_rows] = el;
+                    for (int q = 0; q < 3; ++q) res_centroid[3 * n_res_rows + q] = rc->centroid[q];
+                }
+                ++n_res_rows;
+            }
+        }
+        for (int64_t i = a0; i < a1; ++i) { first_of_key[s->key[i]] = -1; count_of_key[s->key[i]] = 0; }
+        a0 = a1;
+    }
+    /* domain clouds (692-712) and the totals (714-726) */
+    ora_cloud1 **dpool = (ora_cloud1 **)malloc(sizeof(ora_cloud1 *) * (size_t)(n_dom_pool > 0 ? n_dom_pool : 1));
+    int64_t *dcomp = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_dom_pool > 0 ? n_dom_pool : 1));
+    if (!dpool || !dcomp) return -1;
+    for (int64_t i = 0; i < n_dom_pool; ++i) dpool[i] = &dom_pool[i];
+    const int64_t nd = overlap_components(dpool, n_dom_pool, dcomp);
+    int64_t n_dom_rows = 0;
+    double num_voxels = 0, total_electrons = 0, total_density = 0;
+    for (int64_t c = 0; c < nd; ++c) {
+        int64_t k = 0;
+        for (int64_t i = 0; i < n_dom_pool; ++i) if (dcomp[i] == c) members[k++] = i;
+        ora_cloud1 dc;
+        memset(&dc, 0, sizeof dc);
+        if (cloud_union(m, dpool, members, k, &dc)) return -1;
+        double el = 0;
+        for (int64_t j = 0; j < dc.n_atoms; ++j) el += s->weight[dc.atoms[j]];
+        total_electrons += el; num_voxels += (double)dc.n; total_density += dc.total;
+        if (el >= min_cloud_electrons) {
+            if (n_dom_rows < cap_rows) {
+                dom_residue[n_dom_rows] = dom_res[members[0]]; dom_total[n_dom_rows] = dc.total; dom_n[n_dom_rows] = dc.n; dom_electrons[n_dom_rows] = el;
+                for (int q = 0; q < 3; ++q) dom_centroid[3 * n_dom_rows + q] = dc.centroid[q];
+            }
+            ++n_dom_rows;
+        }
+        cloud_free1(&dc);
+    }
+    counts[0] = n_atom_rows; counts[1] = n_res_rows; counts[2] = n_dom_rows;
+    totals[0] = num_voxels; totals[1] = total_electrons; totals[2] = total_density;
+    for (int64_t i = 0; i < n_dom_pool; ++i) cloud_free1(&dom_pool[i]);
+    free(dom_pool); free(dom_res); free(pool); free(comp); free(members); free(first_of_key); free(count_of_key); free(dpool); free(dcomp);
+    return (n_atom_rows > cap_rows || n_res_rows > cap_rows || n_dom_rows > cap_rows) ? -2 : 0;
+}
