@@ -149,6 +149,7 @@ struct pdbeda_map {
     Geom geom;
     Geom *geom_dev = nullptr;
     int64_t n_vox = 0;
+    double fix_mul = 0.0;             // 2^S of the order-independent blob sums (FixSums); 0 = not yet derived from the map's range
 };
 
 struct pdbeda_bloblist {
@@ -681,6 +682,38 @@ static int reduce_launch(pdbeda_map *m, int mode, const double *mean_dev, double
     return 0;
 }
 
+// The quantum of the order-independent blob sums of this map (see FixSums in pdbeda_kernels.h): S such that neither
+// sum |rho| over the whole map nor the first moment of one tile / one run (<= 2^22 max |rho|) can leave 62 bits.  Two
+// deterministic reductions over the map, once per map (the result is cached; a borrowed device pointer is taken to hold the
+// same grid for the life of the map).
+static int map_fix_mul(pdbeda_map *m) {
+    if (m->fix_mul != 0.0) return 0;
+    pdbeda_ctx *ctx = m->ctx;
+    double *res = ctx->partials + N_PARTIAL + 4;
+    unsigned int *mx = reinterpret_cast<unsigned int *>(ctx->partials + N_PARTIAL + 5);
+    HIP_TRY(ctx, hipMemsetAsync(mx, 0, sizeof(unsigned int), ctx->stream));
+    { PROF(ctx, "k_absmax"); hipLaunchKernelGGL(k_absmax, dim3(N_PARTIAL), dim3(256), 0, ctx->stream, m->dens, m->n_vox, mx); }
+    int rc = reduce_launch(m, 2, nullptr, -1.0, 1.0, 0, res);   // sum |x| over every voxel (|x| > -1), fixed reduction order
+    if (rc) return rc;
+    double sum_abs = 0.0;
+    unsigned int max_bits = 0u;
+    HIP_TRY(ctx, d2h(ctx, &sum_abs, res, sizeof(double)));
+    HIP_TRY(ctx, d2h(ctx, &max_bits, mx, sizeof(unsigned int)));
+    HIP_TRY(ctx, ctx_sync(ctx));
+    float max_abs;
+    memcpy(&max_abs, &max_bits, sizeof max_abs);
+    const double bound = std::max(sum_abs, 4194304.0 * (double)max_abs);
+    int S = 40;
+    if (bound > 0.0 && std::isfinite(bound)) {
+        int e = 0;
+        (void)frexp(bound, &e);        // bound < 2^e
+        S = 61 - e;
+    }
+    S = std::max(-900, std::min(S, 900));
+    m->fix_mul = ldexp(1.0, S);
+    return 0;
+}
+
 extern "C" int pdbeda_map_stats(pdbeda_map *m, double *mean, double *std) {
     if (!m) return PDBEDA_ERR_ARGUMENT;
     pdbeda_ctx *ctx = m->ctx;
@@ -837,10 +870,7 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.vol_sign[0] = job.vol_sign[1] = 1;
     job.parent = cv.take<int32_t>(max_runs);
     job.r_n = cv.take<uint32_t>(max_runs);
-    job.r_rho = cv.take<double>(max_runs);
-    job.r_rho_c = cv.take<double>(max_runs);
-    job.r_rho_r = cv.take<double>(max_runs);
-    job.r_rho_s = cv.take<double>(max_runs);
+    job.r_sum = cv.take<FixSums>(max_runs);
     job.r_c = cv.take<long long>(max_runs);
     job.r_r = cv.take<long long>(max_runs);
     job.r_s = cv.take<long long>(max_runs);
@@ -937,8 +967,11 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
         return fail(ctx, PDBEDA_ERR_ARGUMENT, "grid too large for whole-map labelling: %d x %d x %d voxels need %lld run ids (limit 2^31: about 1100^3 for a fused job)",
                     uc, ur, us, (long long)max_runs);
 
+    int rc_fix = map_fix_mul(m);
+    if (rc_fix) return rc_fix;
     Job job;
     memset(&job, 0, sizeof job);
+    job.fix_mul = m->fix_mul;
     size_t need = job_carve(job, nullptr, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, nullptr, tiles_pp);
     Arena arena;
     int rc = arena_get(ctx, need, &arena);
@@ -1301,8 +1334,11 @@ static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, con
 static int grouped_job(pdbeda_map *m, GroupSetup &gs, int64_t n_items, int64_t n_groups, bool spheres, float cutoff, pdbeda_bloblist **out) {
     pdbeda_ctx *ctx = m->ctx;
     const int64_t max_runs = gs.total_keys / 2 + gs.total_words + 1;
+    int rc_fix = map_fix_mul(m);
+    if (rc_fix) { arena_put(ctx, gs.in_arena); return rc_fix; }
     Job job;
     memset(&job, 0, sizeof job);
+    job.fix_mul = m->fix_mul;
     size_t need = job_carve(job, nullptr, (int)n_groups, gs.total_words, gs.total_keys, max_runs, max_runs, 0, nullptr);
     Arena arena;
     int rc = arena_get(ctx, need, &arena);

@@ -25,6 +25,45 @@ struct VolDesc {
     int64_t key_base;   // first key bit of this volume (key = (c*dim[1] + r)*dim[2] + s)
 };
 
+// ---- Order-independent sums --------------------------------------------------------------------------------------
+// sum(rho) and the first moments sum(rho * c / r / s) of a blob are folded from thousands of partial sums by atomics whose
+// order the hardware picks; in floating point that makes the last bits differ from run to run, and aggregateCloud DECIDES
+// things with these sums (best cloud, centroid-distance cut-off, pooling).  So they are kept as integers: a partial sum is
+// rounded ONCE to a multiple of 2^-S (fix_of; S is chosen per map from sum |rho| and max |rho|, so that no sum can overflow
+// and the quantum is ~1e-12 of a significant voxel), and integer addition commutes.  A moment is two limbs,
+// value = hi * 2^32 + lo: sums of limbs over a whole map stay far inside 64 bits.
+struct FixSums {
+    long long rho, c_lo, c_hi, r_lo, r_hi, s_lo, s_hi;
+};
+__device__ inline long long fix_of(double v, double mul) { return __double2ll_rn(v * mul); }
+__device__ inline void fix_limbs(__int128 v, long long &lo, long long &hi) {
+    lo = (long long)(unsigned long long)((unsigned __int128)v & 0xffffffffu);
+    hi = (long long)(v >> 32);
+}
+__device__ inline double fix_moment(long long lo, long long hi) { return (double)hi * 4294967296.0 + (double)lo; }
+// rho = F and moments F * (c, r, s) + (m_c, m_r, m_s): coordinates of the frame's origin, moments relative to it
+__device__ inline FixSums fix_sums(long long F, long long m_c, long long m_r, long long m_s, long long c0, long long r0, long long s0) {
+    FixSums o;
+    o.rho = F;
+    fix_limbs((__int128)F * c0 + m_c, o.c_lo, o.c_hi);
+    fix_limbs((__int128)F * r0 + m_r, o.r_lo, o.r_hi);
+    fix_limbs((__int128)F * s0 + m_s, o.s_lo, o.s_hi);
+    return o;
+}
+__device__ inline void fix_add(FixSums &a, const FixSums &b) {
+    a.rho += b.rho; a.c_lo += b.c_lo; a.c_hi += b.c_hi; a.r_lo += b.r_lo; a.r_hi += b.r_hi; a.s_lo += b.s_lo; a.s_hi += b.s_hi;
+}
+__device__ inline void fix_atomic_add(FixSums *dst, const FixSums &v) {   // (global or LDS)
+    atomicAdd((unsigned long long *)&dst->rho, (unsigned long long)v.rho);
+    atomicAdd((unsigned long long *)&dst->c_lo, (unsigned long long)v.c_lo);
+    atomicAdd((unsigned long long *)&dst->c_hi, (unsigned long long)v.c_hi);
+    atomicAdd((unsigned long long *)&dst->r_lo, (unsigned long long)v.r_lo);
+    atomicAdd((unsigned long long *)&dst->r_hi, (unsigned long long)v.r_hi);
+    atomicAdd((unsigned long long *)&dst->s_lo, (unsigned long long)v.s_lo);
+    atomicAdd((unsigned long long *)&dst->s_hi, (unsigned long long)v.s_hi);
+}
+__device__ inline FixSums fix_zero() { FixSums z; z.rho = z.c_lo = z.c_hi = z.r_lo = z.r_hi = z.s_lo = z.s_hi = 0; return z; }
+
 struct Counters {
     unsigned int n_runs;
     unsigned int n_comps;
@@ -75,7 +114,8 @@ struct Job {
     // per-component records
     int32_t *parent;
     uint32_t *r_n;
-    double *r_rho, *r_rho_c, *r_rho_r, *r_rho_s;
+    FixSums *r_sum;           // sum(rho) and its moments, as order-independent integers
+    double fix_mul;           // 2^S of this job's map (see FixSums)
     long long *r_c, *r_r, *r_s;
     unsigned long long *r_key;
     uint32_t *r_rank;
@@ -89,9 +129,9 @@ struct Job {
     int32_t n_tiles;          // k_emit visits the ~36 k roots of a 256^3 job, not its 262 k component ids
 };
 
-struct InboxEntry {           // 80 bytes: what a (tile, root) pair folds into the root's record
+struct InboxEntry {           // 104 bytes: what a (tile, root) pair folds into the root's record
     uint32_t local, n;        // component index of the root inside its tile; voxels
-    double rho, rho_c, rho_r, rho_s;
+    FixSums sum;
     unsigned long long c, r, s, key;
 };
 constexpr int INBOX_STRIDE = 32;   // uint32 per inbox counter: a cache line each
@@ -154,10 +194,8 @@ __device__ inline void word_run_records(const Job &job, const Geom &g, const flo
         const uint32_t idx = rec0 + (uint32_t)popc64(starts & bits_below(lane));
         job.parent[idx] = (int32_t)idx;
         job.r_n[idx] = (uint32_t)len;
-        job.r_rho[idx] = s_rho;
-        job.r_rho_c[idx] = (double)rawc0 * s_rho + s_rl;
-        job.r_rho_r[idx] = (double)rawr * s_rho;
-        job.r_rho_s[idx] = (double)raws * s_rho;
+        // (the run's two sums are rounded to the job's quantum here, once; everything downstream is integer arithmetic)
+        job.r_sum[idx] = fix_sums(fix_of(s_rho, job.fix_mul), fix_of(s_rl, job.fix_mul), 0, 0, rawc0, rawr, raws);
         const long long a = (long long)rawc0 + lane;
         job.r_c[idx] = (long long)len * a + (long long)len * (len - 1) / 2;
         job.r_r[idx] = (long long)len * rawr;
@@ -376,10 +414,10 @@ __global__ void __launch_bounds__(256) k_resolve(Job job) {
             if (root == (int)i) root = -1; else job.parent[i] = root;
         }
         uint32_t n = 0;
-        double rho = 0.0, rc = 0.0, rr = 0.0, rs = 0.0;
+        FixSums sum = fix_zero();
         unsigned long long c = 0, r = 0, sv = 0, key = ~0ull;
         if (root >= 0) {
-            n = job.r_n[i]; rho = job.r_rho[i]; rc = job.r_rho_c[i]; rr = job.r_rho_r[i]; rs = job.r_rho_s[i];
+            n = job.r_n[i]; sum = job.r_sum[i];
             c = (unsigned long long)job.r_c[i]; r = (unsigned long long)job.r_r[i]; sv = (unsigned long long)job.r_s[i]; key = job.r_key[i];
         }
         unsigned long long todo = __ballot(root >= 0);
@@ -390,13 +428,16 @@ __global__ void __launch_bounds__(256) k_resolve(Job job) {
             const unsigned long long group = __ballot(mine);
             todo &= ~group;
             uint32_t gn = mine ? n : 0u;
-            double g_rho = mine ? rho : 0.0, g_rc = mine ? rc : 0.0, g_rr = mine ? rr : 0.0, g_rs = mine ? rs : 0.0;
+            FixSums g_sum = mine ? sum : fix_zero();
             unsigned long long g_c = mine ? c : 0ull, g_r = mine ? r : 0ull, g_s = mine ? sv : 0ull, g_key = mine ? key : ~0ull;
             if (group & (group - 1)) {           // more than one lane: butterfly over the wave (lanes outside the group carry the neutral element)
 #pragma unroll
                 for (int d = 32; d > 0; d >>= 1) {
                     gn += __shfl_xor(gn, d);
-                    g_rho += __shfl_xor(g_rho, d); g_rc += __shfl_xor(g_rc, d); g_rr += __shfl_xor(g_rr, d); g_rs += __shfl_xor(g_rs, d);
+                    g_sum.rho += __shfl_xor(g_sum.rho, d);
+                    g_sum.c_lo += __shfl_xor(g_sum.c_lo, d); g_sum.c_hi += __shfl_xor(g_sum.c_hi, d);
+                    g_sum.r_lo += __shfl_xor(g_sum.r_lo, d); g_sum.r_hi += __shfl_xor(g_sum.r_hi, d);
+                    g_sum.s_lo += __shfl_xor(g_sum.s_lo, d); g_sum.s_hi += __shfl_xor(g_sum.s_hi, d);
                     g_c += __shfl_xor(g_c, d); g_r += __shfl_xor(g_r, d); g_s += __shfl_xor(g_s, d);
                     const unsigned long long k2 = __shfl_xor(g_key, d);
                     g_key = k2 < g_key ? k2 : g_key;
@@ -404,10 +445,7 @@ __global__ void __launch_bounds__(256) k_resolve(Job job) {
             }
             if (lane == first) {
                 atomicAdd(&job.r_n[r0], gn);
-                unsafeAtomicAdd(&job.r_rho[r0], g_rho);
-                unsafeAtomicAdd(&job.r_rho_c[r0], g_rc);
-                unsafeAtomicAdd(&job.r_rho_r[r0], g_rr);
-                unsafeAtomicAdd(&job.r_rho_s[r0], g_rs);
+                fix_atomic_add(&job.r_sum[r0], g_sum);
                 atomicAdd((unsigned long long *)&job.r_c[r0], g_c);
                 atomicAdd((unsigned long long *)&job.r_r[r0], g_r);
                 atomicAdd((unsigned long long *)&job.r_s[r0], g_s);
@@ -574,7 +612,9 @@ __global__ void __launch_bounds__(256) k_emit(Job job, const Geom *__restrict__ 
     const uint32_t total = rank_table_lds(job, s_pre, s_wave);
     const Geom &g = *gp;
     auto emit_root = [&](uint32_t id, uint32_t n_vox, unsigned long long first_key) {
-        const double tot = job.r_rho[id], rc = job.r_rho_c[id], rr = job.r_rho_r[id], rs = job.r_rho_s[id];
+        const FixSums fs = job.r_sum[id];
+        const double tot_q = (double)fs.rho, rc = fix_moment(fs.c_lo, fs.c_hi), rr = fix_moment(fs.r_lo, fs.r_hi), rs = fix_moment(fs.s_lo, fs.s_hi);
+        const double tot = tot_q / job.fix_mul;      // (a power of two: exact)
         const long long ic = job.r_c[id], ir = job.r_r[id], is = job.r_s[id];
         const uint32_t rank = rank_of_key(job, s_pre, first_key);
         const int vi = whole_map ? ((int64_t)first_key >= key_base1 ? 1 : 0) : find_vol_by_key(job.vols, job.n_vols, (int64_t)first_key);
@@ -584,7 +624,7 @@ __global__ void __launch_bounds__(256) k_emit(Job job, const Geom *__restrict__ 
         const VolDesc vd = job.vols[vi];
         job.r_rank[id] = rank;
         const double n = (double)n_vox;
-        double wc[3] = {rc / tot, rr / tot, rs / tot};
+        double wc[3] = {rc / tot_q, rr / tot_q, rs / tot_q};   // (the quantum cancels)
         double cc[3] = {(double)ic / n, (double)ir / n, (double)is / n};
         double xyz[3];
         crs2xyz_frac(g, wc, xyz);
@@ -1083,6 +1123,18 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const float *__restrict
     }
     const double t = block_sum(acc, s_part);
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// max |x| over the map, as the bit pattern of a non-negative float (integer max == float max there; order-free)
+__global__ void __launch_bounds__(256) k_absmax(const float *__restrict__ x, int64_t n, unsigned int *__restrict__ out) {
+    unsigned int m = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned int b = __float_as_uint(x[i]) & 0x7fffffffu;
+        m = (b <= 0x7f800000u && b > m) ? b : m;      // (NaNs are not magnitudes)
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const unsigned int o = (unsigned int)__shfl_down((int)m, off); m = o > m ? o : m; }
+    if (lane_id() == 0 && m) atomicMax(out, m);
 }
 
 // Single block: out[0] = sum(partials) [/ n]  [sqrt].

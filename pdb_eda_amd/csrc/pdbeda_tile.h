@@ -173,7 +173,8 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
     // phase B: the waves' edge lists; phase C: the component accumulators (sums relative to the tile origin)
     __shared__ __attribute__((aligned(16))) unsigned char s_blob[CCAP * 48];
     static_assert(NW * ECAPW * 4 <= CCAP * 48, "the edge lists fit the accumulator block");
-    double *s_rho = reinterpret_cast<double *>(s_blob), *s_rho_c = s_rho + CCAP, *s_rho_r = s_rho + 2 * CCAP, *s_rho_s = s_rho + 3 * CCAP;
+    // (integers: multiples of the job's quantum, see FixSums -- LDS atomics fold them in whatever order, the result is the same)
+    unsigned long long *s_rho = reinterpret_cast<unsigned long long *>(s_blob), *s_rho_c = s_rho + CCAP, *s_rho_r = s_rho + 2 * CCAP, *s_rho_s = s_rho + 3 * CCAP;
     // integer sums of a component, relative to the tile origin, packed so that a run costs two LDS atomics, not four:
     // s_pk = voxels (20 bits) | sum (r - r0) << 20 (20 bits) | sum (s - s0) << 40;  s_crel = sum (c - c_tile)
     unsigned long long *s_pk = reinterpret_cast<unsigned long long *>(s_rho + 4 * CCAP);
@@ -429,7 +430,7 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
     //      runs of its word (unit | sign << 8 | first bit << 9) in the idle upper halves of the parent table, so that C2 can
     //      hand ONE RUN to each thread: a lane-per-word loop issues for the word with the most runs and the longest run ----
     for (uint32_t i = tid; i < (uint32_t)CCAP; i += NT) {
-        s_rho[i] = 0.0; s_rho_c[i] = 0.0; s_rho_r[i] = 0.0; s_rho_s[i] = 0.0;
+        s_rho[i] = 0ull; s_rho_c[i] = 0ull; s_rho_r[i] = 0ull; s_rho_s[i] = 0ull;
         s_pk[i] = 0ull; s_crel[i] = 0u; s_key[i] = 0xffffffffu;
     }
     uint16_t *s_half = reinterpret_cast<uint16_t *>(s_parent);   // [2 i]: parent / ROOT16 | component, [2 i + 1]: descriptor of run i
@@ -474,6 +475,7 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
         uint32_t *face_runs = lj.face_runs ? lj.face_runs + (size_t)blockIdx.x * RCAP : nullptr;
         const int ctile = w0 * 64;
         const uint32_t urus = (uint32_t)ur * (uint32_t)us;
+        const double fix_mul = lj.fix_mul;
         for (uint32_t i = tid; i < n_runs; i += NT) {
             const uint32_t pd = s_parent[i], desc = pd >> 16;
             uint32_t x = pd & 0xffffu;
@@ -500,10 +502,12 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
                 for (int k = 0; k < len; ++k) { S += (double)rowptr[a + k]; T += S; }
             }
             const int p0 = rwl * 64 + a;
-            unsafeAtomicAdd(&s_rho[comp], S);
-            unsafeAtomicAdd(&s_rho_c[comp], (double)p0 * S + ((double)len * S - T));
-            unsafeAtomicAdd(&s_rho_r[comp], (double)rrl * S);
-            unsafeAtomicAdd(&s_rho_s[comp], (double)rsl * S);
+            // the run's sums become integers here (rounded once to the job's quantum); moments relative to the tile origin
+            const long long F = fix_of(S, fix_mul), Fc = fix_of((double)p0 * S + ((double)len * S - T), fix_mul);
+            atomicAdd(&s_rho[comp], (unsigned long long)F);
+            atomicAdd(&s_rho_c[comp], (unsigned long long)Fc);
+            atomicAdd(&s_rho_r[comp], (unsigned long long)(F * rrl));
+            atomicAdd(&s_rho_s[comp], (unsigned long long)(F * rsl));
             // (keys of a plane are below 2^31: the host checks)
             atomicMin(&s_key[comp], ((uint32_t)rq << 31) | ((uint32_t)(ctile + p0) * urus + (uint32_t)(r0 + rrl) * (uint32_t)us + (uint32_t)(s0 + rsl)));
             const uint32_t ulen = (uint32_t)len;
@@ -521,12 +525,8 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
         lj.parent[g] = (int32_t)g;
         const unsigned long long pk = s_pk[i];
         const long long n = (long long)(pk & 0xfffffull);
-        const double rho = s_rho[i];
         lj.r_n[g] = (uint32_t)n;
-        lj.r_rho[g] = rho;
-        lj.r_rho_c[g] = (double)(w0 * 64) * rho + s_rho_c[i];
-        lj.r_rho_r[g] = (double)r0 * rho + s_rho_r[i];
-        lj.r_rho_s[g] = (double)s0 * rho + s_rho_s[i];
+        lj.r_sum[g] = fix_sums((long long)s_rho[i], (long long)s_rho_c[i], (long long)s_rho_r[i], (long long)s_rho_s[i], w0 * 64, r0, s0);
         lj.r_c[g] = (long long)s_crel[i] + n * (w0 * 64);
         lj.r_r[g] = (long long)((pk >> 20) & 0xfffffull) + n * r0;
         lj.r_s[g] = (long long)(pk >> 40) + n * s0;
@@ -915,13 +915,10 @@ constexpr int RSLOTS = 256;   // LDS slots for the distinct roots the members of
 __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
     static_assert(CCAP == 256, "one thread per component id of a tile");
     const int tid = threadIdx.x;
-    auto fold = [&](uint32_t root, uint32_t n, double rho, double rc, double rr, double rs, unsigned long long c, unsigned long long r,
+    auto fold = [&](uint32_t root, uint32_t n, const FixSums &sum, unsigned long long c, unsigned long long r,
                     unsigned long long s, unsigned long long key) {
         atomicAdd(&job.r_n[root], n);
-        unsafeAtomicAdd(&job.r_rho[root], rho);
-        unsafeAtomicAdd(&job.r_rho_c[root], rc);
-        unsafeAtomicAdd(&job.r_rho_r[root], rr);
-        unsafeAtomicAdd(&job.r_rho_s[root], rs);
+        fix_atomic_add(&job.r_sum[root], sum);
         atomicAdd((unsigned long long *)&job.r_c[root], c);
         atomicAdd((unsigned long long *)&job.r_r[root], r);
         atomicAdd((unsigned long long *)&job.r_s[root], s);
@@ -933,24 +930,24 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
             const int root = uf_find(job.parent, (int)i);
             if (root == (int)i) continue;
             job.parent[i] = root;
-            fold((uint32_t)root, job.r_n[i], job.r_rho[i], job.r_rho_c[i], job.r_rho_r[i], job.r_rho_s[i], (unsigned long long)job.r_c[i],
+            fold((uint32_t)root, job.r_n[i], job.r_sum[i], (unsigned long long)job.r_c[i],
                  (unsigned long long)job.r_r[i], (unsigned long long)job.r_s[i], job.r_key[i]);
         }
         return;
     }
     __shared__ int s_root[RSLOTS];
-    __shared__ double s_f[4][RSLOTS];
+    __shared__ FixSums s_f[RSLOTS];
     __shared__ unsigned long long s_i[3][RSLOTS], s_key[RSLOTS];
     __shared__ uint32_t s_cnt[RSLOTS];
     const uint32_t i = (uint32_t)blockIdx.x * CCAP + tid;
     // everything this thread may need, in flight at once (unused ids hold stale bytes: loaded, never used)
     const uint32_t n_i = job.r_n[i];
     const int p0 = uf_load(job.parent, (int)i);
-    const double v_rho = job.r_rho[i], v_rc = job.r_rho_c[i], v_rr = job.r_rho_r[i], v_rs = job.r_rho_s[i];
+    const FixSums v_sum = job.r_sum[i];
     const unsigned long long v_c = (unsigned long long)job.r_c[i], v_r = (unsigned long long)job.r_r[i], v_s = (unsigned long long)job.r_s[i], v_key = job.r_key[i];
     for (int k = tid; k < RSLOTS; k += 256) {
         s_root[k] = -1;
-        s_f[0][k] = 0.0; s_f[1][k] = 0.0; s_f[2][k] = 0.0; s_f[3][k] = 0.0;
+        s_f[k] = fix_zero();
         s_i[0][k] = 0ull; s_i[1][k] = 0ull; s_i[2][k] = 0ull; s_key[k] = ~0ull; s_cnt[k] = 0u;
     }
     int root = -1;
@@ -970,10 +967,7 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
             h = (h + 1u) & (RSLOTS - 1);
         }
         atomicAdd(&s_cnt[h], n_i);
-        unsafeAtomicAdd(&s_f[0][h], v_rho);
-        unsafeAtomicAdd(&s_f[1][h], v_rc);
-        unsafeAtomicAdd(&s_f[2][h], v_rr);
-        unsafeAtomicAdd(&s_f[3][h], v_rs);
+        fix_atomic_add(&s_f[h], v_sum);
         atomicAdd(&s_i[0][h], v_c);
         atomicAdd(&s_i[1][h], v_r);
         atomicAdd(&s_i[2][h], v_s);
@@ -988,11 +982,11 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
         if (pos < (uint32_t)INBOX_CAP) {
             InboxEntry e;
             e.local = root % CCAP; e.n = s_cnt[k];
-            e.rho = s_f[0][k]; e.rho_c = s_f[1][k]; e.rho_r = s_f[2][k]; e.rho_s = s_f[3][k];
+            e.sum = s_f[k];
             e.c = s_i[0][k]; e.r = s_i[1][k]; e.s = s_i[2][k]; e.key = s_key[k];
             job.inbox[(size_t)rtile * INBOX_CAP + pos] = e;
         } else {
-            fold(root, s_cnt[k], s_f[0][k], s_f[1][k], s_f[2][k], s_f[3][k], s_i[0][k], s_i[1][k], s_i[2][k], s_key[k]);
+            fold(root, s_cnt[k], s_f[k], s_i[0][k], s_i[1][k], s_i[2][k], s_key[k]);
         }
     }
 }
@@ -1013,7 +1007,7 @@ __global__ void __launch_bounds__(256) k_paint_tiles(Job job, int n_tiles) {
             if (job.parent[i] == (int32_t)i && job.r_n[i] != 0u) paint(job.r_key[i]);
         return;
     }
-    __shared__ double s_f[4][CCAP];
+    __shared__ FixSums s_f[CCAP];
     __shared__ unsigned long long s_i[3][CCAP], s_key[CCAP];
     __shared__ uint32_t s_cnt[CCAP];
     const uint32_t i = (uint32_t)blockIdx.x * CCAP + tid;
@@ -1031,16 +1025,13 @@ __global__ void __launch_bounds__(256) k_paint_tiles(Job job, int n_tiles) {
         const bool have = (uint32_t)tid < n_in;
         if (have) e = job.inbox[(size_t)blockIdx.x * INBOX_CAP + tid];   // (INBOX_CAP <= 256: one entry per thread; loading all 192
                                                                          //  slots unconditionally to save the dependent trip measured SLOWER)
-        s_f[0][tid] = 0.0; s_f[1][tid] = 0.0; s_f[2][tid] = 0.0; s_f[3][tid] = 0.0;
+        s_f[tid] = fix_zero();
         s_i[0][tid] = 0ull; s_i[1][tid] = 0ull; s_i[2][tid] = 0ull; s_key[tid] = ~0ull; s_cnt[tid] = 0u;
         __syncthreads();
         if (have) {
             const uint32_t l = e.local;
             atomicAdd(&s_cnt[l], e.n);
-            unsafeAtomicAdd(&s_f[0][l], e.rho);
-            unsafeAtomicAdd(&s_f[1][l], e.rho_c);
-            unsafeAtomicAdd(&s_f[2][l], e.rho_r);
-            unsafeAtomicAdd(&s_f[3][l], e.rho_s);
+            fix_atomic_add(&s_f[l], e.sum);
             atomicAdd(&s_i[0][l], e.c);
             atomicAdd(&s_i[1][l], e.r);
             atomicAdd(&s_i[2][l], e.s);
@@ -1049,10 +1040,9 @@ __global__ void __launch_bounds__(256) k_paint_tiles(Job job, int n_tiles) {
         __syncthreads();
         if (root && s_cnt[tid] != 0u) {   // (only roots receive: the posting side found this id as its root)
             job.r_n[i] = n_i + s_cnt[tid];
-            job.r_rho[i] += s_f[0][tid];
-            job.r_rho_c[i] += s_f[1][tid];
-            job.r_rho_r[i] += s_f[2][tid];
-            job.r_rho_s[i] += s_f[3][tid];
+            FixSums mine = job.r_sum[i];
+            fix_add(mine, s_f[tid]);
+            job.r_sum[i] = mine;
             job.r_c[i] += (long long)s_i[0][tid];
             job.r_r[i] += (long long)s_i[1][tid];
             job.r_s[i] += (long long)s_i[2][tid];
