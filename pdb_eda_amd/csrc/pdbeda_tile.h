@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
 
     {
         PDBEDA_LATE_JOB(pj);
-        if (tid == 0) { s_ncomp = 0; pj.inbox_count[(size_t)blockIdx.x * INBOX_STRIDE] = 0u; }
+        if (tid == 0) s_ncomp = 0;
         if (blockIdx.x == 0 && tid == 0) {   // read by the kernels that follow; nothing in this kernel touches them
             pj.vols[0] = init.v[0];
             if (td.n_planes > 1) pj.vols[1] = init.v[1];
@@ -206,16 +206,8 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
             c.n_comps = init.comps0;
             *pj.ctr = c;
         }
-        // every tile clears its slice of the first-key bitmap (saves a memset launch; it is painted two kernels later)
-        const int64_t key_words = pj.key_words;
-        const int64_t per = (key_words + gridDim.x - 1) / gridDim.x;
-        const int64_t lo = per * blockIdx.x, hi = lo + per < key_words ? lo + per : key_words;
-        uint64_t *key_bits = pj.key_bits;
-        for (int64_t i = lo + tid; i < hi; i += NT) key_bits[i] = 0ull;
-        const int64_t nfc = pj.n_fine_alloc / 2;   // ... and of the rank counters (16-bit, two per word)
-        const int64_t perc = (nfc + gridDim.x - 1) / gridDim.x, clo = perc * blockIdx.x, chi = clo + perc < nfc ? clo + perc : nfc;
-        uint32_t *fine_count = pj.fine_count;
-        for (int64_t i = clo + tid; i < chi; i += NT) fine_count[i] = 0u;
+        // (the first-key bitmap, the rank counters and the inbox counters are cleared by k_face_merge: this kernel is bound by
+        //  instruction issue, that one by memory round trips -- its issue slots are free)
     }
     for (int i = tid; i < RCAP; i += NT) s_parent[i] = (uint32_t)i;
 
@@ -311,17 +303,20 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
     const int u = wvs * USEC + (act ? usec : 0);
     uint32_t wbase = 0, n_runs = 0, wprev = 0;
     bool from_global = false;
-    {
-        const uint4 t0 = *reinterpret_cast<const uint4 *>(&s_wtot[0]), t1 = *reinterpret_cast<const uint4 *>(&s_wtot[4]);
-        const uint32_t wt[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-#pragma unroll
-        for (int k = 0; k < NW; ++k) {
-            const uint32_t vw = (uint32_t)__builtin_amdgcn_readfirstlane((int)wt[k]), v = vw & 0x7fffffffu;
-            if (k < wvs) wbase += v;
-            if (k == wvs - 1) wprev = v;
-            n_runs += v;
-            from_global = from_global || (vw >> 31) != 0u;
-        }
+    {   // lanes 0..7 hold the sections' totals: count | overflow << 16 (a tile has < 2^16 word-runs), scanned inside the DPP row
+        const uint32_t raw = lane < NW ? s_wtot[lane] : 0u;
+        const uint32_t v = (raw & 0x7fffffffu) | ((raw >> 31) << 16);
+        uint32_t x = v;
+        x += dpp0<DPP_ROW_SHR + 1>(x);
+        x += dpp0<DPP_ROW_SHR + 2>(x);
+        x += dpp0<DPP_ROW_SHR + 4>(x);
+        const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)x, NW - 1);
+        const uint32_t upto = (uint32_t)__builtin_amdgcn_readlane((int)x, wvs), mine = (uint32_t)__builtin_amdgcn_readlane((int)v, wvs);
+        const uint32_t below = (uint32_t)__builtin_amdgcn_readlane((int)v, wvs > 0 ? wvs - 1 : 0);
+        n_runs = all & 0xffffu;
+        from_global = (all >> 16) != 0u;
+        wbase = (upto - mine) & 0xffffu;
+        wprev = wvs > 0 ? (below & 0xffffu) : 0u;
     }
     const uint64_t m = act ? s_mask[q][u] : 0ull, mo = act ? s_mask[q ^ 1][u] : 0ull;
     // my word
@@ -771,6 +766,18 @@ __global__ void __launch_bounds__(256) k_face_merge(Job job, const float *__rest
     const bool merger = tid < 128;   // waves 0 / 1 merge the face rows of sign 0 / 1; all four waves unite the distinct pairs
     const int ur = td.ur, us = td.us;
     const int tile = (int)blockIdx.x - UNIT_BLOCKS, ct = tile % td.ctiles, rt = (tile / td.ctiles) % td.rtiles, st = tile / (td.ctiles * td.rtiles);
+    {   // every tile clears its slice of the first-key bitmap and of the rank counters (saves a memset launch; painted two kernels
+        // later) and its inbox counter (used by the next kernel)
+        const int n_tiles = (int)gridDim.x - UNIT_BLOCKS;
+        const int64_t key_words = job.key_words;
+        const int64_t per = (key_words + n_tiles - 1) / n_tiles;
+        const int64_t lo = per * tile, hi = lo + per < key_words ? lo + per : key_words;
+        for (int64_t i = lo + tid; i < hi; i += 256) job.key_bits[i] = 0ull;
+        const int64_t nfc = job.n_fine_alloc / 2;   // (16-bit counters, two per word)
+        const int64_t perc = (nfc + n_tiles - 1) / n_tiles, clo = perc * tile, chi = clo + perc < nfc ? clo + perc : nfc;
+        for (int64_t i = clo + tid; i < chi; i += 256) job.fine_count[i] = 0u;
+        if (tid == 0) job.inbox_count[(size_t)tile * INBOX_STRIDE] = 0u;
+    }
     for (int i = tid; i < pair_slots; i += 256) s_set[i] = 0ull;   // 0 = empty: a pair (lo << 32 | hi) has hi > lo >= 0
     __syncthreads();
     const uint32_t slot_mask = (uint32_t)pair_slots - 1u;
