@@ -870,7 +870,8 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.vol_sign[0] = job.vol_sign[1] = 1;
     job.parent = cv.take<int32_t>(max_runs);
     job.r_n = cv.take<uint32_t>(max_runs);
-    job.r_sum = cv.take<FixSums>(max_runs);
+    job.r_sum = cv.take<long long>((size_t)7 * max_runs);
+    job.r_sum_stride = max_runs;
     job.r_c = cv.take<long long>(max_runs);
     job.r_r = cv.take<long long>(max_runs);
     job.r_s = cv.take<long long>(max_runs);

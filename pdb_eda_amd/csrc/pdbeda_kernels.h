@@ -62,6 +62,26 @@ __device__ inline void fix_atomic_add(FixSums *dst, const FixSums &v) {   // (gl
     atomicAdd((unsigned long long *)&dst->s_lo, (unsigned long long)v.s_lo);
     atomicAdd((unsigned long long *)&dst->s_hi, (unsigned long long)v.s_hi);
 }
+template <typename JobRef> __device__ inline FixSums fix_load(const JobRef &job, uint32_t i) {
+    const long long *p = job.r_sum + i;
+    const int64_t s = job.r_sum_stride;
+    FixSums o;
+    o.rho = p[0]; o.c_lo = p[s]; o.c_hi = p[2 * s]; o.r_lo = p[3 * s]; o.r_hi = p[4 * s]; o.s_lo = p[5 * s]; o.s_hi = p[6 * s];
+    return o;
+}
+template <typename JobRef> __device__ inline void fix_store(const JobRef &job, uint32_t i, const FixSums &v) {
+    long long *p = job.r_sum + i;
+    const int64_t s = job.r_sum_stride;
+    p[0] = v.rho; p[s] = v.c_lo; p[2 * s] = v.c_hi; p[3 * s] = v.r_lo; p[4 * s] = v.r_hi; p[5 * s] = v.s_lo; p[6 * s] = v.s_hi;
+}
+template <typename JobRef> __device__ inline void fix_fold(const JobRef &job, uint32_t i, const FixSums &v) {   // atomically, into record i
+    unsigned long long *p = (unsigned long long *)(job.r_sum + i);
+    const int64_t s = job.r_sum_stride;
+    atomicAdd(p, (unsigned long long)v.rho);
+    atomicAdd(p + s, (unsigned long long)v.c_lo); atomicAdd(p + 2 * s, (unsigned long long)v.c_hi);
+    atomicAdd(p + 3 * s, (unsigned long long)v.r_lo); atomicAdd(p + 4 * s, (unsigned long long)v.r_hi);
+    atomicAdd(p + 5 * s, (unsigned long long)v.s_lo); atomicAdd(p + 6 * s, (unsigned long long)v.s_hi);
+}
 __device__ inline FixSums fix_zero() { FixSums z; z.rho = z.c_lo = z.c_hi = z.r_lo = z.r_hi = z.s_lo = z.s_hi = 0; return z; }
 
 struct Counters {
@@ -114,7 +134,11 @@ struct Job {
     // per-component records
     int32_t *parent;
     uint32_t *r_n;
-    FixSums *r_sum;           // sum(rho) and its moments, as order-independent integers
+    // sum(rho) and its moments, as order-independent integers: field k of component i at r_sum[k * r_sum_stride + i] -- seven
+    // arrays, not an array of records: the atomics that fold thousands of tile components into ONE root (a blob that spans the
+    // map) then fall on seven cache lines instead of one, where they would serialise
+    long long *r_sum;
+    int64_t r_sum_stride;
     double fix_mul;           // 2^S of this job's map (see FixSums)
     long long *r_c, *r_r, *r_s;
     unsigned long long *r_key;
@@ -195,7 +219,7 @@ __device__ inline void word_run_records(const Job &job, const Geom &g, const flo
         job.parent[idx] = (int32_t)idx;
         job.r_n[idx] = (uint32_t)len;
         // (the run's two sums are rounded to the job's quantum here, once; everything downstream is integer arithmetic)
-        job.r_sum[idx] = fix_sums(fix_of(s_rho, job.fix_mul), fix_of(s_rl, job.fix_mul), 0, 0, rawc0, rawr, raws);
+        fix_store(job, idx, fix_sums(fix_of(s_rho, job.fix_mul), fix_of(s_rl, job.fix_mul), 0, 0, rawc0, rawr, raws));
         const long long a = (long long)rawc0 + lane;
         job.r_c[idx] = (long long)len * a + (long long)len * (len - 1) / 2;
         job.r_r[idx] = (long long)len * rawr;
@@ -417,7 +441,7 @@ __global__ void __launch_bounds__(256) k_resolve(Job job) {
         FixSums sum = fix_zero();
         unsigned long long c = 0, r = 0, sv = 0, key = ~0ull;
         if (root >= 0) {
-            n = job.r_n[i]; sum = job.r_sum[i];
+            n = job.r_n[i]; sum = fix_load(job, i);
             c = (unsigned long long)job.r_c[i]; r = (unsigned long long)job.r_r[i]; sv = (unsigned long long)job.r_s[i]; key = job.r_key[i];
         }
         unsigned long long todo = __ballot(root >= 0);
@@ -445,7 +469,7 @@ __global__ void __launch_bounds__(256) k_resolve(Job job) {
             }
             if (lane == first) {
                 atomicAdd(&job.r_n[r0], gn);
-                fix_atomic_add(&job.r_sum[r0], g_sum);
+                fix_fold(job, (uint32_t)r0, g_sum);
                 atomicAdd((unsigned long long *)&job.r_c[r0], g_c);
                 atomicAdd((unsigned long long *)&job.r_r[r0], g_r);
                 atomicAdd((unsigned long long *)&job.r_s[r0], g_s);
@@ -612,7 +636,7 @@ __global__ void __launch_bounds__(256) k_emit(Job job, const Geom *__restrict__ 
     const uint32_t total = rank_table_lds(job, s_pre, s_wave);
     const Geom &g = *gp;
     auto emit_root = [&](uint32_t id, uint32_t n_vox, unsigned long long first_key) {
-        const FixSums fs = job.r_sum[id];
+        const FixSums fs = fix_load(job, id);
         const double tot_q = (double)fs.rho, rc = fix_moment(fs.c_lo, fs.c_hi), rr = fix_moment(fs.r_lo, fs.r_hi), rs = fix_moment(fs.s_lo, fs.s_hi);
         const double tot = tot_q / job.fix_mul;      // (a power of two: exact)
         const long long ic = job.r_c[id], ir = job.r_r[id], is = job.r_s[id];

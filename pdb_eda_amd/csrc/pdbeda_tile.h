@@ -521,7 +521,7 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
         const unsigned long long pk = s_pk[i];
         const long long n = (long long)(pk & 0xfffffull);
         lj.r_n[g] = (uint32_t)n;
-        lj.r_sum[g] = fix_sums((long long)s_rho[i], (long long)s_rho_c[i], (long long)s_rho_r[i], (long long)s_rho_s[i], w0 * 64, r0, s0);
+        fix_store(lj, g, fix_sums((long long)s_rho[i], (long long)s_rho_c[i], (long long)s_rho_r[i], (long long)s_rho_s[i], w0 * 64, r0, s0));
         lj.r_c[g] = (long long)s_crel[i] + n * (w0 * 64);
         lj.r_r[g] = (long long)((pk >> 20) & 0xfffffull) + n * r0;
         lj.r_s[g] = (long long)(pk >> 40) + n * s0;
@@ -925,7 +925,7 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
     auto fold = [&](uint32_t root, uint32_t n, const FixSums &sum, unsigned long long c, unsigned long long r,
                     unsigned long long s, unsigned long long key) {
         atomicAdd(&job.r_n[root], n);
-        fix_atomic_add(&job.r_sum[root], sum);
+        fix_fold(job, root, sum);
         atomicAdd((unsigned long long *)&job.r_c[root], c);
         atomicAdd((unsigned long long *)&job.r_r[root], r);
         atomicAdd((unsigned long long *)&job.r_s[root], s);
@@ -937,7 +937,7 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
             const int root = uf_find(job.parent, (int)i);
             if (root == (int)i) continue;
             job.parent[i] = root;
-            fold((uint32_t)root, job.r_n[i], job.r_sum[i], (unsigned long long)job.r_c[i],
+            fold((uint32_t)root, job.r_n[i], fix_load(job, i), (unsigned long long)job.r_c[i],
                  (unsigned long long)job.r_r[i], (unsigned long long)job.r_s[i], job.r_key[i]);
         }
         return;
@@ -950,7 +950,7 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
     // everything this thread may need, in flight at once (unused ids hold stale bytes: loaded, never used)
     const uint32_t n_i = job.r_n[i];
     const int p0 = uf_load(job.parent, (int)i);
-    const FixSums v_sum = job.r_sum[i];
+    const FixSums v_sum = fix_load(job, i);
     const unsigned long long v_c = (unsigned long long)job.r_c[i], v_r = (unsigned long long)job.r_r[i], v_s = (unsigned long long)job.r_s[i], v_key = job.r_key[i];
     for (int k = tid; k < RSLOTS; k += 256) {
         s_root[k] = -1;
@@ -1047,9 +1047,9 @@ __global__ void __launch_bounds__(256) k_paint_tiles(Job job, int n_tiles) {
         __syncthreads();
         if (root && s_cnt[tid] != 0u) {   // (only roots receive: the posting side found this id as its root)
             job.r_n[i] = n_i + s_cnt[tid];
-            FixSums mine = job.r_sum[i];
+            FixSums mine = fix_load(job, i);
             fix_add(mine, s_f[tid]);
-            job.r_sum[i] = mine;
+            fix_store(job, i, mine);
             job.r_c[i] += (long long)s_i[0][tid];
             job.r_r[i] += (long long)s_i[1][tid];
             job.r_s[i] += (long long)s_i[2][tid];
