@@ -368,7 +368,7 @@ extern "C" int pdbeda_ctx_create_on_stream(int device_id, void *hip_stream, pdbe
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDBEDA_ERR_DEVICE; }
         ctx->own_stream = true;
     }
-    if (hipMalloc((void **)&ctx->partials, sizeof(double) * (N_PARTIAL + 8)) != hipSuccess) {
+    if (hipMalloc((void **)&ctx->partials, sizeof(double) * (2 * N_PARTIAL + 8)) != hipSuccess) {
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return PDBEDA_ERR_MEMORY;
@@ -689,20 +689,14 @@ static int reduce_launch(pdbeda_map *m, int mode, const double *mean_dev, double
 static int map_fix_mul(pdbeda_map *m) {
     if (m->fix_mul != 0.0) return 0;
     pdbeda_ctx *ctx = m->ctx;
-    double *res = ctx->partials + N_PARTIAL + 4;
-    unsigned int *mx = reinterpret_cast<unsigned int *>(ctx->partials + N_PARTIAL + 5);
-    HIP_TRY(ctx, hipMemsetAsync(mx, 0, sizeof(unsigned int), ctx->stream));
-    { PROF(ctx, "k_absmax"); hipLaunchKernelGGL(k_absmax, dim3(N_PARTIAL), dim3(256), 0, ctx->stream, m->dens, m->n_vox, mx); }
-    int rc = reduce_launch(m, 2, nullptr, -1.0, 1.0, 0, res);   // sum |x| over every voxel (|x| > -1), fixed reduction order
-    if (rc) return rc;
-    double sum_abs = 0.0;
-    unsigned int max_bits = 0u;
-    HIP_TRY(ctx, d2h(ctx, &sum_abs, res, sizeof(double)));
-    HIP_TRY(ctx, d2h(ctx, &max_bits, mx, sizeof(unsigned int)));
+    double *res = ctx->partials + 2 * N_PARTIAL + 4;
+    { PROF(ctx, "k_range_partials"); hipLaunchKernelGGL(k_range_partials, dim3(N_PARTIAL), dim3(256), 0, ctx->stream, m->dens, m->n_vox, ctx->partials, ctx->partials + N_PARTIAL); }
+    hipLaunchKernelGGL(k_range_final, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, ctx->partials + N_PARTIAL, N_PARTIAL, res);
+    HIP_TRY(ctx, hipGetLastError());
+    double range[2] = {0.0, 0.0};   // sum |x|, max |x|: fixed reduction order, so the quantum is the same in every run
+    HIP_TRY(ctx, d2h(ctx, range, res, 2 * sizeof(double)));
     HIP_TRY(ctx, ctx_sync(ctx));
-    float max_abs;
-    memcpy(&max_abs, &max_bits, sizeof max_abs);
-    const double bound = std::max(sum_abs, 4194304.0 * (double)max_abs);
+    const double bound = std::max(range[0], 4194304.0 * range[1]);
     int S = 40;
     if (bound > 0.0 && std::isfinite(bound)) {
         int e = 0;

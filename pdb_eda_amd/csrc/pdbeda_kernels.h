@@ -1149,16 +1149,40 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const float *__restrict
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 
-// max |x| over the map, as the bit pattern of a non-negative float (integer max == float max there; order-free)
-__global__ void __launch_bounds__(256) k_absmax(const float *__restrict__ x, int64_t n, unsigned int *__restrict__ out) {
-    unsigned int m = 0u;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const unsigned int b = __float_as_uint(x[i]) & 0x7fffffffu;
-        m = (b <= 0x7f800000u && b > m) ? b : m;      // (NaNs are not magnitudes)
+// The range of a map in ONE pass: per block sum |x| (fixed order inside the block) and max |x|; k_range_final folds the
+// blocks' partials in index order.  out[0] = sum |x|, out[1] = max |x| (NaNs are not magnitudes).
+__global__ void __launch_bounds__(256) k_range_partials(const float *__restrict__ x, int64_t n, double *__restrict__ part_sum, double *__restrict__ part_max) {
+    __shared__ double s_part[4];
+    __shared__ float s_max[4];
+    double acc = 0.0;
+    float mx = 0.0f;
+    const int64_t n4 = n >> 2;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    auto take = [&](float v) { const float a = fabsf(v); if (a == a) { acc += (double)a; mx = a > mx ? a : mx; } };
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = x4[i];
+        take(v.x); take(v.y); take(v.z); take(v.w);
     }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) take(x[(n4 << 2) + threadIdx.x]);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const unsigned int o = (unsigned int)__shfl_down((int)m, off); m = o > m ? o : m; }
-    if (lane_id() == 0 && m) atomicMax(out, m);
+    for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_down(mx, off); mx = o > mx ? o : mx; }
+    if (lane_id() == 0) s_max[threadIdx.x >> 6] = mx;
+    const double t = block_sum(acc, s_part);   // (its barrier also publishes s_max)
+    if (threadIdx.x == 0) {
+        part_sum[blockIdx.x] = t;
+        part_max[blockIdx.x] = (double)fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    }
+}
+__global__ void __launch_bounds__(256) k_range_final(const double *__restrict__ part_sum, const double *__restrict__ part_max, int n_part, double *__restrict__ out) {
+    __shared__ double s_part[4];
+    __shared__ double s_max[4];
+    double acc = 0.0, mx = 0.0;
+    for (int i = threadIdx.x; i < n_part; i += blockDim.x) { acc += part_sum[i]; mx = part_max[i] > mx ? part_max[i] : mx; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_down(mx, off); mx = o > mx ? o : mx; }
+    if (lane_id() == 0) s_max[threadIdx.x >> 6] = mx;
+    const double t = block_sum(acc, s_part);
+    if (threadIdx.x == 0) { out[0] = t; out[1] = fmax(fmax(s_max[0], s_max[1]), fmax(s_max[2], s_max[3])); }
 }
 
 // Single block: out[0] = sum(partials) [/ n]  [sqrt].

@@ -47,7 +47,10 @@ note = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over
         "k_reduce_partials (a float4 stream of exactly 65536 KB reports ~32792 KB). WRITE_SIZE is exact for streaming stores.")
 sys.path.insert(0, root)
 import bench as bench_module  # noqa: E402  (csrc_sha16: ties these counters to the kernel sources they were collected on)
+avg = pd.read_csv(stats[0])
+avg["k"] = avg["Name"].str.extract(r"(k_\w+)")
+rocprof_avg = {k: round(float(v) / 1e3, 3) for k, v in avg.dropna(subset=["k"]).groupby("k")["AverageNs"].mean().items()}
 with open(os.path.join(dst, tag + "_pmc_traffic.json"), "w") as fh:
-    json.dump({"note": note, "csrc_sha16": bench_module.csrc_sha16(), "kernels": kern}, fh, indent=1)
+    json.dump({"note": note, "csrc_sha16": bench_module.csrc_sha16(), "kernels": kern, "rocprofv3_avg_us": rocprof_avg}, fh, indent=1)
     fh.write("\n")
 print(json.dumps({"ms_per_step": bench["ms_per_step"], "value": bench["value"], "roofline": bench["roofline"], "kernels_us": bench["kernels_us"]}, indent=1))

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Refresh the measurements kept under profiles/ (run on the GPU box through gpurun, from the repo root):
-#   bash tools/profile_round.sh r02
+#   bash tools/profile_round.sh r03
 # 1. bench.py alone                       -> gpurun_out/prof_<tag>/bench.json
 # 2. rocprofv3 --kernel-trace --stats     -> gpurun_out/prof_<tag>/trace/... (bench.py under the profiler; the informational
 #    legs -- CPU baseline, multi-stream, densityAnalysis -- are switched off so the trace holds only the single-stream steps)
 # 3. rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE in SEPARATE passes over tools/profile_step.py
 # tools/make_profiles.py then condenses 1-3 into profiles/<tag>_*.  (Counter passes never carry --stats/traces.)
 set -e -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
