@@ -10,7 +10,9 @@
  * produced by the reference itself (its Cython cutils + ccp4.py + densityAnalysis.py,
  * imported in the build container by tests/golden/refload.py; fixtures in
  * tests/golden/ *.npz, generator tests/golden/make_golden.py) by
- * tests/test_oracle_golden.py.  The reference's own tests need the network and pin
+ * tests/test_oracle_golden.py; the aggregateCloud composite at the end of this file by
+ * tests/test_oracle_cloud.py (five reference runs of DensityAnalysis, three of them at the
+ * BASELINE sizes: tests/golden/make_golden_analysis.py, make_golden_big.py).  The reference's own tests need the network and pin
  * nothing offline.
  *
  * Every function cites the reference lines (relative to /root/reference/) it
