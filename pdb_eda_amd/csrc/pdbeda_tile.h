@@ -11,14 +11,22 @@
 //      the words of the section below as that wave does (so nobody waits for anybody's ids) and places the parked values
 //   B  26-connected components inside the tile, without a run list and without rounds: the touching pairs between
 //      my word and an earlier neighbour row are the set bits of two bit expressions (a pair is charged to the
-//      later of its two run starts, which makes it unique), and every pair is united on the spot in a lock-free
-//      union-find in LDS (atomic min on the larger root).  Waves do not wait for each other.
-//   -- barrier 2 (all unions done) --  C1 roots take component numbers  -- barrier 3 --
-//   C2 the lane walks the runs of its word: exact fp64 (sum rho, sum rho * c) over the parked values, folded into
-//      the component's accumulators (LDS atomics); run -> component ids are published for the label writer and
-//      the runs (start, end, component) exported for the face merge
+//      later of its two run starts, which makes it unique; pairs with the two diagonal rows of the section below
+//      are dropped where a voxel straight below already implies them).  The lanes of a wave LIST their pairs, then
+//      lane k unites pair k, k + 64, ... in a lock-free union-find in LDS (optimistic atomic min on the larger id;
+//      find splits the path it walks).  Waves do not wait for each other.
+//   -- barrier 2 (all unions done) --
+//   C1 roots take component numbers; every lane describes the runs of its word in the idle upper halves of the
+//      parent table
+//   -- barrier 3 --
+//   C2 a THREAD PER RUN: fp64 (sum rho, sum rho * c) over the run's parked values in order, rounded once to the
+//      job's quantum and folded into the component's accumulators with integer LDS atomics (FixSums: the result
+//      does not depend on the order); run -> component ids are published for the label writer and the runs
+//      (start, end, component) exported for the face merge
 //   -- barrier 4 --  one record per tile component is flushed to HBM.
-// Four barriers on a tile's path (round 2: 24); per-run sums never leave the chip.
+// Four barriers on a tile's path (round 2: 24); per-run sums never leave the chip.  The kernel is bound by
+// instruction issue: a divergent per-lane loop issues for its slowest lane, which is why
+// pairs and runs are handed out one per lane instead of being walked word by word.
 // Only component pairs that touch across a tile face are united globally (k_face_merge, after an LDS
 // de-duplication per tile), and only non-root tile components cost global atomics (k_resolve_tiles, after an
 // LDS pre-reduction per tile).  A tile whose run or component count exceeds the LDS capacity falls
