@@ -852,8 +852,7 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.comps_are_runs = n_tiles ? 0 : 1;
     job.comp_of_run = n_tiles ? cv.take<uint32_t>(max_runs) : nullptr;
     job.label_of_comp = n_tiles ? cv.take<int32_t>(max_runs) : nullptr;
-    job.face_runs = n_tiles ? cv.take<uint32_t>((size_t)n_tiles * RCAP) : nullptr;
-    job.face_rows = n_tiles ? cv.take<uint32_t>((size_t)n_tiles * 128) : nullptr;
+    job.word_comps = n_tiles ? cv.take<uint8_t>((size_t)n_tiles * 2 * 256 * 8) : nullptr;
     job.unit_flag = n_tiles ? cv.take<uint32_t>(1) : nullptr;
     job.tile_mode = n_tiles ? cv.take<uint8_t>(n_tiles) : nullptr;
     job.tile_runs = n_tiles ? cv.take<uint32_t>(n_tiles) : nullptr;
@@ -913,7 +912,11 @@ static void launch_tile_label(pdbeda_ctx *ctx, unsigned n_tiles, const Job &job,
                               const JobInit &init, int pair_slots) {
     { PROF(ctx, "k_tile_label"); hipLaunchKernelGGL((k_tile_label<CW>), dim3(n_tiles), dim3(512), 0, ctx->stream, job, dens, geom_dev, td, init); }
     // cross-tile unions; the first UNIT_BLOCKS workgroups are the fallback for tiles that overflowed LDS (rare: they exit at once)
-    { PROF(ctx, "k_face_merge"); hipLaunchKernelGGL((k_face_merge<CW>), dim3(n_tiles + UNIT_BLOCKS), dim3(256), 0, ctx->stream, job, dens, geom_dev, td, pair_slots); }
+    {   // (grids of one tile column have no c faces: two waves fewer per workgroup to dispatch)
+        PROF(ctx, "k_face_merge");
+        if (td.ctiles > 1) hipLaunchKernelGGL((k_face_merge<CW, FM_THREADS_WIDE>), dim3(n_tiles + UNIT_BLOCKS), dim3(FM_THREADS_WIDE), 0, ctx->stream, job, dens, geom_dev, td, pair_slots);
+        else hipLaunchKernelGGL((k_face_merge<CW, FM_THREADS>), dim3(n_tiles + UNIT_BLOCKS), dim3(FM_THREADS), 0, ctx->stream, job, dens, geom_dev, td, pair_slots);
+    }
 }
 
 static void launch_labels(pdbeda_ctx *ctx, const Job &job, const TileDims &td, int32_t *labels_dev) {

@@ -115,10 +115,9 @@ struct Job {
     int32_t comps_are_runs;
     uint32_t *comp_of_run;
     int32_t *label_of_comp;   // final signed label of every component (whole-map jobs)
-    // tiles export their runs (start | end << 8 | tile component << 16, slot order = row order) and, per sign and row,
-    // first slot | count << 16: k_face_merge unites across tile faces by merging two such lists (grids <= 256 wide)
-    uint32_t *face_runs;               // [tile][RCAP]
-    uint32_t *face_rows;               // [tile][2][64]
+    // per tile, sign and mask word: the tile-local components of the word's first 7 word-runs and of the run at its last bit,
+    // a byte each -- k_face_merge unites across tile faces from the mask words and these records alone (one round trip)
+    uint8_t *word_comps;               // [tile][2][256][8]
     uint32_t *unit_flag;      // == epoch iff some tile of THIS job fell back to unit mode (stale values of a recycled arena never match)
     uint32_t epoch;           // job number of the context (never 0)
     uint8_t *tile_mode;       // per tile: 0 = united in LDS, 1 = unit tile
@@ -328,13 +327,20 @@ __device__ inline void uf_unite2(int32_t *p, int a, int b) {
 
 // Optimistic union for the cross-tile merge, where most elements are still roots: hook the larger id under the smaller with
 // ONE atomic min and no find; if the larger one already had a parent, that parent and the smaller id are what is left to
-// unite (the min keeps parent[x] <= x and never undoes a link).  A chain of atomics only where a chain exists.
+// unite (the min keeps parent[x] <= x and never undoes a link) -- hooked the same way, a trip per level instead of the
+// two or three of a find-then-min.  A long chain (a blob that spans the map) falls back to root-to-root unions after four
+// levels: hooking all the way down measured 4 us faster on noise but 4.6 us slower on a protein-like map (deeper trees
+// for k_resolve_tiles); four levels keep the first and lose nothing on the second (r03, tools/exp/ab.sh).
 __device__ inline void uf_hook(int32_t *p, int a, int b) {
-    if (a == b) return;
-    if (a < b) { const int t = a; a = b; b = t; }
-    const int old = atomicMin(p + a, b);
-    if (old == a || old == b) return;
-    uf_unite2(p, old, b);      // a already hung under `old`: unite the two smaller ids root to root (keeps the trees shallow)
+#pragma unroll
+    for (int level = 0; level < 4; ++level) {
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(p + a, b);
+        if (old == a || old == b) return;
+        a = old;
+    }
+    uf_unite2(p, a, b);
 }
 
 __device__ inline void uf_unite(int32_t *p, int a, int b) {

@@ -42,6 +42,7 @@ constexpr int RCAP = 1408;  // word-runs of a tile (both signs) handled in LDS
 constexpr int CCAP = 256;   // tile-local components (both signs together) handled in LDS
 static_assert(CCAP == TILE_COMPS, "k_emit walks the tiles' component ranges");
 constexpr int VCAP = 3584;  // significant values of a tile parked in LDS: one private region of VCAP / 8 per wave (= section)
+constexpr int FACE_K = 7;    // word-runs of a word whose components k_face_merge finds in the word's byte record (the 8th: by run id)
 constexpr int ECAPW = 384;  // touching run pairs a wave lists before it unites them (the list lives where the component sums go later)
 
 struct TileDims {
@@ -189,7 +190,7 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
     uint32_t *s_crel = reinterpret_cast<uint32_t *>(s_pk + CCAP), *s_key = s_crel + CCAP;   // s_key: plane << 31 | c-major key inside the plane (min = first voxel)
     uint32_t *s_edge = reinterpret_cast<uint32_t *>(s_blob) + wvs_edge_base;
     __shared__ __attribute__((aligned(16))) uint32_t s_wtot[NW];   // word-runs of section w (both signs); bit 31: it could not park all its values
-    __shared__ uint16_t s_vb16[256];   // first parked value of every unit
+    __shared__ uint32_t s_ub[2][256];  // per sign and unit: first parked value of the unit | first word-run of the word << 16
     __shared__ uint32_t s_ncomp;
 
     const int uc = td.uc, ur = td.ur, us = td.us;   // (kernel arguments: no dependent load through gp before the stream can start)
@@ -339,7 +340,6 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
         // is labelled by k_unit_fallback (every run its own component)
         if (my_valid) { lj.mask[my_word] = m; lj.run_base[my_word] = 0u; }
         if (tid == 0) { lj.tile_mode[tile_id] = n_runs ? 1 : 0; lj.tile_runs[blockIdx.x] = 0u; if (n_runs) *lj.unit_flag = lj.epoch; }
-        if (lj.face_rows && tid < 128) lj.face_rows[(size_t)blockIdx.x * 128 + tid] = 0u;   // no run lists: nothing / the unit kernels unite
         mark_comps_unused(lj, (uint32_t)blockIdx.x * CCAP, 0u, tid, NT);
         return;
     }
@@ -448,34 +448,28 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
             todo &= todo - 1;
             ++id;
         }
-        if (act && q == 0) s_vb16[u] = (uint16_t)vb;
+        if (act) s_ub[q][u] = vb | (my_base << 16);
     }
     PDBEDA_LATE_JOB(lj);          // (everything below stores through pointers nothing above needs)
     const uint32_t cb = (uint32_t)blockIdx.x * CCAP, rb = (uint32_t)blockIdx.x * (uint32_t)(NU * 32);
     {   // what the later kernels read per word and per row (run bases are wrong for a tile that turns out to be a unit tile
         // below: that path writes them again)
         if (my_valid) { lj.mask[my_word] = m; lj.run_base[my_word] = rb + my_base; }
-        if (lj.face_rows) {   // per sign and row: first run | count << 16 (the first lane of the row adds up its CW words)
-            uint32_t rc = cnt;
-            if (CW > 1) rc += (uint32_t)__shfl_down((int)cnt, 1);
-            if (CW > 2) rc += (uint32_t)__shfl_down((int)cnt, 2);
-            if (CW > 3) rc += (uint32_t)__shfl_down((int)cnt, 3);
-            if (act && wl == 0) lj.face_rows[((size_t)blockIdx.x * 2 + q) * 64 + wvs * TILE_R + rl] = my_base | (rc << 16);
-        }
     }
     __syncthreads();   // ---- barrier 3 ----
     const uint32_t n_comp = s_ncomp;
     if (n_comp > CCAP) {  // block-uniform: too many components for LDS -> unit tile
         if (my_valid) lj.run_base[my_word] = 0u;
         if (tid == 0) { lj.tile_mode[tile_id] = 3; lj.tile_runs[blockIdx.x] = 0u; *lj.unit_flag = lj.epoch; }
-        if (lj.face_rows && tid < 128) lj.face_rows[(size_t)blockIdx.x * 128 + tid] = 0u;   // mode 3: component table overflowed
         mark_comps_unused(lj, (uint32_t)blockIdx.x * CCAP, 0u, tid, NT);
         return;
     }
     // ---- C2: a thread per run: sums over the parked values, fold into the component ----
     {
         uint32_t *comp_of_run = lj.comp_of_run + rb;
-        uint32_t *face_runs = lj.face_runs ? lj.face_runs + (size_t)blockIdx.x * RCAP : nullptr;
+        // k_face_merge reads, per word, the tile-local components of its first FACE_K word-runs and (byte 7) of the run that
+        // reaches the word's last bit, as the bytes of one 64-bit load
+        uint8_t *word_comps = lj.word_comps + (size_t)blockIdx.x * (2 * 256 * 8);
         const int ctile = w0 * 64;
         const uint32_t urus = (uint32_t)ur * (uint32_t)us;
         const double fix_mul = lj.fix_mul;
@@ -487,12 +481,13 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
             const int ru = (int)(desc & 0xffu), rq = (int)((desc >> 8) & 1u), a = (int)(desc >> 9);
             const int rsl = ru / USEC, rrl = (ru % USEC) / CW, rwl = ru % CW;
             const uint64_t rm = s_mask[rq][ru];
+            const uint32_t ub = s_ub[rq][ru];
             const uint64_t inv = ~(rm >> a);
             const int len = inv ? ctz64(inv) : 64;   // (a run that fills bits a..63: rm >> a has 64 - a ones and zeros above)
             // exact sequential fp64 sums: S = sum v_i, T = sum of the running S = sum (len - i) v_i, so sum i v_i = len S - T
             double S = 0.0, T = 0.0;
             if (!from_global) {
-                const uint32_t off = (uint32_t)s_vb16[ru] + (uint32_t)popc64((rm | s_mask[rq ^ 1][ru]) & bits_below(a));
+                const uint32_t off = (ub & 0xffffu) + (uint32_t)popc64((rm | s_mask[rq ^ 1][ru]) & bits_below(a));
                 int k = 0;
                 for (; k + 2 <= len; k += 2) {   // two parked values in flight
                     const float v0 = s_val[off + k], v1 = s_val[off + k + 1];
@@ -517,7 +512,10 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
             atomicAdd(&s_pk[comp], (unsigned long long)ulen | ((unsigned long long)(ulen * (uint32_t)rrl) << 20) | ((unsigned long long)(ulen * (uint32_t)rsl) << 40));
             atomicAdd(&s_crel[comp], ulen * (uint32_t)p0 + ulen * (ulen - 1u) / 2u);
             comp_of_run[i] = cb + comp;
-            if (face_runs) face_runs[i] = (uint32_t)p0 | ((uint32_t)(p0 + len - 1) << 8) | (comp << 16);
+            const uint32_t kw = i - (ub >> 16);   // my place among the word-runs of my word
+            uint8_t *rec = word_comps + ((desc & 0x1ffu) << 3);
+            if (kw < (uint32_t)FACE_K) rec[kw] = (uint8_t)comp;
+            if (a + len == 64) rec[7] = (uint8_t)comp;
         }
         if (tid == 0) lj.tile_mode[tile_id] = 0;
     }
@@ -585,7 +583,7 @@ __device__ void unit_quarter_tile(const Job &job, const float *__restrict__ dens
         }
         __syncthreads();
         if (my_valid) job.run_base[my_word] = s_rb + s_off[tid];
-        for (int j = wv; j < QU; j += 4) {   // a wave per unit: 4 units in flight per workgroup
+        for (int j = wv; j < QU; j += (int)(blockDim.x >> 6)) {   // a wave per unit
             const uint64_t mw = s_m[j];
             if (mw == 0ull) continue;
             const int uu = quarter * QU + j;
@@ -704,23 +702,32 @@ __device__ inline void cross_tile_pairs(uint64_t m, uint32_t my_base, const NbWo
     }
 }
 
-// Cross-tile unions from the tiles' exported run lists: one thread per
-// (tile, sign, row on a tile face, earlier neighbour row in ANOTHER tile) -- 46 such pairs of rows per tile -- merges
-// the two sorted run lists (a dozen two-pointer steps on LDS copies); the distinct COMPONENT pairs of the tile go into an
-// LDS hash set (the runs of a blob cross a face row after row: ~350 touching run pairs per tile are ~110 distinct component
-// pairs), and the set's slots are then united in the global union-find, about one pair per thread -- no pair buffer in
-// HBM, no second launch.  Replaces a word-by-word enumeration of 13 neighbour masks per word: ~10x fewer instructions, no
-// run -> component look-ups afterwards.  Lists of unit / empty tiles are empty (the unit path unites those pairs).  Grids
-// wider than one tile add the c faces: first run of a row against the last runs of the 9 rows around it in the tile to the left.
+// Cross-tile unions, one workgroup per tile and ONE round trip to memory before the pairs are known.  A tile meets
+// earlier tiles across its r / s faces in 46 pairs of rows (a row on a face, an earlier neighbour row in ANOTHER tile of the
+// same c column); a lane owns one mask word of such a pair of rows and loads, all at once, the word of either row, the two
+// words' component records (k_tile_label: the tile-local components of a word's first FACE_K word-runs, a byte each) and the
+// two tile modes.  The touching word-runs then come out of bit arithmetic (as inside k_tile_label): with S = the word-local
+// run starts, every touching pair shows once, at the later of its two starts --
+//     EA = SA & (B | B << 1 | carry B)      EB = SB & (A << 1 | carry A)
+// and at a set bit p both runs are "the last start <= p" of their row: popc(S & bits up to p) numbers them inside the word,
+// count 0 = the run that ends the previous word of the row (one shuffle brings its component).  No run lists, no merge
+// loop: the two-pointer merge of two exported run lists that this replaces spent 7.6 us walking them and 4.2 us loading
+// them behind a first trip for their offsets (r03 stamps: 20.4 us per workgroup, now the trip, ~1 us of arithmetic and the
+// unions).  The distinct COMPONENT pairs of the tile go into an LDS hash set (the runs of a blob cross a face row after row:
+// ~350 touching run pairs per tile are ~110 distinct component pairs), and the set's slots are then united in the global
+// union-find, about one pair per thread -- no pair buffer in HBM, no second launch.  Pairs with a unit tile on either side
+// belong to the unit path (skipped here by the tile modes).  Grids wider than one tile add the c faces (waves 6 / 7): the
+// run at position 0 of a row against the runs that end the 9 rows around it in the tile to the left.
 //
 // The first `n_unit_blocks` workgroups of the launch are the unit-tile fallback (tiles that overflowed LDS in
 // k_tile_label): normally no tile did and they exit on the epoch flag at once -- the rare path costs no launch of its own.
 // Otherwise they label the unit tiles run by run, meet at a grid barrier of their own (they are the first workgroups
 // dispatched and few enough to be co-resident many times over, so concurrent streams cannot starve each other), then
 // unite every pair that has a unit tile on either side.
-constexpr int FACE_L = 16;       // runs of a row copied to LDS (longer rows read the rest from global memory)
 constexpr int PAIR_SLOTS = 1024; // LDS hash set of a tile's distinct cross-face component pairs (a full set unites on the spot)
 constexpr int UNIT_BLOCKS = 128; // workgroups of the unit-tile fallback
+constexpr int FM_THREADS = 384, FM_THREADS_WIDE = 512;  // 2 signs x 46 pairs of rows x 4 word slots = 368 lanes; grids wider than a tile: 128 more for the c faces
+constexpr int FACE_PAIRS = 46;
 
 // One mask word of the unit-tile companion of k_face_merge: it owns EVERY pair that has a unit tile on either side
 // (all rows), and unites on the spot.
@@ -761,32 +768,51 @@ __device__ void unit_fallback_blocks(const Job &job, const float *__restrict__ d
     }
 }
 
-template <int CW>
-__global__ void __launch_bounds__(256) k_face_merge(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td, int pair_slots) {
+template <int CW, int NTH>
+__global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td, int pair_slots) {
     if ((int)blockIdx.x < UNIT_BLOCKS) {   // block-uniform
         if (*job.unit_flag != job.epoch) return;
         unit_fallback_blocks<CW>(job, dens, gp, td, (int)blockIdx.x, UNIT_BLOCKS);
         return;
     }
-    __shared__ __attribute__((aligned(16))) uint32_t s_list[2][FACE_L][128];
-    __shared__ unsigned long long s_set[PAIR_SLOTS];
-    const int tid = threadIdx.x, lane = tid & 63, q = (tid >> 6) & 1, t = lane;
-    const bool merger = tid < 128;   // waves 0 / 1 merge the face rows of sign 0 / 1; all four waves unite the distinct pairs
-    const int ur = td.ur, us = td.us;
+    static_assert(FACE_K == 7, "a word's component record is one 64-bit load: seven runs and the run at the last bit");
+    __shared__ unsigned long long s_set[PAIR_SLOTS], s_pairs[PAIR_SLOTS];
+    __shared__ uint32_t s_wsum[NTH / 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int ur = td.ur, us = td.us, row_words = td.row_words;
     const int tile = (int)blockIdx.x - UNIT_BLOCKS, ct = tile % td.ctiles, rt = (tile / td.ctiles) % td.rtiles, st = tile / (td.ctiles * td.rtiles);
-    {   // every tile clears its slice of the first-key bitmap and of the rank counters (saves a memset launch; painted two kernels
-        // later) and its inbox counter (used by the next kernel)
-        const int n_tiles = (int)gridDim.x - UNIT_BLOCKS;
-        const int64_t key_words = job.key_words;
-        const int64_t per = (key_words + n_tiles - 1) / n_tiles;
-        const int64_t lo = per * tile, hi = lo + per < key_words ? lo + per : key_words;
-        for (int64_t i = lo + tid; i < hi; i += 256) job.key_bits[i] = 0ull;
-        const int64_t nfc = job.n_fine_alloc / 2;   // (16-bit counters, two per word)
-        const int64_t perc = (nfc + n_tiles - 1) / n_tiles, clo = perc * tile, chi = clo + perc < nfc ? clo + perc : nfc;
-        for (int64_t i = clo + tid; i < chi; i += 256) job.fine_count[i] = 0u;
-        if (tid == 0) job.inbox_count[(size_t)tile * INBOX_STRIDE] = 0u;
+    const int w0 = ct * CW;
+    const int64_t plane_words = (int64_t)row_words * ur * us;
+    const unsigned long long *comps64 = reinterpret_cast<const unsigned long long *>(job.word_comps);
+    auto word_at = [&](int q, int r, int s, int wq) { return (int64_t)q * plane_words + ((int64_t)s * ur + r) * row_words + wq; };
+    auto comps_at = [&](uint32_t tl, int q, int r, int s, int wl) { return ((size_t)tl * 2 + q) * 256 + ((s & 7) * TILE_R + (r & 7)) * CW + wl; };
+    // component of word-run k of mask word w by its run id (words with more than FACE_K runs: two dependent loads, rare)
+    auto comp_by_run = [&](int64_t w, uint32_t k) { return job.comp_of_run[job.run_base[w] + k]; };
+
+    // ---- the one trip: everything a lane needs, issued before anything waits ----
+    // r / s faces: lanes 0 .. 367 = sign x pair of rows x word slot
+    const int fq = tid / (FACE_PAIRS * 4), frem = tid % (FACE_PAIRS * 4), ft = frem >> 2, fwl = frem & 3;
+    int rl = 0, sl = 0, dr = 0, ds = -1;
+    bool task = tid < 2 * FACE_PAIRS * 4 && fq < td.n_planes && fwl < CW && w0 + fwl < row_words;
+    if (ft < 8) { rl = 0; sl = ft; dr = -1; ds = 0; }
+    else if (ft < 16) { rl = 0; sl = ft - 8; dr = -1; }
+    else if (ft < 23) { rl = ft - 15; sl = 0; dr = -1; }
+    else if (ft < 31) { rl = ft - 23; sl = 0; dr = 0; }
+    else if (ft < 39) { rl = ft - 31; sl = 0; dr = 1; }
+    else { rl = 7; sl = ft - 38; dr = 1; }
+    const int r = rt * TILE_R + rl, s = st * TILE_S + sl, r2 = r + dr, s2 = s + ds;
+    if (r >= ur || s >= us || r2 < 0 || r2 >= ur || s2 < 0) task = false;
+    const uint32_t tile_b = task ? (uint32_t)(((s2 >> 3) * td.rtiles + (r2 >> 3)) * td.ctiles + ct) : 0u;   // the r / s faces join tiles of one c column
+    const int64_t wA = task ? word_at(fq, r, s, w0 + fwl) : 0, wB = task ? word_at(fq, r2, s2, w0 + fwl) : 0;
+    uint64_t mA = 0ull, mB = 0ull;
+    unsigned long long cA = 0ull, cB = 0ull;
+    uint32_t modes = 0u;
+    if (task) {
+        mA = job.mask[wA]; mB = job.mask[wB];
+        cA = comps64[comps_at((uint32_t)tile, fq, r, s, fwl)]; cB = comps64[comps_at(tile_b, fq, r2, s2, fwl)];
+        modes = (uint32_t)job.tile_mode[tile] | (uint32_t)job.tile_mode[tile_b];
     }
-    for (int i = tid; i < pair_slots; i += 256) s_set[i] = 0ull;   // 0 = empty: a pair (lo << 32 | hi) has hi > lo >= 0
+    for (int i = tid; i < pair_slots; i += NTH) s_set[i] = 0ull;   // 0 = empty: a pair (lo << 32 | hi) has hi > lo >= 0
     __syncthreads();
     const uint32_t slot_mask = (uint32_t)pair_slots - 1u;
     auto add_pair = [&](uint32_t ca, uint32_t cb) {
@@ -799,100 +825,79 @@ __global__ void __launch_bounds__(256) k_face_merge(Job job, const float *__rest
         }
         uf_hook(job.parent, (int)lo, (int)hi);   // the neighbourhood of the slot is full: unite on the spot
     };
-    int rl = 0, sl = 0, dr = 0, ds = -1;
-    bool task = merger && q < td.n_planes;
-    if (t < 8) { rl = 0; sl = t; dr = -1; ds = 0; }
-    else if (t < 16) { rl = 0; sl = t - 8; dr = -1; }
-    else if (t < 23) { rl = t - 15; sl = 0; dr = -1; }
-    else if (t < 31) { rl = t - 23; sl = 0; dr = 0; }
-    else if (t < 39) { rl = t - 31; sl = 0; dr = 1; }
-    else if (t < 46) { rl = 7; sl = t - 38; dr = 1; }
-    else task = false;
-    const int r = rt * TILE_R + rl, s = st * TILE_S + sl, r2 = r + dr, s2 = s + ds;
-    if (r >= ur || s >= us || r2 < 0 || r2 >= ur || s2 < 0) task = false;
-    uint32_t fa = 0, na = 0, fb = 0, nb = 0, tile_b = 0;
-    if (task) {
-        tile_b = (uint32_t)(((s2 >> 3) * td.rtiles + (r2 >> 3)) * td.ctiles + ct);   // the r / s faces join tiles of one c column
-        const uint32_t ra = job.face_rows[((size_t)tile * 2 + q) * 64 + sl * TILE_R + rl];
-        const uint32_t rb = job.face_rows[((size_t)tile_b * 2 + q) * 64 + (s2 & 7) * TILE_R + (r2 & 7)];
-        fa = ra & 0xffffu; na = ra >> 16; fb = rb & 0xffffu; nb = rb >> 16;
-        if (na == 0 || nb == 0) task = false;
-    }
-    const uint32_t *ga = job.face_runs + (size_t)tile * RCAP + fa, *gb = job.face_runs + (size_t)tile_b * RCAP + fb;
-    const int col = tid & 127;
-    if (task) {
-#pragma unroll
-        for (int k = 0; k < FACE_L; ++k) {
-            s_list[0][k][col] = (uint32_t)k < na ? ga[k] : 0u;
-            s_list[1][k][col] = (uint32_t)k < nb ? gb[k] : 0u;
+    {   // ---- r / s faces ----
+        if (modes != 0u) { mA = 0ull; mB = 0ull; }   // a unit tile on either side: the unit path owns the pair
+        const uint64_t SA = mA & ~(mA << 1), SB = mB & ~(mB << 1);   // word-local run starts
+        // what the next word of the row needs of me: do my rows end set, and the components of the runs that end them
+        const uint32_t pack = (uint32_t)(mA >> 63) | ((uint32_t)(mB >> 63) << 1) | ((uint32_t)(cA >> 56) << 8) | ((uint32_t)(cB >> 56) << 16);
+        uint32_t prev = (uint32_t)__shfl_up((int)pack, 1);   // (the four word slots of a pair of rows are four lanes of one wave)
+        if (fwl == 0) prev = 0u;
+        const uint64_t carA = prev & 1u, carB = (prev >> 1) & 1u;
+        uint64_t todo = (SA & (mB | (mB << 1) | carB)) | (SB & ((mA << 1) | carA));
+        const uint32_t baseA = (uint32_t)tile * CCAP, baseB = tile_b * CCAP;
+        uint32_t last_a = ~0u, last_b = ~0u;
+        while (todo) {
+            const int p = ctz64(todo);
+            todo &= todo - 1ull;
+            const uint64_t upto = (2ull << p) - 1ull;   // (p = 63: all ones)
+            const uint32_t ka = (uint32_t)popc64(SA & upto), kb = (uint32_t)popc64(SB & upto);
+            uint32_t ca, cb;
+            if (ka == 0u) ca = baseA + ((prev >> 8) & 0xffu);   // the run that ends the previous word
+            else ca = ka <= (uint32_t)FACE_K ? baseA + (uint32_t)((cA >> ((ka - 1u) * 8u)) & 0xffull) : comp_by_run(wA, ka - 1u);
+            if (kb == 0u) cb = baseB + ((prev >> 16) & 0xffu);
+            else cb = kb <= (uint32_t)FACE_K ? baseB + (uint32_t)((cB >> ((kb - 1u) * 8u)) & 0xffull) : comp_by_run(wB, kb - 1u);
+            if (ca != last_a || cb != last_b) {   // the runs of a blob cross a face in a row: repeats are the rule
+                add_pair(ca, cb);
+                last_a = ca; last_b = cb;
+            }
         }
     }
-    if (task) {   // (only own LDS entries are read back: no barrier)
-        auto ea = [&](uint32_t i) { return i < (uint32_t)FACE_L ? s_list[0][i][col] : ga[i]; };
-        auto eb = [&](uint32_t j) { return j < (uint32_t)FACE_L ? s_list[1][j][col] : gb[j]; };
-        uint32_t i = 0, j = 0, va = ea(0), vb = eb(0), last_a = ~0u, last_b = ~0u;
-        while (true) {
-            const int as = va & 0xff, ae = (va >> 8) & 0xff, bs = vb & 0xff, be = (vb >> 8) & 0xff;
-            bool adv_a;
-            if (be + 1 < as) adv_a = false;
-            else if (ae + 1 < bs) adv_a = true;
-            else {
-                const uint32_t ca = (uint32_t)tile * CCAP + (va >> 16), cb = tile_b * CCAP + (vb >> 16);
-                if (ca != last_a || cb != last_b) {   // the runs of a blob cross a face in a row: repeats are the rule
-                    add_pair(ca, cb);
-                    last_a = ca; last_b = cb;
-                }
-                adv_a = ae < be;
-            }
-            if (adv_a) { if (++i == na) break; va = ea(i); }
-            else { if (++j == nb) break; vb = eb(j); }
+    // ---- c faces (grids wider than one tile), lanes 384 .. 511 = sign x row: row `lane` of this tile may start with a run at
+    // position 0; the rows around it (9 offsets, itself included) in the tile to the LEFT may end with a run at that tile's
+    // last position -- they touch.  (Loaded after the barrier: the registers of the r / s lanes are free by now, and these
+    // waves have nothing else to wait for.)
+    const int cq = (tid - 384) >> 6, crl = lane & 7, csl = lane >> 3;
+    const int cr = rt * TILE_R + crl, cs = st * TILE_S + csl;
+    const bool ctask = NTH > 384 && tid >= 384 && ct > 0 && cq < td.n_planes && cr < ur && cs < us;
+    const uint32_t *mask32 = reinterpret_cast<const uint32_t *>(job.mask);
+    uint32_t m0 = 0u, c0 = 0u, cmodes = 0u, hi9[9], c9[9], mode9[9];   // low half of my word, high halves of theirs; record bytes 0 / 7
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { hi9[k] = 0u; c9[k] = 0u; mode9[k] = 0u; }
+    auto tile9 = [&](int k) { return (uint32_t)((((cs + k / 3 - 1) >> 3) * td.rtiles + ((cr + k % 3 - 1) >> 3)) * td.ctiles + ct - 1); };
+    if (ctask) {
+        m0 = mask32[2 * word_at(cq, cr, cs, w0)];
+        c0 = job.word_comps[comps_at((uint32_t)tile, cq, cr, cs, 0) * 8];
+        cmodes = job.tile_mode[tile];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int r9 = cr + k % 3 - 1, s9 = cs + k / 3 - 1;
+            if (r9 < 0 || r9 >= ur || s9 < 0 || s9 >= us) continue;
+            hi9[k] = mask32[2 * word_at(cq, r9, s9, w0 - 1) + 1];
+            c9[k] = job.word_comps[comps_at(tile9(k), cq, r9, s9, CW - 1) * 8 + 7];
+            mode9[k] = job.tile_mode[tile9(k)];
         }
     }
-    // c faces (grids wider than one tile): row `lane` of this tile starts with a run at position 0; the rows around it
-    // (9 offsets, itself included) in the tile to the LEFT may end with a run at that tile's last position -- they touch.
-    if (merger && ct > 0 && q < td.n_planes) {
-        const int crl = lane & 7, csl = lane >> 3;
-        const int cr = rt * TILE_R + crl, cs = st * TILE_S + csl;
-        const uint32_t mine = (cr < ur && cs < us) ? job.face_rows[((size_t)tile * 2 + q) * 64 + lane] : 0u;
-        if ((mine >> 16) != 0u) {
-            const uint32_t first = job.face_runs[(size_t)tile * RCAP + (mine & 0xffffu)];
-            if ((first & 0xffu) == 0u) {
-                const uint32_t ca = (uint32_t)tile * CCAP + (first >> 16);
-                uint32_t rows9[9], tiles9[9];
+    if (ctask && (m0 & 1u) && cmodes == 0u) {
+        const uint32_t ca = (uint32_t)tile * CCAP + c0;   // (a run at position 0 is the first of its word)
+        uint32_t last_b = ~0u;
 #pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const int r9 = cr + k % 3 - 1, s9 = cs + k / 3 - 1;
-                    const bool ok = r9 >= 0 && r9 < ur && s9 >= 0 && s9 < us;
-                    tiles9[k] = ok ? (uint32_t)(((s9 >> 3) * td.rtiles + (r9 >> 3)) * td.ctiles + ct - 1) : 0u;
-                    rows9[k] = ok ? job.face_rows[((size_t)tiles9[k] * 2 + q) * 64 + (s9 & 7) * TILE_R + (r9 & 7)] : 0u;
-                }
-                uint32_t last9[9];
-#pragma unroll
-                for (int k = 0; k < 9; ++k)
-                    last9[k] = (rows9[k] >> 16) ? job.face_runs[(size_t)tiles9[k] * RCAP + (rows9[k] & 0xffffu) + (rows9[k] >> 16) - 1u] : 0u;
-                uint32_t last_b = ~0u;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    if ((rows9[k] >> 16) != 0u && ((last9[k] >> 8) & 0xffu) == (uint32_t)(td.cw * 64 - 1)) {
-                        const uint32_t cb = tiles9[k] * CCAP + (last9[k] >> 16);
-                        if (cb != last_b) { add_pair(ca, cb); last_b = cb; }
-                    }
-                }
-            }
+        for (int k = 0; k < 9; ++k) {
+            if (!(hi9[k] >> 31) || mode9[k] != 0u) continue;   // (a unit tile: the unit path unites)
+            const uint32_t cb = tile9(k) * CCAP + c9[k];
+            if (cb != last_b) { add_pair(ca, cb); last_b = cb; }
         }
     }
     __syncthreads();
-    // the distinct pairs of this tile: compacted (block prefix over the slots) so that thread k unites pair k, k + 256, ... --
+    // the distinct pairs of this tile: compacted (block prefix over the slots) so that thread k unites pair k, k + 512, ... --
     // a union is a chain of dependent memory round trips, and nobody should walk two chains while others walk none
     // (parents start as the identity, so most unions are two parallel loads and one atomic min)
-    __shared__ uint32_t s_wsum[4];
-    unsigned long long *s_pairs = reinterpret_cast<unsigned long long *>(&s_list[0][0][0]);   // (the run lists are done: 16 KiB = 2048 pairs)
     {
-        const int per = pair_slots / 256 > 0 ? pair_slots / 256 : 1;   // consecutive slots per thread (pair_slots is a power of two)
-        unsigned long long mine[PAIR_SLOTS / 256];
+        constexpr int MAXPER = (PAIR_SLOTS + NTH - 1) / NTH;
+        const int per = (pair_slots + NTH - 1) / NTH;   // consecutive slots per thread
+        unsigned long long mine[MAXPER];
         uint32_t cnt = 0;
 #pragma unroll
-        for (int k = 0; k < PAIR_SLOTS / 256; ++k) {
+        for (int k = 0; k < MAXPER; ++k) {
             const int slot = tid * per + k;
             mine[k] = (k < per && slot < pair_slots) ? s_set[slot] : 0ull;
             cnt += mine[k] != 0ull ? 1u : 0u;
@@ -904,18 +909,33 @@ __global__ void __launch_bounds__(256) k_face_merge(Job job, const float *__rest
             if (lane >= d) x += y;
         }
         if (lane == 63) s_wsum[tid >> 6] = x;
-        __syncthreads();   // (also: every thread is done with s_list)
+        __syncthreads();
         uint32_t at = x - cnt;
         for (int k = 0; k < (tid >> 6); ++k) at += s_wsum[k];
 #pragma unroll
-        for (int k = 0; k < PAIR_SLOTS / 256; ++k)
+        for (int k = 0; k < MAXPER; ++k)
             if (mine[k] != 0ull) s_pairs[at++] = mine[k];
         __syncthreads();
     }
-    const uint32_t n_pairs = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-    for (uint32_t k = tid; k < n_pairs; k += 256) {
+    uint32_t n_pairs = 0;
+#pragma unroll
+    for (int k = 0; k < NTH / 64; ++k) n_pairs += s_wsum[k];
+    for (uint32_t k = tid; k < n_pairs; k += NTH) {
         const unsigned long long key = s_pairs[k];
         uf_hook(job.parent, (int)(key >> 32), (int)(uint32_t)key);
+    }
+    {   // every tile clears its slice of the first-key bitmap and of the rank counters (saves a memset launch; painted two kernels
+        // later) and its inbox counter (used by the next kernel) -- here, behind the last barrier: a barrier waits for the stores
+        // before it to be acknowledged (2 us), the unions below do not
+        const int n_tiles = (int)gridDim.x - UNIT_BLOCKS;
+        const int64_t key_words = job.key_words;
+        const int64_t per = (key_words + n_tiles - 1) / n_tiles;
+        const int64_t lo = per * tile, hi = lo + per < key_words ? lo + per : key_words;
+        for (int64_t i = lo + tid; i < hi; i += NTH) job.key_bits[i] = 0ull;
+        const int64_t nfc = job.n_fine_alloc / 2;   // (16-bit counters, two per word)
+        const int64_t perc = (nfc + n_tiles - 1) / n_tiles, clo = perc * tile, chi = clo + perc < nfc ? clo + perc : nfc;
+        for (int64_t i = clo + tid; i < chi; i += NTH) job.fine_count[i] = 0u;
+        if (tid == 0) job.inbox_count[(size_t)tile * INBOX_STRIDE] = 0u;
     }
 }
 

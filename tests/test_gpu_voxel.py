@@ -289,6 +289,35 @@ def test_empty_full_and_degenerate(gpu_ctx):
     assert np.array_equal(bl.stats()["n"], want["n"])
 
 
+def test_face_words_with_many_runs(gpu_ctx):
+    """Tile faces crossed by words of more runs than their component record holds (7 + the run at the last bit): the
+    cross-tile merge looks those up by run id.  Combs (every other voxel) against solid / shifted combs / other signs, across
+    the r, s and c faces and their diagonals, in tiles that still fit LDS."""
+    from oracle import oracle as ora
+    g = np.zeros((24, 24, 600), dtype=np.float32)          # [s][r][c]: 3 x 3 x 3 tiles (256 x 8 x 8)
+    comb = np.zeros(64, dtype=np.float32); comb[::2] = 1.0
+    g[3, 7, 64:128] = comb;  g[3, 8, 64:128] = 1.0          # r face: 32 runs under one solid run
+    g[5, 15, 0:64] = 1.0;    g[5, 16, 0:64] = comb          # r face, comb on the later side, word 0
+    g[7, 2, 128:192] = comb; g[8, 3, 129:193] = comb        # s face, diagonal in r, combs shifted by one: a zigzag
+    g[15, 20, 192:256] = comb; g[16, 20, 192:256] = np.roll(comb, 1)   # s face: comb ends at bit 254 / shifted comb at 255
+    g[16, 21, 256:300] = 1.0                                # ... and the c face behind the shifted comb's last voxel
+    g[10, 12, 449:512:2] = -1.0; g[10, 13, 512:520] = -1.0  # c face of the second tile column, other sign, diagonal in r
+    g[11, 12, 448:512] = -comb;  g[11, 11, 512] = -1.0
+    g[20, 7, 300:364] = comb; g[20, 7, 364:420] = 0.0; g[20, 8, 301:365:2] = 1.0   # comb against comb shifted across two words
+    dm = _dm(g, gpu_ctx)
+    o = ora.Oracle(dm.header, g)
+    green, red = dm._map.full_blobs_pm(0.5, -0.5, labels=True)
+    for bl, c in ((green, 0.5), (red, -0.5)):
+        want = o.full_blobs(c, labels=True)
+        st = bl.stats()
+        assert np.array_equal(st["n"], want["n"])
+        assert np.array_equal(st["firstKey"], want["firstKey"])
+        assert np.array_equal(bl.labels(dm._map.unique_shape), want["labels"])
+        assert np.allclose(st["totalDensity"], want["totalDensity"], rtol=REL)
+        c = bl.counters()
+        assert c["unit_tiles_runs"] == 0 and c["unit_tiles_comps"] == 0   # (the LDS path and its face records, not the fallback)
+
+
 @pytest.mark.parametrize("shape,seed,nsd", [((128, 128, 128), 5, 1.5), ((96, 100, 200), 6, 3.0), ((61, 67, 130), 8, 1.0),
                                             ((40, 48, 256), 9, 0.3),     # dense: most tiles overflow LDS -> unit-tile fallback
                                             ((24, 40, 600), 10, 0.8)])   # rows wider than one tile (c tiles) + dense
