@@ -1102,10 +1102,14 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS) k_labels_tiles(Job j
     constexpr int NU = 64 * CW;
     constexpr int NTL = PDBEDA_LABELS_NT_THREADS, RPW = 64 / (NTL / 64);   // rows of the tile per wave
     __shared__ int32_t s_lab[CCAP];
-    __shared__ uint8_t s_comp8[LCAP];
-    __shared__ uint64_t s_m[2][256];
-    __shared__ uint32_t s_rb[2][256];
+    __shared__ uint8_t s_comp8[LCAP + 4];
+    // per 32-bit half of a mask word (a lane's 4 voxels live in one half): the mask halves of both signs side by side, and
+    // per sign the half's run starts beside the tile-local id of the run before its first start -- what a lane needs of a
+    // word, as two 8-byte reads, with nothing left to compute per row that does not depend on the lane's own bits
+    __shared__ uint2 s_mh[2 * 256];
+    __shared__ uint2 s_sb[2][2 * 256];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wvs = __builtin_amdgcn_readfirstlane(wv);
     const int uc = td.uc, ur = td.ur, us = td.us, row_words = td.row_words;
     int t = blockIdx.x;
     const int ct = t % td.ctiles; t /= td.ctiles;
@@ -1134,11 +1138,22 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS) k_labels_tiles(Job j
         const bool valid = tid < NU && r < ur && s < us && w0 + wl < row_words;
         const int64_t w = ((int64_t)s * ur + r) * row_words + (w0 + wl);
         if (tid < 256) {
+            uint64_t m[2];
+            uint32_t base[2];
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const bool has = valid && p < td.n_planes;
-                s_m[p][tid] = has ? job.mask[w + p * plane_words] : 0ull;
-                s_rb[p][tid] = has ? job.run_base[w + p * plane_words] : 0u;
+                m[p] = has ? job.mask[w + p * plane_words] : 0ull;
+                base[p] = has ? job.run_base[w + p * plane_words] : 0u;
+            }
+            s_mh[2 * tid] = make_uint2((uint32_t)m[0], (uint32_t)m[1]);
+            s_mh[2 * tid + 1] = make_uint2((uint32_t)(m[0] >> 32), (uint32_t)(m[1] >> 32));
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const uint64_t starts = run_starts(m[p]);
+                const uint32_t slo = (uint32_t)starts, shi = (uint32_t)(starts >> 32), before = base[p] - rb - 1u;
+                s_sb[p][2 * tid] = make_uint2(slo, before);
+                s_sb[p][2 * tid + 1] = make_uint2(shi, before + (uint32_t)__popc(slo));
             }
         }
         if (tid < CCAP) s_lab[tid] = own_list(lab_pre);
@@ -1148,50 +1163,70 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS) k_labels_tiles(Job j
             for (uint32_t i = tid + 4 * NTL; i < n_runs; i += NTL) s_comp8[i] = (uint8_t)(job.comp_of_run[rb + i] - cb);
     }
     __syncthreads();
-    // wave wv writes RPW rows of the tile; a lane owns 4 consecutive voxels of a 256-voxel row (16 waves per tile: the
-    // per-row bit arithmetic is a dependent chain, and small maps leave one workgroup per CU to hide it)
-    for (int rr = 0; rr < RPW; ++rr) {
-        const int rowl = wv * RPW + rr;
-        const int r = r0 + (rowl & 7), s = s0 + (rowl >> 3);
-        if (r >= ur || s >= us) continue;   // wave-uniform
-        const int wl = lane >> 4, bit0 = (lane & 15) * 4;
-        const int c = (w0 + wl) * 64 + bit0;
-        if (wl >= CW || c >= uc) continue;
-        const int u = rowl * CW + wl;
-        int32_t out[4] = {0, 0, 0, 0};
-        const int sh = bit0 & 31;
+    // wave wv writes RPW rows of the tile; a lane owns 4 consecutive voxels of a 256-voxel row.  A voxel carries one sign, and
+    // nearly every 4-voxel group one sign or none: the lane works on the plane that has voxels in its group (a second pass,
+    // taken only by a wave that has a group with both signs, adds the other), and a group of four holds at most two runs --
+    // two table look-ups, not one per voxel.  The kernel is bound by the instructions it issues (8 waves a SIMD, ~0.7 us a
+    // row), not by its 64 MiB of stores: storing only the groups that hold a label into a volume zeroed under k_tile_label
+    // changed nothing (r03), so the row loop is written for instruction count -- tables per half word (above), the in-LDS and
+    // inside-the-grid cases compiled apart.
+    const int hsel = lane >> 3, sh = (lane & 7) * 4;   // which half word of the row; where my 4 bits sit in it
+    const uint32_t lowm = (1u << sh) - 1u;
+    const int c = w0 * 64 + lane * 4;
+    const bool inside = (r0 + TILE_R <= ur) && (s0 + TILE_S <= us) && ((w0 + CW) * 64 <= uc) && (uc & 3) == 0;   // block-uniform
+    auto rows = [&](auto fast_tag, auto inside_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value, INSIDE = decltype(inside_tag)::value;
+        auto group = [&](int p, unsigned nib, int hidx, int32_t (&o)[4]) {
+            const uint2 sb = s_sb[p][hidx];
+            const unsigned snib = (sb.x >> sh) & 0xfu;
+            const unsigned upto_first = (2u << __builtin_ctz(nib)) - 1u;     // the group's bits up to its first voxel
+            const uint32_t run = sb.y + (uint32_t)__popc(sb.x & lowm) + (uint32_t)__popc(snib & upto_first);   // (tile-local; a voxel that continues a run: the last start before it)
+            const unsigned s2 = snib & ~upto_first;                          // a second run starts inside the group
+            const unsigned from2 = 0u - (s2 & (0u - s2));                    // all bits from that start on (0 without one)
+            const unsigned abits = nib & ~from2, bbits = nib & from2;
+            int32_t la, lb;
+            if (FAST) { la = s_lab[s_comp8[run]]; lb = s_lab[s_comp8[run + 1u]]; }   // (lb: read, used only behind s2 -- the table has LCAP + 4 bytes)
+            else {
+                la = own_list(job.label_of_comp[job.parent[job.comp_of_run[run + rb]]]);
+                lb = s2 ? own_list(job.label_of_comp[job.parent[job.comp_of_run[run + rb + 1u]]]) : 0;
+            }
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const uint64_t m = s_m[p][u];
-            const uint32_t half = bit0 >= 32 ? (uint32_t)(m >> 32) : (uint32_t)m;   // my 4 voxels live in one 32-bit half
-            const unsigned nib = (half >> sh) & 0xfu;
-            if (!nib) continue;
-            const uint64_t starts = run_starts(m);
-            const uint32_t base = s_rb[p][u];
-            // starts below my nibble (32-bit halves), then the nibble's own starts bit by bit
-            const uint32_t slo = (uint32_t)starts, shi = (uint32_t)(starts >> 32);
-            const uint32_t below = bit0 >= 32 ? (uint32_t)__popc(slo) + (uint32_t)__popc(shi & ((1u << sh) - 1u)) : (uint32_t)__popc(slo & ((1u << sh) - 1u));
-            const unsigned snib = ((bit0 >= 32 ? shi : slo) >> sh) & 0xfu;
+            for (int k = 0; k < 4; ++k)
+                o[k] |= (__builtin_amdgcn_sbfe((int)abits, k, 1) & la) | (__builtin_amdgcn_sbfe((int)bbits, k, 1) & lb);
+        };
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if ((nib >> q) & 1u) {
-                    const uint32_t run = base + below + (uint32_t)__popc(snib & ((2u << q) - 1u)) - 1u;
-                    out[q] = fast ? s_lab[s_comp8[run - rb]] : own_list(job.label_of_comp[job.parent[job.comp_of_run[run]]]);
-                }
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int rowl = wvs * RPW + rr;
+            const int r = r0 + (rowl & 7), s = s0 + (rowl >> 3);
+            if (!INSIDE && (r >= ur || s >= us)) continue;   // wave-uniform
+            if (hsel >= 2 * CW || (!INSIDE && c >= uc)) continue;
+            const int hidx = rowl * (2 * CW) + hsel;
+            const uint2 mh = s_mh[hidx];
+            const unsigned nib0 = (mh.x >> sh) & 0xfu, nib1 = (mh.y >> sh) & 0xfu;
+            int32_t out[4] = {0, 0, 0, 0};
+            {
+                const bool second = nib0 == 0u;
+                const unsigned nib = second ? nib1 : nib0;
+                if (nib) group(second ? 1 : 0, nib, hidx, out);
+            }
+            if (__ballot(nib0 != 0u && nib1 != 0u)) {   // wave-uniform, rare
+                if (nib0 != 0u && nib1 != 0u) group(1, nib1, hidx, out);
+            }
+            int32_t *dst = labels + ((int64_t)s * ur + r) * uc + c;
+            if (INSIDE || (c + 3 < uc && ((uc & 3) == 0))) {
+                // streaming store: the labels are not read again by this job, and keeping them out of L2 measured 2.4 us faster
+                typedef int v4i __attribute__((ext_vector_type(4)));
+                const v4i o4 = {out[0], out[1], out[2], out[3]};
+                __builtin_nontemporal_store(o4, reinterpret_cast<v4i *>(dst));
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (c + q < uc) dst[q] = out[q];
             }
         }
-        int32_t *dst = labels + ((int64_t)s * ur + r) * uc + c;
-        if (c + 3 < uc && ((uc & 3) == 0)) {
-            // streaming store: the labels are not read again by this job, and keeping them out of L2 measured 2.4 us faster
-            typedef int v4i __attribute__((ext_vector_type(4)));
-            const v4i o4 = {out[0], out[1], out[2], out[3]};
-            __builtin_nontemporal_store(o4, reinterpret_cast<v4i *>(dst));
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (c + q < uc) dst[q] = out[q];
-        }
-    }
+    };
+    if (fast) { if (inside) rows(std::true_type{}, std::true_type{}); else rows(std::true_type{}, std::false_type{}); }
+    else { if (inside) rows(std::false_type{}, std::true_type{}); else rows(std::false_type{}, std::false_type{}); }
 }
 
 // Decode the signed volume for one list: -1 background / other sign, else 0-based blob index.
