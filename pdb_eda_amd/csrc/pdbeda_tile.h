@@ -21,8 +21,8 @@
 //   -- barrier 3 --
 //   C2 a THREAD PER RUN: fp64 (sum rho, sum rho * c) over the run's parked values in order, rounded once to the
 //      job's quantum and folded into the component's accumulators with integer LDS atomics (FixSums: the result
-//      does not depend on the order); run -> component ids are published for the label writer and the runs
-//      (start, end, component) exported for the face merge
+//      does not depend on the order); run -> component ids are published for the label writer, and per mask word
+//      the components of its first 7 runs and of the run at its last bit, a byte each, for the face merge
 //   -- barrier 4 --  one record per tile component is flushed to HBM.
 // Four barriers on a tile's path (round 2: 24); per-run sums never leave the chip.  The kernel is bound by
 // instruction issue: a divergent per-lane loop issues for its slowest lane, which is why
