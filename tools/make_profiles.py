@@ -15,10 +15,12 @@ def last_json_line(path):
     return json.loads(lines[-1])
 
 
-bench = last_json_line(os.path.join(src, "bench.json"))
-with open(os.path.join(dst, tag + "_bench.json"), "w") as fh:
-    json.dump(bench, fh)
-    fh.write("\n")
+bench = None
+if os.path.exists(os.path.join(src, "bench.json")):   # (profile_round.sh calls this once before bench.py has run: the counters first)
+    bench = last_json_line(os.path.join(src, "bench.json"))
+    with open(os.path.join(dst, tag + "_bench.json"), "w") as fh:
+        json.dump(bench, fh)
+        fh.write("\n")
 under = last_json_line(os.path.join(src, "bench_under_rocprof.json"))
 with open(os.path.join(dst, tag + "_bench_under_rocprof.json"), "w") as fh:
     json.dump(under, fh)
@@ -53,4 +55,5 @@ rocprof_avg = {k: round(float(v) / 1e3, 3) for k, v in avg.dropna(subset=["k"]).
 with open(os.path.join(dst, tag + "_pmc_traffic.json"), "w") as fh:
     json.dump({"note": note, "csrc_sha16": bench_module.csrc_sha16(), "kernels": kern, "rocprofv3_avg_us": rocprof_avg}, fh, indent=1)
     fh.write("\n")
-print(json.dumps({"ms_per_step": bench["ms_per_step"], "value": bench["value"], "roofline": bench["roofline"], "kernels_us": bench["kernels_us"]}, indent=1))
+if bench is not None:
+    print(json.dumps({"ms_per_step": bench["ms_per_step"], "value": bench["value"], "roofline": bench["roofline"], "kernels_us": bench["kernels_us"]}, indent=1))
