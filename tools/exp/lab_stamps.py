@@ -12,15 +12,11 @@ if sys.argv[1] == "build":
         global t
         assert t.count(old) == 1, old
         t = t.replace(old, new)
-    once("    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;\n    const int uc = td.uc, ur = td.ur, us = td.us, row_words = td.row_words;\n    int t = blockIdx.x;",
-         "    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;\n    " + ST % (0, 0) + "\n    const int uc = td.uc, ur = td.ur, us = td.us, row_words = td.row_words;\n    int t = blockIdx.x;")
+    once("    const int wvs = __builtin_amdgcn_readfirstlane(wv);\n    const int uc = td.uc, ur = td.ur, us = td.us, row_words = td.row_words;\n    int t = blockIdx.x;",
+         "    const int wvs = __builtin_amdgcn_readfirstlane(wv);\n    " + ST % (0, 0) + "\n    const int uc = td.uc, ur = td.ur, us = td.us, row_words = td.row_words;\n    int t = blockIdx.x;")
     once("    __syncthreads();\n    // wave wv writes RPW rows of the tile;", "    " + ST % (0, 1) + "\n    __syncthreads();\n    " + ST % (0, 2) + "\n    // wave wv writes RPW rows of the tile;")
-    a = t.index("__global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS) k_labels_tiles")
-    b = t.index("// Decode the signed volume for one list")
-    body = t[a:b]
-    end = body.rindex("    }\n}")
-    body = body[:end] + "    }\n    " + ST % (0, 3) + "\n    " + ST % (448, 4) + "\n}" + body[end + len("    }\n}"):]
-    t = t[:a] + body + t[b:]
+    once("    else { if (inside) rows(std::false_type{}, std::true_type{}); else rows(std::false_type{}, std::false_type{}); }\n}",
+         "    else { if (inside) rows(std::false_type{}, std::true_type{}); else rows(std::false_type{}, std::false_type{}); }\n    " + ST % (0, 3) + "\n    " + ST % (448, 4) + "\n}")
     open(os.path.join(dst, "pdbeda_tile.h"), "w").write(t)
     k = open(os.path.join(dst, "pdbeda_kernels.h")).read()
     k = k.replace("    uint64_t *root_mask;", "    unsigned long long *stamps;\n    uint64_t *root_mask;", 1)
