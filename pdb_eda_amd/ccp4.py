@@ -21,11 +21,15 @@ from . import _native
 __all__ = ["read", "parse", "read_grid", "DensityHeader", "DensityMatrix", "DensityBlob"]
 
 
-def read(ccp4Filename, pdbid=None, verbose=False, ctx=None):
+def read(ccp4Filename, pdbid=None, verbose=False, ctx=None, lazy=False):
     """``ccp4.read`` (ref ccp4.py:58-74); ``ctx``: the context (= stream) the map becomes resident on.
 
-    An uncompressed mode-2 file goes from the page cache to HBM through the library's pinned double buffer
-    (``pdbeda_map_upload_file``): only the header is parsed here, and ``DensityMatrix.density`` is fetched back on demand."""
+    An uncompressed mode-2 file goes from the page cache to HBM through the library's pinned ring
+    (``pdbeda_map_upload_file``): only the header is parsed here, and ``DensityMatrix.density`` is fetched back on demand.
+    ``lazy``: the header is read and the file's size checked now, the grid goes to HBM when something first asks for it
+    (``DensityMatrix.resident`` tells) -- the Fo-Fc map of an entry whose analysis never looks at difference density (every
+    record of ``pdb_eda multiple``, multipleStructures.py:320-356, reads its header only) then costs 1 KiB instead of a 32 MB
+    upload.  A file that needs the parser (other modes, odd sizes) is read at once either way."""
     if not pdbid:
         pdbid = ccp4Filename
     with open(ccp4Filename, "rb") as fileHandle:
@@ -41,8 +45,12 @@ def read(ccp4Filename, pdbid=None, verbose=False, ctx=None):
         header.symmetry = fileHandle.read(header.symmetryBytes)
     ctx = ctx if ctx is not None else _native.default_context()
     swapped = header.endian != ("<" if sys.byteorder == "little" else ">")
-    device_map = _native.DeviceMap.from_file(ctx, ccp4Filename, 1024 + header.symmetryBytes, swapped, header.geometry())
-    return DensityMatrix.fromDeviceMap(header, header.origin, device_map, pdbid, ctx)
+    offset, geometry = 1024 + header.symmetryBytes, header.geometry()
+    if lazy:
+        dm = DensityMatrix.fromDeviceMap(header, header.origin, None, pdbid, ctx)
+        dm._map_loader = lambda: _native.DeviceMap.from_file(ctx, ccp4Filename, offset, swapped, geometry)
+        return dm
+    return DensityMatrix.fromDeviceMap(header, header.origin, _native.DeviceMap.from_file(ctx, ccp4Filename, offset, swapped, geometry), pdbid, ctx)
 
 
 def read_grid(handle):
@@ -239,6 +247,41 @@ class DensityMatrix(object):
         self._meanDensity = None
         self._stdDensity = None
         self._totalAbsDensity = {}
+
+    # the resident map: made on first use when the file was read lazily (``ccp4.read(..., lazy=True)``)
+    @property
+    def _map(self):
+        device_map = self.__dict__.get("_map_obj")
+        if device_map is None:
+            loader = self.__dict__.get("_map_loader")
+            if loader is None:
+                raise AttributeError("_map")
+            device_map = self.__dict__["_map_obj"] = loader()
+            self.__dict__["_map_loader"] = None
+        return device_map
+
+    @_map.setter
+    def _map(self, value):
+        self.__dict__["_map_obj"] = value
+
+    @property
+    def resident(self):
+        """Whether the grid is in HBM already (False: a lazily read file nobody has asked for yet)."""
+        return self.__dict__.get("_map_obj") is not None
+
+    # ref densityAnalysis.py:148 sets ``diffDensityCutoff = meanDensity + 3 * stdDensity`` when the Fo-Fc map is loaded; here
+    # the attribute computes itself on first use unless somebody assigned it (the value is the same; a lazily read map is
+    # not brought in just to have it)
+    @property
+    def diffDensityCutoff(self):
+        value = self.__dict__.get("_diffDensityCutoff")
+        if value is None:
+            value = self.__dict__["_diffDensityCutoff"] = self.meanDensity + 3 * self.stdDensity
+        return value
+
+    @diffDensityCutoff.setter
+    def diffDensityCutoff(self, value):
+        self.__dict__["_diffDensityCutoff"] = value
 
     @property
     def density(self):

@@ -48,9 +48,12 @@ struct pdbeda_ctx {
     size_t pinned_cap = 0, pinned_used = 0;
     struct Pending { void *dst; size_t off, bytes; };
     std::vector<Pending> pending;
-    // file -> device uploads (pdbeda_map_upload_file): two pinned chunks filled by pread() while the other one is in flight
-    char *ring[2] = {nullptr, nullptr};
-    hipEvent_t ring_done[2] = {nullptr, nullptr};
+    // file -> device uploads (pdbeda_map_upload_file): pinned chunks filled by pread() while others are in flight
+    static constexpr int RING = 4;
+    char *ring[RING] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ring_done[RING] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t ring_stream = nullptr;   // the second reader's copies: two streams keep the link busy across the gap between two copies of one
+    hipEvent_t ring_joined = nullptr;
     int live_handles = 0;
     // optional per-kernel timing with HIP events on ctx->stream (bench.py's roofline leg)
     bool profiling = false;
@@ -92,7 +95,9 @@ static void ctx_release_device(pdbeda_ctx *ctx, bool lent_too) {
     }
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-    for (int k = 0; k < 2; ++k) {
+    if (ctx->ring_stream) (void)hipStreamDestroy(ctx->ring_stream);
+    if (ctx->ring_joined) (void)hipEventDestroy(ctx->ring_joined);
+    for (int k = 0; k < pdbeda_ctx::RING; ++k) {
         if (ctx->ring[k]) (void)hipHostFree(ctx->ring[k]);
         if (ctx->ring_done[k]) (void)hipEventDestroy(ctx->ring_done[k]);
     }
@@ -547,10 +552,14 @@ static hipError_t event_wait(pdbeda_ctx *ctx, hipEvent_t ev) {
     }
 }
 
-// The grid of a CCP4 file straight into HBM: pread() fills one pinned chunk while the previous one is on its way over PCIe,
-// so an entry costs max(page-cache copy, DMA) instead of read + copy to a staging buffer + DMA, and no host copy of the map
-// is ever made (ccp4.py:77-127 unpacks it into a Python tuple).  byteswap: the file has the other endianness.
+// The grid of a CCP4 file straight into HBM: pread() fills pinned chunks while earlier ones are on their way over PCIe, and
+// no host copy of the map is ever made (ccp4.py:77-127 unpacks it into a Python tuple).  TWO readers (the caller and a helper
+// thread, two chunks each): one thread copies out of the page cache at 29-36 GB/s, the link takes 54 -- a 32 MB map arrived in
+// 0.9-1.1 ms with one reader, and four worker processes together reached 39 GB/s (`tools/exp/file_h2d.py`; a pageable copy
+// out of an mmap of the file runs at link speed only while its pages stay mapped -- a fresh mapping per file pays 0.6 ms of
+// page faults per 32 MB before the first byte moves).  byteswap: the file has the other endianness.
 static const size_t FILE_CHUNK = (size_t)4 << 20;
+static const int FILE_READERS = 2;
 extern "C" int pdbeda_map_upload_file(pdbeda_ctx *ctx, const char *path, int64_t offset, int byteswap, const pdbeda_geometry *geom, pdbeda_map **out) {
     if (!ctx || !path || !geom || !out || offset < 0) return PDBEDA_ERR_ARGUMENT;
     *out = nullptr;
@@ -565,11 +574,14 @@ extern "C" int pdbeda_map_upload_file(pdbeda_ctx *ctx, const char *path, int64_t
         close(fd);
         return fail(ctx, PDBEDA_ERR_ARGUMENT, "%s holds fewer than %lld grid bytes after offset %lld", path, (long long)need, (long long)offset);
     }
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < pdbeda_ctx::RING; ++k) {
         if (!ctx->ring[k] && hipHostMalloc((void **)&ctx->ring[k], FILE_CHUNK, hipHostMallocDefault) != hipSuccess) { ctx->ring[k] = nullptr; (void)hipGetLastError(); }
         if (!ctx->ring_done[k] && hipEventCreateWithFlags(&ctx->ring_done[k], hipEventDisableTiming) != hipSuccess) { ctx->ring_done[k] = nullptr; (void)hipGetLastError(); }
         if (!ctx->ring[k] || !ctx->ring_done[k]) { close(fd); return fail(ctx, PDBEDA_ERR_MEMORY, "no pinned chunk for the file upload"); }
     }
+    if (!ctx->ring_stream && hipStreamCreateWithFlags(&ctx->ring_stream, hipStreamNonBlocking) != hipSuccess) { ctx->ring_stream = nullptr; (void)hipGetLastError(); }
+    if (!ctx->ring_joined && hipEventCreateWithFlags(&ctx->ring_joined, hipEventDisableTiming) != hipSuccess) { ctx->ring_joined = nullptr; (void)hipGetLastError(); }
+    if (!ctx->ring_stream || !ctx->ring_joined) { close(fd); return fail(ctx, PDBEDA_ERR_MEMORY, "no second stream for the file upload"); }
     pdbeda_map *m = new pdbeda_map();
     m->ctx = ctx;
     int rc = fill_geom(ctx, geom, &m->geom);
@@ -583,21 +595,61 @@ extern "C" int pdbeda_map_upload_file(pdbeda_ctx *ctx, const char *path, int64_t
     m->own_dens = true;
     hipError_t e = hipMemcpyAsync(m->geom_dev, &m->geom, sizeof(Geom), hipMemcpyHostToDevice, ctx->stream);
     const char *why = nullptr;
-    int64_t chunk_no = 0;
-    for (size_t pos = 0; pos < need && e == hipSuccess && !why; pos += FILE_CHUNK, ++chunk_no) {
-        const int b = (int)(chunk_no & 1);
-        if (chunk_no >= 2) e = event_wait(ctx, ctx->ring_done[b]);        // the chunk sent from this buffer two rounds ago has left it
-        if (e != hipSuccess) break;
-        const size_t len = std::min(FILE_CHUNK, need - pos);
-        for (size_t got = 0; got < len;) {
-            const ssize_t r = pread(fd, ctx->ring[b] + got, len - got, (off_t)(offset + (int64_t)pos + (int64_t)got));
-            if (r < 0 && errno == EINTR) continue;
-            if (r <= 0) { why = r < 0 ? strerror(errno) : "unexpected end of file"; break; }
-            got += (size_t)r;
+    {
+        // reader t takes chunks t, t + READERS, ... through its own ring slots (t, t + READERS): nothing is shared but the
+        // stream, and the order in which the chunks' copies are queued does not matter (disjoint destinations)
+        static_assert(pdbeda_ctx::RING == 2 * FILE_READERS, "two ring slots per reader");
+        const int64_t n_chunks = (int64_t)((need + FILE_CHUNK - 1) / FILE_CHUNK);
+        const double timeout_s = ctx->timeout_s;
+        const auto deadline = ctx->deadline;
+        struct ReaderResult { hipError_t e = hipSuccess; const char *why = nullptr; bool timed_out = false; };
+        auto reader = [&](int t, ReaderResult *res) {
+            if (t != 0 && hipSetDevice(ctx->device) != hipSuccess) { res->e = hipGetLastError(); return; }
+            const hipStream_t my_stream = t == 0 ? ctx->stream : ctx->ring_stream;
+            int64_t mine = 0;
+            for (int64_t c = t; c < n_chunks; c += FILE_READERS, ++mine) {
+                const int slot = t + FILE_READERS * (int)(mine & 1);
+                if (mine >= 2) {   // the chunk sent from this slot two rounds ago must have left it
+                    for (unsigned spins = 0;; ++spins) {
+                        const hipError_t q = hipEventQuery(ctx->ring_done[slot]);
+                        if (q == hipSuccess) break;
+                        if (q != hipErrorNotReady) { res->e = q; return; }
+                        if (spins > 256) {
+                            if (timeout_s > 0.0 && std::chrono::steady_clock::now() > deadline) { res->timed_out = true; return; }   // (the entry's one deadline, as ctx_wait)
+                            std::this_thread::sleep_for(std::chrono::microseconds(20));
+                        }
+                    }
+                }
+                const size_t pos = (size_t)c * FILE_CHUNK, len = std::min(FILE_CHUNK, need - pos);
+                for (size_t got = 0; got < len;) {
+                    const ssize_t r = pread(fd, ctx->ring[slot] + got, len - got, (off_t)(offset + (int64_t)pos + (int64_t)got));
+                    if (r < 0 && errno == EINTR) continue;
+                    if (r <= 0) { res->why = r < 0 ? strerror(errno) : "unexpected end of file"; return; }
+                    got += (size_t)r;
+                }
+                hipError_t ce = hipMemcpyAsync((char *)d + pos, ctx->ring[slot], len, hipMemcpyHostToDevice, my_stream);
+                if (ce == hipSuccess) ce = hipEventRecord(ctx->ring_done[slot], my_stream);
+                if (ce != hipSuccess) { res->e = ce; return; }
+            }
+        };
+        ReaderResult rr[FILE_READERS];
+        if (e == hipSuccess && !ctx->timed_out) {
+            std::thread helper;
+            if (n_chunks > 1) helper = std::thread(reader, 1, &rr[1]);
+            reader(0, &rr[0]);
+            if (helper.joinable()) helper.join();
+            // the context's stream waits for the helper's copies: everything behind this call is ordered after the whole map
+            if (hipEventRecord(ctx->ring_joined, ctx->ring_stream) != hipSuccess || hipStreamWaitEvent(ctx->stream, ctx->ring_joined, 0) != hipSuccess) e = hipGetLastError();
+            for (int t = 0; t < FILE_READERS; ++t) {
+                if (rr[t].e != hipSuccess && e == hipSuccess) e = rr[t].e;
+                if (rr[t].why && !why) why = rr[t].why;
+                if (rr[t].timed_out) {
+                    ctx->timed_out = true;
+                    ctx->err = "watchdog: the stream did not drain within the per-entry time-out; context abandoned";
+                    if (e == hipSuccess) e = hipErrorNotReady;
+                }
+            }
         }
-        if (why) break;
-        e = hipMemcpyAsync((char *)d + pos, ctx->ring[b], len, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipEventRecord(ctx->ring_done[b], ctx->stream);
     }
     close(fd);
     if (e == hipSuccess && !why && byteswap) {

@@ -106,8 +106,9 @@ def _attachCutoffs(densityObj, diffDensityObj):
     if densityObj is not None:
         densityObj.densityCutoff = densityObj.meanDensity + 1.5 * densityObj.stdDensity
         densityObj.densityCutoffFromHeader = densityObj.header.densityMean + 1.5 * densityObj.header.rmsd
-    if diffDensityObj is not None:
+    if diffDensityObj is not None and getattr(diffDensityObj, "resident", True):
         diffDensityObj.diffDensityCutoff = diffDensityObj.meanDensity + 3 * diffDensityObj.stdDensity
+    # (a lazily read Fo-Fc map computes the same value when it is first asked for: ccp4.DensityMatrix.diffDensityCutoff)
 
 
 def residueAtomName(atom):

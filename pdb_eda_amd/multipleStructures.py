@@ -54,19 +54,28 @@ def _drop(pdbid, reason, failures, silent):
     return 0
 
 
-def loadMap(source, pdbid, ctx=None):
-    """A resident DensityMatrix from what an entry loader hands over: CCP4 bytes, or the path of a CCP4 file."""
+def loadMap(source, pdbid, ctx=None, lazy=False):
+    """A DensityMatrix from what an entry loader hands over: CCP4 bytes, or the path of a CCP4 file (``lazy``: resident on
+    first use, see ``ccp4.read``)."""
     if isinstance(source, (str, os.PathLike)):
-        return ccp4.read(os.fspath(source), pdbid, ctx=ctx)
+        return ccp4.read(os.fspath(source), pdbid, ctx=ctx, lazy=lazy)
     return ccp4.parse(io.BytesIO(source), pdbid, ctx=ctx)
 
 
+def lazyDiffMap():
+    """The record of ``pdb_eda multiple`` reads the Fo-Fc map's HEADER (``diff_density_mean``) and nothing of its grid, so the
+    grid of an entry's Fo-Fc file is uploaded only if something asks for it.  PDBEDA_EAGER_DIFF_MAP=1 brings it in with the
+    2Fo-Fc map as the reference's loader does (densityAnalysis.py:145-148) -- bench.py times both."""
+    return os.environ.get("PDBEDA_EAGER_DIFF_MAP", "0") in ("", "0")
+
+
 def loadEntry(entry, ctx=None):
-    """The first half of an entry: its loader, both maps resident on ``ctx`` (file or bytes -> HBM), mean / std and the default
-    cutoffs.  Returns (densityObj, diffDensityObj, biopdbObj, pdbObj); raises what the loader / parser raise."""
+    """The first half of an entry: its loader, the 2Fo-Fc map resident on ``ctx`` (file or bytes -> HBM) with mean / std and the
+    default cutoff, the Fo-Fc map's header read and its grid ready to follow (``lazyDiffMap``).  Returns (densityObj,
+    diffDensityObj, biopdbObj, pdbObj); raises what the loader / parser raise."""
     dens, diff, biopdbObj, pdbObj = entry.loader()
     densityObj = loadMap(dens, entry.pdbid, ctx)
-    diffDensityObj = loadMap(diff, entry.pdbid, ctx)
+    diffDensityObj = loadMap(diff, entry.pdbid, ctx, lazy=lazyDiffMap())
     densityAnalysis._attachCutoffs(densityObj, diffDensityObj)
     return densityObj, diffDensityObj, biopdbObj, pdbObj
 
@@ -326,11 +335,13 @@ class ProcessPool(object):
 
     def map(self, entries, chunk=None):
         """Records of ``entries`` in order (0 for a failed entry, its reason in ``self.failures``).  The entries go to the
-        workers in chunks (default: about four chunks per worker, at most 8 entries each) so that a worker can bring the
-        next entry's maps in while it analyses the current one (``_worker_chunk``)."""
+        workers in chunks (default: at most 8 entries each, and a whole number of rounds over the workers -- 125 entries on 4
+        workers are 16 chunks of 8, not 18 of 7 with half a round left over) so that a worker can bring the next entry's maps
+        in while it analyses the current one (``_worker_chunk``)."""
         entries = list(entries)
         if chunk is None:
-            chunk = max(1, min(8, len(entries) // (4 * self.n_workers)))
+            rounds = max(1, -(-len(entries) // (8 * self.n_workers)))
+            chunk = max(1, -(-len(entries) // (rounds * self.n_workers)))
         chunks = [entries[k:k + chunk] for k in range(0, len(entries), chunk)]
         results = [pair for part in self.run(_worker_chunk, chunks) for pair in part]
         self.failures = {e.pdbid: why for e, (rec, why) in zip(entries, results) if why}

@@ -224,3 +224,49 @@ def test_ccp4_file_goes_straight_to_the_device(tmp_path, gpu_ctx):
     with pytest.raises(OSError):
         DeviceMap.from_file(gpu_ctx, str(tmp_path / "absent.ccp4"), 1024, False, hdr.geometry())
     assert len(ccp4.read(str(tmp_path / "little.ccp4"), ctx=gpu_ctx).createFullBlobList(cut)) == len(b)      # the context is still good
+
+
+def test_lazy_diff_map(tmp_path, gpu_ctx, monkeypatch):
+    """``ccp4.read(..., lazy=True)``: header now, grid when first asked for -- the same map as the eager read; the loader of
+    multiple-structure mode leaves the Fo-Fc grid of an entry on disk (its record reads the header only) and gives the record of
+    the loader that uploads both maps (PDBEDA_EAGER_DIFF_MAP=1), file by file and through the process pool."""
+    from pdb_eda_amd import ccp4, synthetic, densityAnalysis, multipleStructures
+    params = synthetic.synthetic_params()
+    densityAnalysis.setGlobals(params)
+    loader = synthetic.write_entry_files(str(tmp_path), "lazy", 72, 24, 411, as_paths=True)
+    eager = ccp4.read(loader.diff_path, "e", ctx=gpu_ctx)
+    lazy = ccp4.read(loader.diff_path, "l", ctx=gpu_ctx, lazy=True)
+    assert eager.resident and not lazy.resident
+    assert lazy.header.ncrs == eager.header.ncrs and lazy.header.densityMean == eager.header.densityMean and not lazy.resident
+    assert lazy.diffDensityCutoff == eager.meanDensity + 3 * eager.stdDensity and lazy.resident        # first use brought it in
+    assert (lazy.meanDensity, lazy.stdDensity) == (eager.meanDensity, eager.stdDensity)
+    green = lazy.createFullBlobList(lazy.diffDensityCutoff)
+    assert [b.numVoxels for b in green] == [b.numVoxels for b in eager.createFullBlobList(eager.diffDensityCutoff)]
+    # the loader of multiple-structure mode
+    entry = multipleStructures.Entry("lazy", loader)
+    assert multipleStructures.lazyDiffMap()
+    loaded = multipleStructures.loadEntry(entry, gpu_ctx)
+    assert loaded[0].resident and not loaded[1].resident
+    rec_lazy = multipleStructures.analyzeEntry(entry, gpu_ctx, silent=True, loaded=loaded)
+    assert rec_lazy and not loaded[1].resident                              # the record never touched the Fo-Fc grid
+    an = densityAnalysis.DensityAnalysis("lazy", *loaded)
+    assert len(an.greenBlobList) == len(green) and loaded[1].resident       # ... and an analysis that does gets it
+    monkeypatch.setenv("PDBEDA_EAGER_DIFF_MAP", "1")
+    assert not multipleStructures.lazyDiffMap()
+    loaded = multipleStructures.loadEntry(entry, gpu_ctx)
+    assert loaded[1].resident
+    rec_eager = multipleStructures.analyzeEntry(entry, gpu_ctx, silent=True, loaded=loaded)
+    for rec in (rec_lazy, rec_eager):
+        rec.pop("execution_time")
+    assert rec_lazy == rec_eager and rec_lazy["stats"]["diff_density_mean"] == eager.header.densityMean
+    monkeypatch.delenv("PDBEDA_EAGER_DIFF_MAP")
+    entries = [multipleStructures.Entry("p%d" % i, loader) for i in range(5)]
+    pool = multipleStructures.ProcessPool(device=0, n_workers=2, params=params, silent=True)
+    try:
+        par = pool.map(entries)
+    finally:
+        pool.close()
+    for rec in par:
+        rec.pop("execution_time"); rec.pop("pdbid")
+    want = dict(rec_lazy); want.pop("pdbid")
+    assert all(rec == want for rec in par)
