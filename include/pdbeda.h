@@ -101,8 +101,8 @@ int pdbeda_map_upload(pdbeda_ctx *ctx, const float *density, const pdbeda_geomet
 /* density_dev: a device pointer the caller keeps alive (zero-copy, e.g. a torch tensor). */
 int pdbeda_map_from_device(pdbeda_ctx *ctx, const float *density_dev, const pdbeda_geometry *geom, pdbeda_map **out);
 /* The grid of a CCP4 FILE straight into HBM (ccp4.read -> parse, ccp4.py:58-127): n = ncrs[0]*ncrs[1]*ncrs[2] float32 values
- * starting at byte `offset` (1024 + the symmetry records) of `path`, read through two pinned chunks that alternate between
- * pread() and the PCIe copy; byteswap != 0 when the file has the other endianness (swapped on the device).  No host copy
+ * starting at byte `offset` (1024 + the symmetry records) of `path`, read through a ring of pinned chunks (two pread() readers,
+ * their PCIe copies queued on two streams; the context's stream is ordered behind both); byteswap != 0 when the file has the other endianness (swapped on the device).  No host copy
  * of the map exists afterwards (pdbeda_map_download fetches one on demand). */
 int pdbeda_map_upload_file(pdbeda_ctx *ctx, const char *path, int64_t offset, int byteswap, const pdbeda_geometry *geom, pdbeda_map **out);
 int pdbeda_map_free(pdbeda_map *map);

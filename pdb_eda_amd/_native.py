@@ -376,7 +376,7 @@ class DeviceMap(object):
 
     @classmethod
     def from_file(cls, ctx, path, offset, byteswap, geometry):
-        """The float32 grid stored at byte ``offset`` of ``path`` straight into HBM (pinned double buffer: file read and PCIe
+        """The float32 grid stored at byte ``offset`` of ``path`` straight into HBM (pinned ring, two readers: file read and PCIe
         copy overlap; no host copy of the map is kept)."""
         self = cls.__new__(cls)
         self._ctx, self._geom, self._keep = ctx, geometry, None
