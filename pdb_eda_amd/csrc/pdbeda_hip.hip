@@ -9,6 +9,8 @@
 #include <algorithm>
 #include <chrono>
 #include <thread>
+#include <atomic>
+#include <random>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -64,7 +66,6 @@ struct pdbeda_ctx {
     // cross-tile pair buffer so the shard-overflow path runs on small inputs.
     bool debug_poison = false;
     int64_t debug_edge_cap = 0;
-    uint32_t next_epoch = 1;            // whole-map job numbers (Job::epoch)
     // per-entry watchdog (multipleStructures.py:359-377 wraps every entry in a SIGALRM timeout; threads cannot): when
     // timeout_s > 0 every wait on the stream is a timed hipStreamQuery loop; a wait that expires marks the context
     // abandoned: every later call fails at once with PDBEDA_ERR_TIMEOUT and destroy does not wait for the stream.
@@ -905,6 +906,7 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.comp_of_run = n_tiles ? cv.take<uint32_t>(max_runs) : nullptr;
     job.label_of_comp = n_tiles ? cv.take<int32_t>(max_runs) : nullptr;
     job.word_comps = n_tiles ? cv.take<uint8_t>((size_t)n_tiles * 2 * 256 * 8) : nullptr;
+    job.unit_done = n_tiles ? cv.take<uint32_t>((size_t)n_tiles) : nullptr;
     job.unit_flag = n_tiles ? cv.take<uint32_t>(1) : nullptr;
     job.tile_mode = n_tiles ? cv.take<uint8_t>(n_tiles) : nullptr;
     job.tile_runs = n_tiles ? cv.take<uint32_t>(n_tiles) : nullptr;
@@ -963,11 +965,11 @@ template <int CW>
 static void launch_tile_label(pdbeda_ctx *ctx, unsigned n_tiles, const Job &job, const float *dens, const Geom *geom_dev, const TileDims &td,
                               const JobInit &init, int pair_slots) {
     { PROF(ctx, "k_tile_label"); hipLaunchKernelGGL((k_tile_label<CW>), dim3(n_tiles), dim3(512), 0, ctx->stream, job, dens, geom_dev, td, init); }
-    // cross-tile unions; the first UNIT_BLOCKS workgroups are the fallback for tiles that overflowed LDS (rare: they exit at once)
+    // cross-tile unions (and, when a tile overflowed LDS, every pair that has such a tile on either side)
     {   // (grids of one tile column have no c faces: two waves fewer per workgroup to dispatch)
         PROF(ctx, "k_face_merge");
-        if (td.ctiles > 1) hipLaunchKernelGGL((k_face_merge<CW, FM_THREADS_WIDE>), dim3(n_tiles + UNIT_BLOCKS), dim3(FM_THREADS_WIDE), 0, ctx->stream, job, dens, geom_dev, td, pair_slots);
-        else hipLaunchKernelGGL((k_face_merge<CW, FM_THREADS>), dim3(n_tiles + UNIT_BLOCKS), dim3(FM_THREADS), 0, ctx->stream, job, dens, geom_dev, td, pair_slots);
+        if (td.ctiles > 1) hipLaunchKernelGGL((k_face_merge<CW, FM_THREADS_WIDE>), dim3(n_tiles), dim3(FM_THREADS_WIDE), 0, ctx->stream, job, dens, geom_dev, td, pair_slots);
+        else hipLaunchKernelGGL((k_face_merge<CW, FM_THREADS>), dim3(n_tiles), dim3(FM_THREADS), 0, ctx->stream, job, dens, geom_dev, td, pair_slots);
     }
 }
 
@@ -1030,8 +1032,10 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
     job_carve(job, arena.base, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, &labels_dev, tiles_pp);
     job.vol_sign[0] = td.sign[0];
     job.vol_sign[1] = td.sign[1];
-    job.epoch = ctx->next_epoch++;
-    if (ctx->next_epoch == 0xffffffffu) ctx->next_epoch = 1;   // never 0 / the poison pattern
+    // the job's number: unique in the process (contexts recycle each other's memory through the driver), started at a random value
+    // (so is another process's); stale flags of an earlier job in recycled memory never match it.  Never 0 / the poison pattern.
+    static std::atomic<uint32_t> g_epoch{(uint32_t)std::random_device{}() | 1u};
+    do { job.epoch = g_epoch.fetch_add(1u); } while (job.epoch == 0u || job.epoch == 0xffffffffu);
 
     JobInit init;
     memset(&init, 0, sizeof init);

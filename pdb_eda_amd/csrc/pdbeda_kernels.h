@@ -89,7 +89,7 @@ struct Counters {
     unsigned int n_comps;
     unsigned int n_blobs;
     unsigned int n_blobs_vol0;   // blobs whose first key lies in volume 0 (the split of a fused green / red job's table)
-    unsigned int barrier;        // arrivals at the grid barrier of k_unit_fallback
+    unsigned int reserved;
     unsigned int unit_tiles[3];  // whole-map tiles that fell back to unit mode: run slots / edge buffer / component table full
     unsigned long long n_voxels;
     long long total_words;
@@ -118,6 +118,7 @@ struct Job {
     // per tile, sign and mask word: the tile-local components of the word's first 7 word-runs and of the run at its last bit,
     // a byte each -- k_face_merge unites across tile faces from the mask words and these records alone (one round trip)
     uint8_t *word_comps;               // [tile][2][256][8]
+    uint32_t *unit_done;               // [tile]: == epoch once the tile's workgroup of k_face_merge has labelled it (unit tiles) or has nothing to label
     uint32_t *unit_flag;      // == epoch iff some tile of THIS job fell back to unit mode (stale values of a recycled arena never match)
     uint32_t epoch;           // job number of the context (never 0)
     uint8_t *tile_mode;       // per tile: 0 = united in LDS, 1 = unit tile
@@ -128,7 +129,7 @@ struct Job {
     // the inbox in LDS before it paints the final first keys.  A full inbox falls back to the atomics.
     struct InboxEntry *inbox;     // [tile][INBOX_CAP]
     uint32_t *inbox_count;        // [tile * INBOX_STRIDE]: one counter per 128-B line (atomics on one line serialise); cleared by the
-                                  // tile's own k_tile_label workgroup
+                                  // tile's own k_face_merge workgroup
     int32_t vol_sign[2];      // whole-map jobs: +1 / -1 list of volume p
     // per-component records
     int32_t *parent;

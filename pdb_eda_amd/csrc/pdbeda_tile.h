@@ -30,7 +30,8 @@
 // Only component pairs that touch across a tile face are united globally (k_face_merge, after an LDS
 // de-duplication per tile), and only non-root tile components cost global atomics (k_resolve_tiles, after an
 // LDS pre-reduction per tile).  A tile whose run or component count exceeds the LDS capacity falls
-// back to "unit mode" (k_unit_fallback: every run its own component, united globally): slower, same result.
+// back to "unit mode" (its workgroup of k_face_merge labels it run by run, every run its own component, and unites its pairs
+// globally): slower, same result.
 #pragma once
 #include "pdbeda_kernels.h"
 #include <type_traits>
@@ -61,7 +62,7 @@ __host__ __device__ inline int64_t tile_index(const TileDims &td, int plane, int
 
 // What workgroup 0 of k_tile_label publishes for the later kernels of the job (descriptors by value: no host
 // staging buffer, no memset / init launch, no sync): the volume descriptors and the id counters.  Run / component
-// ids below runs0 / comps0 are owned tile by tile; k_unit_fallback allocates above them.
+// ids below runs0 / comps0 are owned tile by tile; unit tiles take theirs above them (unit_label_tile).
 struct JobInit {
     VolDesc v[2];
     unsigned int runs0, comps0;
@@ -161,6 +162,67 @@ __device__ __forceinline__ void lds_unite(uint32_t *parent, uint32_t a, uint32_t
         if (old == hi) return;
         a = old;
         b = lo;
+    }
+}
+
+// Generic labelling of a tile k_tile_label could not hold in LDS ("unit tile"): every run is its own component with its own
+// record (wave prefix sums per word, as k_run_index), ids from the job's counters above the per-tile ranges; the pairs of such a
+// tile are then ALL united globally.  Called by the tile's own workgroup of k_face_merge (round 3: this used to be 128 extra
+// workgroups of that kernel behind a grid barrier of their own -- 1.3 ms for a map whose tiles all overflow; and inside
+// k_tile_label, where the tile has everything at hand, the cold code cost the other tiles 3 us of spilled scalars).  A quarter
+// of the tile (16 rows) at a time; `scratch`: 1 KiB of LDS nobody else uses.
+template <int CW>
+__device__ void unit_label_tile(const Job &job, const float *__restrict__ dens, const Geom *__restrict__ gp, const TileDims &td,
+                                int w0, int r0, int s0, unsigned char *scratch) {
+    constexpr int QU = 16 * CW;   // units of a quarter tile
+    uint64_t *s_m = reinterpret_cast<uint64_t *>(scratch);          // [64]
+    uint32_t *s_off = reinterpret_cast<uint32_t *>(scratch + 512);  // [64]
+    uint32_t *s_base = reinterpret_cast<uint32_t *>(scratch + 768); // [2]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n_waves = (int)(blockDim.x >> 6);
+    const Geom &g = *gp;
+    const int ur = td.ur, us = td.us, row_words = td.row_words;
+    const int64_t plane_words = (int64_t)row_words * ur * us;
+    for (int q = 0; q < td.n_planes; ++q) {
+        const VolDesc vd = job.vols[q];
+        for (int quarter = 0; quarter < 4; ++quarter) {
+            // thread tid < QU owns unit quarter * QU + tid
+            const int u = quarter * QU + tid;
+            const int my_wl = u % CW, my_rowl = (u / CW) & 63;
+            const int my_rl = my_rowl & 7, my_sl = my_rowl >> 3;
+            const bool my_valid = (tid < QU) && (r0 + my_rl < ur) && (s0 + my_sl < us) && (w0 + my_wl < row_words);
+            const int64_t my_word = (int64_t)q * plane_words + ((int64_t)(s0 + my_sl) * ur + (r0 + my_rl)) * row_words + (w0 + my_wl);
+            const uint64_t m = my_valid ? job.mask[my_word] : 0ull;
+            const uint32_t cnt = (uint32_t)popc64(run_starts(m));
+            uint32_t x = (wv == 0) ? cnt : 0u;   // QU <= 64: all owners sit in wave 0
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(x, d);
+                if (lane >= d) x += y;
+            }
+            if (tid < 64) { s_m[tid] = (tid < QU) ? m : 0ull; s_off[tid] = x - cnt; }
+            if (tid == 63) {
+                s_base[0] = x ? atomicAdd(&job.ctr->n_runs, x) : 0u;
+                s_base[1] = x ? atomicAdd(&job.ctr->n_comps, x) : 0u;
+            }
+            __syncthreads();
+            const uint32_t run_first = s_base[0], comp_first = s_base[1];
+            if (my_valid) job.run_base[my_word] = run_first + s_off[tid];
+            for (int j = wv; j < QU; j += n_waves) {   // a wave per unit
+                const uint64_t mw = s_m[j];
+                if (mw == 0ull) continue;
+                const int uu = quarter * QU + j;
+                const int wl = uu % CW, rowl = (uu / CW) & 63;
+                const int r = r0 + (rowl & 7), s = s0 + (rowl >> 3), c0 = (w0 + wl) * 64;
+                const uint32_t run0 = run_first + s_off[j], comp0 = comp_first + s_off[j];
+                word_run_records(job, g, dens, vd, mw, lane, c0, r, s, c0, r, s, comp0);
+                const uint64_t starts = run_starts(mw);
+                if ((starts >> lane) & 1ull) {
+                    const uint32_t k = (uint32_t)popc64(starts & bits_below(lane));
+                    job.comp_of_run[run0 + k] = comp0 + k;
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -336,8 +398,8 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
 
     if (n_runs == 0 || n_runs > (uint32_t)RCAP) {   // block-uniform
         PDBEDA_LATE_JOB(lj);
-        // nothing significant, or too many runs for LDS: publish the masks; an overflowing tile
-        // is labelled by k_unit_fallback (every run its own component)
+        // nothing significant, or too many runs for LDS: publish the masks; an overflowing tile is labelled run by run
+        // (every run its own component) by its workgroup of k_face_merge
         if (my_valid) { lj.mask[my_word] = m; lj.run_base[my_word] = 0u; }
         if (tid == 0) { lj.tile_mode[tile_id] = n_runs ? 1 : 0; lj.tile_runs[blockIdx.x] = 0u; if (n_runs) *lj.unit_flag = lj.epoch; }
         mark_comps_unused(lj, (uint32_t)blockIdx.x * CCAP, 0u, tid, NT);
@@ -538,70 +600,6 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
     if (tid == 0) lj.tile_runs[blockIdx.x] = n_runs;
 }
 
-// Generic labelling of the tiles k_tile_label could not hold in LDS ("unit tiles"): every run
-// is its own component with its own record (wave prefix sums per word, as k_run_index);
-// the cross-tile kernels then unite ALL touching pairs of such a tile globally.  One workgroup per
-// QUARTER tile (16 rows: 4x the parallelism of the rare slow path); run / component ids come from the
-// global counters, above the per-tile ranges.
-template <int CW>
-__device__ void unit_quarter_tile(const Job &job, const float *__restrict__ dens, const Geom *__restrict__ gp, const TileDims &td, int qt) {
-    constexpr int QU = 16 * CW;   // units of a quarter tile
-    __shared__ uint64_t s_m[64];
-    __shared__ uint32_t s_off[64];
-    __shared__ uint32_t s_rb, s_cb;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int t = qt >> 2;
-    const int quarter = qt & 3;
-    const int ct = t % td.ctiles; t /= td.ctiles;
-    const int rt = t % td.rtiles; t /= td.rtiles;
-    const int st = t;
-    const int w0 = ct * CW, r0 = rt * TILE_R, s0 = st * TILE_S;
-    if (job.tile_mode[tile_index(td, 0, w0, r0, s0)] == 0) return;   // block-uniform
-    const Geom &g = *gp;
-    const int ur = g.unique_ncrs[1], us = g.unique_ncrs[2];
-    const int row_words = (g.unique_ncrs[0] + 63) >> 6;
-    for (int q = 0; q < td.n_planes; ++q) {
-        const VolDesc vd = job.vols[q];
-        // thread tid < QU owns unit quarter*QU + tid
-        const int u = quarter * QU + tid;
-        const int my_wl = u % CW, my_rowl = (u / CW) & 63;
-        const int my_rl = my_rowl & 7, my_sl = my_rowl >> 3;
-        const bool my_valid = (tid < QU) && (r0 + my_rl < ur) && (s0 + my_sl < us) && (w0 + my_wl < row_words);
-        const int64_t my_word = vd.word_base + ((int64_t)(s0 + my_sl) * ur + (r0 + my_rl)) * row_words + (w0 + my_wl);
-        const uint64_t m = my_valid ? job.mask[my_word] : 0ull;
-        const uint32_t cnt = (uint32_t)popc64(run_starts(m));
-        uint32_t x = (wv == 0) ? cnt : 0u;   // QU <= 64: all owners sit in wave 0
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t y = __shfl_up(x, d);
-            if (lane >= d) x += y;
-        }
-        if (tid < 64) { s_m[tid] = (tid < QU) ? m : 0ull; s_off[tid] = x - cnt; }
-        if (tid == 63) {
-            s_rb = x ? atomicAdd(&job.ctr->n_runs, x) : 0u;
-            s_cb = x ? atomicAdd(&job.ctr->n_comps, x) : 0u;
-        }
-        __syncthreads();
-        if (my_valid) job.run_base[my_word] = s_rb + s_off[tid];
-        for (int j = wv; j < QU; j += (int)(blockDim.x >> 6)) {   // a wave per unit
-            const uint64_t mw = s_m[j];
-            if (mw == 0ull) continue;
-            const int uu = quarter * QU + j;
-            const int wl = uu % CW, rowl = (uu / CW) & 63;
-            const int r = r0 + (rowl & 7), s = s0 + (rowl >> 3), c0 = (w0 + wl) * 64;
-            const uint32_t run0 = s_rb + s_off[j], comp0 = s_cb + s_off[j];
-            word_run_records(job, g, dens, vd, mw, lane, c0, r, s, c0, r, s, comp0);
-            const uint64_t starts = run_starts(mw);
-            if ((starts >> lane) & 1ull) {
-                const uint32_t k = (uint32_t)popc64(starts & bits_below(lane));
-                job.comp_of_run[run0 + k] = comp0 + k;
-            }
-        }
-        __syncthreads();
-    }
-}
-
-
 // Cross-tile pairs of one mask word.  All global loads (the 13 neighbour masks and run bases)
 // are issued up front and unconditionally -- one memory latency instead of one per neighbour --
 // then the touching RUN pairs are enumerated from registers.  Pairs inside one normally
@@ -719,13 +717,9 @@ __device__ inline void cross_tile_pairs(uint64_t m, uint32_t my_base, const NbWo
 // belong to the unit path (skipped here by the tile modes).  Grids wider than one tile add the c faces (waves 6 / 7): the
 // run at position 0 of a row against the runs that end the 9 rows around it in the tile to the left.
 //
-// The first `n_unit_blocks` workgroups of the launch are the unit-tile fallback (tiles that overflowed LDS in
-// k_tile_label): normally no tile did and they exit on the epoch flag at once -- the rare path costs no launch of its own.
-// Otherwise they label the unit tiles run by run, meet at a grid barrier of their own (they are the first workgroups
-// dispatched and few enough to be co-resident many times over, so concurrent streams cannot starve each other), then
-// unite every pair that has a unit tile on either side.
+// Tiles that overflowed LDS in k_tile_label ("unit tiles") are handled at the end of the same workgroups: normally no tile did
+// (one flag, read with everything else) and the rare path costs neither a launch nor a workgroup of its own.
 constexpr int PAIR_SLOTS = 1024; // LDS hash set of a tile's distinct cross-face component pairs (a full set unites on the spot)
-constexpr int UNIT_BLOCKS = 128; // workgroups of the unit-tile fallback
 constexpr int FM_THREADS = 384, FM_THREADS_WIDE = 512;  // 2 signs x 46 pairs of rows x 4 word slots = 368 lanes; grids wider than a tile: 128 more for the c faces
 constexpr int FACE_PAIRS = 46;
 
@@ -742,45 +736,15 @@ __device__ void unit_edges_word(const Job &job, const TileDims &td, const VolDes
     cross_tile_pairs(m, my_base, nw, [&](uint32_t a, uint32_t b) { uf_unite(job.parent, (int)job.comp_of_run[a], (int)job.comp_of_run[b]); });
 }
 
-template <int CW>
-__device__ void unit_fallback_blocks(const Job &job, const float *__restrict__ dens, const Geom *__restrict__ gp, const TileDims &td, int block, int n_blocks) {
-    const int n_qt = td.ctiles * td.rtiles * td.stiles * 4;
-    for (int qt = block; qt < n_qt; qt += n_blocks) {   // block-uniform trip count
-        unit_quarter_tile<CW>(job, dens, gp, td, qt);
-        __syncthreads();
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();   // publish run bases / records / run -> component ids
-        atomicAdd(&job.ctr->barrier, 1u);
-        while (__hip_atomic_load(&job.ctr->barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)n_blocks) __builtin_amdgcn_s_sleep(8);
-        __threadfence();
-    }
-    __syncthreads();
-    const VolDesc v0 = job.vols[0];
-    const int64_t per_plane = (int64_t)v0.row_words * v0.dim[1] * v0.dim[2], total = per_plane * td.n_planes;
-    for (int64_t L = (int64_t)block * blockDim.x + threadIdx.x; L < total; L += (int64_t)n_blocks * blockDim.x) {
-        const int plane = (int)(L / per_plane);
-        const int64_t rem = L % per_plane;
-        const int wq = (int)(rem % v0.row_words);
-        const int64_t row = rem / v0.row_words;
-        unit_edges_word(job, td, v0, plane, (int)(row / v0.dim[1]), (int)(row % v0.dim[1]), wq);
-    }
-}
-
 template <int CW, int NTH>
 __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td, int pair_slots) {
-    if ((int)blockIdx.x < UNIT_BLOCKS) {   // block-uniform
-        if (*job.unit_flag != job.epoch) return;
-        unit_fallback_blocks<CW>(job, dens, gp, td, (int)blockIdx.x, UNIT_BLOCKS);
-        return;
-    }
+    const bool any_unit = *job.unit_flag == job.epoch;   // block-uniform: some tile of this job is a unit tile (rare)
     static_assert(FACE_K == 7, "a word's component record is one 64-bit load: seven runs and the run at the last bit");
     __shared__ unsigned long long s_set[PAIR_SLOTS], s_pairs[PAIR_SLOTS];
     __shared__ uint32_t s_wsum[NTH / 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int ur = td.ur, us = td.us, row_words = td.row_words;
-    const int tile = (int)blockIdx.x - UNIT_BLOCKS, ct = tile % td.ctiles, rt = (tile / td.ctiles) % td.rtiles, st = tile / (td.ctiles * td.rtiles);
+    const int tile = (int)blockIdx.x, ct = tile % td.ctiles, rt = (tile / td.ctiles) % td.rtiles, st = tile / (td.ctiles * td.rtiles);
     const int w0 = ct * CW;
     const int64_t plane_words = (int64_t)row_words * ur * us;
     const unsigned long long *comps64 = reinterpret_cast<const unsigned long long *>(job.word_comps);
@@ -927,7 +891,7 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__r
     {   // every tile clears its slice of the first-key bitmap and of the rank counters (saves a memset launch; painted two kernels
         // later) and its inbox counter (used by the next kernel) -- here, behind the last barrier: a barrier waits for the stores
         // before it to be acknowledged (2 us), the unions below do not
-        const int n_tiles = (int)gridDim.x - UNIT_BLOCKS;
+        const int n_tiles = (int)gridDim.x;
         const int64_t key_words = job.key_words;
         const int64_t per = (key_words + n_tiles - 1) / n_tiles;
         const int64_t lo = per * tile, hi = lo + per < key_words ? lo + per : key_words;
@@ -936,6 +900,46 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__r
         const int64_t perc = (nfc + n_tiles - 1) / n_tiles, clo = perc * tile, chi = clo + perc < nfc ? clo + perc : nfc;
         for (int64_t i = clo + tid; i < chi; i += NTH) job.fine_count[i] = 0u;
         if (tid == 0) job.inbox_count[(size_t)tile * INBOX_STRIDE] = 0u;
+    }
+    if (any_unit) {
+        // Some tile overflowed LDS in k_tile_label.  Its own workgroup labels it here, run by run (phase 1), and every pair with
+        // such a tile on either side is then united word by word (phase 2) by the workgroup of the tile that holds the LATER
+        // word of the pair: all of its words if the tile is a unit tile itself, else the words on its faces that look at one.
+        // Phase 2 reads what phase 1 of the neighbour tiles wrote: a flag per tile says that it has.  The earlier WORDS a word
+        // looks at lie in the 17 tiles around with ds <= 0 -- 13 earlier tiles and 4 later ones (a word on the tile's last
+        // row looks at row r + 1 of section s - 1, which is the next tile along r unless s starts the tile; its last word
+        // looks into the next tile along c).  Nobody waits before its own phase 1 is published, so a wait can only be for a
+        // workgroup that has not been dispatched yet, and that one is at most ctiles + 1 indices ahead: the launch moves as long
+        // as that many consecutive workgroups are resident -- no grid barrier, nothing that needs the whole grid at once
+        // (the 128 fallback workgroups this replaces had to be co-resident, all of them).
+        __syncthreads();   // (everybody is done with the pair tables: their LDS is the scratch below)
+        const bool mine_unit = job.tile_mode[tile] != 0;   // block-uniform
+        if (mine_unit) {
+            unit_label_tile<CW>(job, dens, gp, td, w0, rt * TILE_R, st * TILE_S, reinterpret_cast<unsigned char *>(s_set));
+            __threadfence();   // publish run bases / records / run -> component ids to the other XCDs
+        }
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_store(&job.unit_done[tile], job.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < 18; ++k) {   // (dc, dr, ds) with ds = -1 or 0, but for the tile itself
+                const int dc = k % 3 - 1, dr = (k / 3) % 3 - 1, ds = k / 9 - 1;
+                if (dc == 0 && dr == 0 && ds == 0) continue;
+                const int c2 = ct + dc, r2 = rt + dr, s2 = st + ds;
+                if (c2 < 0 || c2 >= td.ctiles || r2 < 0 || r2 >= td.rtiles || s2 < 0) continue;
+                const int nb = (s2 * td.rtiles + r2) * td.ctiles + c2;
+                if (job.tile_mode[nb] == 0) continue;
+                while (__hip_atomic_load(&job.unit_done[nb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != job.epoch) __builtin_amdgcn_s_sleep(16);
+            }
+            __threadfence();
+        }
+        __syncthreads();
+        const VolDesc v0 = job.vols[0];
+        constexpr int NU = 64 * CW;
+        for (int k = tid; k < td.n_planes * NU; k += NTH) {
+            const int plane = k / NU, u = k % NU, wl = u % CW, rowl = u / CW;
+            const int r = rt * TILE_R + (rowl & 7), s = st * TILE_S + (rowl >> 3), wq = w0 + wl;
+            if (r < ur && s < us && wq < row_words) unit_edges_word(job, td, v0, plane, s, r, wq);
+        }
     }
 }
 
@@ -959,21 +963,51 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
         atomicAdd((unsigned long long *)&job.r_s[root], s);
         atomicMin(&job.r_key[root], key);
     };
-    if ((int)blockIdx.x >= n_tiles) {
-        const uint32_t n_comp = n_components(job);
-        for (uint32_t i = (uint32_t)n_tiles * CCAP + (blockIdx.x - n_tiles) * 256u + tid; i < n_comp; i += (gridDim.x - n_tiles) * 256u) {
-            const int root = uf_find(job.parent, (int)i);
-            if (root == (int)i) continue;
-            job.parent[i] = root;
-            fold((uint32_t)root, job.r_n[i], fix_load(job, i), (unsigned long long)job.r_c[i],
-                 (unsigned long long)job.r_r[i], (unsigned long long)job.r_s[i], job.r_key[i]);
-        }
-        return;
-    }
     __shared__ int s_root[RSLOTS];
     __shared__ FixSums s_f[RSLOTS];
     __shared__ unsigned long long s_i[3][RSLOTS], s_key[RSLOTS];
     __shared__ uint32_t s_cnt[RSLOTS];
+    if ((int)blockIdx.x >= n_tiles) {
+        // the components of unit tiles (every run its own component): 256 at a time, and the same pre-reduction -- the members of
+        // a round that share a root are summed in the LDS table and folded with ONE set of atomics.  Folding them one by one put
+        // hundreds of thousands of same-address atomics on the record of a map-spanning blob (a protein-like map at 0.5 sigma:
+        // 2.3 ms in this kernel alone).
+        const uint32_t n_comp = n_components(job), stride = (gridDim.x - (uint32_t)n_tiles) * 256u;
+        for (uint32_t base = (uint32_t)n_tiles * CCAP + (blockIdx.x - (uint32_t)n_tiles) * 256u; base < n_comp; base += stride) {   // block-uniform
+            for (int k = tid; k < RSLOTS; k += 256) {
+                s_root[k] = -1;
+                s_f[k] = fix_zero();
+                s_i[0][k] = 0ull; s_i[1][k] = 0ull; s_i[2][k] = 0ull; s_key[k] = ~0ull; s_cnt[k] = 0u;
+            }
+            const uint32_t i = base + tid;
+            int root = -1;
+            if (i < n_comp) {
+                root = uf_find(job.parent, (int)i);
+                if (root == (int)i) root = -1;
+                else job.parent[i] = root;
+            }
+            __syncthreads();
+            if (root >= 0) {
+                uint32_t h = ((uint32_t)root * 2654435761u) >> 24;   // 8 bits
+                while (true) {                                         // (<= 256 members, 256 slots: a slot always turns up)
+                    const int old = atomicCAS(&s_root[h], -1, root);
+                    if (old == -1 || old == root) break;
+                    h = (h + 1u) & (RSLOTS - 1);
+                }
+                atomicAdd(&s_cnt[h], job.r_n[i]);
+                fix_atomic_add(&s_f[h], fix_load(job, i));
+                atomicAdd(&s_i[0][h], (unsigned long long)job.r_c[i]);
+                atomicAdd(&s_i[1][h], (unsigned long long)job.r_r[i]);
+                atomicAdd(&s_i[2][h], (unsigned long long)job.r_s[i]);
+                atomicMin(&s_key[h], job.r_key[i]);
+            }
+            __syncthreads();
+            for (int k = tid; k < RSLOTS; k += 256)
+                if (s_root[k] >= 0) fold((uint32_t)s_root[k], s_cnt[k], s_f[k], s_i[0][k], s_i[1][k], s_i[2][k], s_key[k]);
+            __syncthreads();   // (the next round clears the table)
+        }
+        return;
+    }
     const uint32_t i = (uint32_t)blockIdx.x * CCAP + tid;
     // everything this thread may need, in flight at once (unused ids hold stale bytes: loaded, never used)
     const uint32_t n_i = job.r_n[i];

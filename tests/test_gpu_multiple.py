@@ -51,19 +51,21 @@ def test_stream_pool_matches_sequential(gpu_ctx):
 
 
 @pytest.mark.timeout(240)
-def test_unit_fallback_on_many_streams():
-    """Dense maps (tiles overflow LDS -> k_unit_fallback, which holds a grid barrier) labelled concurrently on six
-    streams: every stream gets the oracle's answer and nobody starves the others of workgroup slots."""
+@pytest.mark.parametrize("shape", [(40, 48, 256), (24, 40, 600)])       # one tile column; three (the last one partial)
+def test_unit_fallback_on_many_streams(shape):
+    """Dense maps (tiles overflow LDS -> their workgroups of k_face_merge label them run by run and wait for each other's
+    flags, later tiles along r and c included) labelled concurrently on six streams: every stream gets the oracle's answer
+    (counts, keys and the label volume) and nobody starves the others of workgroup slots."""
     import io
     from oracle import oracle as ora
     from pdb_eda_amd import ccp4, synthetic, multipleStructures
-    g = synthetic.smooth_noise((40, 48, 256), 9, 1.5)
-    spec = synthetic.MapSpec(ncrs=(256, 48, 40))
+    g = synthetic.smooth_noise(shape, 9, 1.5)
+    spec = synthetic.MapSpec(ncrs=shape[::-1])
     blob = synthetic.ccp4_bytes(spec, g)
     header = ccp4.DensityHeader.fromFileHeader(blob[:1024])
     mean, std = float(np.mean(g, dtype=np.float64)), float(np.std(g.astype(np.float64)))
     cut = mean + 0.3 * std
-    want = ora.Oracle(header, g).full_blobs(cut)
+    want = ora.Oracle(header, g).full_blobs(cut, labels=True)
 
     def work(k, ctx):
         dm = ccp4.parse(io.BytesIO(blob), "dense%d" % k, ctx=ctx)
@@ -71,7 +73,9 @@ def test_unit_fallback_on_many_streams():
         for _ in range(4):
             green, red = dm._map.full_blobs_pm(cut, -cut, labels=True)
             st = green.stats()
-            out.append((np.array_equal(st["n"], want["n"]), green.counters()["unit_tiles_runs"] + green.counters()["unit_tiles_comps"]))
+            same = np.array_equal(st["n"], want["n"]) and np.array_equal(st["firstKey"], want["firstKey"]) and \
+                np.array_equal(green.labels(dm._map.unique_shape), want["labels"])
+            out.append((same, green.counters()["unit_tiles_runs"] + green.counters()["unit_tiles_comps"]))
         return out
     res = multipleStructures.StreamPool(device=0, n_streams=6).map(work, list(range(12)))
     assert all(r != 0 for r in res)
