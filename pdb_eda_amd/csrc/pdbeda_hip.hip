@@ -1115,6 +1115,7 @@ static int list_resolve_counts(pdbeda_bloblist *bl) {
     Counters ctr;
     HIP_TRY(ctx, d2h(ctx, &ctr, job.ctr, sizeof ctr));
     HIP_TRY(ctx, ctx_sync(ctx));
+    if (bl->whole_map && ctr.unit_wait_failed) return fail(ctx, PDBEDA_ERR_DEVICE, "whole-map labelling: a tile waited in vain for the labels of a neighbour tile that overflowed LDS (k_face_merge)");
     if (bl->vol_lo == 0 && bl->vol_hi == job.n_vols) { bl->rank_lo = 0; bl->rank_hi = ctr.n_blobs; }
     else if (bl->whole_map && job.n_vols == 2 && bl->vol_hi == bl->vol_lo + 1) {
         bl->rank_lo = bl->vol_lo == 0 ? 0 : ctr.n_blobs_vol0;

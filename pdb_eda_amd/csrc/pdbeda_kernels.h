@@ -89,7 +89,7 @@ struct Counters {
     unsigned int n_comps;
     unsigned int n_blobs;
     unsigned int n_blobs_vol0;   // blobs whose first key lies in volume 0 (the split of a fused green / red job's table)
-    unsigned int reserved;
+    unsigned int unit_wait_failed;   // k_face_merge: a unit tile waited a second for a neighbour's labels (see there): the job's results are void
     unsigned int unit_tiles[3];  // whole-map tiles that fell back to unit mode: run slots / edge buffer / component table full
     unsigned long long n_voxels;
     long long total_words;

@@ -928,7 +928,13 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__r
                 if (c2 < 0 || c2 >= td.ctiles || r2 < 0 || r2 >= td.rtiles || s2 < 0) continue;
                 const int nb = (s2 * td.rtiles + r2) * td.ctiles + c2;
                 if (job.tile_mode[nb] == 0) continue;
-                while (__hip_atomic_load(&job.unit_done[nb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != job.epoch) __builtin_amdgcn_s_sleep(16);
+                // (bounded: about a second.  A flag that never comes up -- it cannot, while workgroups are dispatched in order --
+                //  must not hang the GPU: the job is marked failed instead, and the host turns that into an error)
+                unsigned spins = 0;
+                while (__hip_atomic_load(&job.unit_done[nb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != job.epoch) {
+                    if (++spins > (1u << 21)) { __hip_atomic_store(&job.ctr->unit_wait_failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    __builtin_amdgcn_s_sleep(16);
+                }
             }
             __threadfence();
         }
