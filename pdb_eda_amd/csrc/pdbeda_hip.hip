@@ -636,9 +636,13 @@ extern "C" int pdbeda_map_upload_file(pdbeda_ctx *ctx, const char *path, int64_t
         ReaderResult rr[FILE_READERS];
         if (e == hipSuccess && !ctx->timed_out) {
             std::thread helper;
-            if (n_chunks > 1) helper = std::thread(reader, 1, &rr[1]);
+            bool helped = false;
+            if (n_chunks > 1) {
+                try { helper = std::thread(reader, 1, &rr[1]); helped = true; } catch (...) { helped = false; }   // (no thread to be had: one reader does both shares)
+            }
             reader(0, &rr[0]);
             if (helper.joinable()) helper.join();
+            if (!helped && n_chunks > 1 && rr[0].e == hipSuccess && !rr[0].why && !rr[0].timed_out) reader(1, &rr[1]);
             // the context's stream waits for the helper's copies: everything behind this call is ordered after the whole map
             if (hipEventRecord(ctx->ring_joined, ctx->ring_stream) != hipSuccess || hipStreamWaitEvent(ctx->stream, ctx->ring_joined, 0) != hipSuccess) e = hipGetLastError();
             for (int t = 0; t < FILE_READERS; ++t) {
@@ -1034,7 +1038,12 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
     job.vol_sign[1] = td.sign[1];
     // the job's number: unique in the process (contexts recycle each other's memory through the driver), started at a random value
     // (so is another process's); stale flags of an earlier job in recycled memory never match it.  Never 0 / the poison pattern.
-    static std::atomic<uint32_t> g_epoch{(uint32_t)std::random_device{}() | 1u};
+    static std::atomic<uint32_t> g_epoch{[] {
+        uint32_t seed;
+        try { seed = (uint32_t)std::random_device{}(); }
+        catch (...) { seed = (uint32_t)std::chrono::steady_clock::now().time_since_epoch().count() ^ ((uint32_t)getpid() * 2654435761u); }
+        return seed | 1u;
+    }()};
     do { job.epoch = g_epoch.fetch_add(1u); } while (job.epoch == 0u || job.epoch == 0xffffffffu);
 
     JobInit init;
