@@ -100,6 +100,10 @@ int pdbeda_ctx_profile_end(pdbeda_ctx *ctx, char *buf, int64_t cap);
 int pdbeda_map_upload(pdbeda_ctx *ctx, const float *density, const pdbeda_geometry *geom, pdbeda_map **out);
 /* density_dev: a device pointer the caller keeps alive (zero-copy, e.g. a torch tensor). */
 int pdbeda_map_from_device(pdbeda_ctx *ctx, const float *density_dev, const pdbeda_geometry *geom, pdbeda_map **out);
+/* The caller has rewritten a borrowed buffer in place: drop what the library cached about the map's contents (the quantum of
+ * the order-independent blob sums, derived once per map from sum |rho| and max |rho|).  The reference has no counterpart: its
+ * DensityMatrix owns its array (ccp4.py:322-341).  A map that holds a NaN or an infinity is refused by the labelling calls. */
+int pdbeda_map_invalidate(pdbeda_map *map);
 /* The grid of a CCP4 FILE straight into HBM (ccp4.read -> parse, ccp4.py:58-127): n = ncrs[0]*ncrs[1]*ncrs[2] float32 values
  * starting at byte `offset` (1024 + the symmetry records) of `path`, read through a ring of pinned chunks (two pread() readers,
  * their PCIe copies queued on two streams; the context's stream is ordered behind both); byteswap != 0 when the file has the other endianness (swapped on the device).  No host copy

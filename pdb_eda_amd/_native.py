@@ -84,6 +84,7 @@ _SIGS = {
     "pdbeda_map_upload": (C.c_int, [_p, _p, C.POINTER(Geometry), C.POINTER(_p)]),
     "pdbeda_map_upload_file": (C.c_int, [_p, C.c_char_p, _i64, C.c_int, C.POINTER(Geometry), C.POINTER(_p)]),
     "pdbeda_map_from_device": (C.c_int, [_p, _p, C.POINTER(Geometry), C.POINTER(_p)]),
+    "pdbeda_map_invalidate": (C.c_int, [_p]),
     "pdbeda_map_free": (C.c_int, [_p]),
     "pdbeda_map_combine": (C.c_int, [_p, _p, C.c_double, C.POINTER(_p)]),
     "pdbeda_map_download": (C.c_int, [_p, _p]),
@@ -373,6 +374,10 @@ class DeviceMap(object):
         ctx.check(rc, "pdbeda_map_upload")
         self._h = h
         self.unique_shape = tuple(min(geometry.ncrs[k], geometry.xyz_interval[geometry.map2crs[k]]) for k in (2, 1, 0))
+
+    def invalidate(self):
+        """The caller rewrote a borrowed device buffer in place: drop what the library cached about its contents."""
+        self._ctx.check(self._ctx._lib.pdbeda_map_invalidate(self._h), "pdbeda_map_invalidate")
 
     @classmethod
     def from_file(cls, ctx, path, offset, byteswap, geometry):

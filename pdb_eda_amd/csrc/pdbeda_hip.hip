@@ -109,14 +109,19 @@ static void ctx_release_device(pdbeda_ctx *ctx, bool lent_too) {
 // Destroy the abandoned contexts whose stream has drained meanwhile; returns how many are still parked.
 static size_t reap_abandoned() {
     std::lock_guard<std::mutex> g(g_ctx_mu);
+    if (g_abandoned.empty()) return 0;
+    int caller_device = -1;
+    if (hipGetDevice(&caller_device) != hipSuccess) caller_device = -1;   // (the caller's current device is put back below)
     for (size_t i = 0; i < g_abandoned.size();) {
         pdbeda_ctx *ctx = g_abandoned[i];
         (void)hipSetDevice(ctx->device);
-        if (hipStreamQuery(ctx->stream) == hipErrorNotReady) { ++i; continue; }   // still running (or hung): try again later
+        // still running (or hung) on either of its streams -- the file upload queues copies on the second one: try again later
+        if (hipStreamQuery(ctx->stream) == hipErrorNotReady || (ctx->ring_stream && hipStreamQuery(ctx->ring_stream) == hipErrorNotReady)) { ++i; continue; }
         ctx_release_device(ctx, true);
         delete ctx;
         g_abandoned.erase(g_abandoned.begin() + i);
     }
+    if (caller_device >= 0) (void)hipSetDevice(caller_device);
     return g_abandoned.size();
 }
 
@@ -595,6 +600,12 @@ extern "C" int pdbeda_map_upload_file(pdbeda_ctx *ctx, const char *path, int64_t
     m->dens = d;
     m->own_dens = true;
     hipError_t e = hipMemcpyAsync(m->geom_dev, &m->geom, sizeof(Geom), hipMemcpyHostToDevice, ctx->stream);
+    // The arena may be a recycled one: the pool protects a recycled arena by STREAM ORDER on ctx->stream (maps and lists are
+    // freed without a host sync while their kernels are still queued; the debug poison fill above is queued there too).  The
+    // helper's copies go through ring_stream, which knows nothing of that order -- so it waits, once, for everything queued
+    // on ctx->stream up to here before its first chunk may land.
+    if (e == hipSuccess) e = hipEventRecord(ctx->ring_joined, ctx->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->ring_stream, ctx->ring_joined, 0);
     const char *why = nullptr;
     {
         // reader t takes chunks t, t + READERS, ... through its own ring slots (t, t + READERS): nothing is shared but the
@@ -753,6 +764,10 @@ static int map_fix_mul(pdbeda_map *m) {
     double range[2] = {0.0, 0.0};   // sum |x|, max |x|: fixed reduction order, so the quantum is the same in every run
     HIP_TRY(ctx, d2h(ctx, range, res, 2 * sizeof(double)));
     HIP_TRY(ctx, ctx_sync(ctx));
+    // the integer sums cannot hold a NaN or an infinity (fix_of would saturate without a word): such a map is refused here,
+    // once, instead of producing wrong blob totals (the reference's sums would be NaN / inf for every blob that holds one)
+    if (!std::isfinite(range[0]) || !std::isfinite(range[1]))
+        return fail(ctx, PDBEDA_ERR_ARGUMENT, "the map holds non-finite density values: blob sums are undefined");
     const double bound = std::max(range[0], 4194304.0 * range[1]);
     int S = 40;
     if (bound > 0.0 && std::isfinite(bound)) {
@@ -763,6 +778,15 @@ static int map_fix_mul(pdbeda_map *m) {
     S = std::max(-900, std::min(S, 900));
     m->fix_mul = ldexp(1.0, S);
     return 0;
+}
+
+// A map made by pdbeda_map_from_device borrows the caller's buffer; what the library caches about its CONTENTS -- the quantum of
+// the order-independent blob sums, derived from sum |rho| and max |rho| -- must be dropped when the caller rewrites the buffer
+// in place (larger values would overflow the 62-bit sums silently).
+extern "C" int pdbeda_map_invalidate(pdbeda_map *m) {
+    if (!m) return PDBEDA_ERR_ARGUMENT;
+    m->fix_mul = 0.0;
+    return PDBEDA_OK;
 }
 
 extern "C" int pdbeda_map_stats(pdbeda_map *m, double *mean, double *std) {
@@ -920,6 +944,7 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.inbox_count = n_tiles ? cv.take<uint32_t>((size_t)n_tiles * INBOX_STRIDE) : nullptr;
     job.vol_sign[0] = job.vol_sign[1] = 1;
     job.parent = cv.take<int32_t>(max_runs);
+    job.kpar = n_tiles ? cv.take<unsigned long long>(max_runs) : nullptr;
     job.r_n = cv.take<uint32_t>(max_runs);
     job.r_sum = cv.take<long long>((size_t)7 * max_runs);
     job.r_sum_stride = max_runs;
@@ -1069,8 +1094,7 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
         default: launch_tile_label<4>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init, pair_slots); break;
     }
     { PROF(ctx, "k_resolve_tiles"); hipLaunchKernelGGL(k_resolve_tiles, dim3((unsigned)tiles_pp + 64u), dim3(256), 0, st, job, (int)tiles_pp); }
-    { PROF(ctx, "k_paint_tiles"); hipLaunchKernelGGL(k_paint_tiles, dim3((unsigned)tiles_pp + 64u), dim3(256), 0, st, job, (int)tiles_pp); }
-    { PROF(ctx, "k_emit"); hipLaunchKernelGGL(k_emit, dim3(std::min<unsigned>(512u, ((unsigned)tiles_pp + 1u) / 2u)), dim3(256), 0, st, job, m->geom_dev); }
+    { PROF(ctx, "k_emit_tiles"); hipLaunchKernelGGL(k_emit_tiles, dim3(std::min<unsigned>(512u, ((unsigned)tiles_pp + 1u) / 2u)), dim3(256), 0, st, job, m->geom_dev); }
     if (labels) {
         PROF(ctx, "k_labels_tiles");
         launch_labels(ctx, job, td, labels_dev);
@@ -1256,6 +1280,10 @@ extern "C" int pdbeda_bloblist_labels(pdbeda_bloblist *bl, int32_t *labels_host)
     if (!bl->whole_map) return fail(bl->ctx, PDBEDA_ERR_STATE, "dense labels exist only for whole-map blob lists");
     pdbeda_ctx *ctx = bl->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    {   // a job whose unit tiles waited in vain (k_face_merge) has no valid labels either: the same check the blob table makes
+        const int rc_counts = list_resolve_counts(bl);
+        if (rc_counts) return rc_counts;
+    }
     const Geom &g = bl->map->geom;
     const int uc = g.unique_ncrs[0], ur = g.unique_ncrs[1], us = g.unique_ncrs[2];
     const int64_t nvox = (int64_t)uc * ur * us;
@@ -1545,9 +1573,11 @@ extern "C" int pdbeda_test_overlap(pdbeda_ctx *ctx, const int32_t *crs, const in
 extern "C" int pdbeda_symmetry_atoms(pdbeda_ctx *ctx, const double *xyz, int64_t n_atoms, const double *rot, int32_t n_ops,
                                      const double ortho[9], const double bbox_lo[3], const double bbox_hi[3], int32_t *atom_index,
                                      int32_t *symmetry, double *out_xyz, int64_t cap, int64_t *n_out) {
-    if (!ctx || n_atoms < 0 || n_ops <= 0 || !rot || !ortho || !bbox_lo || !bbox_hi || !n_out || (n_atoms > 0 && !xyz)) return PDBEDA_ERR_ARGUMENT;
+    if (!ctx || n_atoms < 0 || n_ops < 0 || (n_ops > 0 && !rot) || !ortho || !bbox_lo || !bbox_hi || !n_out || (n_atoms > 0 && !xyz)) return PDBEDA_ERR_ARGUMENT;
     *n_out = 0;
-    if (n_atoms == 0) return PDBEDA_OK;
+    // no operators (a file without REMARK 290): the reference's loop over them runs zero times and builds an empty list
+    // (densityAnalysis.py:896-912) -- not an error
+    if (n_atoms == 0 || n_ops == 0) return PDBEDA_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t total = 27ll * n_ops * n_atoms, n_words = (total + 63) / 64;
     std::vector<unsigned long long> h_keep((size_t)n_words);

@@ -149,14 +149,20 @@ struct Job {
     int32_t *b_group;
     // (last: the tile kernel's scalar-register allocation is sensitive to the offsets of the fields above -- inserting these
     //  in the middle cost it 10 more SGPR spills and 1.6 us)
-    uint64_t *root_mask;      // per tile: which of its TILE_COMPS component slots are blob roots (4 ballots, written by k_paint_tiles):
+    uint64_t *root_mask;      // per tile: which of its TILE_COMPS component slots are blob roots (4 ballots, written by k_resolve_tiles):
     int32_t n_tiles;          // k_emit visits the ~36 k roots of a 256^3 job, not its 262 k component ids
+    // Whole-map jobs unite by FIRST KEY, not by id (round 4): kpar[x] = key32(parent) << 32 | parent, key32 = plane << 31 | the
+    // c-major key of the component's first voxel inside its plane (unique: a position).  The root of a blob is then the
+    // component that holds the blob's first voxel, its own key IS the blob's first key as soon as the unions are done, and the
+    // kernel that used to fold min keys into the roots before the keys could be painted (k_paint_tiles) is gone.  The value read
+    // from kpar[x] carries the parent's key AND its id: a find costs the same trips as on ids.  ~0 = unused id.
+    unsigned long long *kpar;
 };
 
-struct InboxEntry {           // 104 bytes: what a (tile, root) pair folds into the root's record
+struct InboxEntry {           // 88 bytes: what a (tile, root) pair folds into the root's record (no key: the root holds the first voxel)
     uint32_t local, n;        // component index of the root inside its tile; voxels
     FixSums sum;
-    unsigned long long c, r, s, key;
+    unsigned long long c, r, s;
 };
 constexpr int INBOX_STRIDE = 32;   // uint32 per inbox counter: a cache line each
 constexpr int INBOX_CAP = 192;   // entries per tile (a root tile of a map-spanning blob overflows: those pairs fold with atomics)
@@ -224,7 +230,10 @@ __device__ inline void word_run_records(const Job &job, const Geom &g, const flo
         job.r_c[idx] = (long long)len * a + (long long)len * (len - 1) / 2;
         job.r_r[idx] = (long long)len * rawr;
         job.r_s[idx] = (long long)len * raws;
-        job.r_key[idx] = (unsigned long long)(vd.key_base + ((int64_t)(cl0 + lane) * vd.dim[1] + rl) * vd.dim[2] + sl);
+        const int64_t key_in = ((int64_t)(cl0 + lane) * vd.dim[1] + rl) * vd.dim[2] + sl;
+        job.r_key[idx] = (unsigned long long)(vd.key_base + key_in);
+        // (whole-map jobs, unit tiles: the volume's group is its plane, keys inside a plane are below 2^31)
+        if (job.kpar) job.kpar[idx] = ((unsigned long long)(((uint32_t)vd.group << 31) | (uint32_t)key_in) << 32) | idx;
     }
 }
 
@@ -354,6 +363,61 @@ __device__ inline void uf_unite(int32_t *p, int a, int b) {
         if (old == a) return;
         a = old;
     }
+}
+
+// ---- The same union-find on PACKED parents (whole-map jobs): a value is key32 << 32 | id, ordered by key (keys are unique
+// positions, so the order of the values is the order of the keys), kpar[x] <= P(x) with equality exactly at roots, and the
+// larger VALUE hangs under the smaller: a root is the component with the smallest first key of its set.  Everything above
+// carries over (the min is authoritative, every value a load can return was the node's parent at some time); a value names
+// its node (the low half), so the walk needs no second table.
+typedef unsigned long long kp_t;
+constexpr kp_t KP_UNUSED = ~0ull;
+__device__ __forceinline__ uint32_t kp_id(kp_t v) { return (uint32_t)v; }
+__device__ inline kp_t kuf_load(const kp_t *p, uint32_t id) {
+    return __hip_atomic_load(p + id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// root of the set of the node named by x (x = a value read from the table, or P of a node)
+__device__ inline kp_t kuf_find_from(kp_t *p, kp_t x) {
+    kp_t q;
+    while ((q = kuf_load(p, kp_id(x))) != x) {
+        const kp_t gp = kuf_load(p, kp_id(q));
+        if (gp != q) atomicMin(p + kp_id(x), gp);
+        x = gp;
+    }
+    return x;
+}
+__device__ inline void kuf_unite_vals(kp_t *p, kp_t a, kp_t b) {
+    while (true) {
+        kp_t qa = kuf_load(p, kp_id(a)), qb = kuf_load(p, kp_id(b));
+        while (qa != a || qb != b) {   // the two finds walk in step: their loads share the round trips
+            const kp_t ga = qa != a ? kuf_load(p, kp_id(qa)) : qa, gb = qb != b ? kuf_load(p, kp_id(qb)) : qb;
+            if (qa != a && ga != qa) atomicMin(p + kp_id(a), ga);
+            if (qb != b && gb != qb) atomicMin(p + kp_id(b), gb);
+            a = ga; b = gb;
+            qa = kuf_load(p, kp_id(a)); qb = kuf_load(p, kp_id(b));
+        }
+        if (a == b) return;
+        if (a < b) { const kp_t t = a; a = b; b = t; }
+        const kp_t old = atomicMin(p + kp_id(a), b);
+        if (old == a) return;
+        a = old;
+    }
+}
+// optimistic hook (see uf_hook) of two values that name nodes of the two sets -- e.g. what kpar[] held for the two components
+// a moment ago: an ancestor-or-self each, which is all a union needs
+__device__ inline void kuf_hook_vals(kp_t *p, kp_t a, kp_t b) {
+#pragma unroll
+    for (int level = 0; level < 4; ++level) {
+        if (a == b) return;
+        if (a < b) { const kp_t t = a; a = b; b = t; }
+        const kp_t old = atomicMin(p + kp_id(a), b);
+        if (old == a || old == b) return;
+        a = old;
+    }
+    kuf_unite_vals(p, a, b);
+}
+__device__ inline void kuf_unite(kp_t *p, uint32_t ia, uint32_t ib) {
+    kuf_unite_vals(p, kuf_load(p, ia), kuf_load(p, ib));
 }
 
 // Index of the run of word `nm` that contains set bit p.
@@ -602,11 +666,6 @@ __device__ inline uint32_t rank_of_key(const Job &job, const uint32_t *s_pre, un
     return rank + (uint32_t)popc64(job.key_bits[kw] & bits_below((int)(key & 63)));
 }
 
-// Thread per ROOT component: its rank, its final signed label (whole-map jobs; the label writer follows parent[] to it) and
-// its blob table row (DensityBlob.fromCrsList, ccp4.py:542-545).  Block 0 publishes the blob counts.  A root's work is a
-// chain of dependent memory round trips -- (parent, n) -> (key + the whole record) -> (counters + bitmap words) -- so each
-// step issues everything the next one needs at once (the key rides with the first step: unused ids hold stale keys that are
-// loaded and never used), and the first step is issued before the prefix table is built.
 // Position of the k-th (0-based) set bit of m (k < popcount(m)).
 __device__ __forceinline__ int nth_set_bit(uint64_t m, int k) {
     int pos = 0;
@@ -618,90 +677,159 @@ __device__ __forceinline__ int nth_set_bit(uint64_t m, int k) {
     return pos;
 }
 
-__global__ void __launch_bounds__(256) k_emit(Job job, const Geom *__restrict__ gp) {
-    __shared__ uint32_t s_pre[KEY_GROUPS];
-    __shared__ uint32_t s_wave[4];
-    const uint32_t n_comp = n_components(job);
-    const bool whole_map = job.label_of_comp != nullptr;
+// One blob table row (DensityBlob.fromCrsList, ccp4.py:542-545), the root's rank and -- whole-map jobs -- its signed label.
+__device__ __forceinline__ void emit_row(const Job &job, const Geom &g, const uint32_t *s_pre, bool whole_map, int64_t key_base1, uint32_t id,
+                                         uint32_t n_vox, unsigned long long first_key, const FixSums &fs, long long ic, long long ir, long long is) {
+    const double tot_q = (double)fs.rho, rc = fix_moment(fs.c_lo, fs.c_hi), rr = fix_moment(fs.r_lo, fs.r_hi), rs = fix_moment(fs.s_lo, fs.s_hi);
+    const double tot = tot_q / job.fix_mul;      // (a power of two: exact)
+    const uint32_t rank = rank_of_key(job, s_pre, first_key);
+    const int vi = whole_map ? ((int64_t)first_key >= key_base1 ? 1 : 0) : find_vol_by_key(job.vols, job.n_vols, (int64_t)first_key);
+    // signed by its list, numbered by its rank in the WHOLE table: k_labels_tiles takes the blobs of volume 0 off the
+    // labels of volume 1 (ctr->n_blobs_vol0) -- here that count would be a second dependent round trip before any root
+    if (whole_map) job.label_of_comp[id] = job.vol_sign[vi] > 0 ? 1 + (int32_t)rank : -1 - (int32_t)rank;
+    const VolDesc vd = job.vols[vi];
+    job.r_rank[id] = rank;
+    const double n = (double)n_vox;
+    double wc[3] = {rc / tot_q, rr / tot_q, rs / tot_q};   // (the quantum cancels)
+    double cc[3] = {(double)ic / n, (double)ir / n, (double)is / n};
+    double xyz[3];
+    crs2xyz_frac(g, wc, xyz);
+    job.b_centroid[3 * rank + 0] = xyz[0];
+    job.b_centroid[3 * rank + 1] = xyz[1];
+    job.b_centroid[3 * rank + 2] = xyz[2];
+    crs2xyz_frac(g, cc, xyz);
+    job.b_center[3 * rank + 0] = xyz[0];
+    job.b_center[3 * rank + 1] = xyz[1];
+    job.b_center[3 * rank + 2] = xyz[2];
+    job.b_n[rank] = (int64_t)n_vox;
+    job.b_total[rank] = tot;
+    job.b_volume[rank] = g.unit_volume * n;
+    job.b_key[rank] = (int64_t)first_key - vd.key_base;
+    job.b_group[rank] = vd.group;
+}
+
+// Grid-stride over component ids [first, n_comp): the roots among them emit their rows (generic jobs: every id; whole-map
+// jobs: the unit components above the tiles' id ranges).  The next trip's first step rides along.
+__device__ inline void emit_ids(const Job &job, const Geom &g, const uint32_t *s_pre, bool whole_map, int64_t key_base1, uint32_t first, uint32_t n_comp) {
     const uint32_t stride = gridDim.x * blockDim.x;
-    // Whole-map jobs: half a workgroup per tile, thread k of the half takes the tile's k-th root (k_paint_tiles left a
-    // 256-bit root mask per tile), so ONE pass covers the job; the first trip's loads are issued before the rank table is
-    // built.  Generic jobs (and the unit components of a whole-map job, ids above the tiles' ranges): grid-stride over ids.
-    const int half = threadIdx.x >> 7, k0 = threadIdx.x & 127;
-    int tile = whole_map ? (int)blockIdx.x * 2 + half : 0;
-    uint64_t rm[4] = {0ull, 0ull, 0ull, 0ull};
-    if (whole_map && tile < job.n_tiles) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rm[q] = job.root_mask[(size_t)tile * 4 + q];
-    }
-    uint32_t i = whole_map ? (uint32_t)job.n_tiles * (uint32_t)TILE_COMPS + blockIdx.x * blockDim.x + threadIdx.x : blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i = first + blockIdx.x * blockDim.x + threadIdx.x;
     int32_t par = i < n_comp ? job.parent[i] : -1;
     uint32_t cnt = i < n_comp ? job.r_n[i] : 0u;
     unsigned long long key = i < n_comp ? job.r_key[i] : 0ull;
-    // first key of volume 1 (fused green / red job); loaded before the table so that nothing below waits for it
-    const int64_t key_base1 = (whole_map && job.n_vols > 1) ? job.vols[1].key_base : INT64_MAX;
-    const uint32_t total = rank_table_lds(job, s_pre, s_wave);
-    const Geom &g = *gp;
-    auto emit_root = [&](uint32_t id, uint32_t n_vox, unsigned long long first_key) {
-        const FixSums fs = fix_load(job, id);
-        const double tot_q = (double)fs.rho, rc = fix_moment(fs.c_lo, fs.c_hi), rr = fix_moment(fs.r_lo, fs.r_hi), rs = fix_moment(fs.s_lo, fs.s_hi);
-        const double tot = tot_q / job.fix_mul;      // (a power of two: exact)
-        const long long ic = job.r_c[id], ir = job.r_r[id], is = job.r_s[id];
-        const uint32_t rank = rank_of_key(job, s_pre, first_key);
-        const int vi = whole_map ? ((int64_t)first_key >= key_base1 ? 1 : 0) : find_vol_by_key(job.vols, job.n_vols, (int64_t)first_key);
-        // signed by its list, numbered by its rank in the WHOLE table: k_labels_tiles takes the blobs of volume 0 off the
-        // labels of volume 1 (ctr->n_blobs_vol0) -- here that count would be a second dependent round trip before any root
-        if (whole_map) job.label_of_comp[id] = job.vol_sign[vi] > 0 ? 1 + (int32_t)rank : -1 - (int32_t)rank;
-        const VolDesc vd = job.vols[vi];
-        job.r_rank[id] = rank;
-        const double n = (double)n_vox;
-        double wc[3] = {rc / tot_q, rr / tot_q, rs / tot_q};   // (the quantum cancels)
-        double cc[3] = {(double)ic / n, (double)ir / n, (double)is / n};
-        double xyz[3];
-        crs2xyz_frac(g, wc, xyz);
-        job.b_centroid[3 * rank + 0] = xyz[0];
-        job.b_centroid[3 * rank + 1] = xyz[1];
-        job.b_centroid[3 * rank + 2] = xyz[2];
-        crs2xyz_frac(g, cc, xyz);
-        job.b_center[3 * rank + 0] = xyz[0];
-        job.b_center[3 * rank + 1] = xyz[1];
-        job.b_center[3 * rank + 2] = xyz[2];
-        job.b_n[rank] = (int64_t)n_vox;
-        job.b_total[rank] = tot;
-        job.b_volume[rank] = g.unit_volume * n;
-        job.b_key[rank] = (int64_t)first_key - vd.key_base;
-        job.b_group[rank] = vd.group;
-    };
-    if (whole_map) {
-        for (; tile < job.n_tiles; tile += (int)gridDim.x * 2) {
-            const int c0 = popc64(rm[0]), c1 = c0 + popc64(rm[1]), c2 = c1 + popc64(rm[2]), n_roots = c2 + popc64(rm[3]);
-            const int next = tile + (int)gridDim.x * 2;
-            uint64_t nm[4] = {0ull, 0ull, 0ull, 0ull};
-            if (next < job.n_tiles) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) nm[q] = job.root_mask[(size_t)next * 4 + q];
-            }
-            for (int k = k0; k < n_roots; k += 128) {
-                const int q = k < c0 ? 0 : (k < c1 ? 1 : (k < c2 ? 2 : 3));
-                const int before = q == 0 ? 0 : (q == 1 ? c0 : (q == 2 ? c1 : c2));
-                const uint64_t word = q == 0 ? rm[0] : (q == 1 ? rm[1] : (q == 2 ? rm[2] : rm[3]));
-                const uint32_t id = (uint32_t)tile * (uint32_t)TILE_COMPS + (uint32_t)(64 * q + nth_set_bit(word, k - before));
-                emit_root(id, job.r_n[id], job.r_key[id]);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) rm[q] = nm[q];
-        }
-    }
     for (; i < n_comp; i += stride) {
         const bool root = par == (int32_t)i && cnt != 0u;   // else: not a root / unused component id
         const uint32_t nx = i + stride;
-        const int32_t par_next = nx < n_comp ? job.parent[nx] : -1;   // (next trip's first step rides along)
+        const int32_t par_next = nx < n_comp ? job.parent[nx] : -1;
         const uint32_t cnt_next = nx < n_comp ? job.r_n[nx] : 0u;
         const unsigned long long key_next = nx < n_comp ? job.r_key[nx] : 0ull;
-        if (root) emit_root(i, cnt, key);
+        if (root) emit_row(job, g, s_pre, whole_map, key_base1, i, cnt, key, fix_load(job, i), job.r_c[i], job.r_r[i], job.r_s[i]);
         par = par_next;
         cnt = cnt_next;
         key = key_next;
+    }
+}
+
+// Generic jobs -- thread per ROOT component: its rank and its blob table row.  Block 0 publishes the blob counts.  A root's
+// work is a chain of dependent memory round trips -- (parent, n) -> (key + the whole record) -> (counters + bitmap words) --
+// so each step issues everything the next one needs at once.
+__global__ void __launch_bounds__(256) k_emit(Job job, const Geom *__restrict__ gp) {
+    __shared__ uint32_t s_pre[KEY_GROUPS];
+    __shared__ uint32_t s_wave[4];
+    const uint32_t total = rank_table_lds(job, s_pre, s_wave);
+    emit_ids(job, *gp, s_pre, false, INT64_MAX, 0u, n_components(job));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        job.ctr->n_blobs = total;
+        job.ctr->n_blobs_vol0 = total;
+    }
+}
+
+// Whole-map jobs: half a workgroup per tile, thread k of the half takes the tile's k-th root (k_resolve_tiles left a 256-bit
+// root mask per tile), so ONE pass covers the job.  A root's sums are its own record plus what the other tiles' members of
+// its blob POSTED to its tile's inbox (k_resolve_tiles): the inbox is summed in LDS first (round 4: this was a kernel of its
+// own, k_paint_tiles, which also folded the first keys -- the roots hold them by construction now).  The unit components of
+// the job (ids above the tiles' ranges; rare) follow, id by id.
+__global__ void __launch_bounds__(256) k_emit_tiles(Job job, const Geom *__restrict__ gp) {
+    __shared__ uint32_t s_pre[KEY_GROUPS];
+    __shared__ uint32_t s_wave[4];
+    __shared__ unsigned long long s_acc[2][10][TILE_COMPS];   // per half: the seven FixSums fields, sum c / r / s
+    __shared__ uint32_t s_accn[2][TILE_COMPS];
+    const int half = threadIdx.x >> 7, k0 = threadIdx.x & 127;
+    const int n_tiles = job.n_tiles;
+    int tile = (int)blockIdx.x * 2 + half;
+    uint64_t rm[4] = {0ull, 0ull, 0ull, 0ull};
+    uint32_t n_in = 0;
+    if (tile < n_tiles) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rm[q] = job.root_mask[(size_t)tile * 4 + q];
+        n_in = job.inbox_count[(size_t)tile * INBOX_STRIDE];
+    }
+    // first key of volume 1 (fused green / red job); loaded before the table so that nothing below waits for it
+    const int64_t key_base1 = job.n_vols > 1 ? job.vols[1].key_base : INT64_MAX;
+    const uint32_t total = rank_table_lds(job, s_pre, s_wave);
+    const Geom &g = *gp;
+    for (int t0 = (int)blockIdx.x * 2; t0 < n_tiles; t0 += (int)gridDim.x * 2) {   // (block-uniform trip count: barriers inside)
+        tile = t0 + half;
+        n_in = min(n_in, (uint32_t)INBOX_CAP);
+        const int next = tile + (int)gridDim.x * 2;
+        uint64_t nm[4] = {0ull, 0ull, 0ull, 0ull};
+        uint32_t n_in_next = 0;
+        if (next < n_tiles) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nm[q] = job.root_mask[(size_t)next * 4 + q];
+            n_in_next = job.inbox_count[(size_t)next * INBOX_STRIDE];
+        }
+        // my inbox entries (<= 2 per thread), in flight beside the roots' records below
+        InboxEntry e0, e1;
+        const bool have0 = (uint32_t)k0 < n_in, have1 = (uint32_t)k0 + 128u < n_in;
+        if (have0) e0 = job.inbox[(size_t)tile * INBOX_CAP + k0];
+        if (have1) e1 = job.inbox[(size_t)tile * INBOX_CAP + k0 + 128];
+        if (n_in != 0u) {   // (uniform over the half)
+#pragma unroll
+            for (int f = 0; f < 10; ++f) { s_acc[half][f][k0] = 0ull; s_acc[half][f][k0 + 128] = 0ull; }
+            s_accn[half][k0] = 0u; s_accn[half][k0 + 128] = 0u;
+        }
+        __syncthreads();
+        auto absorb = [&](const InboxEntry &e) {
+            const uint32_t l = e.local;
+            atomicAdd(&s_accn[half][l], e.n);
+            atomicAdd(&s_acc[half][0][l], (unsigned long long)e.sum.rho);
+            atomicAdd(&s_acc[half][1][l], (unsigned long long)e.sum.c_lo); atomicAdd(&s_acc[half][2][l], (unsigned long long)e.sum.c_hi);
+            atomicAdd(&s_acc[half][3][l], (unsigned long long)e.sum.r_lo); atomicAdd(&s_acc[half][4][l], (unsigned long long)e.sum.r_hi);
+            atomicAdd(&s_acc[half][5][l], (unsigned long long)e.sum.s_lo); atomicAdd(&s_acc[half][6][l], (unsigned long long)e.sum.s_hi);
+            atomicAdd(&s_acc[half][7][l], e.c); atomicAdd(&s_acc[half][8][l], e.r); atomicAdd(&s_acc[half][9][l], e.s);
+        };
+        if (have0) absorb(e0);
+        if (have1) absorb(e1);
+        __syncthreads();
+        const int c0 = popc64(rm[0]), c1 = c0 + popc64(rm[1]), c2 = c1 + popc64(rm[2]), n_roots = c2 + popc64(rm[3]);
+        for (int k = k0; k < n_roots; k += 128) {
+            const int q = k < c0 ? 0 : (k < c1 ? 1 : (k < c2 ? 2 : 3));
+            const int before = q == 0 ? 0 : (q == 1 ? c0 : (q == 2 ? c1 : c2));
+            const uint64_t word = q == 0 ? rm[0] : (q == 1 ? rm[1] : (q == 2 ? rm[2] : rm[3]));
+            const uint32_t l = (uint32_t)(64 * q + nth_set_bit(word, k - before));
+            const uint32_t id = (uint32_t)tile * (uint32_t)TILE_COMPS + l;
+            uint32_t n_vox = job.r_n[id];
+            const unsigned long long key = job.r_key[id];
+            FixSums fs = fix_load(job, id);
+            long long ic = job.r_c[id], ir = job.r_r[id], is = job.r_s[id];
+            if (n_in != 0u) {
+                n_vox += s_accn[half][l];
+                fs.rho += (long long)s_acc[half][0][l];
+                fs.c_lo += (long long)s_acc[half][1][l]; fs.c_hi += (long long)s_acc[half][2][l];
+                fs.r_lo += (long long)s_acc[half][3][l]; fs.r_hi += (long long)s_acc[half][4][l];
+                fs.s_lo += (long long)s_acc[half][5][l]; fs.s_hi += (long long)s_acc[half][6][l];
+                ic += (long long)s_acc[half][7][l]; ir += (long long)s_acc[half][8][l]; is += (long long)s_acc[half][9][l];
+            }
+            emit_row(job, g, s_pre, true, key_base1, id, n_vox, key, fs, ic, ir, is);
+        }
+        __syncthreads();   // (the next round clears the tables)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rm[q] = nm[q];
+        n_in = n_in_next;
+    }
+    {   // unit components (every run of a tile that overflowed LDS its own component): none on ordinary maps
+        const uint32_t n_comp = n_components(job), first = (uint32_t)n_tiles * (uint32_t)TILE_COMPS;
+        if (n_comp > first) emit_ids(job, g, s_pre, true, key_base1, first, n_comp);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {   // the table's totals, for the host and for k_labels_tiles
         uint32_t below1 = total;                 // blobs before volume 1; every blob when there is one volume
@@ -1165,7 +1293,8 @@ __global__ void __launch_bounds__(256) k_range_partials(const float *__restrict_
     float mx = 0.0f;
     const int64_t n4 = n >> 2;
     const float4 *x4 = reinterpret_cast<const float4 *>(x);
-    auto take = [&](float v) { const float a = fabsf(v); if (a == a) { acc += (double)a; mx = a > mx ? a : mx; } };
+    // (a NaN or an infinity makes the maximum infinite: the host refuses to derive a quantum from such a map)
+    auto take = [&](float v) { const float a = fabsf(v); if (a < INFINITY) { acc += (double)a; mx = a > mx ? a : mx; } else mx = INFINITY; };
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 v = x4[i];
         take(v.x); take(v.y); take(v.z); take(v.w);

@@ -119,13 +119,11 @@ __device__ __forceinline__ void wave_lds_sync() {
 // allocation atomics on the fast path.  Unused component ids are marked empty (r_n = 0).
 template <typename JobRef>
 __device__ inline void mark_comps_unused(const JobRef &job, uint32_t cb, uint32_t from, int tid, int nt) {
-    int32_t *parent = job.parent;
+    unsigned long long *kpar = job.kpar;
     uint32_t *r_n = job.r_n;
-    unsigned long long *r_key = job.r_key;
     for (uint32_t i = from + tid; i < (uint32_t)CCAP; i += nt) {
-        parent[cb + i] = (int32_t)(cb + i);
+        kpar[cb + i] = KP_UNUSED;   // (parent[] of every id of a tile is written by k_resolve_tiles)
         r_n[cb + i] = 0u;
-        r_key[cb + i] = ~0ull;
     }
 }
 
@@ -585,7 +583,6 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
     const int64_t keys_pp = (int64_t)uc * ur * us;
     for (uint32_t i = tid; i < n_comp; i += NT) {
         const uint32_t g = cb + i;
-        lj.parent[g] = (int32_t)g;
         const unsigned long long pk = s_pk[i];
         const long long n = (long long)(pk & 0xfffffull);
         lj.r_n[g] = (uint32_t)n;
@@ -595,6 +592,7 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
         lj.r_s[g] = (long long)(pk >> 40) + n * s0;
         const uint32_t key = s_key[i];
         lj.r_key[g] = (unsigned long long)((key >> 31) ? keys_pp : 0) + (key & 0x7fffffffu);
+        lj.kpar[g] = ((unsigned long long)key << 32) | g;   // a root, named by its first key: the cross-tile unions hang the later first voxel under the earlier
     }
     mark_comps_unused(lj, cb, n_comp, tid, NT);
     if (tid == 0) lj.tile_runs[blockIdx.x] = n_runs;
@@ -733,7 +731,7 @@ __device__ void unit_edges_word(const Job &job, const TileDims &td, const VolDes
     NbWords nw;
     uint32_t my_base;
     if (!load_cross_tile(job, td, w, m, nw, my_base, true)) return;
-    cross_tile_pairs(m, my_base, nw, [&](uint32_t a, uint32_t b) { uf_unite(job.parent, (int)job.comp_of_run[a], (int)job.comp_of_run[b]); });
+    cross_tile_pairs(m, my_base, nw, [&](uint32_t a, uint32_t b) { kuf_unite(job.kpar, job.comp_of_run[a], job.comp_of_run[b]); });
 }
 
 template <int CW, int NTH>
@@ -742,6 +740,10 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__r
     static_assert(FACE_K == 7, "a word's component record is one 64-bit load: seven runs and the run at the last bit");
     __shared__ unsigned long long s_set[PAIR_SLOTS], s_pairs[PAIR_SLOTS];
     __shared__ uint32_t s_wsum[NTH / 64];
+    // what kpar[] holds for the components of this tile and of the four tiles it meets across its r / s faces, fetched with
+    // everything else: a union starts from two VALUES (an ancestor-or-self of either component, named by its first key), and
+    // these are such values whatever the other workgroups have united meanwhile -- no trip for them in front of the first hook
+    __shared__ kp_t s_kp[5][CCAP];
     const int tid = threadIdx.x, lane = tid & 63;
     const int ur = td.ur, us = td.us, row_words = td.row_words;
     const int tile = (int)blockIdx.x, ct = tile % td.ctiles, rt = (tile / td.ctiles) % td.rtiles, st = tile / (td.ctiles * td.rtiles);
@@ -776,8 +778,38 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__r
         cA = comps64[comps_at((uint32_t)tile, fq, r, s, fwl)]; cB = comps64[comps_at(tile_b, fq, r2, s2, fwl)];
         modes = (uint32_t)job.tile_mode[tile] | (uint32_t)job.tile_mode[tile_b];
     }
+    // the five tables: this tile, (rt - 1, st), (rt - 1, st - 1), (rt, st - 1), (rt + 1, st - 1)
+    uint32_t tiles5[5];
+    {
+        const int drs[5] = {0, -1, -1, 0, 1}, dss[5] = {0, 0, -1, -1, -1};
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int r5 = rt + drs[j], s5 = st + dss[j];
+            tiles5[j] = (r5 >= 0 && r5 < td.rtiles && s5 >= 0) ? (uint32_t)((s5 * td.rtiles + r5) * td.ctiles + ct) : 0xffffffffu;
+        }
+    }
+    constexpr int KPL = (5 * CCAP + NTH - 1) / NTH;
+    kp_t kp_pre[KPL];
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) {
+        const int e = tid + k * NTH, j = e / CCAP;
+        const uint32_t t5 = j == 0 ? tiles5[0] : (j == 1 ? tiles5[1] : (j == 2 ? tiles5[2] : (j == 3 ? tiles5[3] : tiles5[4])));
+        kp_pre[k] = (e < 5 * CCAP && t5 != 0xffffffffu) ? kuf_load(job.kpar, t5 * (uint32_t)CCAP + (uint32_t)(e % CCAP)) : KP_UNUSED;
+    }
     for (int i = tid; i < pair_slots; i += NTH) s_set[i] = 0ull;   // 0 = empty: a pair (lo << 32 | hi) has hi > lo >= 0
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) {
+        const int e = tid + k * NTH;
+        if (e < 5 * CCAP) (&s_kp[0][0])[e] = kp_pre[k];
+    }
     __syncthreads();
+    auto val_of = [&](uint32_t id) -> kp_t {   // a value that names a node of id's set
+        const uint32_t t = id / (uint32_t)CCAP;
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+            if (t == tiles5[j]) return s_kp[j][id % (uint32_t)CCAP];
+        return kuf_load(job.kpar, id);   // (the c faces of a grid wider than one tile)
+    };
     const uint32_t slot_mask = (uint32_t)pair_slots - 1u;
     auto add_pair = [&](uint32_t ca, uint32_t cb) {
         const uint32_t lo = ca < cb ? ca : cb, hi = ca < cb ? cb : ca;
@@ -787,7 +819,7 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__r
             const unsigned long long old = atomicCAS(&s_set[h], 0ull, key);
             if (old == 0ull || old == key) return;
         }
-        uf_hook(job.parent, (int)lo, (int)hi);   // the neighbourhood of the slot is full: unite on the spot
+        kuf_hook_vals(job.kpar, val_of(lo), val_of(hi));   // the neighbourhood of the slot is full: unite on the spot
     };
     {   // ---- r / s faces ----
         if (modes != 0u) { mA = 0ull; mB = 0ull; }   // a unit tile on either side: the unit path owns the pair
@@ -886,7 +918,7 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__r
     for (int k = 0; k < NTH / 64; ++k) n_pairs += s_wsum[k];
     for (uint32_t k = tid; k < n_pairs; k += NTH) {
         const unsigned long long key = s_pairs[k];
-        uf_hook(job.parent, (int)(key >> 32), (int)(uint32_t)key);
+        kuf_hook_vals(job.kpar, val_of((uint32_t)(key >> 32)), val_of((uint32_t)key));
     }
     {   // every tile clears its slice of the first-key bitmap and of the rank counters (saves a memset launch; painted two kernels
         // later) and its inbox counter (used by the next kernel) -- here, behind the last barrier: a barrier waits for the stores
@@ -949,30 +981,56 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__r
     }
 }
 
-// Whole-map k_resolve: one workgroup per tile (its CCAP component ids).  Every component finds its root; the
-// non-root components of a tile that share a root are first summed in LDS (a small hash table keyed by the root), then ONE
-// set of global atomics per (tile, root) folds them into the root record.  A blob that spans the map (the chain of a
-// protein at 1.5 sigma: tens of thousands of tile components) would otherwise pile 9 same-address atomics per
-// component on one record.  All loads of a component's record are issued up front, beside the first step of the find
-// (the kernel is a chain of dependent memory round trips, not bandwidth).  Workgroups beyond the tiles handle the
-// components of unit tiles one by one.
+// Whole-map k_resolve: one workgroup per tile (its CCAP component ids).  Every component finds its root -- the component of
+// its blob with the smallest first key (the unions hang by key) -- so a ROOT knows the blob's first key without hearing from
+// anybody: it paints that key into the bitmap and bumps its rank counter here (round 4: a kernel of its own before, behind
+// the fold of the members' keys).  The non-root components of a tile that share a root are first summed in LDS (a small hash
+// table keyed by the root), then ONE record per (tile, root) is POSTED to the inbox of the tile that owns the root -- a
+// returning atomic on a counter with a cache line of its own + plain stores; k_emit_tiles / the label writer absorb the
+// inbox.  A blob that spans the map (the chain of a protein at 1.5 sigma: tens of thousands of tile components) would
+// otherwise pile 9 same-address atomics per component on one record.  All loads of a component's record are issued up
+// front, beside the first step of the find (the kernel is a chain of dependent memory round trips, not bandwidth).
+// Workgroups beyond the tiles handle the components of unit tiles, 256 at a time.
 constexpr int RSLOTS = 256;   // LDS slots for the distinct roots the members of one tile fold into (<= 256 members: always enough)
 __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
     static_assert(CCAP == 256, "one thread per component id of a tile");
     const int tid = threadIdx.x;
-    auto fold = [&](uint32_t root, uint32_t n, const FixSums &sum, unsigned long long c, unsigned long long r,
-                    unsigned long long s, unsigned long long key) {
+    auto fold = [&](uint32_t root, uint32_t n, const FixSums &sum, unsigned long long c, unsigned long long r, unsigned long long s) {
         atomicAdd(&job.r_n[root], n);
         fix_fold(job, root, sum);
         atomicAdd((unsigned long long *)&job.r_c[root], c);
         atomicAdd((unsigned long long *)&job.r_r[root], r);
         atomicAdd((unsigned long long *)&job.r_s[root], s);
-        atomicMin(&job.r_key[root], key);
+    };
+    auto paint = [&](unsigned long long key) {
+        const uint32_t f = (uint32_t)((key >> 6) / KEY_FINE);
+        atomicOr((unsigned long long *)&job.key_bits[key >> 6], 1ull << (key & 63));
+        atomicAdd(&job.fine_count[f >> 1], 1u << ((f & 1u) * 16u));
     };
     __shared__ int s_root[RSLOTS];
     __shared__ FixSums s_f[RSLOTS];
-    __shared__ unsigned long long s_i[3][RSLOTS], s_key[RSLOTS];
+    __shared__ unsigned long long s_i[3][RSLOTS];
     __shared__ uint32_t s_cnt[RSLOTS];
+    auto clear_table = [&]() {
+        for (int k = tid; k < RSLOTS; k += 256) {
+            s_root[k] = -1;
+            s_f[k] = fix_zero();
+            s_i[0][k] = 0ull; s_i[1][k] = 0ull; s_i[2][k] = 0ull; s_cnt[k] = 0u;
+        }
+    };
+    auto table_add = [&](int root, uint32_t n, const FixSums &sum, unsigned long long c, unsigned long long r, unsigned long long s) {
+        uint32_t h = ((uint32_t)root * 2654435761u) >> 24;   // 8 bits
+        while (true) {                                         // (<= 256 members, 256 slots: a slot always turns up)
+            const int old = atomicCAS(&s_root[h], -1, root);
+            if (old == -1 || old == root) break;
+            h = (h + 1u) & (RSLOTS - 1);
+        }
+        atomicAdd(&s_cnt[h], n);
+        fix_atomic_add(&s_f[h], sum);
+        atomicAdd(&s_i[0][h], c);
+        atomicAdd(&s_i[1][h], r);
+        atomicAdd(&s_i[2][h], s);
+    };
     if ((int)blockIdx.x >= n_tiles) {
         // the components of unit tiles (every run its own component): 256 at a time, and the same pre-reduction -- the members of
         // a round that share a root are summed in the LDS table and folded with ONE set of atomics.  Folding them one by one put
@@ -980,36 +1038,20 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
         // 2.3 ms in this kernel alone).
         const uint32_t n_comp = n_components(job), stride = (gridDim.x - (uint32_t)n_tiles) * 256u;
         for (uint32_t base = (uint32_t)n_tiles * CCAP + (blockIdx.x - (uint32_t)n_tiles) * 256u; base < n_comp; base += stride) {   // block-uniform
-            for (int k = tid; k < RSLOTS; k += 256) {
-                s_root[k] = -1;
-                s_f[k] = fix_zero();
-                s_i[0][k] = 0ull; s_i[1][k] = 0ull; s_i[2][k] = 0ull; s_key[k] = ~0ull; s_cnt[k] = 0u;
-            }
+            clear_table();
             const uint32_t i = base + tid;
             int root = -1;
             if (i < n_comp) {
-                root = uf_find(job.parent, (int)i);
-                if (root == (int)i) root = -1;
-                else job.parent[i] = root;
+                const kp_t rp = kuf_find_from(job.kpar, kuf_load(job.kpar, i));
+                if (kp_id(rp) == i) paint(job.r_key[i]);   // (a run has voxels: a root among the unit components is a blob)
+                else { root = (int)kp_id(rp); job.parent[i] = root; job.kpar[i] = rp; }
             }
             __syncthreads();
-            if (root >= 0) {
-                uint32_t h = ((uint32_t)root * 2654435761u) >> 24;   // 8 bits
-                while (true) {                                         // (<= 256 members, 256 slots: a slot always turns up)
-                    const int old = atomicCAS(&s_root[h], -1, root);
-                    if (old == -1 || old == root) break;
-                    h = (h + 1u) & (RSLOTS - 1);
-                }
-                atomicAdd(&s_cnt[h], job.r_n[i]);
-                fix_atomic_add(&s_f[h], fix_load(job, i));
-                atomicAdd(&s_i[0][h], (unsigned long long)job.r_c[i]);
-                atomicAdd(&s_i[1][h], (unsigned long long)job.r_r[i]);
-                atomicAdd(&s_i[2][h], (unsigned long long)job.r_s[i]);
-                atomicMin(&s_key[h], job.r_key[i]);
-            }
+            if (root >= 0)
+                table_add(root, job.r_n[i], fix_load(job, i), (unsigned long long)job.r_c[i], (unsigned long long)job.r_r[i], (unsigned long long)job.r_s[i]);
             __syncthreads();
             for (int k = tid; k < RSLOTS; k += 256)
-                if (s_root[k] >= 0) fold((uint32_t)s_root[k], s_cnt[k], s_f[k], s_i[0][k], s_i[1][k], s_i[2][k], s_key[k]);
+                if (s_root[k] >= 0) fold((uint32_t)s_root[k], s_cnt[k], s_f[k], s_i[0][k], s_i[1][k], s_i[2][k]);
             __syncthreads();   // (the next round clears the table)
         }
         return;
@@ -1017,37 +1059,28 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
     const uint32_t i = (uint32_t)blockIdx.x * CCAP + tid;
     // everything this thread may need, in flight at once (unused ids hold stale bytes: loaded, never used)
     const uint32_t n_i = job.r_n[i];
-    const int p0 = uf_load(job.parent, (int)i);
+    const kp_t p0 = kuf_load(job.kpar, i);
     const FixSums v_sum = fix_load(job, i);
     const unsigned long long v_c = (unsigned long long)job.r_c[i], v_r = (unsigned long long)job.r_r[i], v_s = (unsigned long long)job.r_s[i], v_key = job.r_key[i];
-    for (int k = tid; k < RSLOTS; k += 256) {
-        s_root[k] = -1;
-        s_f[k] = fix_zero();
-        s_i[0][k] = 0ull; s_i[1][k] = 0ull; s_i[2][k] = 0ull; s_key[k] = ~0ull; s_cnt[k] = 0u;
+    clear_table();
+    const bool used = n_i > 0u && p0 != KP_UNUSED;
+    const bool is_root = used && kp_id(p0) == i;
+    const bool member = used && !is_root;   // non-root component with voxels
+    int root = (int)i;
+    if (member) {
+        const kp_t rp = kuf_find_from(job.kpar, p0);
+        root = (int)kp_id(rp);
+        job.kpar[i] = rp;
     }
-    int root = -1;
-    bool member = false;   // non-root component with voxels
-    if (n_i > 0u && p0 != (int)i) {
-        root = uf_find(job.parent, p0);
-        member = true;
-        job.parent[i] = root;
+    job.parent[i] = root;   // (every id of the tile: the accessors and the label writer go through parent[])
+    {   // the tile's roots as four ballots: k_emit_tiles maps its threads onto the set bits instead of scanning every component id
+        const unsigned long long rbits = __ballot(is_root);
+        if ((tid & 63) == 0) job.root_mask[(size_t)blockIdx.x * 4 + (tid >> 6)] = rbits;
     }
+    if (is_root) paint(v_key);
     __syncthreads();
     if (__syncthreads_or(member ? 1 : 0) == 0) return;   // nothing to fold in this tile
-    if (member) {
-        uint32_t h = ((uint32_t)root * 2654435761u) >> 24;   // 8 bits
-        while (true) {                                         // (<= 256 members, 256 slots: a slot always turns up)
-            const int old = atomicCAS(&s_root[h], -1, root);
-            if (old == -1 || old == root) break;
-            h = (h + 1u) & (RSLOTS - 1);
-        }
-        atomicAdd(&s_cnt[h], n_i);
-        fix_atomic_add(&s_f[h], v_sum);
-        atomicAdd(&s_i[0][h], v_c);
-        atomicAdd(&s_i[1][h], v_r);
-        atomicAdd(&s_i[2][h], v_s);
-        atomicMin(&s_key[h], v_key);
-    }
+    if (member) table_add(root, n_i, v_sum, v_c, v_r, v_s);
     __syncthreads();
     for (int k = tid; k < RSLOTS; k += 256) {
         if (s_root[k] < 0) continue;
@@ -1058,73 +1091,12 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
             InboxEntry e;
             e.local = root % CCAP; e.n = s_cnt[k];
             e.sum = s_f[k];
-            e.c = s_i[0][k]; e.r = s_i[1][k]; e.s = s_i[2][k]; e.key = s_key[k];
+            e.c = s_i[0][k]; e.r = s_i[1][k]; e.s = s_i[2][k];
             job.inbox[(size_t)rtile * INBOX_CAP + pos] = e;
         } else {
-            fold(root, s_cnt[k], s_f[k], s_i[0][k], s_i[1][k], s_i[2][k], s_key[k]);
+            fold(root, s_cnt[k], s_f[k], s_i[0][k], s_i[1][k], s_i[2][k]);
         }
     }
-}
-
-// Whole-map k_paint_keys, a workgroup per tile: first the tile's roots absorb what k_resolve_tiles posted to the tile's inbox
-// (summed in LDS, written back with plain stores), then every root paints its -- now final -- first key and bumps its
-// rank counter.  Workgroups beyond the tiles paint the roots among the unit components.
-__global__ void __launch_bounds__(256) k_paint_tiles(Job job, int n_tiles) {
-    const int tid = threadIdx.x;
-    auto paint = [&](unsigned long long key) {
-        const uint32_t f = (uint32_t)((key >> 6) / KEY_FINE);
-        atomicOr((unsigned long long *)&job.key_bits[key >> 6], 1ull << (key & 63));
-        atomicAdd(&job.fine_count[f >> 1], 1u << ((f & 1u) * 16u));
-    };
-    if ((int)blockIdx.x >= n_tiles) {
-        const uint32_t n_comp = n_components(job);
-        for (uint32_t i = (uint32_t)n_tiles * CCAP + (blockIdx.x - n_tiles) * 256u + tid; i < n_comp; i += (gridDim.x - n_tiles) * 256u)
-            if (job.parent[i] == (int32_t)i && job.r_n[i] != 0u) paint(job.r_key[i]);
-        return;
-    }
-    __shared__ FixSums s_f[CCAP];
-    __shared__ unsigned long long s_i[3][CCAP], s_key[CCAP];
-    __shared__ uint32_t s_cnt[CCAP];
-    const uint32_t i = (uint32_t)blockIdx.x * CCAP + tid;
-    const uint32_t n_in = min(job.inbox_count[(size_t)blockIdx.x * INBOX_STRIDE], (uint32_t)INBOX_CAP);   // block-uniform
-    const int32_t par = job.parent[i];
-    const uint32_t n_i = job.r_n[i];
-    unsigned long long key = job.r_key[i];
-    const bool root = par == (int32_t)i && n_i != 0u;
-    {   // the tile's roots as four ballots: k_emit maps its threads onto the set bits instead of scanning every component id
-        const unsigned long long rbits = __ballot(root);
-        if ((tid & 63) == 0) job.root_mask[(size_t)blockIdx.x * 4 + (tid >> 6)] = rbits;
-    }
-    if (n_in != 0u) {
-        InboxEntry e;
-        const bool have = (uint32_t)tid < n_in;
-        if (have) e = job.inbox[(size_t)blockIdx.x * INBOX_CAP + tid];   // (INBOX_CAP <= 256: one entry per thread; loading all 192
-                                                                         //  slots unconditionally to save the dependent trip measured SLOWER)
-        s_f[tid] = fix_zero();
-        s_i[0][tid] = 0ull; s_i[1][tid] = 0ull; s_i[2][tid] = 0ull; s_key[tid] = ~0ull; s_cnt[tid] = 0u;
-        __syncthreads();
-        if (have) {
-            const uint32_t l = e.local;
-            atomicAdd(&s_cnt[l], e.n);
-            fix_atomic_add(&s_f[l], e.sum);
-            atomicAdd(&s_i[0][l], e.c);
-            atomicAdd(&s_i[1][l], e.r);
-            atomicAdd(&s_i[2][l], e.s);
-            atomicMin(&s_key[l], e.key);
-        }
-        __syncthreads();
-        if (root && s_cnt[tid] != 0u) {   // (only roots receive: the posting side found this id as its root)
-            job.r_n[i] = n_i + s_cnt[tid];
-            FixSums mine = fix_load(job, i);
-            fix_add(mine, s_f[tid]);
-            fix_store(job, i, mine);
-            job.r_c[i] += (long long)s_i[0][tid];
-            job.r_r[i] += (long long)s_i[1][tid];
-            job.r_s[i] += (long long)s_i[2][tid];
-            if (s_key[tid] < key) { key = s_key[tid]; job.r_key[i] = key; }
-        }
-    }
-    if (root) paint(key);
 }
 
 // Signed labels, one workgroup per tile, all look-ups in LDS: the tile's label-of-component table

@@ -553,6 +553,10 @@ class DensityAnalysis(object):
         ratio = self.densityElectronRatio
         if not blobList:
             return []
+        if len(symmetryAtomCoords) == 0:
+            # no symmetry atoms (a file without REMARK 290 has no operators): the reference's cdist() of a centroid against an
+            # empty coordinate array raises this ValueError (densityAnalysis.py:933) -- an ordinary per-entry failure, not a device error
+            raise ValueError("XB must be a 2-dimensional array.")
         centroid = [blob.centroid for blob in blobList]
         total = np.array([blob.totalDensity for blob in blobList], dtype=np.float64)
         idx, dist = self.densityObj._ctx.nearest_atom(np.array(centroid, dtype=np.float64), np.asarray(symmetryAtomCoords, dtype=np.float64))

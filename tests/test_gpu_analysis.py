@@ -149,3 +149,30 @@ def test_silent_failure_contract(gpu_ctx):
     an2.aggregateCloud = lambda *a, **k: None
     with pytest.raises(RuntimeError):
         an2.calculateRegionDiscrepancy([st.child_list[0].child_list[0].child_list[0].child_list[0].coord], 3.5)
+
+
+def test_structure_without_symmetry_operators(gpu_ctx):
+    """A PDB file without REMARK 290 has NO operators (tests/golden/pdbheader.json): the reference then builds empty symmetry
+    atom lists (densityAnalysis.py:896-912, the loop over rotationMats runs zero times) and its blob statistics fail with
+    cdist's ValueError on the empty coordinate array (:933) -- an ordinary exception that drops the entry, never a library
+    error that stops a pool."""
+    import copy
+    from pdb_eda_amd import ccp4, synthetic, densityAnalysis
+    z, spec, st, pdb, params = load_analysis_case(ANALYSIS_CASES[0])
+    densityAnalysis.setGlobals(params)
+    dens = ccp4.parse(io.BytesIO(synthetic.ccp4_bytes(spec, z["dens"])), "nosym", ctx=gpu_ctx)
+    diff = ccp4.parse(io.BytesIO(synthetic.ccp4_bytes(spec, z["diff"])), "nosym", ctx=gpu_ctx)
+    densityAnalysis._attachCutoffs(dens, diff)
+    pdb = copy.deepcopy(pdb)
+    pdb.header.rotationMats = []
+    an = densityAnalysis.DensityAnalysis("nosym", dens, diff, st, pdb)
+    assert len(an.symmetryAtoms) == 0 and len(an.symmetryOnlyAtoms) == 0 and len(an.asymmetryAtoms) == 0
+    assert np.asarray(an.symmetryAtomCoords).shape[0] == 0
+    assert an.calculateAtomSpecificBlobStatistics([]) == []
+    blobs = an.greenBlobList
+    assert blobs
+    with pytest.raises(ValueError):
+        an.calculateAtomSpecificBlobStatistics(blobs)
+    # the raw C entry point with zero operators is an empty result, not an argument error
+    idx, sym, xyz = gpu_ctx.symmetry_atoms(np.zeros((3, 3)), np.zeros((0, 12)), np.eye(3), np.zeros(3), np.ones(3))
+    assert len(idx) == 0 and len(sym) == 0 and len(xyz) == 0
