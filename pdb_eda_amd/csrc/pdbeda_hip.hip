@@ -929,6 +929,7 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     // the rank counters sit right behind the bitmap (ONE clear covers both), padded to whole groups
     job.n_fine_alloc = (int32_t)((job.n_fine + job.fine_per_group - 1) / job.fine_per_group * job.fine_per_group);
     job.fine_count = cv.take<uint32_t>((size_t)std::max(job.n_fine_alloc / 2, 8));   // 16-bit counters, two per word
+    job.mid_count = cv.take<uint32_t>((size_t)(job.key_words + KEY_FINE - 1) / KEY_FINE * (KEY_FINE / 16));   // a byte per 4 key words: 8 per bucket
     job.run_base = cv.take<uint32_t>(total_words);
     job.comps_are_runs = n_tiles ? 0 : 1;
     job.comp_of_run = n_tiles ? cv.take<uint32_t>(max_runs) : nullptr;
@@ -1002,13 +1003,15 @@ static void launch_tile_label(pdbeda_ctx *ctx, unsigned n_tiles, const Job &job,
     }
 }
 
-static void launch_labels(pdbeda_ctx *ctx, const Job &job, const TileDims &td, int32_t *labels_dev) {
+// fused: the launch also ranks the roots and writes the blob table (k_emit_tiles is then not launched) -- see k_labels_tiles
+template <bool FUSED>
+static void launch_labels(pdbeda_ctx *ctx, const Job &job, const TileDims &td, int32_t *labels_dev, const Geom *geom_dev) {
     const unsigned n_tiles = (unsigned)(td.ctiles * td.rtiles * td.stiles);
     switch (td.cw) {
-        case 1: hipLaunchKernelGGL((k_labels_tiles<1>), dim3(n_tiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev); break;
-        case 2: hipLaunchKernelGGL((k_labels_tiles<2>), dim3(n_tiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev); break;
-        case 3: hipLaunchKernelGGL((k_labels_tiles<3>), dim3(n_tiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev); break;
-        default: hipLaunchKernelGGL((k_labels_tiles<4>), dim3(n_tiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev); break;
+        case 1: hipLaunchKernelGGL((k_labels_tiles<1, FUSED>), dim3(n_tiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev, geom_dev); break;
+        case 2: hipLaunchKernelGGL((k_labels_tiles<2, FUSED>), dim3(n_tiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev, geom_dev); break;
+        case 3: hipLaunchKernelGGL((k_labels_tiles<3, FUSED>), dim3(n_tiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev, geom_dev); break;
+        default: hipLaunchKernelGGL((k_labels_tiles<4, FUSED>), dim3(n_tiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev, geom_dev); break;
     }
 }
 
@@ -1094,10 +1097,12 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
         default: launch_tile_label<4>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init, pair_slots); break;
     }
     { PROF(ctx, "k_resolve_tiles"); hipLaunchKernelGGL(k_resolve_tiles, dim3((unsigned)tiles_pp + 64u), dim3(256), 0, st, job, (int)tiles_pp); }
-    { PROF(ctx, "k_emit_tiles"); hipLaunchKernelGGL(k_emit_tiles, dim3(std::min<unsigned>(512u, ((unsigned)tiles_pp + 1u) / 2u)), dim3(256), 0, st, job, m->geom_dev); }
-    if (labels) {
+    if (labels) {   // the label writer ranks the roots and writes the blob table itself: one launch
         PROF(ctx, "k_labels_tiles");
-        launch_labels(ctx, job, td, labels_dev);
+        launch_labels<true>(ctx, job, td, labels_dev, m->geom_dev);
+    } else {
+        PROF(ctx, "k_emit_tiles");
+        hipLaunchKernelGGL(k_emit_tiles, dim3(std::min<unsigned>(512u, ((unsigned)tiles_pp + 1u) / 2u)), dim3(256), 0, st, job, m->geom_dev);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { arena_put(ctx, arena); return fail(ctx, PDBEDA_ERR_DEVICE, "whole-map labelling launch: %s", hipGetErrorString(e)); }
@@ -1296,7 +1301,7 @@ extern "C" int pdbeda_bloblist_labels(pdbeda_bloblist *bl, int32_t *labels_host)
     const int32_t *signed_vol = bl->labels_dev;
     if (!have) {
         int32_t *tmp = (int32_t *)(a.base + align_up(4 * nvox));
-        launch_labels(ctx, bl->job, bl->td, tmp);
+        launch_labels<false>(ctx, bl->job, bl->td, tmp, bl->map->geom_dev);
         signed_vol = tmp;
     }
     hipLaunchKernelGGL(k_labels_decode, dim3(grid_for(nvox, 256, 4096)), dim3(256), 0, ctx->stream, signed_vol, nvox, bl->sign, decoded);
@@ -1441,7 +1446,7 @@ static int grouped_job(pdbeda_map *m, GroupSetup &gs, int64_t n_items, int64_t n
     if (n_groups > 0) e = hipMemcpyAsync(job.vols, gs.d_vols, sizeof(VolDesc) * n_groups, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess) e = hipMemsetAsync(job.ctr, 0, sizeof(Counters), st);
     if (e == hipSuccess)   // first-key bitmap + both levels of rank counters (adjacent in the arena)
-        e = hipMemsetAsync(job.key_bits, 0, (size_t)((char *)(job.fine_count + job.n_fine_alloc / 2) - (char *)job.key_bits), st);
+        e = hipMemsetAsync(job.key_bits, 0, (size_t)((char *)(job.mid_count + (job.key_words + KEY_FINE - 1) / KEY_FINE * (KEY_FINE / 16)) - (char *)job.key_bits), st);
     if (e == hipSuccess && job.total_words > 0) e = hipMemsetAsync(job.mask, 0, 8 * job.total_words, st);
     if (e == hipSuccess && n_items > 0) {
         if (spheres)

@@ -157,6 +157,10 @@ struct Job {
     // kernel that used to fold min keys into the roots before the keys could be painted (k_paint_tiles) is gone.  The value read
     // from kpar[x] carries the parent's key AND its id: a find costs the same trips as on ids.  ~0 = unused id.
     unsigned long long *kpar;
+    // a third level between the 16-bit counters (2048 keys) and the bitmap: one BYTE per 256 keys (4 bitmap words; two first
+    // voxels are never neighbours along s, so a byte holds at most 128) -- rank_of_key then reads 32 + 8 + 32 bytes where it read
+    // 32 + 256, few enough registers for the label writer to rank its own components (round 4)
+    uint32_t *mid_count;
 };
 
 struct InboxEntry {           // 88 bytes: what a (tile, root) pair folds into the root's record (no key: the root holds the first voxel)
@@ -491,7 +495,8 @@ __global__ void __launch_bounds__(256) k_union(Job job) {
     }
 }
 
-__device__ inline uint32_t n_components(const Job &job) { return job.comps_are_runs ? job.ctr->n_runs : job.ctr->n_comps; }
+template <typename JobRef>
+__device__ inline uint32_t n_components(const JobRef &job) { return job.comps_are_runs ? job.ctr->n_runs : job.ctr->n_comps; }
 
 // Thread per component: flatten, and fold non-root partial sums into the root record.  Runs are numbered in word order,
 // so the lanes of a wave mostly belong to a handful of components: the lanes that share a root are summed in the wave
@@ -550,6 +555,16 @@ __global__ void __launch_bounds__(256) k_resolve(Job job) {
     }
 }
 
+// A root paints its first key: the bit, the byte counter of the bit's 256-key cell, the 16-bit counter of its 2048-key bucket.
+template <typename JobRef>
+__device__ __forceinline__ void paint_key(const JobRef &job, unsigned long long key) {
+    const uint32_t f = (uint32_t)((key >> 6) / KEY_FINE);
+    const uint32_t cell = (uint32_t)(key >> 8);
+    atomicOr((unsigned long long *)&job.key_bits[key >> 6], 1ull << (key & 63));
+    atomicAdd(&job.mid_count[cell >> 2], 1u << ((cell & 3u) * 8u));
+    atomicAdd(&job.fine_count[f >> 1], 1u << ((f & 1u) * 16u));   // (a fine bucket holds 2048 keys: its count fits 16 bits)
+}
+
 // Blob order = ascending key of the blob's first voxel in the reference's c-major
 // enumeration (cutils.pyx:199 + 59-69).  Keys are unique positions, so the rank of a blob
 // is a prefix population count over a bitmap of first-voxel keys -- no sort needed, and no scan launch: k_paint_keys
@@ -562,9 +577,7 @@ __global__ void __launch_bounds__(256) k_paint_keys(Job job) {
         const uint32_t cnt = job.r_n[i];
         const unsigned long long key = job.r_key[i];    // (loaded beside the other two, not after them: one round trip, then the atomics)
         if (par != (int32_t)i || cnt == 0u) continue;   // not a root / unused id
-        const uint32_t f = (uint32_t)((key >> 6) / KEY_FINE);
-        atomicOr((unsigned long long *)&job.key_bits[key >> 6], 1ull << (key & 63));
-        atomicAdd(&job.fine_count[f >> 1], 1u << ((f & 1u) * 16u));   // (a fine bucket holds 2048 keys: its count fits 16 bits)
+        paint_key(job, key);
     }
 }
 
@@ -585,8 +598,9 @@ __device__ __forceinline__ uint32_t sum_u16_first(const uint4 q, int take) {
 // A thread owns KEY_GROUPS / 256 = 4 consecutive groups: all its loads are in flight at once (the table is one memory
 // round trip + one block scan, not a loop of dependent trips; 32 KiB per block at 256^3).  fine_count is padded to whole
 // groups and cleared with the bitmap.
-__device__ inline uint32_t rank_table_lds(const Job &job, uint32_t *s_pre /* [KEY_GROUPS] */, uint32_t *s_wave /* [4] */) {
-    constexpr int PER = KEY_GROUPS / 256;
+template <int NT = 256, typename JobRef = Job>
+__device__ inline uint32_t rank_table_lds(const JobRef &job, uint32_t *s_pre /* [KEY_GROUPS] */, uint32_t *s_wave /* [NT / 64] */) {
+    constexpr int PER = KEY_GROUPS / NT;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int G = job.fine_per_group, n_groups = (job.n_fine + G - 1) / G, Q = G / 8;   // quads (8 counters = 16 B) per group
     const uint4 *fine4 = reinterpret_cast<const uint4 *>(job.fine_count);
@@ -622,48 +636,48 @@ __device__ inline uint32_t rank_table_lds(const Job &job, uint32_t *s_pre /* [KE
     }
     if (lane == 63) s_wave[wv] = x;
     __syncthreads();
-    uint32_t pre = x - mine;
-    for (int k = 0; k < wv; ++k) pre += s_wave[k];
+    uint32_t pre = x - mine, total = 0;
+#pragma unroll
+    for (int k = 0; k < NT / 64; ++k) { const uint32_t w = s_wave[k]; pre += k < wv ? w : 0u; total += w; }
 #pragma unroll
     for (int k = 0; k < PER; ++k) { s_pre[tid * PER + k] = pre; pre += v[k]; }
-    const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
     __syncthreads();
     return total;
 }
 
-// Number of painted keys below `key` (s_pre: this block's rank_table_lds).  Branch-free for the common group size: the two
-// counter quads of the key's group and the 16 word pairs of its fine bucket are loaded whole and masked, so all 18 loads of a
-// thread are in flight together and the lanes of a wave do not wait for each other's trip counts.
-__device__ inline uint32_t rank_of_key(const Job &job, const uint32_t *s_pre, unsigned long long key) {
+// Number of painted keys below `key` (s_pre: this block's rank_table_lds) = table entry + the 16-bit counters of the key's group
+// before its bucket + the byte counters of the bucket before its cell + the bits of the cell's four words below the key.
+// Branch-free for the common group size: five loads (2 x 16 B of counters, 8 B of bytes, 2 x 16 B of bitmap), all in flight
+// together, masked afterwards -- the lanes of a wave do not wait for each other's trip counts.
+template <typename JobRef>
+__device__ inline uint32_t rank_of_key(const JobRef &job, const uint32_t *s_pre, unsigned long long key) {
     const int64_t kw = (int64_t)(key >> 6);
     const int G = job.fine_per_group, Q = G / 8;
     const int64_t f = kw / KEY_FINE, e = f / G;
     uint32_t rank = s_pre[e];
     const uint4 *fine4 = reinterpret_cast<const uint4 *>(job.fine_count) + e * Q;
     const int nf = (int)(f - e * G);                       // counters of my group before mine: < G
-    const ulonglong2 *bits2 = reinterpret_cast<const ulonglong2 *>(job.key_bits + f * KEY_FINE);   // (32 words: 16-B aligned; the bitmap is
-    const int nw = (int)(kw - f * KEY_FINE);               // whole words of my fine bucket before mine: < 32      padded to whole buckets)
+    const uint2 mid = reinterpret_cast<const uint2 *>(job.mid_count)[f];   // the 8 byte counters of my bucket (the tables are padded to whole buckets)
+    const ulonglong2 *bits2 = reinterpret_cast<const ulonglong2 *>(job.key_bits + (kw & ~(int64_t)3));   // my cell: 4 words, 32-B aligned
+    const int cell = (int)((kw - f * KEY_FINE) >> 2);      // cells of my bucket before mine: < 8
+    const int wi = (int)(kw & 3);                          // words of my cell before mine
+    const ulonglong2 b0 = bits2[0], b1 = bits2[1];
     if (Q == 2) {
         const uint4 q0 = fine4[0], q1 = fine4[1];
-        ulonglong2 b[KEY_FINE / 2];
-#pragma unroll
-        for (int k = 0; k < KEY_FINE / 2; ++k) b[k] = bits2[k];
         rank += sum_u16_first(q0, nf) + sum_u16_first(q1, nf - 8);
+    } else {
+        for (int k = 0; k * 8 < nf; ++k) rank += sum_u16_first(fine4[k], nf - k * 8);
+    }
+    {   // bytes 0 .. cell - 1 of the eight
+        const uint32_t lo = cell >= 4 ? mid.x : (mid.x & ((1u << (8 * cell)) - 1u));
+        const uint32_t hi = cell > 4 ? (mid.y & ((1u << (8 * (cell - 4))) - 1u)) : 0u;
+        rank += __builtin_amdgcn_sad_u8(lo, 0u, 0u) + __builtin_amdgcn_sad_u8(hi, 0u, 0u);
+    }
+    const uint64_t below = bits_below((int)(key & 63));
+    const uint64_t w[4] = {b0.x, b0.y, b1.x, b1.y};
 #pragma unroll
-        for (int k = 0; k < KEY_FINE / 2; ++k) {
-            const uint64_t lo = 2 * k < nw ? b[k].x : (2 * k == nw ? b[k].x & bits_below((int)(key & 63)) : 0ull);
-            const uint64_t hi = 2 * k + 1 < nw ? b[k].y : (2 * k + 1 == nw ? b[k].y & bits_below((int)(key & 63)) : 0ull);
-            rank += (uint32_t)popc64(lo) + (uint32_t)popc64(hi);
-        }
-        return rank;
-    }
-    for (int k = 0; k * 8 < nf; ++k) rank += sum_u16_first(fine4[k], nf - k * 8);
-#pragma unroll 4
-    for (int k = 0; k * 2 < nw; ++k) {
-        const ulonglong2 q = bits2[k];
-        rank += (uint32_t)popc64(q.x) + (nw - k * 2 > 1 ? (uint32_t)popc64(q.y) : 0u);
-    }
-    return rank + (uint32_t)popc64(job.key_bits[kw] & bits_below((int)(key & 63)));
+    for (int k = 0; k < 4; ++k) rank += (uint32_t)popc64(k < wi ? w[k] : (k == wi ? w[k] & below : 0ull));
+    return rank;
 }
 
 // Position of the k-th (0-based) set bit of m (k < popcount(m)).
@@ -678,11 +692,11 @@ __device__ __forceinline__ int nth_set_bit(uint64_t m, int k) {
 }
 
 // One blob table row (DensityBlob.fromCrsList, ccp4.py:542-545), the root's rank and -- whole-map jobs -- its signed label.
-__device__ __forceinline__ void emit_row(const Job &job, const Geom &g, const uint32_t *s_pre, bool whole_map, int64_t key_base1, uint32_t id,
-                                         uint32_t n_vox, unsigned long long first_key, const FixSums &fs, long long ic, long long ir, long long is) {
+template <typename JobRef>
+__device__ __forceinline__ void emit_row_ranked(const JobRef &job, const Geom &g, bool whole_map, int64_t key_base1, uint32_t id, uint32_t n_vox,
+                                                unsigned long long first_key, const FixSums &fs, long long ic, long long ir, long long is, uint32_t rank) {
     const double tot_q = (double)fs.rho, rc = fix_moment(fs.c_lo, fs.c_hi), rr = fix_moment(fs.r_lo, fs.r_hi), rs = fix_moment(fs.s_lo, fs.s_hi);
     const double tot = tot_q / job.fix_mul;      // (a power of two: exact)
-    const uint32_t rank = rank_of_key(job, s_pre, first_key);
     const int vi = whole_map ? ((int64_t)first_key >= key_base1 ? 1 : 0) : find_vol_by_key(job.vols, job.n_vols, (int64_t)first_key);
     // signed by its list, numbered by its rank in the WHOLE table: k_labels_tiles takes the blobs of volume 0 off the
     // labels of volume 1 (ctr->n_blobs_vol0) -- here that count would be a second dependent round trip before any root
@@ -707,10 +721,16 @@ __device__ __forceinline__ void emit_row(const Job &job, const Geom &g, const ui
     job.b_key[rank] = (int64_t)first_key - vd.key_base;
     job.b_group[rank] = vd.group;
 }
+template <typename JobRef>
+__device__ __forceinline__ void emit_row(const JobRef &job, const Geom &g, const uint32_t *s_pre, bool whole_map, int64_t key_base1, uint32_t id,
+                                         uint32_t n_vox, unsigned long long first_key, const FixSums &fs, long long ic, long long ir, long long is) {
+    emit_row_ranked(job, g, whole_map, key_base1, id, n_vox, first_key, fs, ic, ir, is, rank_of_key(job, s_pre, first_key));
+}
 
 // Grid-stride over component ids [first, n_comp): the roots among them emit their rows (generic jobs: every id; whole-map
 // jobs: the unit components above the tiles' id ranges).  The next trip's first step rides along.
-__device__ inline void emit_ids(const Job &job, const Geom &g, const uint32_t *s_pre, bool whole_map, int64_t key_base1, uint32_t first, uint32_t n_comp) {
+template <typename JobRef>
+__device__ inline void emit_ids(const JobRef &job, const Geom &g, const uint32_t *s_pre, bool whole_map, int64_t key_base1, uint32_t first, uint32_t n_comp) {
     const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t i = first + blockIdx.x * blockDim.x + threadIdx.x;
     int32_t par = i < n_comp ? job.parent[i] : -1;

@@ -931,6 +931,9 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__r
         const int64_t nfc = job.n_fine_alloc / 2;   // (16-bit counters, two per word)
         const int64_t perc = (nfc + n_tiles - 1) / n_tiles, clo = perc * tile, chi = clo + perc < nfc ? clo + perc : nfc;
         for (int64_t i = clo + tid; i < chi; i += NTH) job.fine_count[i] = 0u;
+        const int64_t nmid = (key_words + KEY_FINE - 1) / KEY_FINE * (KEY_FINE / 16);   // (a byte per 4 key words, four per word; whole buckets)
+        const int64_t perm = (nmid + n_tiles - 1) / n_tiles, mlo = perm * tile, mhi = mlo + perm < nmid ? mlo + perm : nmid;
+        for (int64_t i = mlo + tid; i < mhi; i += NTH) job.mid_count[i] = 0u;
         if (tid == 0) job.inbox_count[(size_t)tile * INBOX_STRIDE] = 0u;
     }
     if (any_unit) {
@@ -1002,11 +1005,7 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
         atomicAdd((unsigned long long *)&job.r_r[root], r);
         atomicAdd((unsigned long long *)&job.r_s[root], s);
     };
-    auto paint = [&](unsigned long long key) {
-        const uint32_t f = (uint32_t)((key >> 6) / KEY_FINE);
-        atomicOr((unsigned long long *)&job.key_bits[key >> 6], 1ull << (key & 63));
-        atomicAdd(&job.fine_count[f >> 1], 1u << ((f & 1u) * 16u));
-    };
+    auto paint = [&](unsigned long long key) { paint_key(job, key); };
     __shared__ int s_root[RSLOTS];
     __shared__ FixSums s_f[RSLOTS];
     __shared__ unsigned long long s_i[3][RSLOTS];
@@ -1105,21 +1104,42 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
 // Unit tiles / tiles with too many runs take the global look-up path (same result).
 // (Measured and dropped: two tiles per workgroup with the second tile's tables fetched under the first tile's stores --
 //  27.8 us against 20.4; the store stream of a plain zero fill of the volume takes 10 us.)
+//
+// FUSED (round 4; the launch that labels a job as part of pdbeda_full_blobs*): the kernel also does what k_emit_tiles does.
+// A component's root is named by its FIRST KEY (kpar[], compressed by k_resolve_tiles), and a label is the rank of that key:
+// every tile ranks the roots of its own components itself (the prefix table over the rank counters is built by every
+// workgroup, as in k_emit_tiles; rank_of_key is five loads), so nobody waits for a label table that another kernel wrote --
+// the prologue stays at two memory round trips (kpar + masks + table | ranks + inbox), where a separate k_emit_tiles in
+// front cost a launch, a table and three trips of its own.  Waves 4-7 meanwhile hold the records of the tile's own
+// components: the roots among them add what the other tiles POSTED to the tile's inbox (summed in LDS) and write their blob
+// table rows.  The non-fused form (labels asked for later, pdbeda_bloblist_labels) reads the label table k_emit_tiles wrote.
 constexpr int LCAP = 4096;  // word-runs of a tile whose run -> component bytes fit the LDS table
-template <int CW>
 #ifndef PDBEDA_LABELS_NT_THREADS
 #define PDBEDA_LABELS_NT_THREADS 512
 #endif
-__global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS) k_labels_tiles(Job job, TileDims td, int32_t *__restrict__ labels) {
+template <int CW, bool FUSED>
+__global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS, FUSED ? 8 : 1) k_labels_tiles(Job job_arg, TileDims td, int32_t *__restrict__ labels, const Geom *__restrict__ gp) {
+    // the job is read from the kernel-argument segment where it is used (see PDBEDA_LATE_JOB): its ~45 pointers do not fit the
+    // scalar registers beside the row loop -- passed by value they were copied to scratch at entry
+    PDBEDA_LATE_JOB(lj);
     constexpr int NU = 64 * CW;
     constexpr int NTL = PDBEDA_LABELS_NT_THREADS, RPW = 64 / (NTL / 64);   // rows of the tile per wave
     __shared__ int32_t s_lab[CCAP];
-    __shared__ uint8_t s_comp8[LCAP + 4];
     // per 32-bit half of a mask word (a lane's 4 voxels live in one half): the mask halves of both signs side by side, and
     // per sign the half's run starts beside the tile-local id of the run before its first start -- what a lane needs of a
-    // word, as two 8-byte reads, with nothing left to compute per row that does not depend on the lane's own bits
-    __shared__ uint2 s_mh[2 * 256];
-    __shared__ uint2 s_sb[2][2 * 256];
+    // word, as two 8-byte reads, with nothing left to compute per row that does not depend on the lane's own bits.
+    // FUSED: the inbox accumulators (20 KiB + 1 KiB) live in the same bytes first -- the row tables are written once the roots
+    // have read them (the kernel must stay at four workgroups a CU: 1 024 tiles, one round).
+    constexpr size_t TABLE_BYTES = (LCAP + 8) + sizeof(uint2) * (2 * 256) * 3, ACC_BYTES = 8 * 10 * CCAP + 4 * CCAP;
+    __shared__ __attribute__((aligned(16))) unsigned char s_buf[FUSED ? (ACC_BYTES > TABLE_BYTES ? ACC_BYTES : TABLE_BYTES) : TABLE_BYTES];
+    uint2 *s_mh = reinterpret_cast<uint2 *>(s_buf);                                   // [2 * 256]
+    uint2 (*s_sb)[2 * 256] = reinterpret_cast<uint2 (*)[2 * 256]>(s_buf + sizeof(uint2) * 2 * 256);   // [2][2 * 256]
+    uint8_t *s_comp8 = s_buf + sizeof(uint2) * (2 * 256) * 3;                         // [LCAP + 4]
+    unsigned long long (*s_acc)[CCAP] = reinterpret_cast<unsigned long long (*)[CCAP]>(s_buf);   // [10][CCAP]: the seven FixSums fields, sum c / r / s
+    uint32_t *s_accn = reinterpret_cast<uint32_t *>(s_buf + 8 * 10 * CCAP);          // [CCAP]
+    __shared__ uint32_t s_pre[FUSED ? KEY_GROUPS : 1];
+    __shared__ uint32_t s_wave[NTL / 64];
+    __shared__ uint32_t s_vol0;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wvs = __builtin_amdgcn_readfirstlane(wv);
     const int uc = td.uc, ur = td.ur, us = td.us, row_words = td.row_words;
@@ -1135,29 +1155,148 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS) k_labels_tiles(Job j
     static_assert(NTL == 512 && LCAP == 4096, "four unconditional comp loads per thread cover the first 2048 runs");
     uint32_t c_pre[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) c_pre[k] = job.comp_of_run[rb + tid + NTL * k];
-    const int32_t lab_pre = tid < CCAP ? job.label_of_comp[job.parent[cb + tid]] : 0;   // (the root of a component carries its label)
-    // k_emit numbers the blobs of volume 1 by their rank in the whole table: their labels are -1 - rank, and the blobs of
-    // volume 0 come off here (one scalar load beside the others)
-    const int32_t vol0 = job.n_vols > 1 ? (int32_t)job.ctr->n_blobs_vol0 : 0;
+    for (int k = 0; k < 4; ++k) c_pre[k] = lj.comp_of_run[rb + tid + NTL * k];
+    // (tile-local: a byte each -- packed at once, one register through the prologue instead of four)
+    const uint32_t c_pack = ((c_pre[0] - cb) & 0xffu) | (((c_pre[1] - cb) & 0xffu) << 8) | (((c_pre[2] - cb) & 0xffu) << 16) | ((c_pre[3] - cb) << 24);
+    // non-fused: the root of a component carries its label (k_emit_tiles).  k_emit_tiles numbers the blobs of volume 1 by their
+    // rank in the whole table: their labels are -1 - rank, and the blobs of volume 0 come off here (one scalar load beside the others)
+    int32_t lab_pre = 0;
+    int32_t vol0 = 0;
+    if (!FUSED) {
+        lab_pre = tid < CCAP ? lj.label_of_comp[lj.parent[cb + tid]] : 0;
+        vol0 = lj.n_vols > 1 ? (int32_t)lj.ctr->n_blobs_vol0 : 0;
+    }
+    // fused: what kpar[] holds for my component -- its root's first key and id
+    kp_t kp = KP_UNUSED;
+    const int64_t key_base1 = (FUSED && lj.n_vols > 1) ? lj.vols[1].key_base : INT64_MAX;
+    uint32_t n_in = 0;
+    // (waves 4-7, thread j = tid - 256: the record of component j of the tile if it is a root, loaded beside the inbox)
+    const uint32_t jd = cb + (uint32_t)(tid & 255);
+    uint32_t rec_n = 0;
+    FixSums rec_f = fix_zero();
+    long long rec_c = 0, rec_r = 0, rec_s = 0;
+    if (FUSED) {
+        kp = kuf_load(lj.kpar, jd);
+        n_in = lj.inbox_count[(size_t)blockIdx.x * INBOX_STRIDE];
+    }
     auto own_list = [&](int32_t lab) { return lab < 0 ? lab + vol0 : lab; };
-    const bool unit = job.tile_mode[tile_index(td, 0, w0, r0, s0)] != 0;
-    const uint32_t n_runs = unit ? 0u : job.tile_runs[blockIdx.x];
+    const bool unit = lj.tile_mode[tile_index(td, 0, w0, r0, s0)] != 0;
+    const uint32_t n_runs = unit ? 0u : lj.tile_runs[blockIdx.x];
     const bool fast = !unit && n_runs <= (uint32_t)LCAP;   // block-uniform
-    {
-        const int wl = tid % CW, rowl = (tid / CW) & 63;
-        const int r = r0 + (rowl & 7), s = s0 + (rowl >> 3);
-        const bool valid = tid < NU && r < ur && s < us && w0 + wl < row_words;
-        const int64_t w = ((int64_t)s * ur + r) * row_words + (w0 + wl);
-        if (tid < 256) {
-            uint64_t m[2];
-            uint32_t base[2];
+    const int pwl = tid % CW, prowl = (tid / CW) & 63;
+    const int pr = r0 + (prowl & 7), ps = s0 + (prowl >> 3);
+    const bool pvalid = tid < NU && pr < ur && ps < us && w0 + pwl < row_words;
+    const int64_t pw = ((int64_t)ps * ur + pr) * row_words + (w0 + pwl);
+    uint64_t m[2] = {0ull, 0ull};
+    uint32_t base[2] = {0u, 0u};
+    if (tid < 256) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const bool has = valid && p < td.n_planes;
-                m[p] = has ? job.mask[w + p * plane_words] : 0ull;
-                base[p] = has ? job.run_base[w + p * plane_words] : 0u;
+        for (int p = 0; p < 2; ++p) {
+            const bool has = pvalid && p < td.n_planes;
+            m[p] = has ? lj.mask[pw + p * plane_words] : 0ull;
+            base[p] = has ? lj.run_base[pw + p * plane_words] : 0u;
+        }
+    }
+    uint32_t total_blobs = 0;
+    // label of the blob whose root is named by value v: signed by the root's plane, numbered by the rank of its first key
+    auto label_of_value = [&](kp_t v) -> int32_t {
+        const uint32_t key32 = (uint32_t)(v >> 32);
+        const int plane = (int)(key32 >> 31);
+        const unsigned long long key = (unsigned long long)(plane ? key_base1 : 0) + (key32 & 0x7fffffffu);
+        const int32_t rank = (int32_t)rank_of_key(lj, s_pre, key);
+        return lj.vol_sign[plane] > 0 ? 1 + rank : -1 - rank;
+    };
+    if (FUSED) {
+        // (unconditionally: waiting for the inbox count here would hold back the table's loads; its barriers publish the zeros)
+        for (int i = tid; i < 10 * CCAP; i += NTL) (&s_acc[0][0])[i] = 0ull;
+        if (tid < CCAP) s_accn[tid] = 0u;
+        total_blobs = rank_table_lds<NTL>(lj, s_pre, s_wave);   // (two barriers inside)
+        n_in = min(n_in, (uint32_t)INBOX_CAP);
+        // ---- second trip: waves 0-3 fetch the tile's inbox (an entry per thread) and rank the roots of their components;
+        //      waves 4-7 fetch the records of the tile's own roots.  Everything is issued before anything is consumed. ----
+        static_assert(INBOX_CAP <= 256, "an inbox entry per thread of the lower half");
+        const bool used = kp != KP_UNUSED;
+        // an inbox entry is eleven 8-byte words (local | n, the seven FixSums fields, sum c / r / s): thread t of the lower half
+        // takes words 0-4 of entry t, thread t + 256 words 5-10 (and word 0 again, for the slot).  The two halves of the
+        // workgroup run DIFFERENT code from here to the barrier (whole waves: no divergence), and what one half holds is
+        // defined inside its own region -- a value loaded in front of the other half's code would be live across it for the
+        // register allocator (22 registers of entry + 24 of record beside the rank loads spilled to scratch).
+        static_assert(sizeof(InboxEntry) == 88, "eleven words");
+        const bool have = (uint32_t)(tid & 255) < n_in;
+        const unsigned long long *ew = reinterpret_cast<const unsigned long long *>(lj.inbox + (size_t)blockIdx.x * INBOX_CAP + (tid & 255));
+        const bool my_root = tid >= 256 && used && kp_id(kp) == jd;   // a root of this tile: its blob's table row is mine
+        if (tid < 256) {
+            unsigned long long e_head = 0ull, e_w[4] = {0ull, 0ull, 0ull, 0ull};
+            if (have) {
+                e_head = ew[0];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e_w[k] = ew[1 + k];
             }
+            // thread 255 also ranks the first key of volume 1 (= the blobs of volume 0): in the slot of its own component if
+            // that id is unused, as it nearly always is -- a second pass otherwise
+            const bool vol0_lane = tid == 255 && key_base1 != INT64_MAX;
+            int32_t raw = 0;
+            if (used || vol0_lane) {
+                const uint32_t key32 = (uint32_t)(kp >> 32);
+                const int plane = used ? (int)(key32 >> 31) : 1;
+                const unsigned long long key = (unsigned long long)(plane ? key_base1 : 0) + (used ? (key32 & 0x7fffffffu) : 0u);
+                const int32_t rank = (int32_t)rank_of_key(lj, s_pre, key);
+                if (used) raw = lj.vol_sign[plane] > 0 ? 1 + rank : -1 - rank;
+                else s_vol0 = (uint32_t)rank;
+            }
+            if (vol0_lane && used) s_vol0 = rank_of_key(lj, s_pre, (unsigned long long)key_base1);   // (a tile with all 256 ids in use)
+            if (tid == 255 && key_base1 == INT64_MAX) s_vol0 = total_blobs;
+            s_lab[tid] = raw;
+            if (have) {   // (the accumulators were cleared in front of the table's barriers)
+                const uint32_t l = (uint32_t)e_head;
+                atomicAdd(&s_accn[l], (uint32_t)(e_head >> 32));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) atomicAdd(&s_acc[k][l], e_w[k]);
+            }
+        } else {
+            unsigned long long e_head = 0ull, e_w[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+            if (have) {
+                e_head = ew[0];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) e_w[k] = ew[5 + k];
+            }
+            if (my_root) {
+                rec_n = lj.r_n[jd];
+                rec_f = fix_load(lj, jd);
+                rec_c = lj.r_c[jd]; rec_r = lj.r_r[jd]; rec_s = lj.r_s[jd];
+            }
+            if (have) {
+                const uint32_t l = (uint32_t)e_head;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) atomicAdd(&s_acc[4 + k][l], e_w[k]);
+            }
+        }
+        __syncthreads();
+        const uint32_t blobs_vol0 = s_vol0;                            // (one volume: every blob, as k_emit_tiles publishes it)
+        vol0 = key_base1 != INT64_MAX ? (int32_t)blobs_vol0 : 0;       // what comes off the labels of volume 1
+        if (my_root) {
+            const int l = tid - 256;
+            if (n_in != 0u) {
+                rec_n += s_accn[l];
+                rec_f.rho += (long long)s_acc[0][l];
+                rec_f.c_lo += (long long)s_acc[1][l]; rec_f.c_hi += (long long)s_acc[2][l];
+                rec_f.r_lo += (long long)s_acc[3][l]; rec_f.r_hi += (long long)s_acc[4][l];
+                rec_f.s_lo += (long long)s_acc[5][l]; rec_f.s_hi += (long long)s_acc[6][l];
+                rec_c += (long long)s_acc[7][l]; rec_r += (long long)s_acc[8][l]; rec_s += (long long)s_acc[9][l];
+            }
+            const uint32_t key32 = (uint32_t)(kp >> 32);
+            const unsigned long long key = (unsigned long long)((key32 >> 31) ? key_base1 : 0) + (key32 & 0x7fffffffu);
+            const int32_t lab = s_lab[l];
+            emit_row_ranked(lj, *gp, true, key_base1, jd, rec_n, key, rec_f, rec_c, rec_r, rec_s, (uint32_t)(lab > 0 ? lab - 1 : -1 - lab));
+        }
+        if (blockIdx.x == 0 && tid == 0) {   // the table's totals, for the host
+            lj.ctr->n_blobs = total_blobs;
+            lj.ctr->n_blobs_vol0 = blobs_vol0;
+        }
+        __syncthreads();   // (the accumulators have been read: their bytes become the row tables)
+    }
+    {
+        if (tid < 256) {
             s_mh[2 * tid] = make_uint2((uint32_t)m[0], (uint32_t)m[1]);
             s_mh[2 * tid + 1] = make_uint2((uint32_t)(m[0] >> 32), (uint32_t)(m[1] >> 32));
 #pragma unroll
@@ -1168,11 +1307,11 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS) k_labels_tiles(Job j
                 s_sb[p][2 * tid + 1] = make_uint2(shi, before + (uint32_t)__popc(slo));
             }
         }
-        if (tid < CCAP) s_lab[tid] = own_list(lab_pre);
+        if (tid < CCAP) s_lab[tid] = own_list(FUSED ? s_lab[tid] : lab_pre);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s_comp8[tid + NTL * k] = (uint8_t)(c_pre[k] - cb);
+        for (int k = 0; k < 4; ++k) s_comp8[tid + NTL * k] = (uint8_t)(c_pack >> (8 * k));
         if (fast)
-            for (uint32_t i = tid + 4 * NTL; i < n_runs; i += NTL) s_comp8[i] = (uint8_t)(job.comp_of_run[rb + i] - cb);
+            for (uint32_t i = tid + 4 * NTL; i < n_runs; i += NTL) s_comp8[i] = (uint8_t)(lj.comp_of_run[rb + i] - cb);
     }
     __syncthreads();
     // wave wv writes RPW rows of the tile; a lane owns 4 consecutive voxels of a 256-voxel row.  A voxel carries one sign, and
@@ -1186,6 +1325,12 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS) k_labels_tiles(Job j
     const uint32_t lowm = (1u << sh) - 1u;
     const int c = w0 * 64 + lane * 4;
     const bool inside = (r0 + TILE_R <= ur) && (s0 + TILE_S <= us) && ((w0 + CW) * 64 <= uc) && (uc & 3) == 0;   // block-uniform
+    // the label of a run by its global id (unit tiles): through its component to the root; fused, the root's key is ranked here
+    auto label_of_run = [&](uint32_t run) -> int32_t {
+        const uint32_t comp = lj.comp_of_run[run];
+        if (FUSED) return own_list(label_of_value(kuf_load(lj.kpar, comp)));
+        return own_list(lj.label_of_comp[lj.parent[comp]]);
+    };
     auto rows = [&](auto fast_tag, auto inside_tag) {
         constexpr bool FAST = decltype(fast_tag)::value, INSIDE = decltype(inside_tag)::value;
         auto group = [&](int p, unsigned nib, int hidx, int32_t (&o)[4]) {
@@ -1199,14 +1344,15 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS) k_labels_tiles(Job j
             int32_t la, lb;
             if (FAST) { la = s_lab[s_comp8[run]]; lb = s_lab[s_comp8[run + 1u]]; }   // (lb: read, used only behind s2 -- the table has LCAP + 4 bytes)
             else {
-                la = own_list(job.label_of_comp[job.parent[job.comp_of_run[run + rb]]]);
-                lb = s2 ? own_list(job.label_of_comp[job.parent[job.comp_of_run[run + rb + 1u]]]) : 0;
+                la = label_of_run(run + rb);
+                lb = s2 ? label_of_run(run + rb + 1u) : 0;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 o[k] |= (__builtin_amdgcn_sbfe((int)abits, k, 1) & la) | (__builtin_amdgcn_sbfe((int)bbits, k, 1) & lb);
         };
-#pragma unroll
+        constexpr int ROW_UNROLL = FAST ? RPW : 1;
+#pragma unroll ROW_UNROLL   // (the look-ups of a unit tile go through memory and, fused, through rank_of_key: rare, kept small)
         for (int rr = 0; rr < RPW; ++rr) {
             const int rowl = wvs * RPW + rr;
             const int r = r0 + (rowl & 7), s = s0 + (rowl >> 3);
@@ -1239,6 +1385,13 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS) k_labels_tiles(Job j
     };
     if (fast) { if (inside) rows(std::true_type{}, std::true_type{}); else rows(std::true_type{}, std::false_type{}); }
     else { if (inside) rows(std::false_type{}, std::true_type{}); else rows(std::false_type{}, std::false_type{}); }
+    if (FUSED) {   // unit components (every run of a tile that overflowed LDS its own component): none on ordinary maps
+        const bool any_unit = *lj.unit_flag == lj.epoch;   // block-uniform
+        if (any_unit) {
+            const uint32_t n_comp = n_components(lj), first = (uint32_t)lj.n_tiles * (uint32_t)TILE_COMPS;
+            if (n_comp > first) emit_ids(lj, *gp, s_pre, true, key_base1, first, n_comp);
+        }
+    }
 }
 
 // Decode the signed volume for one list: -1 background / other sign, else 0-based blob index.
