@@ -994,7 +994,7 @@ static pdbeda_bloblist *new_list(pdbeda_ctx *ctx, pdbeda_map *m) {
 template <int CW>
 static void launch_tile_label(pdbeda_ctx *ctx, unsigned n_tiles, const Job &job, const float *dens, const Geom *geom_dev, const TileDims &td,
                               const JobInit &init, int pair_slots) {
-    { PROF(ctx, "k_tile_label"); hipLaunchKernelGGL((k_tile_label<CW>), dim3(n_tiles), dim3(512), 0, ctx->stream, job, dens, geom_dev, td, init); }
+    { PROF(ctx, "k_tile_label"); hipLaunchKernelGGL((k_tile_label<CW>), dim3(td.ctiles, td.rtiles, td.stiles), dim3(512), 0, ctx->stream, job, dens, geom_dev, td, init); }
     // cross-tile unions (and, when a tile overflowed LDS, every pair that has such a tile on either side)
     {   // (grids of one tile column have no c faces: two waves fewer per workgroup to dispatch)
         PROF(ctx, "k_face_merge");
@@ -1008,10 +1008,10 @@ template <bool FUSED>
 static void launch_labels(pdbeda_ctx *ctx, const Job &job, const TileDims &td, int32_t *labels_dev, const Geom *geom_dev) {
     const unsigned n_tiles = (unsigned)(td.ctiles * td.rtiles * td.stiles);
     switch (td.cw) {
-        case 1: hipLaunchKernelGGL((k_labels_tiles<1, FUSED>), dim3(n_tiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev, geom_dev); break;
-        case 2: hipLaunchKernelGGL((k_labels_tiles<2, FUSED>), dim3(n_tiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev, geom_dev); break;
-        case 3: hipLaunchKernelGGL((k_labels_tiles<3, FUSED>), dim3(n_tiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev, geom_dev); break;
-        default: hipLaunchKernelGGL((k_labels_tiles<4, FUSED>), dim3(n_tiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev, geom_dev); break;
+        case 1: hipLaunchKernelGGL((k_labels_tiles<1, FUSED>), dim3(td.ctiles, td.rtiles, td.stiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev, geom_dev); break;
+        case 2: hipLaunchKernelGGL((k_labels_tiles<2, FUSED>), dim3(td.ctiles, td.rtiles, td.stiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev, geom_dev); break;
+        case 3: hipLaunchKernelGGL((k_labels_tiles<3, FUSED>), dim3(td.ctiles, td.rtiles, td.stiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev, geom_dev); break;
+        default: hipLaunchKernelGGL((k_labels_tiles<4, FUSED>), dim3(td.ctiles, td.rtiles, td.stiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev, geom_dev); break;
     }
 }
 

@@ -730,9 +730,10 @@ __device__ __forceinline__ void emit_row(const JobRef &job, const Geom &g, const
 // Grid-stride over component ids [first, n_comp): the roots among them emit their rows (generic jobs: every id; whole-map
 // jobs: the unit components above the tiles' id ranges).  The next trip's first step rides along.
 template <typename JobRef>
-__device__ inline void emit_ids(const JobRef &job, const Geom &g, const uint32_t *s_pre, bool whole_map, int64_t key_base1, uint32_t first, uint32_t n_comp) {
-    const uint32_t stride = gridDim.x * blockDim.x;
-    uint32_t i = first + blockIdx.x * blockDim.x + threadIdx.x;
+__device__ inline void emit_ids(const JobRef &job, const Geom &g, const uint32_t *s_pre, bool whole_map, int64_t key_base1, uint32_t first, uint32_t n_comp,
+                                uint32_t block, uint32_t n_blocks) {   // (the caller's linear workgroup id and count: its grid may be 3-D)
+    const uint32_t stride = n_blocks * blockDim.x;
+    uint32_t i = first + block * blockDim.x + threadIdx.x;
     int32_t par = i < n_comp ? job.parent[i] : -1;
     uint32_t cnt = i < n_comp ? job.r_n[i] : 0u;
     unsigned long long key = i < n_comp ? job.r_key[i] : 0ull;
@@ -756,7 +757,7 @@ __global__ void __launch_bounds__(256) k_emit(Job job, const Geom *__restrict__ 
     __shared__ uint32_t s_pre[KEY_GROUPS];
     __shared__ uint32_t s_wave[4];
     const uint32_t total = rank_table_lds(job, s_pre, s_wave);
-    emit_ids(job, *gp, s_pre, false, INT64_MAX, 0u, n_components(job));
+    emit_ids(job, *gp, s_pre, false, INT64_MAX, 0u, n_components(job), blockIdx.x, gridDim.x);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         job.ctr->n_blobs = total;
         job.ctr->n_blobs_vol0 = total;
@@ -849,7 +850,7 @@ __global__ void __launch_bounds__(256) k_emit_tiles(Job job, const Geom *__restr
     }
     {   // unit components (every run of a tile that overflowed LDS its own component): none on ordinary maps
         const uint32_t n_comp = n_components(job), first = (uint32_t)n_tiles * (uint32_t)TILE_COMPS;
-        if (n_comp > first) emit_ids(job, g, s_pre, true, key_base1, first, n_comp);
+        if (n_comp > first) emit_ids(job, g, s_pre, true, key_base1, first, n_comp, blockIdx.x, gridDim.x);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {   // the table's totals, for the host and for k_labels_tiles
         uint32_t below1 = total;                 // blobs before volume 1; every blob when there is one volume

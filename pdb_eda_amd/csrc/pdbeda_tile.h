@@ -136,6 +136,20 @@ typedef const Job __attribute__((address_space(4))) *JobKernarg;
     asm volatile("" : "+s"(name##_p));                                             \
     const Job __attribute__((address_space(4))) &name = *name##_p
 
+// A kernel that reads its arguments late reads them in many small scalar loads, each behind a wait; the kernel-argument
+// segment is cold in the scalar cache at kernel start, so every new 64-byte line of it costs a trip to memory -- ten of them in
+// a row held the fused label writer's first loads back by ~5 us (stamps).  Touching all lines at once, at entry, makes that
+// one trip: the later loads hit the scalar cache.  (seven lines: Job + TileDims + the two pointers behind them)
+__device__ __forceinline__ void kernarg_prefetch7() {
+    JobKernarg ka = (JobKernarg)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t d0, d1, d2, d3, d4, d5, d6;
+    asm volatile("s_load_dword %0, %7, 0x0\n\ts_load_dword %1, %7, 0x40\n\ts_load_dword %2, %7, 0x80\n\ts_load_dword %3, %7, 0xc0\n\t"
+                 "s_load_dword %4, %7, 0x100\n\ts_load_dword %5, %7, 0x140\n\ts_load_dword %6, %7, 0x180\n\t"
+                 "s_waitcnt lgkmcnt(0)"   // (inside the statement: the registers are the compiler's again behind it, and a load must not land later)
+                 : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6) : "s"(ka) : "memory");
+}
+static_assert(sizeof(Job) + sizeof(TileDims) + 16 > 0x180 && sizeof(Job) + sizeof(TileDims) + 16 <= 0x1c0, "seven 64-byte lines of kernel arguments");
+
 // Lock-free union in an LDS parent table (parent[x] <= x, roots point at themselves): find both roots, hang the larger
 // under the smaller with an atomic min; if the larger was no root any more, carry on with its new parent.
 // (find splits the path it walks: every node on it is re-pointed at its grandparent with a plain store.  A store that
@@ -255,10 +269,10 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
 
     const int uc = td.uc, ur = td.ur, us = td.us;   // (kernel arguments: no dependent load through gp before the stream can start)
     const int nc = td.nc, nr = td.nr;
-    int t = blockIdx.x;
-    const int ct = t % td.ctiles; t /= td.ctiles;
-    const int rt = t % td.rtiles; t /= td.rtiles;
-    const int st = t;
+    // (a 3-D grid: the tile coordinates come with the workgroup -- two integer divisions here were ~50 scalar instructions in
+    //  every wave, and the scalar unit of a CU serves all 32 of them.  Workgroups are dealt x fastest: tile order, as before)
+    const int ct = (int)blockIdx.x, rt = (int)blockIdx.y, st = (int)blockIdx.z;
+    const uint32_t bid = ((uint32_t)st * (uint32_t)td.rtiles + (uint32_t)rt) * (uint32_t)td.ctiles + (uint32_t)ct;
     const int w0 = ct * CW, r0 = rt * TILE_R, s0 = st * TILE_S;
     const int row_words = (uc + 63) >> 6;
     const int n_planes = td.n_planes;
@@ -266,7 +280,7 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
     {
         PDBEDA_LATE_JOB(pj);
         if (tid == 0) s_ncomp = 0;
-        if (blockIdx.x == 0 && tid == 0) {   // read by the kernels that follow; nothing in this kernel touches them
+        if (bid == 0 && tid == 0) {   // read by the kernels that follow; nothing in this kernel touches them
             pj.vols[0] = init.v[0];
             if (td.n_planes > 1) pj.vols[1] = init.v[1];
             Counters c;
@@ -392,15 +406,15 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
     const bool my_valid = act && q < n_planes && (r0 + rl < ur) && (s0 + wvs < us) && (w0 + wl < row_words);
     const int64_t plane_words = (int64_t)row_words * ur * us;
     const int64_t my_word = (int64_t)q * plane_words + ((int64_t)(s0 + wvs) * ur + (r0 + rl)) * row_words + (w0 + wl);
-    const int64_t tile_id = tile_index(td, 0, w0, r0, s0);
+    const int64_t tile_id = (int64_t)bid;
 
     if (n_runs == 0 || n_runs > (uint32_t)RCAP) {   // block-uniform
         PDBEDA_LATE_JOB(lj);
         // nothing significant, or too many runs for LDS: publish the masks; an overflowing tile is labelled run by run
         // (every run its own component) by its workgroup of k_face_merge
         if (my_valid) { lj.mask[my_word] = m; lj.run_base[my_word] = 0u; }
-        if (tid == 0) { lj.tile_mode[tile_id] = n_runs ? 1 : 0; lj.tile_runs[blockIdx.x] = 0u; if (n_runs) *lj.unit_flag = lj.epoch; }
-        mark_comps_unused(lj, (uint32_t)blockIdx.x * CCAP, 0u, tid, NT);
+        if (tid == 0) { lj.tile_mode[tile_id] = n_runs ? 1 : 0; lj.tile_runs[bid] = 0u; if (n_runs) *lj.unit_flag = lj.epoch; }
+        mark_comps_unused(lj, (uint32_t)bid * CCAP, 0u, tid, NT);
         return;
     }
 
@@ -511,7 +525,7 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
         if (act) s_ub[q][u] = vb | (my_base << 16);
     }
     PDBEDA_LATE_JOB(lj);          // (everything below stores through pointers nothing above needs)
-    const uint32_t cb = (uint32_t)blockIdx.x * CCAP, rb = (uint32_t)blockIdx.x * (uint32_t)(NU * 32);
+    const uint32_t cb = (uint32_t)bid * CCAP, rb = (uint32_t)bid * (uint32_t)(NU * 32);
     {   // what the later kernels read per word and per row (run bases are wrong for a tile that turns out to be a unit tile
         // below: that path writes them again)
         if (my_valid) { lj.mask[my_word] = m; lj.run_base[my_word] = rb + my_base; }
@@ -520,8 +534,8 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
     const uint32_t n_comp = s_ncomp;
     if (n_comp > CCAP) {  // block-uniform: too many components for LDS -> unit tile
         if (my_valid) lj.run_base[my_word] = 0u;
-        if (tid == 0) { lj.tile_mode[tile_id] = 3; lj.tile_runs[blockIdx.x] = 0u; *lj.unit_flag = lj.epoch; }
-        mark_comps_unused(lj, (uint32_t)blockIdx.x * CCAP, 0u, tid, NT);
+        if (tid == 0) { lj.tile_mode[tile_id] = 3; lj.tile_runs[bid] = 0u; *lj.unit_flag = lj.epoch; }
+        mark_comps_unused(lj, (uint32_t)bid * CCAP, 0u, tid, NT);
         return;
     }
     // ---- C2: a thread per run: sums over the parked values, fold into the component ----
@@ -529,7 +543,7 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
         uint32_t *comp_of_run = lj.comp_of_run + rb;
         // k_face_merge reads, per word, the tile-local components of its first FACE_K word-runs and (byte 7) of the run that
         // reaches the word's last bit, as the bytes of one 64-bit load
-        uint8_t *word_comps = lj.word_comps + (size_t)blockIdx.x * (2 * 256 * 8);
+        uint8_t *word_comps = lj.word_comps + (size_t)bid * (2 * 256 * 8);
         const int ctile = w0 * 64;
         const uint32_t urus = (uint32_t)ur * (uint32_t)us;
         const double fix_mul = lj.fix_mul;
@@ -595,7 +609,7 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
         lj.kpar[g] = ((unsigned long long)key << 32) | g;   // a root, named by its first key: the cross-tile unions hang the later first voxel under the earlier
     }
     mark_comps_unused(lj, cb, n_comp, tid, NT);
-    if (tid == 0) lj.tile_runs[blockIdx.x] = n_runs;
+    if (tid == 0) lj.tile_runs[bid] = n_runs;
 }
 
 // Cross-tile pairs of one mask word.  All global loads (the 13 neighbour masks and run bases)
@@ -736,6 +750,7 @@ __device__ void unit_edges_word(const Job &job, const TileDims &td, const VolDes
 
 template <int CW, int NTH>
 __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td, int pair_slots) {
+    /*@F0*/
     const bool any_unit = *job.unit_flag == job.epoch;   // block-uniform: some tile of this job is a unit tile (rare)
     static_assert(FACE_K == 7, "a word's component record is one 64-bit load: seven runs and the run at the last bit");
     __shared__ unsigned long long s_set[PAIR_SLOTS], s_pairs[PAIR_SLOTS];
@@ -803,6 +818,7 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__r
         if (e < 5 * CCAP) (&s_kp[0][0])[e] = kp_pre[k];
     }
     __syncthreads();
+    /*@F1*/
     auto val_of = [&](uint32_t id) -> kp_t {   // a value that names a node of id's set
         const uint32_t t = id / (uint32_t)CCAP;
 #pragma unroll
@@ -884,6 +900,7 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__r
         }
     }
     __syncthreads();
+    /*@F2*/
     // the distinct pairs of this tile: compacted (block prefix over the slots) so that thread k unites pair k, k + 512, ... --
     // a union is a chain of dependent memory round trips, and nobody should walk two chains while others walk none
     // (parents start as the identity, so most unions are two parallel loads and one atomic min)
@@ -913,6 +930,7 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__r
             if (mine[k] != 0ull) s_pairs[at++] = mine[k];
         __syncthreads();
     }
+    /*@F3*/
     uint32_t n_pairs = 0;
 #pragma unroll
     for (int k = 0; k < NTH / 64; ++k) n_pairs += s_wsum[k];
@@ -920,6 +938,7 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__r
         const unsigned long long key = s_pairs[k];
         kuf_hook_vals(job.kpar, val_of((uint32_t)(key >> 32)), val_of((uint32_t)key));
     }
+    /*@F4*/
     {   // every tile clears its slice of the first-key bitmap and of the rank counters (saves a memset launch; painted two kernels
         // later) and its inbox counter (used by the next kernel) -- here, behind the last barrier: a barrier waits for the stores
         // before it to be acknowledged (2 us), the unions below do not
@@ -936,6 +955,7 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__r
         for (int64_t i = mlo + tid; i < mhi; i += NTH) job.mid_count[i] = 0u;
         if (tid == 0) job.inbox_count[(size_t)tile * INBOX_STRIDE] = 0u;
     }
+    /*@F5*/
     if (any_unit) {
         // Some tile overflowed LDS in k_tile_label.  Its own workgroup labels it here, run by run (phase 1), and every pair with
         // such a tile on either side is then united word by word (phase 2) by the workgroup of the tile that holds the LATER
@@ -1055,6 +1075,7 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
         }
         return;
     }
+    /*@R0*/
     const uint32_t i = (uint32_t)blockIdx.x * CCAP + tid;
     // everything this thread may need, in flight at once (unused ids hold stale bytes: loaded, never used)
     const uint32_t n_i = job.r_n[i];
@@ -1066,11 +1087,13 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
     const bool is_root = used && kp_id(p0) == i;
     const bool member = used && !is_root;   // non-root component with voxels
     int root = (int)i;
+    /*@R1*/
     if (member) {
         const kp_t rp = kuf_find_from(job.kpar, p0);
         root = (int)kp_id(rp);
         job.kpar[i] = rp;
     }
+    /*@R2*/
     job.parent[i] = root;   // (every id of the tile: the accessors and the label writer go through parent[])
     {   // the tile's roots as four ballots: k_emit_tiles maps its threads onto the set bits instead of scanning every component id
         const unsigned long long rbits = __ballot(is_root);
@@ -1078,9 +1101,11 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
     }
     if (is_root) paint(v_key);
     __syncthreads();
+    /*@R3*/
     if (__syncthreads_or(member ? 1 : 0) == 0) return;   // nothing to fold in this tile
     if (member) table_add(root, n_i, v_sum, v_c, v_r, v_s);
     __syncthreads();
+    /*@R4*/
     for (int k = tid; k < RSLOTS; k += 256) {
         if (s_root[k] < 0) continue;
         const uint32_t root = (uint32_t)s_root[k], rtile = root / CCAP;
@@ -1096,6 +1121,7 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
             fold(root, s_cnt[k], s_f[k], s_i[0][k], s_i[1][k], s_i[2][k]);
         }
     }
+    /*@R5*/
 }
 
 // Signed labels, one workgroup per tile, all look-ups in LDS: the tile's label-of-component table
@@ -1121,6 +1147,7 @@ template <int CW, bool FUSED>
 __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS, FUSED ? 8 : 1) k_labels_tiles(Job job_arg, TileDims td, int32_t *__restrict__ labels, const Geom *__restrict__ gp) {
     // the job is read from the kernel-argument segment where it is used (see PDBEDA_LATE_JOB): its ~45 pointers do not fit the
     // scalar registers beside the row loop -- passed by value they were copied to scratch at entry
+    kernarg_prefetch7();
     PDBEDA_LATE_JOB(lj);
     constexpr int NU = 64 * CW;
     constexpr int NTL = PDBEDA_LABELS_NT_THREADS, RPW = 64 / (NTL / 64);   // rows of the tile per wave
@@ -1128,28 +1155,29 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS, FUSED ? 8 : 1) k_lab
     // per 32-bit half of a mask word (a lane's 4 voxels live in one half): the mask halves of both signs side by side, and
     // per sign the half's run starts beside the tile-local id of the run before its first start -- what a lane needs of a
     // word, as two 8-byte reads, with nothing left to compute per row that does not depend on the lane's own bits.
-    // FUSED: the inbox accumulators (20 KiB + 1 KiB) live in the same bytes first -- the row tables are written once the roots
-    // have read them (the kernel must stay at four workgroups a CU: 1 024 tiles, one round).
-    constexpr size_t TABLE_BYTES = (LCAP + 8) + sizeof(uint2) * (2 * 256) * 3, ACC_BYTES = 8 * 10 * CCAP + 4 * CCAP;
-    __shared__ __attribute__((aligned(16))) unsigned char s_buf[FUSED ? (ACC_BYTES > TABLE_BYTES ? ACC_BYTES : TABLE_BYTES) : TABLE_BYTES];
-    uint2 *s_mh = reinterpret_cast<uint2 *>(s_buf);                                   // [2 * 256]
-    uint2 (*s_sb)[2 * 256] = reinterpret_cast<uint2 (*)[2 * 256]>(s_buf + sizeof(uint2) * 2 * 256);   // [2][2 * 256]
-    uint8_t *s_comp8 = s_buf + sizeof(uint2) * (2 * 256) * 3;                         // [LCAP + 4]
-    unsigned long long (*s_acc)[CCAP] = reinterpret_cast<unsigned long long (*)[CCAP]>(s_buf);   // [10][CCAP]: the seven FixSums fields, sum c / r / s
-    uint32_t *s_accn = reinterpret_cast<uint32_t *>(s_buf + 8 * 10 * CCAP);          // [CCAP]
-    __shared__ uint32_t s_pre[FUSED ? KEY_GROUPS : 1];
+    // FUSED: 37.6 KiB in all -- four workgroups a CU (1 024 tiles: one round) leave nothing to spare.  The run -> component
+    // bytes take the place of the rank prefix table once every rank has been taken (behind a barrier); the inbox accumulators
+    // (20 KiB + 1 KiB) stay until the roots have written their rows, which waves 4-7 do while waves 0-3 already store labels.
+    __shared__ __attribute__((aligned(16))) uint2 s_mh[2 * 256];
+    __shared__ __attribute__((aligned(16))) uint2 s_sb[2][2 * 256];
+    __shared__ __attribute__((aligned(16))) unsigned char s_pc[(LCAP + 8) > 4 * KEY_GROUPS ? (LCAP + 8) : 4 * KEY_GROUPS];
+    uint8_t *s_comp8 = s_pc;                                   // [LCAP + 4]
+    uint32_t *s_pre = reinterpret_cast<uint32_t *>(s_pc);      // [KEY_GROUPS] (fused)
+    __shared__ unsigned long long s_acc[FUSED ? 10 : 1][FUSED ? CCAP : 1];   // the seven FixSums fields, sum c / r / s
+    __shared__ uint32_t s_accn[FUSED ? CCAP : 1];
     __shared__ uint32_t s_wave[NTL / 64];
     __shared__ uint32_t s_vol0;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wvs = __builtin_amdgcn_readfirstlane(wv);
     const int uc = td.uc, ur = td.ur, us = td.us, row_words = td.row_words;
-    int t = blockIdx.x;
-    const int ct = t % td.ctiles; t /= td.ctiles;
-    const int rt = t % td.rtiles; t /= td.rtiles;
-    const int st = t;
+    // (a 3-D grid: the tile coordinates come with the workgroup -- two integer divisions here were ~50 scalar instructions in
+    //  every wave, and the scalar unit of a CU serves all 32 of them.  Workgroups are dealt x fastest: tile order, as before)
+    const int ct = (int)blockIdx.x, rt = (int)blockIdx.y, st = (int)blockIdx.z;
+    const uint32_t bid = ((uint32_t)st * (uint32_t)td.rtiles + (uint32_t)rt) * (uint32_t)td.ctiles + (uint32_t)ct;
+    /*@L0*/
     const int w0 = ct * CW, r0 = rt * TILE_R, s0 = st * TILE_S;
     const int64_t plane_words = (int64_t)row_words * ur * us;
-    const uint32_t rb = (uint32_t)blockIdx.x * (uint32_t)(NU * 32), cb = (uint32_t)blockIdx.x * CCAP;
+    const uint32_t rb = (uint32_t)bid * (uint32_t)(NU * 32), cb = (uint32_t)bid * CCAP;
     // every load of the prologue is issued before anything depends on one: the tile's first 2048 run -> component ids and its
     // label table do not wait for tile_mode / tile_runs (ids beyond the tile's run count hold stale bytes: stored, never used)
     static_assert(NTL == 512 && LCAP == 4096, "four unconditional comp loads per thread cover the first 2048 runs");
@@ -1168,7 +1196,9 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS, FUSED ? 8 : 1) k_lab
     }
     // fused: what kpar[] holds for my component -- its root's first key and id
     kp_t kp = KP_UNUSED;
-    const int64_t key_base1 = (FUSED && lj.n_vols > 1) ? lj.vols[1].key_base : INT64_MAX;
+    // first key of volume 1 = the keys of a plane (from the kernel arguments: loading it from the volume descriptor was a
+    // dependent trip in front of every other load of the prologue -- 2 us, stamps)
+    const int64_t key_base1 = (FUSED && td.n_planes > 1) ? (int64_t)uc * ur * us : INT64_MAX;
     uint32_t n_in = 0;
     // (waves 4-7, thread j = tid - 256: the record of component j of the tile if it is a root, loaded beside the inbox)
     const uint32_t jd = cb + (uint32_t)(tid & 255);
@@ -1177,11 +1207,12 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS, FUSED ? 8 : 1) k_lab
     long long rec_c = 0, rec_r = 0, rec_s = 0;
     if (FUSED) {
         kp = kuf_load(lj.kpar, jd);
-        n_in = lj.inbox_count[(size_t)blockIdx.x * INBOX_STRIDE];
+        n_in = lj.inbox_count[(size_t)bid * INBOX_STRIDE];
     }
     auto own_list = [&](int32_t lab) { return lab < 0 ? lab + vol0 : lab; };
-    const bool unit = lj.tile_mode[tile_index(td, 0, w0, r0, s0)] != 0;
-    const uint32_t n_runs = unit ? 0u : lj.tile_runs[blockIdx.x];
+    const bool unit = lj.tile_mode[(int64_t)bid] != 0;
+    const uint32_t n_runs_raw = lj.tile_runs[bid];   // (beside the mode, not behind it)
+    const uint32_t n_runs = unit ? 0u : n_runs_raw;
     const bool fast = !unit && n_runs <= (uint32_t)LCAP;   // block-uniform
     const int pwl = tid % CW, prowl = (tid / CW) & 63;
     const int pr = r0 + (prowl & 7), ps = s0 + (prowl >> 3);
@@ -1197,7 +1228,21 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS, FUSED ? 8 : 1) k_lab
             base[p] = has ? lj.run_base[pw + p * plane_words] : 0u;
         }
     }
-    uint32_t total_blobs = 0;
+    uint32_t total_blobs = 0, blobs_vol0 = 0;
+    bool my_root = false;
+    auto write_mask_tables = [&]() {
+        if (tid < 256) {
+            s_mh[2 * tid] = make_uint2((uint32_t)m[0], (uint32_t)m[1]);
+            s_mh[2 * tid + 1] = make_uint2((uint32_t)(m[0] >> 32), (uint32_t)(m[1] >> 32));
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const uint64_t starts = run_starts(m[p]);
+                const uint32_t slo = (uint32_t)starts, shi = (uint32_t)(starts >> 32), before = base[p] - rb - 1u;
+                s_sb[p][2 * tid] = make_uint2(slo, before);
+                s_sb[p][2 * tid + 1] = make_uint2(shi, before + (uint32_t)__popc(slo));
+            }
+        }
+    };
     // label of the blob whose root is named by value v: signed by the root's plane, numbered by the rank of its first key
     auto label_of_value = [&](kp_t v) -> int32_t {
         const uint32_t key32 = (uint32_t)(v >> 32);
@@ -1210,8 +1255,11 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS, FUSED ? 8 : 1) k_lab
         // (unconditionally: waiting for the inbox count here would hold back the table's loads; its barriers publish the zeros)
         for (int i = tid; i < 10 * CCAP; i += NTL) (&s_acc[0][0])[i] = 0ull;
         if (tid < CCAP) s_accn[tid] = 0u;
+        /*@L7*/
         total_blobs = rank_table_lds<NTL>(lj, s_pre, s_wave);   // (two barriers inside)
+        /*@L1*/
         n_in = min(n_in, (uint32_t)INBOX_CAP);
+        write_mask_tables();   // (the masks are back by now; their registers are free for the second trip)
         // ---- second trip: waves 0-3 fetch the tile's inbox (an entry per thread) and rank the roots of their components;
         //      waves 4-7 fetch the records of the tile's own roots.  Everything is issued before anything is consumed. ----
         static_assert(INBOX_CAP <= 256, "an inbox entry per thread of the lower half");
@@ -1223,8 +1271,8 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS, FUSED ? 8 : 1) k_lab
         // register allocator (22 registers of entry + 24 of record beside the rank loads spilled to scratch).
         static_assert(sizeof(InboxEntry) == 88, "eleven words");
         const bool have = (uint32_t)(tid & 255) < n_in;
-        const unsigned long long *ew = reinterpret_cast<const unsigned long long *>(lj.inbox + (size_t)blockIdx.x * INBOX_CAP + (tid & 255));
-        const bool my_root = tid >= 256 && used && kp_id(kp) == jd;   // a root of this tile: its blob's table row is mine
+        const unsigned long long *ew = reinterpret_cast<const unsigned long long *>(lj.inbox + (size_t)bid * INBOX_CAP + (tid & 255));
+        my_root = tid >= 256 && used && kp_id(kp) == jd;   // a root of this tile: its blob's table row is mine
         if (tid < 256) {
             unsigned long long e_head = 0ull, e_w[4] = {0ull, 0ull, 0ull, 0ull};
             if (have) {
@@ -1271,9 +1319,29 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS, FUSED ? 8 : 1) k_lab
                 for (int k = 0; k < 6; ++k) atomicAdd(&s_acc[4 + k][l], e_w[k]);
             }
         }
+        /*@L2*/
         __syncthreads();
-        const uint32_t blobs_vol0 = s_vol0;                            // (one volume: every blob, as k_emit_tiles publishes it)
+        /*@L3*/
+        blobs_vol0 = s_vol0;                                           // (one volume: every blob, as k_emit_tiles publishes it)
         vol0 = key_base1 != INT64_MAX ? (int32_t)blobs_vol0 : 0;       // what comes off the labels of volume 1
+    }
+    {
+        if (!FUSED) write_mask_tables();
+        if (tid < CCAP) s_lab[tid] = own_list(FUSED ? s_lab[tid] : lab_pre);
+        // (fused: every rank of this tile has been taken -- the bytes take the place of the prefix table.  A unit tile takes
+        //  ranks in its rows: it keeps the table, and does not read the bytes)
+        if (!FUSED || fast) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s_comp8[tid + NTL * k] = (uint8_t)(c_pack >> (8 * k));
+        }
+        if (fast)
+            for (uint32_t i = tid + 4 * NTL; i < n_runs; i += NTL) s_comp8[i] = (uint8_t)(lj.comp_of_run[rb + i] - cb);
+    }
+    __syncthreads();
+    /*@L4*/
+    if (FUSED) {
+        // waves 4-7: the blob table rows of the tile's own roots -- record + inbox sums, rank from the label -- while waves 0-3
+        // are already storing label rows
         if (my_root) {
             const int l = tid - 256;
             if (n_in != 0u) {
@@ -1286,34 +1354,15 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS, FUSED ? 8 : 1) k_lab
             }
             const uint32_t key32 = (uint32_t)(kp >> 32);
             const unsigned long long key = (unsigned long long)((key32 >> 31) ? key_base1 : 0) + (key32 & 0x7fffffffu);
-            const int32_t lab = s_lab[l];
-            emit_row_ranked(lj, *gp, true, key_base1, jd, rec_n, key, rec_f, rec_c, rec_r, rec_s, (uint32_t)(lab > 0 ? lab - 1 : -1 - lab));
+            const int32_t lab = s_lab[l];   // (final: a blob of volume 1 carries -1 - (rank - vol0))
+            emit_row_ranked(lj, *gp, true, key_base1, jd, rec_n, key, rec_f, rec_c, rec_r, rec_s, (uint32_t)(lab > 0 ? lab - 1 : vol0 - 1 - lab));
         }
-        if (blockIdx.x == 0 && tid == 0) {   // the table's totals, for the host
+        if (bid == 0 && tid == 0) {   // the table's totals, for the host
             lj.ctr->n_blobs = total_blobs;
             lj.ctr->n_blobs_vol0 = blobs_vol0;
         }
-        __syncthreads();   // (the accumulators have been read: their bytes become the row tables)
+        /*@L5*/
     }
-    {
-        if (tid < 256) {
-            s_mh[2 * tid] = make_uint2((uint32_t)m[0], (uint32_t)m[1]);
-            s_mh[2 * tid + 1] = make_uint2((uint32_t)(m[0] >> 32), (uint32_t)(m[1] >> 32));
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const uint64_t starts = run_starts(m[p]);
-                const uint32_t slo = (uint32_t)starts, shi = (uint32_t)(starts >> 32), before = base[p] - rb - 1u;
-                s_sb[p][2 * tid] = make_uint2(slo, before);
-                s_sb[p][2 * tid + 1] = make_uint2(shi, before + (uint32_t)__popc(slo));
-            }
-        }
-        if (tid < CCAP) s_lab[tid] = own_list(FUSED ? s_lab[tid] : lab_pre);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) s_comp8[tid + NTL * k] = (uint8_t)(c_pack >> (8 * k));
-        if (fast)
-            for (uint32_t i = tid + 4 * NTL; i < n_runs; i += NTL) s_comp8[i] = (uint8_t)(lj.comp_of_run[rb + i] - cb);
-    }
-    __syncthreads();
     // wave wv writes RPW rows of the tile; a lane owns 4 consecutive voxels of a 256-voxel row.  A voxel carries one sign, and
     // nearly every 4-voxel group one sign or none: the lane works on the plane that has voxels in its group (a second pass,
     // taken only by a wave that has a group with both signs, adds the other), and a group of four holds at most two runs --
@@ -1385,11 +1434,14 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS, FUSED ? 8 : 1) k_lab
     };
     if (fast) { if (inside) rows(std::true_type{}, std::true_type{}); else rows(std::true_type{}, std::false_type{}); }
     else { if (inside) rows(std::false_type{}, std::true_type{}); else rows(std::false_type{}, std::false_type{}); }
+    /*@L6*/
     if (FUSED) {   // unit components (every run of a tile that overflowed LDS its own component): none on ordinary maps
         const bool any_unit = *lj.unit_flag == lj.epoch;   // block-uniform
         if (any_unit) {
+            __syncthreads();   // (everybody is done with the run -> component bytes: the prefix table comes back)
+            rank_table_lds<NTL>(lj, s_pre, s_wave);
             const uint32_t n_comp = n_components(lj), first = (uint32_t)lj.n_tiles * (uint32_t)TILE_COMPS;
-            if (n_comp > first) emit_ids(lj, *gp, s_pre, true, key_base1, first, n_comp);
+            if (n_comp > first) emit_ids(lj, *gp, s_pre, true, key_base1, first, n_comp, bid, (uint32_t)lj.n_tiles);
         }
     }
 }
