@@ -921,7 +921,10 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.total_words = total_words;
     job.key_words = (total_keys + 63) / 64;
     job.n_fine = (int32_t)((job.key_words + KEY_FINE - 1) / KEY_FINE);
-    job.fine_per_group = std::max(16, ((job.n_fine + KEY_GROUPS - 1) / KEY_GROUPS + 7) / 8 * 8);
+    job.fine_shift = 4;   // counters per table entry: a power of two >= 16 that covers the job with KEY_GROUPS entries
+    while (((int64_t)KEY_GROUPS << job.fine_shift) < job.n_fine) job.fine_shift++;
+    job.fine_per_group = 1 << job.fine_shift;
+    job.n_groups = (job.n_fine + job.fine_per_group - 1) / job.fine_per_group;
     job.ctr = cv.take<Counters>(1);
     job.vols = cv.take<VolDesc>(std::max(n_vols, 1));
     job.mask = cv.take<uint64_t>(total_words);

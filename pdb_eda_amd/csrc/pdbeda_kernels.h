@@ -161,6 +161,9 @@ struct Job {
     // voxels are never neighbours along s, so a byte holds at most 128) -- rank_of_key then reads 32 + 8 + 32 bytes where it read
     // 32 + 256, few enough registers for the label writer to rank its own components (round 4)
     uint32_t *mid_count;
+    // fine_per_group is a power of two (>= 16): a key's group is a shift, and the number of groups comes with the job -- the
+    // integer divisions they replace ran in the prologue of every wave of the label writer
+    int32_t fine_shift, n_groups;
 };
 
 struct InboxEntry {           // 88 bytes: what a (tile, root) pair folds into the root's record (no key: the root holds the first voxel)
@@ -598,23 +601,30 @@ __device__ __forceinline__ uint32_t sum_u16_first(const uint4 q, int take) {
 // A thread owns KEY_GROUPS / 256 = 4 consecutive groups: all its loads are in flight at once (the table is one memory
 // round trip + one block scan, not a loop of dependent trips; 32 KiB per block at 256^3).  fine_count is padded to whole
 // groups and cleared with the bitmap.
-template <int NT = 256, typename JobRef = Job>
-__device__ inline uint32_t rank_table_lds(const JobRef &job, uint32_t *s_pre /* [KEY_GROUPS] */, uint32_t *s_wave /* [NT / 64] */) {
-    constexpr int PER = KEY_GROUPS / NT;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int G = job.fine_per_group, n_groups = (job.n_fine + G - 1) / G, Q = G / 8;   // quads (8 counters = 16 B) per group
-    const uint4 *fine4 = reinterpret_cast<const uint4 *>(job.fine_count);
+// The table in two steps, so that a caller can put other loads in flight between them: rank_table_issue loads the calling
+// thread's counters (groups of 16: two quads a group -- the common case; larger groups are summed in place, a loop of loads),
+// rank_table_finish sums them, scans the block and writes the table (two barriers).
+template <int NT>
+struct RankTableLoads {
+    static constexpr int PER = KEY_GROUPS / NT;
+    uint4 q[2 * PER];
     uint32_t v[PER];
+    bool summed;
+};
+template <int NT = 256, typename JobRef = Job>
+__device__ __forceinline__ void rank_table_issue(const JobRef &job, RankTableLoads<NT> &ld) {
+    constexpr int PER = KEY_GROUPS / NT;
+    const int tid = threadIdx.x;
+    const int G = job.fine_per_group, n_groups = job.n_groups, Q = G / 8;   // quads (8 counters = 16 B) per group
+    const uint4 *fine4 = reinterpret_cast<const uint4 *>(job.fine_count);
+    ld.summed = Q != 2;
     if (Q == 2) {   // (maps up to 2^25 keys: 256^3 fused)
-        uint4 q[2 * PER];
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int e = tid * PER + k;
-            q[2 * k] = e < n_groups ? fine4[(size_t)e * 2] : make_uint4(0, 0, 0, 0);
-            q[2 * k + 1] = e < n_groups ? fine4[(size_t)e * 2 + 1] : make_uint4(0, 0, 0, 0);
+            ld.q[2 * k] = e < n_groups ? fine4[(size_t)e * 2] : make_uint4(0, 0, 0, 0);
+            ld.q[2 * k + 1] = e < n_groups ? fine4[(size_t)e * 2 + 1] : make_uint4(0, 0, 0, 0);
         }
-#pragma unroll
-        for (int k = 0; k < PER; ++k) v[k] = sum_u16x8(q[2 * k]) + sum_u16x8(q[2 * k + 1]);
     } else {
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
@@ -622,12 +632,21 @@ __device__ inline uint32_t rank_table_lds(const JobRef &job, uint32_t *s_pre /* 
             uint32_t acc = 0;
             if (e < n_groups)
                 for (int j = 0; j < Q; ++j) acc += sum_u16x8(fine4[(size_t)e * Q + j]);
-            v[k] = acc;
+            ld.v[k] = acc;
         }
+    }
+}
+template <int NT = 256>
+__device__ __forceinline__ uint32_t rank_table_finish(RankTableLoads<NT> &ld, uint32_t *s_pre /* [KEY_GROUPS] */, uint32_t *s_wave /* [NT / 64] */) {
+    constexpr int PER = KEY_GROUPS / NT;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (!ld.summed) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) ld.v[k] = sum_u16x8(ld.q[2 * k]) + sum_u16x8(ld.q[2 * k + 1]);
     }
     uint32_t mine = 0;
 #pragma unroll
-    for (int k = 0; k < PER; ++k) mine += v[k];
+    for (int k = 0; k < PER; ++k) mine += ld.v[k];
     uint32_t x = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -640,34 +659,72 @@ __device__ inline uint32_t rank_table_lds(const JobRef &job, uint32_t *s_pre /* 
 #pragma unroll
     for (int k = 0; k < NT / 64; ++k) { const uint32_t w = s_wave[k]; pre += k < wv ? w : 0u; total += w; }
 #pragma unroll
-    for (int k = 0; k < PER; ++k) { s_pre[tid * PER + k] = pre; pre += v[k]; }
+    for (int k = 0; k < PER; ++k) { s_pre[tid * PER + k] = pre; pre += ld.v[k]; }
     __syncthreads();
     return total;
+}
+// Exclusive prefix table over groups of fine_per_group counters, built by the calling block in LDS; returns the total.
+// A thread owns KEY_GROUPS / NT consecutive groups: all its loads are in flight at once (the table is one memory
+// round trip + one block scan, not a loop of dependent trips; 32 KiB per block at 256^3).  fine_count is padded to whole
+// groups and cleared with the bitmap.
+template <int NT = 256, typename JobRef = Job>
+__device__ inline uint32_t rank_table_lds(const JobRef &job, uint32_t *s_pre /* [KEY_GROUPS] */, uint32_t *s_wave /* [NT / 64] */) {
+    RankTableLoads<NT> ld;
+    rank_table_issue<NT>(job, ld);
+    return rank_table_finish<NT>(ld, s_pre, s_wave);
 }
 
 // Number of painted keys below `key` (s_pre: this block's rank_table_lds) = table entry + the 16-bit counters of the key's group
 // before its bucket + the byte counters of the bucket before its cell + the bits of the cell's four words below the key.
 // Branch-free for the common group size: five loads (2 x 16 B of counters, 8 B of bytes, 2 x 16 B of bitmap), all in flight
 // together, masked afterwards -- the lanes of a wave do not wait for each other's trip counts.
+// (keys are below 2^32 -- two planes of fewer than 2^31 voxels, or the volumes of a batch -- so word indices fit 32 bits)
+struct RankLoads {
+    uint4 q0, q1;        // the 16 counters of the key's group (groups of 16)
+    uint2 mid;           // the 8 byte counters of its bucket
+    ulonglong2 b0, b1;   // the 4 bitmap words of its cell
+};
+template <typename JobRef>
+__device__ __forceinline__ void rank_issue(const JobRef &job, unsigned long long key, RankLoads &ld) {   // groups of 16 only
+    const uint32_t kw = (uint32_t)(key >> 6), f = kw / (uint32_t)KEY_FINE, e = f >> 4;
+    const uint4 *fine4 = reinterpret_cast<const uint4 *>(job.fine_count) + (size_t)e * 2;
+    ld.q0 = fine4[0]; ld.q1 = fine4[1];
+    ld.mid = reinterpret_cast<const uint2 *>(job.mid_count)[f];
+    const ulonglong2 *bits2 = reinterpret_cast<const ulonglong2 *>(job.key_bits + (kw & ~3u));
+    ld.b0 = bits2[0]; ld.b1 = bits2[1];
+}
+__device__ __forceinline__ uint32_t rank_finish(const uint32_t *s_pre, unsigned long long key, const RankLoads &ld) {
+    const uint32_t kw = (uint32_t)(key >> 6), f = kw / (uint32_t)KEY_FINE, e = f >> 4;
+    const int nf = (int)(f & 15u), cell = (int)((kw & (uint32_t)(KEY_FINE - 1)) >> 2), wi = (int)(kw & 3u);
+    uint32_t rank = s_pre[e] + sum_u16_first(ld.q0, nf) + sum_u16_first(ld.q1, nf - 8);
+    const uint32_t lo = cell >= 4 ? ld.mid.x : (ld.mid.x & ((1u << (8 * cell)) - 1u));
+    const uint32_t hi = cell > 4 ? (ld.mid.y & ((1u << (8 * (cell - 4))) - 1u)) : 0u;
+    rank += __builtin_amdgcn_sad_u8(lo, 0u, 0u) + __builtin_amdgcn_sad_u8(hi, 0u, 0u);
+    const uint64_t below = bits_below((int)(key & 63));
+    const uint64_t w[4] = {ld.b0.x, ld.b0.y, ld.b1.x, ld.b1.y};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rank += (uint32_t)popc64(k < wi ? w[k] : (k == wi ? w[k] & below : 0ull));
+    return rank;
+}
 template <typename JobRef>
 __device__ inline uint32_t rank_of_key(const JobRef &job, const uint32_t *s_pre, unsigned long long key) {
-    const int64_t kw = (int64_t)(key >> 6);
-    const int G = job.fine_per_group, Q = G / 8;
-    const int64_t f = kw / KEY_FINE, e = f / G;
-    uint32_t rank = s_pre[e];
-    const uint4 *fine4 = reinterpret_cast<const uint4 *>(job.fine_count) + e * Q;
-    const int nf = (int)(f - e * G);                       // counters of my group before mine: < G
-    const uint2 mid = reinterpret_cast<const uint2 *>(job.mid_count)[f];   // the 8 byte counters of my bucket (the tables are padded to whole buckets)
-    const ulonglong2 *bits2 = reinterpret_cast<const ulonglong2 *>(job.key_bits + (kw & ~(int64_t)3));   // my cell: 4 words, 32-B aligned
-    const int cell = (int)((kw - f * KEY_FINE) >> 2);      // cells of my bucket before mine: < 8
-    const int wi = (int)(kw & 3);                          // words of my cell before mine
-    const ulonglong2 b0 = bits2[0], b1 = bits2[1];
-    if (Q == 2) {
-        const uint4 q0 = fine4[0], q1 = fine4[1];
-        rank += sum_u16_first(q0, nf) + sum_u16_first(q1, nf - 8);
-    } else {
-        for (int k = 0; k * 8 < nf; ++k) rank += sum_u16_first(fine4[k], nf - k * 8);
+    const int shift = job.fine_shift;
+    if (shift == 4) {
+        RankLoads ld;
+        rank_issue(job, key, ld);
+        return rank_finish(s_pre, key, ld);
     }
+    const uint32_t kw = (uint32_t)(key >> 6), f = kw / (uint32_t)KEY_FINE, e = f >> shift;
+    const int Q = 1 << (shift - 3);
+    uint32_t rank = s_pre[e];
+    const uint4 *fine4 = reinterpret_cast<const uint4 *>(job.fine_count) + (size_t)e * Q;
+    const int nf = (int)(f - (e << shift));                // counters of my group before mine
+    const uint2 mid = reinterpret_cast<const uint2 *>(job.mid_count)[f];   // the 8 byte counters of my bucket (the tables are padded to whole buckets)
+    const ulonglong2 *bits2 = reinterpret_cast<const ulonglong2 *>(job.key_bits + (kw & ~3u));   // my cell: 4 words, 32-B aligned
+    const int cell = (int)((kw & (uint32_t)(KEY_FINE - 1)) >> 2);   // cells of my bucket before mine: < 8
+    const int wi = (int)(kw & 3u);                         // words of my cell before mine
+    const ulonglong2 b0 = bits2[0], b1 = bits2[1];
+    for (int k = 0; k * 8 < nf; ++k) rank += sum_u16_first(fine4[k], nf - k * 8);
     {   // bytes 0 .. cell - 1 of the eight
         const uint32_t lo = cell >= 4 ? mid.x : (mid.x & ((1u << (8 * cell)) - 1u));
         const uint32_t hi = cell > 4 ? (mid.y & ((1u << (8 * (cell - 4))) - 1u)) : 0u;

@@ -1253,7 +1253,9 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS, FUSED ? 8 : 1) k_lab
     };
     if (FUSED) {
         // (unconditionally: waiting for the inbox count here would hold back the table's loads; its barriers publish the zeros)
-        for (int i = tid; i < 10 * CCAP; i += NTL) (&s_acc[0][0])[i] = 0ull;
+        static_assert(10 * CCAP == 5 * NTL, "five accumulator words per thread");
+#pragma unroll
+        for (int k = 0; k < 5; ++k) (&s_acc[0][0])[tid + NTL * k] = 0ull;
         if (tid < CCAP) s_accn[tid] = 0u;
         /*@L7*/
         total_blobs = rank_table_lds<NTL>(lj, s_pre, s_wave);   // (two barriers inside)
