@@ -49,6 +49,8 @@ def parse_args():
     ap.add_argument("--entry-residues", type=int, default=100, help="multiple-structure leg: poly-ALA residues per entry (~500 atoms)")
     ap.add_argument("--sweep-entries", type=int, default=32, help="optimise-mode leg (BASELINE configs[4]): resident entries per rank; 0 = skip")
     ap.add_argument("--sweep-iterations", type=int, default=3, help="optimise-mode leg: parameter tables evaluated (one changed radius each)")
+    ap.add_argument("--sweep-seconds", type=float, default=1.0, help="optimise-mode leg: repeat the sweep over the tables until the timed region is at least this long")
+    ap.add_argument("--stream-seconds", type=float, default=0.5, help="multi-stream leg: entries are dealt to the streams until the timed region is at least this long")
     return ap.parse_args()
 
 
@@ -150,8 +152,28 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
     try:
         t0 = time.perf_counter()
         distinct = max(1, args.entry_files)   # distinct synthetic entries on disk (each = 2 x 32 MB of CCP4 files at 200^3; generating one costs ~0.3 s)
-        loaders = [synthetic.write_entry_files(tmp, "e%d" % k, args.entry_size, args.entry_residues, 1000 * rank + k, as_paths=True) for k in range(distinct)]
+        # entry 0 of every rank is the configs[3] entry the REFERENCE was run on (synthetic.BIG_CASES["c3_multiple_entry"]: 200^3, 100
+        # residues, seed 0): its records are checked against the reference's numbers after every pool has returned
+        golden_case = synthetic.BIG_CASES["c3_multiple_entry"]
+        golden_ok = (args.entry_size, args.entry_residues) == (golden_case[0][0], golden_case[1])
+        loaders = [synthetic.write_entry_files(tmp, "e%d" % k, args.entry_size, args.entry_residues, (golden_case[2] if k == 0 else 1000 * rank + k), as_paths=True)
+                   for k in range(distinct)]
         gen_s = time.perf_counter() - t0
+        golden = np.load(os.path.join(ROOT, "tests", "golden", "analysis_big_c3_multiple_entry.npz"), allow_pickle=False) if golden_ok else None
+        checked = {"records": 0}
+
+        def check_golden(records):
+            # file -> pinned ring -> pool at 200^3: a wrong-but-non-zero record must not pass the bench
+            if golden is None:
+                return
+            for i, r in enumerate(records):
+                if i % distinct != 0:
+                    continue
+                assert r, "the golden entry failed in the pool"
+                got = r["stats"]["density_electron_ratio"]
+                assert abs(got - float(golden["ratio"])) <= 1e-8 * abs(float(golden["ratio"])), "multiple_structures: golden entry ratio %r vs the reference's %r" % (got, float(golden["ratio"]))
+                assert r["stats"]["num_voxels_aggregated"] == int(golden["num_voxels"]), "multiple_structures: golden entry voxel count differs from the reference's"
+                checked["records"] += 1
         entries = [multipleStructures.Entry("r%de%04d" % (rank, i), loaders[i % distinct], cost_hint=0.0) for i in range(args.entries)]
         pool.warm()
         pool.map(entries[:2 * args.workers])                          # untimed: first-use costs of every worker (imports, arenas)
@@ -165,6 +187,7 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
             elapsed += time.perf_counter() - t0
             ok += sum(1 for r in records if r)
             passes += 1
+            check_golden(records)
         n_done = passes * args.entries
         own_rate = 60.0 * n_done / elapsed
         # ONE worker process of the same kind for comparison (the pool is closed first: few processes may share the GPU)
@@ -198,6 +221,7 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
                 lazy_elapsed += time.perf_counter() - t1
                 lazy_ok += sum(1 for r in lazy_records if r)
                 lazy_passes += 1
+                check_golden(lazy_records)
         finally:
             lazy.close()
         lazy_done = lazy_passes * args.entries
@@ -215,6 +239,23 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
             per_rank = [float(r.item()) for r in rates]
         n_atoms = len(list(loaders[0].structure()[0].get_atoms()))
         file_mb = 2 * 4 * args.entry_size ** 3 / 1e6
+        # the leg's roofline is the host link: an entry's map bytes must cross it, whatever else happens.  The link's rate is
+        # measured HERE (a pinned 64 MiB buffer, ten copies), so the fraction compares like with like.
+        pin = torch.empty(16 << 20, dtype=torch.float32).pin_memory()
+        dev = torch.empty(16 << 20, dtype=torch.float32, device="cuda")
+        dev.copy_(pin, non_blocking=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            dev.copy_(pin, non_blocking=True)
+        torch.cuda.synchronize()
+        h2d_gbs = 10 * pin.numel() * 4 / (time.perf_counter() - t1) / 1e9
+        del pin, dev
+        per_gpu_rate = total_done / world / elapsed                     # entries / s / GPU
+        lazy_rate = lazy_done / world / lazy_elapsed
+        pcie = {"bound": "pcie", "unit": "GB/s", "peak": h2d_gbs, "peak_source": "pinned host -> HBM copy of 64 MiB measured in this run (PCIe Gen5 x16: 63 GB/s spec)",
+                "both_maps": {"bytes_per_entry": file_mb * 1e6, "achieved": file_mb * 1e6 * per_gpu_rate / 1e9, "frac": file_mb * 1e6 * per_gpu_rate / 1e9 / h2d_gbs},
+                "lazy_diff_map": {"bytes_per_entry": file_mb * 1e6 / 2, "achieved": file_mb * 1e6 / 2 * lazy_rate / 1e9, "frac": file_mb * 1e6 / 2 * lazy_rate / 1e9 / h2d_gbs}}
         # the same entries on the host cores of this box (rank 0, N = 1 only): the CPU restatement ("port": the product's host code over
         # oracle/pdbeda_oracle.c) in a multiprocessing.Pool on ALL cores -- the reference's own shape (multipleStructures.py:167-168)
         cpu_pool = None
@@ -236,6 +277,8 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
                 "entries_per_min_per_rank": [round(v, 1) for v in per_rank],
                 "one_worker_ms_per_entry": 1e3 * single, "one_worker_entries_per_min": 60.0 / single,
                 "pool_vs_one_worker": (total_done / world / elapsed) * single, "generation_s": gen_s,
+                "roofline": pcie,
+                "golden_records_checked": checked["records"] if golden is not None else None,
                 "lazy_diff_map": {"entries": lazy_done, "entries_ok": lazy_ok, "seconds": lazy_elapsed, "entries_per_min": 60.0 * lazy_done / lazy_elapsed,
                                   "note": "the same entry list with the product's default loader: the Fo-Fc file's header is read, its grid would follow on first use "
                                           "and nothing in the record of `pdb_eda multiple` uses it (32 MB per entry over PCIe instead of 64); same records"},
@@ -266,21 +309,26 @@ def sweep_leg(args, rank, local_rank, world, barrier, dist, torch):
         sets = [sets[k % len(sets)] for k in range(1, args.sweep_iterations + 1)]
         sw.iteration(sets[0])                                   # untimed: first-use costs of the workers
         barrier()
-        t0 = time.perf_counter()
-        for params in sets:
-            reduction, records = sw.iteration(params)
-        barrier()
-        elapsed = time.perf_counter() - t0
+        # the timed region is whole sweeps over the parameter tables, repeated until it has run for at least --sweep-seconds
+        # (three iterations over 32 entries are 35 ms: not a measurement)
+        elapsed, n_iter = 0.0, 0
+        while n_iter == 0 or (elapsed < args.sweep_seconds and n_iter < 4096):
+            t0 = time.perf_counter()
+            for params in sets:
+                reduction, records = sw.iteration(params)
+            barrier()
+            elapsed += time.perf_counter() - t0
+            n_iter += len(sets)
         ok = sum(1 for r in records if r)
         if dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        per = elapsed / (len(sets) * max(1, args.sweep_entries))
+        per = elapsed / (n_iter * max(1, args.sweep_entries))
         return {"workload": "configs[4]: %d resident entries per rank (%d^3 maps, ~%d atoms), %d parameter tables of a radius sweep: per table every entry is "
                             "re-analysed (aggregateCloud -> diffs / slopes / overlap counters) and the records are reduced over all ranks" %
                             (args.sweep_entries, args.entry_size, 5 * args.entry_residues, len(sets)),
-                "entries": args.sweep_entries * world, "iterations": len(sets), "workers_per_gpu": args.workers, "seconds": elapsed,
+                "entries": args.sweep_entries * world, "iterations": n_iter, "parameter_tables": len(sets), "workers_per_gpu": args.workers, "seconds": elapsed,
                 "ms_per_entry_iteration_per_gpu": 1e3 * per, "entry_iterations_per_s": world / per, "entries_ok_last_iteration": ok,
                 "reduced_types": len(reduction[0]), "load_s": load_s,
                 "reduction": "optimizeStats: all_gather of per-entry rows + all_reduce of counters (%s)" % ("RCCL" if dist is not None else "single process: no group"),
@@ -424,6 +472,31 @@ def main():
     n_green, n_red = len(green), len(red)
     sig_vox = int(green.stats()["n"].sum() + red.stats()["n"].sum())
 
+    # ---- the same map at pdb_eda's own green / red default, +-(mean + 3 std) (densityAnalysis.py:148) -- informational, never `value`
+    sigma3 = None
+    if args.nsd != 3.0:
+        cut3 = mean + 3.0 * std
+        for _ in range(max(args.warmup, 2)):
+            keep3 = dmap.full_blobs_pm(cut3, -cut3, labels=labels)
+        barrier()
+        n3 = max(args.steps, 50)
+        t1 = time.perf_counter()
+        for _ in range(n3):
+            keep3 = dmap.full_blobs_pm(cut3, -cut3, labels=labels)
+        barrier()
+        el3 = time.perf_counter() - t1
+        ctx.profile_begin()
+        for _ in range(n3):
+            keep3 = dmap.full_blobs_pm(cut3, -cut3, labels=labels)
+        prof3 = ctx.profile_end()
+        ev3 = 1e3 * sum(ms for _, ms in prof3.values()) / n3
+        gap3 = max(0.0, (ev3 - 1e6 * el3 / n3) / (sum(c for c, _ in prof3.values()) / n3))
+        sigma3 = {"cutoff_sigma": 3.0, "steps": n3, "ms_per_step": 1e3 * el3 / n3, "value": n_vox * n3 / el3 / 1e6, "unit": "Mvoxels/s",
+                  "blobs": {"green": len(keep3[0]), "red": len(keep3[1])},
+                  "kernels_us": {k: round(max(1e3 * ms / c - gap3, 0.0), 2) for k, (c, ms) in sorted(prof3.items())},
+                  "note": "pdb_eda's default green / red cutoff on the same resident map; parity at this cutoff: tests/test_gpu_voxel.py (nsd 3.0)"}
+        del keep3
+
     # final statistics reduction (the only collective of the path; KB-scale, outside the voxel work)
     totals = torch.tensor([n_green, n_red, sig_vox], dtype=torch.int64, device="cuda")
     if world > 1:
@@ -443,31 +516,50 @@ def main():
             mu, sd = mk.stats()
             lanes.append({"ctx": c, "map": mk, "tensor": tk, "cut": mu + args.nsd * sd, "keep": None})
 
-        def run_lane(lane, count):
-            for _ in range(count):
-                lane["keep"] = lane["map"].full_blobs_pm(lane["cut"], -lane["cut"], labels=labels)
-            lane["ctx"].synchronize()
+        # one host thread per stream for the life of the leg: started and parked on a barrier BEFORE the clock starts (thread
+        # start-up inside a 4 ms region made the driver's figure at --steps 20 contradict the design notes), then every thread
+        # labels its share of the entries and drains its stream
+        gate = threading.Barrier(args.streams + 1)
+        plan = {"counts": [0] * args.streams, "stop": False}
+
+        def lane_thread(k):
+            lane = lanes[k]
+            while True:
+                gate.wait()                      # start of a round
+                if plan["stop"]:
+                    return
+                for _ in range(plan["counts"][k]):
+                    lane["keep"] = lane["map"].full_blobs_pm(lane["cut"], -lane["cut"], labels=labels)
+                lane["ctx"].synchronize()
+                gate.wait()                      # end of the round
+
+        threads = [threading.Thread(target=lane_thread, args=(k,), daemon=True) for k in range(args.streams)]
+        for t in threads:
+            t.start()
 
         def run_all(total):
-            counts = [total // args.streams + (1 if k < total % args.streams else 0) for k in range(args.streams)]
-            th = [threading.Thread(target=run_lane, args=(lanes[k], counts[k])) for k in range(args.streams)]
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
-        run_all(args.warmup * args.streams)
+            plan["counts"] = [total // args.streams + (1 if k < total % args.streams else 0) for k in range(args.streams)]
+            gate.wait()
+            t_start = time.perf_counter()
+            gate.wait()
+            return time.perf_counter() - t_start
+        run_all(max(args.warmup, 2) * args.streams)
+        # entries of the timed round: what a single stream would need --stream-seconds for, so the region is at least that long
+        n_multi = max(2 * args.steps, int(args.stream_seconds / max(0.75 * elapsed / args.steps, 1e-6)) + 1)
         barrier()
-        t1 = time.perf_counter()
-        run_all(2 * args.steps)
+        el = run_all(n_multi)
         barrier()
-        el = time.perf_counter() - t1
+        plan["stop"] = True
+        gate.wait()
+        for t in threads:
+            t.join()
         if world > 1:
             t = torch.tensor([el], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        multi = {"streams_per_gpu": args.streams, "entries": 2 * args.steps, "value": world * n_vox * 2 * args.steps / el / 1e6, "unit": "Mvoxels/s",
-                 "ms_per_entry": 1e3 * el / (2 * args.steps),
-                 "note": "different 256^3 entries resident in HBM, one per stream, host thread per stream; the latency-bound merge kernels of one entry overlap the tile kernel of another"}
+        multi = {"streams_per_gpu": args.streams, "entries": n_multi, "seconds": el, "value": world * n_vox * n_multi / el / 1e6, "unit": "Mvoxels/s",
+                 "ms_per_entry": 1e3 * el / n_multi,
+                 "note": "different 256^3 entries resident in HBM, one per stream, host thread per stream (parked before the clock starts); the latency-bound merge kernels of one entry overlap the tile kernel of another"}
         for lane in lanes[1:]:
             lane["keep"] = None
         lanes = lanes[:1]
@@ -587,6 +679,8 @@ def main():
                 "note": "pageable host buffer -> HBM through pdbeda_map_upload; reported for information, never part of value"},
         "fallback_tiles": green.counters(),
     }
+    if sigma3:
+        out["sigma3"] = sigma3
     if multi:
         out["multi_stream"] = multi
     if analysis:

@@ -194,7 +194,7 @@ class Oracle(object):
         st = self.L.ora_cloud_begin(C.byref(self.m), n, _ptr(xyz), _ptr(a["radius"]), _ptr(a["weight"]), _ptr(a["residue"]), _ptr(a["alias"]), _ptr(a["key"]),
                                     len(a["bonded_off"]) - 1, _ptr(a["bonded_off"]), _ptr(a["bonded"]), no, _ptr(a["owner_key"]), C.c_float(cutoff), _ptr(dist))
         if not st:
-            raise ValueError("the oracle composite does not model atoms that share a coordinate")
+            raise ValueError("ora_cloud_begin failed (allocation, or an alias index out of range)")
         try:
             d = dist[:n][~np.isnan(dist[:n])]
             import warnings

@@ -513,8 +513,10 @@ int64_t ora_full_blobs(const ora_map *m, float cutoff, int64_t *out_n, double *o
  * entries of thousands of atoms, where the reference itself takes minutes; pinned on the reference's analysis goldens by
  * tests/test_oracle_cloud.py.  Two phases, because the cut-off between them is numpy's (np.nanmedian + 2.5 np.nanstd, 607):
  * the caller computes it with numpy itself from the distances of phase 1.
- * Not modelled: atoms that share a coordinate (allAtomClouds is keyed by the coordinate, 604: the later atom's clouds
- * replace the earlier one's) -- ora_cloud_begin refuses them (alias[i] != i).
+ * Atoms that share a coordinate (round 4; pinned on tests/golden/analysis_alias.npz): allAtomClouds is keyed by
+ * tuple(atom.coord) (605), so phase 2 hands every atom of a coordinate the clouds of the LAST eligible one (alias[i]; found
+ * with that atom's radius) -- the same DensityBlob objects, whose .atoms the atom loop overwrites (639): a residue's pool may
+ * hold one object twice, naming only the later of its two atoms.  Phase 1's distances (606) are each atom's own.
  * --------------------------------------------------------------------------------- */
 typedef struct ora_cloud1 {      /* one cloud: sorted distinct voxels + fromCrsList statistics */
     int32_t *crs;
@@ -529,7 +531,7 @@ typedef struct ora_cloud_state {
     const ora_map *m;
     int64_t n;
     const double *xyz, *weight;
-    const int32_t *residue, *key;
+    const int32_t *residue, *key, *alias;
     int64_t n_keys;
     const int64_t *bonded_off;
     const int32_t *bonded;
@@ -603,10 +605,10 @@ void ora_cloud_end(ora_cloud_state *s) {
 ora_cloud_state *ora_cloud_begin(const ora_map *m, int64_t n, const double *xyz, const float *radius, const double *weight, const int32_t *residue,
                                  const int32_t *alias, const int32_t *key, int64_t n_keys, const int64_t *bonded_off, const int32_t *bonded,
                                  int64_t n_owners, const int32_t *owner_key, float density_cutoff, double *min_distance) {
-    for (int64_t i = 0; i < n; ++i) if (alias[i] != (int32_t)i) return NULL;   /* shared coordinates: not modelled */
+    for (int64_t i = 0; i < n; ++i) if (alias[i] < 0 || alias[i] >= n) return NULL;
     ora_cloud_state *s = (ora_cloud_state *)calloc(1, sizeof *s);
     if (!s) return NULL;
-    s->m = m; s->n = n; s->xyz = xyz; s->weight = weight; s->residue = residue; s->key = key; s->n_keys = n_keys;
+    s->m = m; s->n = n; s->xyz = xyz; s->weight = weight; s->residue = residue; s->key = key; s->alias = alias; s->n_keys = n_keys;
     s->bonded_off = bonded_off; s->bonded = bonded; s->n_owners = n_owners; s->owner_key = owner_key;
     s->clouds = (ora_cloud1 **)calloc((size_t)(n > 0 ? n : 1), sizeof *s->clouds);
     s->n_clouds = (int64_t *)calloc((size_t)(n > 0 ? n : 1), sizeof *s->n_clouds);
@@ -688,7 +690,9 @@ int ora_cloud_finish(ora_cloud_state *s, double centroid_cutoff, double min_clou
         while (a1 < s->n && s->residue[a1] == s->residue[a0]) ++a1;
         int64_t n_pool = 0;
         for (int64_t i = a0; i < a1; ++i) {
-            const int64_t nc = s->n_clouds[i];
+            const int64_t ia = s->alias[i];                         /* allAtomClouds[tuple(atom.coord)] (622): the last atom of this coordinate */
+            ora_cloud1 *const mine = s->clouds[ia];
+            const int64_t nc = s->n_clouds[ia];
             if (nc == 0) continue;
             int64_t best = 0;
             double best_d = 0;
@@ -696,7 +700,7 @@ int ora_cloud_finish(ora_cloud_state *s, double centroid_cutoff, double min_clou
                 double dmin = INFINITY;
                 for (int64_t c = 0; c < nc; ++c) {
                     double d2 = 0;
-                    for (int k = 0; k < 3; ++k) { const double d = s->xyz[3 * i + k] - s->clouds[i][c].centroid[k]; d2 += d * d; }
+                    for (int k = 0; k < 3; ++k) { const double d = s->xyz[3 * i + k] - mine[c].centroid[k]; d2 += d * d; }
                     const double d = sqrt(d2);
                     if (d < dmin) { dmin = d; best = c; }          /* distances.index(min): first */
                 }
@@ -705,9 +709,12 @@ int ora_cloud_finish(ora_cloud_state *s, double centroid_cutoff, double min_clou
             }
             first_of_key[s->key[i]] = n_pool;                       /* atomCloudIndeces[resAtom]: the LAST atom of that name wins (640) */
             count_of_key[s->key[i]] = nc;
-            for (int64_t c = 0; c < nc; ++c) pool[n_pool++] = &s->clouds[i][c];
+            for (int64_t c = 0; c < nc; ++c) {
+                mine[c].atoms[0] = (int32_t)i;                      /* aCloud.atoms = [atom] (639): the shared object now names THIS atom */
+                pool[n_pool++] = &mine[c];
+            }
             if (n_atom_rows < cap_rows) {
-                const ora_cloud1 *b = &s->clouds[i][best];
+                const ora_cloud1 *b = &mine[best];
                 atom_idx[n_atom_rows] = (int32_t)i; atom_total[n_atom_rows] = b->total; atom_n[n_atom_rows] = b->n;
                 for (int k = 0; k < 3; ++k) atom_centroid[3 * n_atom_rows + k] = b->centroid[k];
                 atom_distance[n_atom_rows] = best_d;

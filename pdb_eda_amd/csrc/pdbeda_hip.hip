@@ -1001,8 +1001,8 @@ static void launch_tile_label(pdbeda_ctx *ctx, unsigned n_tiles, const Job &job,
     // cross-tile unions (and, when a tile overflowed LDS, every pair that has such a tile on either side)
     {   // (grids of one tile column have no c faces: two waves fewer per workgroup to dispatch)
         PROF(ctx, "k_face_merge");
-        if (td.ctiles > 1) hipLaunchKernelGGL((k_face_merge<CW, FM_THREADS_WIDE>), dim3(n_tiles), dim3(FM_THREADS_WIDE), 0, ctx->stream, job, dens, geom_dev, td, pair_slots);
-        else hipLaunchKernelGGL((k_face_merge<CW, FM_THREADS>), dim3(n_tiles), dim3(FM_THREADS), 0, ctx->stream, job, dens, geom_dev, td, pair_slots);
+        if (td.ctiles > 1) hipLaunchKernelGGL((k_face_merge<CW, FM_THREADS_WIDE>), dim3(td.ctiles, td.rtiles, td.stiles), dim3(FM_THREADS_WIDE), 0, ctx->stream, job, dens, geom_dev, td, pair_slots);
+        else hipLaunchKernelGGL((k_face_merge<CW, FM_THREADS>), dim3(td.ctiles, td.rtiles, td.stiles), dim3(FM_THREADS), 0, ctx->stream, job, dens, geom_dev, td, pair_slots);
     }
 }
 
@@ -1894,18 +1894,41 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
     for (int64_t q = 0; q < n_pairs; ++q)
         if (!touch[(size_t)q]) res->owner_state[(size_t)pair_owner[(size_t)q]] = 2;
     std::vector<double> electrons((size_t)nu, 0.0);
-    std::vector<int32_t> last_atom((size_t)nu, -1);
     std::vector<int64_t> first_pool((size_t)nu, n_pool);
+    // Whose electrons a pooled cloud carries (cloud.atoms, 639 / 690 / 718).  The atoms of one coordinate share the cloud OBJECTS
+    // of the last of them (605, 622), and the atom loop of a residue overwrites their .atoms (639): when two pooled atoms of ONE
+    // residue share a coordinate, both pool entries are the same objects and name only the LATER atom -- the earlier one's
+    // electrons are in no residue or domain cloud (golden analysis_alias; round 3 counted both).  Atoms of different residues
+    // each get their own residue's snapshot (clone(), 675), so both count there and in the domain.
+    std::vector<int32_t> named_by((size_t)n);
+    for (int64_t i = 0; i < n; ++i) named_by[(size_t)i] = (int32_t)i;
+    {
+        std::vector<int32_t> last_of_alias((size_t)n, -1);             // per residue: the last pooled atom that uses the clouds of alias a
+        size_t r0 = 0;
+        const std::vector<int32_t> &pooled = res->atom_idx;            // (in atom order, hence residue by residue)
+        while (r0 < pooled.size()) {
+            size_t r1 = r0;
+            while (r1 < pooled.size() && at->residue[pooled[r1]] == at->residue[pooled[r0]]) ++r1;
+            for (size_t q = r0; q < r1; ++q) last_of_alias[(size_t)at->alias[pooled[q]]] = pooled[q];
+            for (size_t q = r0; q < r1; ++q) named_by[(size_t)pooled[q]] = last_of_alias[(size_t)at->alias[pooled[q]]];
+            for (size_t q = r0; q < r1; ++q) last_of_alias[(size_t)at->alias[pooled[q]]] = -1;
+            r0 = r1;
+        }
+    }
+    std::vector<std::pair<int32_t, int32_t>> members;                  // (union component, atom named by a pooled cloud in it): distinct pairs add electrons once
+    members.reserve(2 * (size_t)n_pool);
     for (int kind = 0; kind < 2; ++kind) {
         for (int64_t p = 0; p < n_pool; ++p) {
             const int32_t k = comp[(size_t)(kind * n_pool + p)];
             if (k < 0 || k >= nu) { delete res; *out = nullptr; return fail(ctx, PDBEDA_ERR_STATE, "aggregate cloud: component rank out of range"); }
-            if (last_atom[(size_t)k] != pool_atom[(size_t)p]) {      // a cloud's atoms are distinct atoms: each adds its electrons once (690, 718)
-                electrons[(size_t)k] += at->weight[pool_atom[(size_t)p]];
-                last_atom[(size_t)k] = pool_atom[(size_t)p];
-            }
+            members.emplace_back(k, named_by[(size_t)pool_atom[(size_t)p]]);
             if (p < first_pool[(size_t)k]) first_pool[(size_t)k] = p;
         }
+    }
+    {   // (summed in atom order per component, as before: pool order is atom order)
+        std::stable_sort(members.begin(), members.end());
+        for (size_t q = 0; q < members.size(); ++q)
+            if (q == 0 || members[q] != members[q - 1]) electrons[(size_t)members[q].first] += at->weight[members[q].second];
     }
     std::vector<int64_t> order((size_t)nu);
     for (int64_t k = 0; k < nu; ++k) order[(size_t)k] = k;

@@ -212,7 +212,8 @@ __device__ inline double wave_incl_scan(double x, int lane) {
 // (getPointDensityFromCrs), two wave prefix sums (rho, rho*lane), run sums by difference at the
 // run's first lane; writes one record per run at index rec0 + (run number inside the word).
 // (cl0, rl, sl) = volume-local coordinates of lane 0, (rawc0, rawr, raws) = raw crs of lane 0.
-__device__ inline void word_run_records(const Job &job, const Geom &g, const float *__restrict__ dens, const VolDesc &vd, uint64_t mw,
+template <typename JobRef>
+__device__ inline void word_run_records(const JobRef &job, const Geom &g, const float *__restrict__ dens, const VolDesc &vd, uint64_t mw,
                                         int lane, int cl0, int rl, int sl, int rawc0, int rawr, int raws, uint32_t rec0) {
     const bool bit = (mw >> lane) & 1ull;
     const double rho = bit ? (double)fetch_wrapped(g, dens, rawc0 + lane, rawr, raws) : 0.0;

@@ -183,8 +183,8 @@ __device__ __forceinline__ void lds_unite(uint32_t *parent, uint32_t a, uint32_t
 // workgroups of that kernel behind a grid barrier of their own -- 1.3 ms for a map whose tiles all overflow; and inside
 // k_tile_label, where the tile has everything at hand, the cold code cost the other tiles 3 us of spilled scalars).  A quarter
 // of the tile (16 rows) at a time; `scratch`: 1 KiB of LDS nobody else uses.
-template <int CW>
-__device__ void unit_label_tile(const Job &job, const float *__restrict__ dens, const Geom *__restrict__ gp, const TileDims &td,
+template <int CW, typename JobRef>
+__device__ void unit_label_tile(const JobRef &job, const float *__restrict__ dens, const Geom *__restrict__ gp, const TileDims &td,
                                 int w0, int r0, int s0, unsigned char *scratch) {
     constexpr int QU = 16 * CW;   // units of a quarter tile
     uint64_t *s_m = reinterpret_cast<uint64_t *>(scratch);          // [64]
@@ -623,7 +623,8 @@ struct NbWords {
 };
 
 // unit_only: keep only the pairs with a unit tile on either side (the companion of k_face_merge).
-__device__ inline bool load_cross_tile(const Job &job, const TileDims &td, int64_t w, uint64_t m, NbWords &nw, uint32_t &my_base, bool unit_only = false) {
+template <typename JobRef>
+__device__ inline bool load_cross_tile(const JobRef &job, const TileDims &td, int64_t w, uint64_t m, NbWords &nw, uint32_t &my_base, bool unit_only = false) {
     const int plane = (job.n_vols > 1 && w >= job.vols[1].word_base) ? 1 : 0;
     const VolDesc vd = job.vols[plane];
     const int64_t rem = w - vd.word_base;
@@ -737,7 +738,8 @@ constexpr int FACE_PAIRS = 46;
 
 // One mask word of the unit-tile companion of k_face_merge: it owns EVERY pair that has a unit tile on either side
 // (all rows), and unites on the spot.
-__device__ void unit_edges_word(const Job &job, const TileDims &td, const VolDesc &v0, int plane, int sl, int r, int wq) {
+template <typename JobRef>
+__device__ void unit_edges_word(const JobRef &job, const TileDims &td, const VolDesc &v0, int plane, int sl, int r, int wq) {
     const int rw = v0.row_words;
     const int64_t w = (int64_t)plane * rw * v0.dim[1] * v0.dim[2] + ((int64_t)sl * v0.dim[1] + r) * rw + wq;
     const uint64_t m = job.mask[w];
@@ -749,9 +751,13 @@ __device__ void unit_edges_word(const Job &job, const TileDims &td, const VolDes
 }
 
 template <int CW, int NTH>
-__global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td, int pair_slots) {
+__global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job_arg, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td, int pair_slots) {
+    // (the job is read from the kernel-argument segment where it is used: the ~45 pointers of a by-value Job sat in scalar registers
+    //  -- and spilled into vector lanes -- through the whole kernel for the sake of its cold tail)
+    kernarg_prefetch7();
+    PDBEDA_LATE_JOB(lj);
     /*@F0*/
-    const bool any_unit = *job.unit_flag == job.epoch;   // block-uniform: some tile of this job is a unit tile (rare)
+    const bool any_unit = *lj.unit_flag == lj.epoch;   // block-uniform: some tile of this job is a unit tile (rare)
     static_assert(FACE_K == 7, "a word's component record is one 64-bit load: seven runs and the run at the last bit");
     __shared__ unsigned long long s_set[PAIR_SLOTS], s_pairs[PAIR_SLOTS];
     __shared__ uint32_t s_wsum[NTH / 64];
@@ -761,14 +767,16 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__r
     __shared__ kp_t s_kp[5][CCAP];
     const int tid = threadIdx.x, lane = tid & 63;
     const int ur = td.ur, us = td.us, row_words = td.row_words;
-    const int tile = (int)blockIdx.x, ct = tile % td.ctiles, rt = (tile / td.ctiles) % td.rtiles, st = tile / (td.ctiles * td.rtiles);
+    // (3-D grid: the tile coordinates come with the workgroup, x fastest = tile order)
+    const int ct = (int)blockIdx.x, rt = (int)blockIdx.y, st = (int)blockIdx.z;
+    const int tile = (st * td.rtiles + rt) * td.ctiles + ct;
     const int w0 = ct * CW;
     const int64_t plane_words = (int64_t)row_words * ur * us;
-    const unsigned long long *comps64 = reinterpret_cast<const unsigned long long *>(job.word_comps);
+    const unsigned long long *comps64 = reinterpret_cast<const unsigned long long *>(lj.word_comps);
     auto word_at = [&](int q, int r, int s, int wq) { return (int64_t)q * plane_words + ((int64_t)s * ur + r) * row_words + wq; };
     auto comps_at = [&](uint32_t tl, int q, int r, int s, int wl) { return ((size_t)tl * 2 + q) * 256 + ((s & 7) * TILE_R + (r & 7)) * CW + wl; };
     // component of word-run k of mask word w by its run id (words with more than FACE_K runs: two dependent loads, rare)
-    auto comp_by_run = [&](int64_t w, uint32_t k) { return job.comp_of_run[job.run_base[w] + k]; };
+    auto comp_by_run = [&](int64_t w, uint32_t k) { return lj.comp_of_run[lj.run_base[w] + k]; };
 
     // ---- the one trip: everything a lane needs, issued before anything waits ----
     // r / s faces: lanes 0 .. 367 = sign x pair of rows x word slot
@@ -789,9 +797,9 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__r
     unsigned long long cA = 0ull, cB = 0ull;
     uint32_t modes = 0u;
     if (task) {
-        mA = job.mask[wA]; mB = job.mask[wB];
+        mA = lj.mask[wA]; mB = lj.mask[wB];
         cA = comps64[comps_at((uint32_t)tile, fq, r, s, fwl)]; cB = comps64[comps_at(tile_b, fq, r2, s2, fwl)];
-        modes = (uint32_t)job.tile_mode[tile] | (uint32_t)job.tile_mode[tile_b];
+        modes = (uint32_t)lj.tile_mode[tile] | (uint32_t)lj.tile_mode[tile_b];
     }
     // the five tables: this tile, (rt - 1, st), (rt - 1, st - 1), (rt, st - 1), (rt + 1, st - 1)
     uint32_t tiles5[5];
@@ -809,7 +817,7 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__r
     for (int k = 0; k < KPL; ++k) {
         const int e = tid + k * NTH, j = e / CCAP;
         const uint32_t t5 = j == 0 ? tiles5[0] : (j == 1 ? tiles5[1] : (j == 2 ? tiles5[2] : (j == 3 ? tiles5[3] : tiles5[4])));
-        kp_pre[k] = (e < 5 * CCAP && t5 != 0xffffffffu) ? kuf_load(job.kpar, t5 * (uint32_t)CCAP + (uint32_t)(e % CCAP)) : KP_UNUSED;
+        kp_pre[k] = (e < 5 * CCAP && t5 != 0xffffffffu) ? kuf_load(lj.kpar, t5 * (uint32_t)CCAP + (uint32_t)(e % CCAP)) : KP_UNUSED;
     }
     for (int i = tid; i < pair_slots; i += NTH) s_set[i] = 0ull;   // 0 = empty: a pair (lo << 32 | hi) has hi > lo >= 0
 #pragma unroll
@@ -824,7 +832,7 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__r
 #pragma unroll
         for (int j = 0; j < 5; ++j)
             if (t == tiles5[j]) return s_kp[j][id % (uint32_t)CCAP];
-        return kuf_load(job.kpar, id);   // (the c faces of a grid wider than one tile)
+        return kuf_load(lj.kpar, id);   // (the c faces of a grid wider than one tile)
     };
     const uint32_t slot_mask = (uint32_t)pair_slots - 1u;
     auto add_pair = [&](uint32_t ca, uint32_t cb) {
@@ -835,7 +843,7 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__r
             const unsigned long long old = atomicCAS(&s_set[h], 0ull, key);
             if (old == 0ull || old == key) return;
         }
-        kuf_hook_vals(job.kpar, val_of(lo), val_of(hi));   // the neighbourhood of the slot is full: unite on the spot
+        kuf_hook_vals(lj.kpar, val_of(lo), val_of(hi));   // the neighbourhood of the slot is full: unite on the spot
     };
     {   // ---- r / s faces ----
         if (modes != 0u) { mA = 0ull; mB = 0ull; }   // a unit tile on either side: the unit path owns the pair
@@ -871,22 +879,22 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__r
     const int cq = (tid - 384) >> 6, crl = lane & 7, csl = lane >> 3;
     const int cr = rt * TILE_R + crl, cs = st * TILE_S + csl;
     const bool ctask = NTH > 384 && tid >= 384 && ct > 0 && cq < td.n_planes && cr < ur && cs < us;
-    const uint32_t *mask32 = reinterpret_cast<const uint32_t *>(job.mask);
+    const uint32_t *mask32 = reinterpret_cast<const uint32_t *>(lj.mask);
     uint32_t m0 = 0u, c0 = 0u, cmodes = 0u, hi9[9], c9[9], mode9[9];   // low half of my word, high halves of theirs; record bytes 0 / 7
 #pragma unroll
     for (int k = 0; k < 9; ++k) { hi9[k] = 0u; c9[k] = 0u; mode9[k] = 0u; }
     auto tile9 = [&](int k) { return (uint32_t)((((cs + k / 3 - 1) >> 3) * td.rtiles + ((cr + k % 3 - 1) >> 3)) * td.ctiles + ct - 1); };
     if (ctask) {
         m0 = mask32[2 * word_at(cq, cr, cs, w0)];
-        c0 = job.word_comps[comps_at((uint32_t)tile, cq, cr, cs, 0) * 8];
-        cmodes = job.tile_mode[tile];
+        c0 = lj.word_comps[comps_at((uint32_t)tile, cq, cr, cs, 0) * 8];
+        cmodes = lj.tile_mode[tile];
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             const int r9 = cr + k % 3 - 1, s9 = cs + k / 3 - 1;
             if (r9 < 0 || r9 >= ur || s9 < 0 || s9 >= us) continue;
             hi9[k] = mask32[2 * word_at(cq, r9, s9, w0 - 1) + 1];
-            c9[k] = job.word_comps[comps_at(tile9(k), cq, r9, s9, CW - 1) * 8 + 7];
-            mode9[k] = job.tile_mode[tile9(k)];
+            c9[k] = lj.word_comps[comps_at(tile9(k), cq, r9, s9, CW - 1) * 8 + 7];
+            mode9[k] = lj.tile_mode[tile9(k)];
         }
     }
     if (ctask && (m0 & 1u) && cmodes == 0u) {
@@ -936,24 +944,24 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__r
     for (int k = 0; k < NTH / 64; ++k) n_pairs += s_wsum[k];
     for (uint32_t k = tid; k < n_pairs; k += NTH) {
         const unsigned long long key = s_pairs[k];
-        kuf_hook_vals(job.kpar, val_of((uint32_t)(key >> 32)), val_of((uint32_t)key));
+        kuf_hook_vals(lj.kpar, val_of((uint32_t)(key >> 32)), val_of((uint32_t)key));
     }
     /*@F4*/
     {   // every tile clears its slice of the first-key bitmap and of the rank counters (saves a memset launch; painted two kernels
         // later) and its inbox counter (used by the next kernel) -- here, behind the last barrier: a barrier waits for the stores
         // before it to be acknowledged (2 us), the unions below do not
-        const int n_tiles = (int)gridDim.x;
-        const int64_t key_words = job.key_words;
+        const int n_tiles = (int)(gridDim.x * gridDim.y * gridDim.z);
+        const int64_t key_words = lj.key_words;
         const int64_t per = (key_words + n_tiles - 1) / n_tiles;
         const int64_t lo = per * tile, hi = lo + per < key_words ? lo + per : key_words;
-        for (int64_t i = lo + tid; i < hi; i += NTH) job.key_bits[i] = 0ull;
-        const int64_t nfc = job.n_fine_alloc / 2;   // (16-bit counters, two per word)
+        for (int64_t i = lo + tid; i < hi; i += NTH) lj.key_bits[i] = 0ull;
+        const int64_t nfc = lj.n_fine_alloc / 2;   // (16-bit counters, two per word)
         const int64_t perc = (nfc + n_tiles - 1) / n_tiles, clo = perc * tile, chi = clo + perc < nfc ? clo + perc : nfc;
-        for (int64_t i = clo + tid; i < chi; i += NTH) job.fine_count[i] = 0u;
+        for (int64_t i = clo + tid; i < chi; i += NTH) lj.fine_count[i] = 0u;
         const int64_t nmid = (key_words + KEY_FINE - 1) / KEY_FINE * (KEY_FINE / 16);   // (a byte per 4 key words, four per word; whole buckets)
         const int64_t perm = (nmid + n_tiles - 1) / n_tiles, mlo = perm * tile, mhi = mlo + perm < nmid ? mlo + perm : nmid;
-        for (int64_t i = mlo + tid; i < mhi; i += NTH) job.mid_count[i] = 0u;
-        if (tid == 0) job.inbox_count[(size_t)tile * INBOX_STRIDE] = 0u;
+        for (int64_t i = mlo + tid; i < mhi; i += NTH) lj.mid_count[i] = 0u;
+        if (tid == 0) lj.inbox_count[(size_t)tile * INBOX_STRIDE] = 0u;
     }
     /*@F5*/
     if (any_unit) {
@@ -968,38 +976,38 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job, const float *__r
         // as that many consecutive workgroups are resident -- no grid barrier, nothing that needs the whole grid at once
         // (the 128 fallback workgroups this replaces had to be co-resident, all of them).
         __syncthreads();   // (everybody is done with the pair tables: their LDS is the scratch below)
-        const bool mine_unit = job.tile_mode[tile] != 0;   // block-uniform
+        const bool mine_unit = lj.tile_mode[tile] != 0;   // block-uniform
         if (mine_unit) {
-            unit_label_tile<CW>(job, dens, gp, td, w0, rt * TILE_R, st * TILE_S, reinterpret_cast<unsigned char *>(s_set));
+            unit_label_tile<CW>(lj, dens, gp, td, w0, rt * TILE_R, st * TILE_S, reinterpret_cast<unsigned char *>(s_set));
             __threadfence();   // publish run bases / records / run -> component ids to the other XCDs
         }
         __syncthreads();
         if (tid == 0) {
-            __hip_atomic_store(&job.unit_done[tile], job.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&lj.unit_done[tile], lj.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             for (int k = 0; k < 18; ++k) {   // (dc, dr, ds) with ds = -1 or 0, but for the tile itself
                 const int dc = k % 3 - 1, dr = (k / 3) % 3 - 1, ds = k / 9 - 1;
                 if (dc == 0 && dr == 0 && ds == 0) continue;
                 const int c2 = ct + dc, r2 = rt + dr, s2 = st + ds;
                 if (c2 < 0 || c2 >= td.ctiles || r2 < 0 || r2 >= td.rtiles || s2 < 0) continue;
                 const int nb = (s2 * td.rtiles + r2) * td.ctiles + c2;
-                if (job.tile_mode[nb] == 0) continue;
+                if (lj.tile_mode[nb] == 0) continue;
                 // (bounded: about a second.  A flag that never comes up -- it cannot, while workgroups are dispatched in order --
                 //  must not hang the GPU: the job is marked failed instead, and the host turns that into an error)
                 unsigned spins = 0;
-                while (__hip_atomic_load(&job.unit_done[nb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != job.epoch) {
-                    if (++spins > (1u << 21)) { __hip_atomic_store(&job.ctr->unit_wait_failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                while (__hip_atomic_load(&lj.unit_done[nb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != lj.epoch) {
+                    if (++spins > (1u << 21)) { __hip_atomic_store(&lj.ctr->unit_wait_failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                     __builtin_amdgcn_s_sleep(16);
                 }
             }
             __threadfence();
         }
         __syncthreads();
-        const VolDesc v0 = job.vols[0];
+        const VolDesc v0 = lj.vols[0];
         constexpr int NU = 64 * CW;
         for (int k = tid; k < td.n_planes * NU; k += NTH) {
             const int plane = k / NU, u = k % NU, wl = u % CW, rowl = u / CW;
             const int r = rt * TILE_R + (rowl & 7), s = st * TILE_S + (rowl >> 3), wq = w0 + wl;
-            if (r < ur && s < us && wq < row_words) unit_edges_word(job, td, v0, plane, s, r, wq);
+            if (r < ur && s < us && wq < row_words) unit_edges_word(lj, td, v0, plane, s, r, wq);
         }
     }
 }

@@ -43,7 +43,7 @@ def crs_set(a):
     return {tuple(int(x) for x in v) for v in np.asarray(a).reshape(-1, 3)}
 
 
-ANALYSIS_CASES = ["orth", "hex"]
+ANALYSIS_CASES = ["orth", "hex", "alias"]   # alias: atoms that share a coordinate (round 4)
 
 
 def load_analysis_case(name):

@@ -187,4 +187,5 @@ if __name__ == "__main__":
             voxel_case(name, ccp4)
     if not sys.argv[1:] or "analysis" in sys.argv[1:]:
         import make_golden_analysis
-        make_golden_analysis.main(ccp4, da)
+        # (`analysis alias`: only the named analysis cases)
+        make_golden_analysis.main(ccp4, da, only=[a for a in sys.argv[1:] if a in make_golden_analysis.CASES] or None)

@@ -18,6 +18,10 @@ from pdb_eda_amd import ccp4 as my_ccp4  # noqa: E402  (host-side header only: n
 from pdb_eda_amd import structure as my_structure  # noqa: E402
 
 CASES = {
+    # "alias" (round 4): atoms that SHARE a float32 coordinate.  The reference keys allAtomClouds by tuple(atom.coord)
+    # (densityAnalysis.py:605, read back at :622): all eligible atoms of one coordinate use the clouds of the LAST of them (found
+    # with ITS radius), as the same DensityBlob objects -- whose .atoms the loop overwrites (:639).  Three kinds, see alias_sites().
+    "alias": dict(spec=dict(ncrs=(72, 64, 68), spacing=0.5), n_res=60, seed=27, alias=True),
     "orth": dict(spec=dict(ncrs=(72, 64, 68), spacing=0.5), n_res=56, seed=21),
     "hex": dict(spec=dict(ncrs=(64, 60, 56), interval=(72, 80, 64), crs_start=(-4, 6, 3), axis_order=(2, 1, 3),
                           cell=(40.0, 36.0, 32.0), angles=(90.0, 90.0, 120.0)), n_res=40, seed=22),
@@ -35,12 +39,35 @@ def entry(name):
         mid = (lo + hi) / 2
         lo, hi = mid - (hi - lo) / 4, mid + (hi - lo) / 4
     st = synthetic.chain_structure(cfg["n_res"], cfg["seed"], lo, hi, hetero_every=9, zero_occupancy_every=37)
+    if cfg.get("alias"):
+        alias_sites(st)
     params = synthetic.synthetic_params()
     dens = synthetic.gaussian_sum_grid(header, st, params["full_atom_name_map_electrons"], sigma=0.55, noise=0.02, seed=cfg["seed"])
     diff = (synthetic.noise_grid(spec, cfg["seed"] + 100, 1.2) * 0.12).astype(np.float32)
     rot = [np.hstack([np.eye(3), np.zeros((3, 1))]),
            np.array([[-1.0, 0.0, 0.0, 0.5 * header.xlength], [0.0, -1.0, 0.0, 0.0], [0.0, 0.0, 1.0, 0.5 * header.zlength]])]
     return spec, st, params, dens, diff, rot
+
+
+def alias_sites(st):
+    """Coincident coordinates of three kinds (alternate locations collapsed onto one site, placeholders): (i) two atoms of ONE
+    residue -- the side-chain atom put on the C-alpha, and, in another residue, the EARLIER atom put on a later one; (ii) atoms of
+    two DIFFERENT residues with different atom types, hence different radii -- a carbonyl O on the next residue's N, and a
+    C-beta on the C of a residue further on; (iii) an atom with a ZERO-occupancy twin (the twin is skipped by both loops and must
+    not become the alias).  Plain (non-hetero) residues only, occupancies untouched elsewhere."""
+    res = [r for r in st.get_residues() if r.id[0] == " "]
+    def atom(r, name):
+        return next(a for a in r.child_list if a.name == name)
+    atom(res[8], "CB").coord = atom(res[8], "CA").coord.copy()            # (i) later atom takes the earlier one's place
+    atom(res[14], "N").coord = atom(res[14], "O").coord.copy()            # (i) earlier atom onto a later one: the O's radius finds both
+    atom(res[20], "O").coord = atom(res[21], "N").coord.copy()            # (ii) O (residue k) and N (residue k + 1)
+    atom(res[30], "CB").coord = atom(res[33], "C").coord.copy()           # (ii) three residues apart
+    twin = atom(res[40], "CB")                                            # (iii) zero-occupancy twin of the C-alpha, listed after it
+    twin.coord = atom(res[40], "CA").coord.copy()
+    twin.occupancy = 0.0
+    twin2 = atom(res[44], "N")                                            # (iii) ... and listed BEFORE the atom it shadows
+    twin2.coord = atom(res[44], "C").coord.copy()
+    twin2.occupancy = 0.0
 
 
 def structure_arrays(st):
@@ -51,8 +78,10 @@ def structure_arrays(st):
             "atom_het": np.array([a.parent.id[0] for a in atoms]), "atom_resname": np.array([a.parent.resname for a in atoms])}
 
 
-def main(ccp4, da):
+def main(ccp4, da, only=None):
     for name in CASES:
+        if only and name not in only:
+            continue
         spec, st, params, dens, diff, rot = entry(name)
         da.setGlobals(params)
         densityObj = ccp4.parse(io.BytesIO(synthetic.ccp4_bytes(spec, dens)), name)

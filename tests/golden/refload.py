@@ -7,7 +7,7 @@ bench.py (``/root/reference`` does not exist on the GPU box).
 Recipe:
   * the reference's only native module, ``pdb_eda/cutils.pyx``, is cythonized from
     where it lies with the same flags as the reference's setup.py:42-44 (``-O3``) and
-    the build products go to ``oracle/_pyref/`` (git-ignored AND gpurun-ignored);
+    the build products go to ``$TMPDIR/pdbeda_pyref`` (``PDBEDA_PYREF``), outside the repository;
   * ``import pdb_eda`` itself fails here (biopython/docopt are not installed), so an
     empty package module whose ``__path__`` is [built cutils dir, reference dir] is
     registered and ``pdb_eda.ccp4`` / ``pdb_eda.densityAnalysis`` are imported from it;
@@ -21,7 +21,9 @@ import types
 
 REF_ROOT = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
-PYREF = os.path.normpath(os.path.join(HERE, "..", "..", "oracle", "_pyref"))
+# build products of the reference's Cython module: OUTSIDE the repository (round 4 -- the cythonized cutils.c is derived from
+# the reference and must not sit under the repo root, ignored or not)
+PYREF = os.environ.get("PDBEDA_PYREF") or os.path.join(os.environ.get("TMPDIR") or "/tmp", "pdbeda_pyref")
 
 
 def reference_available():

@@ -41,7 +41,7 @@ def test_atom_cloud_descriptions(analysis):
         assert np.array_equal(np.asarray(atoms[f]), z["acd_" + f]), f
     for f in ("density_electron_ratio", "bfactor", "centroid_distance", "centroid_xyz", "adj_density_electron_ratio", "domain_fraction",
               "corrected_fraction", "corrected_density_electron_ratio", "volume"):
-        assert np.allclose(np.asarray(atoms[f]), z["acd_" + f], rtol=1e-7, atol=1e-9), f
+        assert np.allclose(np.asarray(atoms[f]), z["acd_" + f], rtol=1e-8, atol=1e-9), f
 
 
 def test_residue_and_domain_clouds(analysis):
@@ -51,11 +51,11 @@ def test_residue_and_domain_clouds(analysis):
     assert got.shape == want.shape
     # the reference's order inside a residue depends on CPython set order: compare as sorted multisets
     key = lambda a: a[np.lexsort((a[:, 7], a[:, 2], a[:, 0]))]
-    assert np.allclose(key(got), key(want), rtol=1e-7, atol=1e-9)
+    assert np.allclose(key(got), key(want), rtol=1e-8, atol=1e-9)
     got = np.array([[r[3], r[4], r[5], r[6]] + list(r[7]) for r in an.domainCloudDescriptions], dtype=np.float64).reshape(-1, 7)
     want = z["dom_rows"]
     assert got.shape == want.shape
-    assert np.allclose(got[np.argsort(got[:, 0])], want[np.argsort(want[:, 0])], rtol=1e-7, atol=1e-9)
+    assert np.allclose(got[np.argsort(got[:, 0])], want[np.argsort(want[:, 0])], rtol=1e-8, atol=1e-9)
 
 
 def test_medians_and_overlap_counts(analysis):
@@ -64,7 +64,7 @@ def test_medians_and_overlap_counts(analysis):
     assert set(an.medians) == set(want)
     for col, d in want.items():
         for t, v in d.items():
-            assert float(an.medians[col][t]) == pytest.approx(v, rel=1e-7, abs=1e-10), (col, t)
+            assert float(an.medians[col][t]) == pytest.approx(v, rel=1e-8, abs=1e-10), (col, t)
     assert dict(an.atomTypeOverlapCompleteness) == json.loads(str(z["overlap_complete"]))
     assert dict(an.atomTypeOverlapIncompleteness) == json.loads(str(z["overlap_incomplete"]))
 
@@ -104,10 +104,10 @@ def test_blob_statistics(analysis):
         want = z["blob_%s_num" % tag]
         assert len(stats) == len(want)
         got = np.array([[s[0], s[2], s[3], s[4]] for s in stats], dtype=np.float64).reshape(-1, 4)
-        assert np.allclose(got, want, rtol=1e-7, atol=1e-10)
+        assert np.allclose(got, want, rtol=1e-8, atol=1e-10)
         assert [s[1] for s in stats] == list(z["blob_%s_sign" % tag])
         assert ["%s|%s|%s|%s" % (s[6], s[7], s[8], tuple(int(v) for v in s[9])) for s in stats] == list(z["blob_%s_atom" % tag])
-        assert np.allclose(np.array([list(s[11]) for s in stats]).reshape(-1, 3), z["blob_%s_centroid" % tag], rtol=1e-7, atol=1e-9)
+        assert np.allclose(np.array([list(s[11]) for s in stats]).reshape(-1, 3), z["blob_%s_centroid" % tag], rtol=1e-8, atol=1e-9)
 
 
 def test_rscc_rsr_metrics(analysis):
@@ -116,10 +116,10 @@ def test_rscc_rsr_metrics(analysis):
     an.biopdbObj.header = {"resolution": 2.0}
     rm = an.residueMetrics()
     assert ["%s|%s|%s" % (r[0], r[1], r[2]) for r in rm] == list(z["residue_metrics_id"])
-    assert np.allclose(np.array([[r[3], r[4], r[5], r[6]] for r in rm]), z["residue_metrics"], rtol=1e-7, atol=1e-12)
+    assert np.allclose(np.array([[r[3], r[4], r[5], r[6]] for r in rm]), z["residue_metrics"], rtol=1e-8, atol=1e-12)
     am = an.atomMetrics()
     assert ["%s|%s|%s|%s" % (r[0], r[1], r[2], r[3]) for r in am] == list(z["atom_metrics_id"])
-    assert np.allclose(np.array([[r[6], r[7], r[8], r[9]] for r in am]), z["atom_metrics"], rtol=1e-7, atol=1e-12)
+    assert np.allclose(np.array([[r[6], r[7], r[8], r[9]] for r in am]), z["atom_metrics"], rtol=1e-8, atol=1e-12)
     assert np.allclose(an.medianAbsFoFc(), z["median_abs_fo_fc"], rtol=1e-9)
     fc = an.fc
     assert np.allclose([fc.meanDensity, fc.stdDensity], z["fc_mean_std"], rtol=1e-9)    # the reference's Fc keeps the Fo statistics

@@ -274,3 +274,29 @@ def test_lazy_diff_map(tmp_path, gpu_ctx, monkeypatch):
         rec.pop("execution_time"); rec.pop("pdbid")
     want = dict(rec_lazy); want.pop("pdbid")
     assert all(rec == want for rec in par)
+
+
+def test_file_upload_into_a_recycled_arena(tmp_path, monkeypatch):
+    """the helper reader's chunks go through a second stream, and the pool hands out arenas whose last user may still
+    be queued on the context's stream (maps and lists are freed without a host sync) -- the second stream has to wait for that
+    work before its first chunk lands.  A whole-map job is queued on a large map, lists and map are freed with no accessor in
+    between, and a file larger than one 4 MiB chunk goes straight into the arena that comes back (poisoned: 0xFF is queued on
+    the context's stream too); the download must equal the file."""
+    import numpy as np
+    from pdb_eda_amd import _native, ccp4, synthetic
+    monkeypatch.setenv("PDBEDA_DEBUG_POISON", "1")
+    ctx = _native.Context(0)
+    spec = synthetic.MapSpec(ncrs=(200, 176, 190), spacing=0.45)           # 26.8 MB: seven chunks, both readers busy
+    grid = synthetic.smooth_noise((190, 176, 200), seed=5, sigma_voxels=1.3)
+    path = tmp_path / "m.ccp4"
+    path.write_bytes(synthetic.ccp4_bytes(spec, grid))
+    header = ccp4.DensityHeader.fromFileHeader(synthetic.ccp4_header_bytes(spec))
+    for rep in range(4):
+        dmap = _native.DeviceMap(ctx, grid if rep % 2 == 0 else grid[::-1].copy(), header.geometry())     # same size: its arena is the one that comes back
+        mean, std = dmap.stats()
+        green, red = dmap.full_blobs_pm(mean + 1.5 * std, -(mean + 1.5 * std), labels=True)
+        green.free(); red.free(); dmap.free()                                # kernels still queued; nothing has synchronised
+        got = _native.DeviceMap.from_file(ctx, str(path), 1024, False, header.geometry())
+        assert np.array_equal(got.download().reshape(grid.shape), grid), rep
+        got.free()
+    ctx.close()
