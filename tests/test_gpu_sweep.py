@@ -87,7 +87,7 @@ def test_sweep_function_shards_by_rank():
     whole = optimizeSweep.sweep(entries, sets, device=0, n_streams=2)
     half = optimizeSweep.sweep(entries, sets, device=0, n_streams=1, rank=0, world_size=2)      # no process group: this rank's shard only
     assert len(whole) == len(half) == 2
-    assert whole[0][4] != half[0][4] and max(half[0][4].values()) == 1
+    assert whole[0][4] != half[0][4] and max(half[0][4].values()) == (len(entries) + 1) // 2      # rank 0 of 2: every other entry, longest first
 
 
 @pytest.mark.timeout(300)
