@@ -66,6 +66,7 @@ struct pdbeda_ctx {
     // cross-tile pair buffer so the shard-overflow path runs on small inputs.
     bool debug_poison = false;
     int64_t debug_edge_cap = 0;
+    bool debug_worst_case_arena = false;   // PDBEDA_DEBUG_WORST_CASE_ARENA=1: whole-map jobs are carved for the worst case at once (no second run)
     // per-entry watchdog (multipleStructures.py:359-377 wraps every entry in a SIGALRM timeout; threads cannot): when
     // timeout_s > 0 every wait on the stream is a timed hipStreamQuery loop; a wait that expires marks the context
     // abandoned: every later call fails at once with PDBEDA_ERR_TIMEOUT and destroy does not wait for the stream.
@@ -186,6 +187,11 @@ struct pdbeda_bloblist {
     bool whole_map = false;
     TileDims td;
     int sign = 1;
+    // whole-map jobs: what it takes to run the job again (a typical-size arena that turned out too small: see whole_map_enqueue)
+    float cut_pos = 0.0f, cut_neg = 0.0f;
+    bool want_pos = false, want_neg = false;
+    uint32_t flags = 0;
+    int tier = 0, reruns = 0;
 };
 
 static const int N_PARTIAL = 2048;
@@ -387,6 +393,7 @@ extern "C" int pdbeda_ctx_create_on_stream(int device_id, void *hip_stream, pdbe
     if (hipHostMalloc((void **)&ctx->pinned, 1 << 20, hipHostMallocDefault) == hipSuccess) ctx->pinned_cap = 1 << 20;   // (without it results are copied directly)
     if (const char *v = getenv("PDBEDA_DEBUG_POISON")) ctx->debug_poison = v[0] && v[0] != '0';
     if (const char *v = getenv("PDBEDA_DEBUG_EDGE_CAP")) ctx->debug_edge_cap = atoll(v);
+    if (const char *v = getenv("PDBEDA_DEBUG_WORST_CASE_ARENA")) ctx->debug_worst_case_arena = v[0] && v[0] != '0';
     if (const char *v = getenv("PDBEDA_POOL_CAP_MB")) ctx->pool_cap = (size_t)std::max<long long>(atoll(v), 0) << 20;
     reap_abandoned();   // (what the watchdog left behind earlier may have drained by now)
     {
@@ -914,8 +921,11 @@ extern "C" int pdbeda_xyz2crs(pdbeda_map *m, const double *xyz, int64_t n, int32
 // ------------------------------------------------------------------------------------
 // Carve a job out of an arena.  max_runs / max_blobs are worst-case bounds (a run needs a
 // gap: <= bits/2 + 1 per word; a blob owns >= one 2x2x2 cell... we simply bound blobs by runs).
+// max_runs: run ids (comp_of_run); max_comps: component ids (every per-component array; generic jobs: == max_runs, a run is a component)
 static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, int64_t total_keys, int64_t max_runs,
-                        int64_t max_blobs, size_t extra_labels, int32_t **labels_out, int64_t n_tiles = 0) {
+                        int64_t max_blobs, size_t extra_labels, int32_t **labels_out, int64_t n_tiles = 0, int64_t max_comps = -1) {
+    if (max_comps < 0) max_comps = max_runs;
+    job.run_cap = (uint32_t)max_runs; job.comp_cap = (uint32_t)max_comps; job.blob_cap = (uint32_t)std::min<int64_t>(max_blobs, 0xffffffffll);
     Carver cv(base);
     job.n_vols = n_vols;
     job.total_words = total_words;
@@ -936,7 +946,7 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.run_base = cv.take<uint32_t>(total_words);
     job.comps_are_runs = n_tiles ? 0 : 1;
     job.comp_of_run = n_tiles ? cv.take<uint32_t>(max_runs) : nullptr;
-    job.label_of_comp = n_tiles ? cv.take<int32_t>(max_runs) : nullptr;
+    job.label_of_comp = n_tiles ? cv.take<int32_t>(max_comps) : nullptr;
     job.word_comps = n_tiles ? cv.take<uint8_t>((size_t)n_tiles * 2 * 256 * 8) : nullptr;
     job.unit_done = n_tiles ? cv.take<uint32_t>((size_t)n_tiles) : nullptr;
     job.unit_flag = n_tiles ? cv.take<uint32_t>(1) : nullptr;
@@ -947,16 +957,16 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.inbox = n_tiles ? cv.take<InboxEntry>((size_t)n_tiles * INBOX_CAP) : nullptr;
     job.inbox_count = n_tiles ? cv.take<uint32_t>((size_t)n_tiles * INBOX_STRIDE) : nullptr;
     job.vol_sign[0] = job.vol_sign[1] = 1;
-    job.parent = cv.take<int32_t>(max_runs);
-    job.kpar = n_tiles ? cv.take<unsigned long long>(max_runs) : nullptr;
-    job.r_n = cv.take<uint32_t>(max_runs);
-    job.r_sum = cv.take<long long>((size_t)7 * max_runs);
-    job.r_sum_stride = max_runs;
-    job.r_c = cv.take<long long>(max_runs);
-    job.r_r = cv.take<long long>(max_runs);
-    job.r_s = cv.take<long long>(max_runs);
-    job.r_key = cv.take<unsigned long long>(max_runs);
-    job.r_rank = cv.take<uint32_t>(max_runs);
+    job.parent = cv.take<int32_t>(max_comps);
+    job.kpar = n_tiles ? cv.take<unsigned long long>(max_comps) : nullptr;
+    job.r_n = cv.take<uint32_t>(max_comps);
+    job.r_sum = cv.take<long long>((size_t)7 * max_comps);
+    job.r_sum_stride = max_comps;
+    job.r_c = cv.take<long long>(max_comps);
+    job.r_r = cv.take<long long>(max_comps);
+    job.r_s = cv.take<long long>(max_comps);
+    job.r_key = cv.take<unsigned long long>(max_comps);
+    job.r_rank = cv.take<uint32_t>(max_comps);
     job.b_n = cv.take<int64_t>(max_blobs);
     job.b_key = cv.take<int64_t>(max_blobs);
     job.b_total = cv.take<double>(max_blobs);
@@ -1009,7 +1019,6 @@ static void launch_tile_label(pdbeda_ctx *ctx, unsigned n_tiles, const Job &job,
 // fused: the launch also ranks the roots and writes the blob table (k_emit_tiles is then not launched) -- see k_labels_tiles
 template <bool FUSED>
 static void launch_labels(pdbeda_ctx *ctx, const Job &job, const TileDims &td, int32_t *labels_dev, const Geom *geom_dev) {
-    const unsigned n_tiles = (unsigned)(td.ctiles * td.rtiles * td.stiles);
     switch (td.cw) {
         case 1: hipLaunchKernelGGL((k_labels_tiles<1, FUSED>), dim3(td.ctiles, td.rtiles, td.stiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev, geom_dev); break;
         case 2: hipLaunchKernelGGL((k_labels_tiles<2, FUSED>), dim3(td.ctiles, td.rtiles, td.stiles), dim3(PDBEDA_LABELS_NT_THREADS), 0, ctx->stream, job, td, labels_dev, geom_dev); break;
@@ -1018,8 +1027,19 @@ static void launch_labels(pdbeda_ctx *ctx, const Job &job, const TileDims &td, i
     }
 }
 
-static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool want_pos, bool want_neg, uint32_t flags,
-                           pdbeda_bloblist **out_pos, pdbeda_bloblist **out_neg) {
+// Enqueue a whole-map job.  tier 0 carves the arena for what maps need in practice -- room for 64 unit tiles' worth of run /
+// component ids above the tiles' own ranges, a blob table of one row per 128 keys -- instead of the worst case (every other
+// voxel a run of a unit tile, a blob per 2x2x2 cell: 2.9 GB at 256^3, of which a job touches a few hundred MB).  A map that
+// needs more raises Counters::overflow on the device, stays inside its arena, and is run again at tier 1 (the worst case)
+// by the first accessor that reads the counters (list_resolve_counts): correct always, slower only where it was slow already.
+struct WholeMapJob {
+    Job job;
+    Arena arena;
+    TileDims td;
+    int32_t *labels_dev = nullptr;
+    bool labels = false;
+};
+static int whole_map_enqueue(pdbeda_map *m, float cut_pos, float cut_neg, bool want_pos, bool want_neg, uint32_t flags, int tier, WholeMapJob *out) {
     pdbeda_ctx *ctx = m->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const Geom &g = m->geom;
@@ -1030,7 +1050,7 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
     const int64_t keys_pp = (int64_t)uc * ur * us;
     const int64_t total_words = words_pp * n_planes, total_keys = keys_pp * n_planes;
     // 26-connectivity: all voxels of an aligned 2x2x2 cell are mutually adjacent -> <= 1 blob per cell
-    const int64_t max_blobs = (int64_t)((uc + 1) / 2) * ((ur + 1) / 2) * ((us + 1) / 2) * n_planes + 1;
+    const int64_t worst_blobs = (int64_t)((uc + 1) / 2) * ((ur + 1) / 2) * ((us + 1) / 2) * n_planes + 1;
     const bool labels = (flags & PDBEDA_FLAG_LABELS) != 0;
     const size_t lab_elems = labels ? (size_t)keys_pp : 0;   // ONE signed volume, also for a fused call
 
@@ -1048,23 +1068,28 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
     td.sign[1] = -1;
     const int64_t tiles_pp = (int64_t)td.ctiles * td.rtiles * td.stiles;
     if (tiles_pp >= (1ll << 31) || keys_pp >= (1ll << 31)) return fail(ctx, PDBEDA_ERR_ARGUMENT, "grid too large");   // (first keys inside a plane are 31-bit)
-    // run / component ids: a fixed range per tile (no allocation atomics) + worst case of the unit tiles above them
-    const int64_t max_runs = tiles_pp * td.cw * 64 * 32 + (int64_t)((uc + 1) / 2) * ur * us * n_planes + 1;
-    if (max_runs >= (1ll << 31))
+    if (td.rtiles > 65535 || td.stiles > 65535) return fail(ctx, PDBEDA_ERR_ARGUMENT, "grid too large");              // (the tile kernels' grids are 3-D)
+    // run / component ids: a fixed range per tile (no allocation atomics) + the ids of the unit tiles above them
+    const int64_t tile_runs = tiles_pp * td.cw * 64 * 32, tile_comps = tiles_pp * CCAP;
+    const int64_t worst_unit = (int64_t)((uc + 1) / 2) * ur * us * n_planes + 1;       // every other voxel a run
+    if (tile_runs + worst_unit >= (1ll << 31))
         return fail(ctx, PDBEDA_ERR_ARGUMENT, "grid too large for whole-map labelling: %d x %d x %d voxels need %lld run ids (limit 2^31: about 1100^3 for a fused job)",
-                    uc, ur, us, (long long)max_runs);
+                    uc, ur, us, (long long)(tile_runs + worst_unit));
+    const int64_t unit_ids = tier == 0 ? std::min<int64_t>(worst_unit, std::max<int64_t>(65536, (int64_t)64 * td.cw * 64 * 32)) : worst_unit;
+    const int64_t max_blobs = tier == 0 ? std::min<int64_t>(worst_blobs, std::max<int64_t>(4096, total_keys / 128)) : worst_blobs;
+    const int64_t max_runs = tile_runs + unit_ids, max_comps = tile_comps + unit_ids;
 
     int rc_fix = map_fix_mul(m);
     if (rc_fix) return rc_fix;
     Job job;
     memset(&job, 0, sizeof job);
     job.fix_mul = m->fix_mul;
-    size_t need = job_carve(job, nullptr, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, nullptr, tiles_pp);
+    size_t need = job_carve(job, nullptr, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, nullptr, tiles_pp, max_comps);
     Arena arena;
     int rc = arena_get(ctx, need, &arena);
     if (rc) return rc;
     int32_t *labels_dev = nullptr;
-    job_carve(job, arena.base, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, &labels_dev, tiles_pp);
+    job_carve(job, arena.base, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, &labels_dev, tiles_pp, max_comps);
     job.vol_sign[0] = td.sign[0];
     job.vol_sign[1] = td.sign[1];
     // the job's number: unique in the process (contexts recycle each other's memory through the driver), started at a random value
@@ -1088,8 +1113,8 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
         v.word_base = words_pp * p;
         v.key_base = keys_pp * p;
     }
-    init.runs0 = (unsigned)(tiles_pp * td.cw * 64 * 32);
-    init.comps0 = (unsigned)(tiles_pp * CCAP);
+    init.runs0 = (unsigned)tile_runs;
+    init.comps0 = (unsigned)tile_comps;
     hipStream_t st = ctx->stream;
     int pair_slots = PAIR_SLOTS;   // test hook: a tiny LDS pair set overflows on small inputs (PDBEDA_DEBUG_EDGE_CAP = slots, a power of two)
     if (ctx->debug_edge_cap > 0) { pair_slots = 1; while (pair_slots * 2 <= std::min<int64_t>(ctx->debug_edge_cap, PAIR_SLOTS)) pair_slots *= 2; }
@@ -1109,20 +1134,32 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { arena_put(ctx, arena); return fail(ctx, PDBEDA_ERR_DEVICE, "whole-map labelling launch: %s", hipGetErrorString(e)); }
+    out->job = job; out->arena = arena; out->td = td; out->labels_dev = labels_dev; out->labels = labels;
+    return PDBEDA_OK;
+}
 
+static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool want_pos, bool want_neg, uint32_t flags,
+                           pdbeda_bloblist **out_pos, pdbeda_bloblist **out_neg) {
+    pdbeda_ctx *ctx = m->ctx;
+    WholeMapJob wj;
+    const int tier = ctx->debug_worst_case_arena ? 1 : 0;
+    int rc = whole_map_enqueue(m, cut_pos, cut_neg, want_pos, want_neg, flags, tier, &wj);
+    if (rc) return rc;
+    const int n_planes = (want_pos ? 1 : 0) + (want_neg ? 1 : 0);
     pdbeda_bloblist *first = nullptr;
     for (int p = 0; p < n_planes; ++p) {
         pdbeda_bloblist *bl = new_list(ctx, m);
-        bl->job = job;
-        bl->td = td;
+        bl->job = wj.job;
+        bl->td = wj.td;
         bl->vol_lo = p;
         bl->vol_hi = p + 1;
         bl->whole_map = true;
-        bl->sign = td.sign[p];
-        if (p == 0) { bl->arena = arena; bl->owns_arena = true; first = bl; }
+        bl->sign = wj.td.sign[p];
+        if (p == 0) { bl->arena = wj.arena; bl->owns_arena = true; first = bl; }
         else { bl->owns_arena = false; bl->sibling = first; first->sibling = bl; }
-        bl->labels_dev = labels_dev;
-        bl->labels_done = labels;
+        bl->labels_dev = wj.labels_dev;
+        bl->labels_done = wj.labels;
+        bl->cut_pos = cut_pos; bl->cut_neg = cut_neg; bl->want_pos = want_pos; bl->want_neg = want_neg; bl->flags = flags; bl->tier = tier;
         if (bl->sign > 0) *out_pos = bl; else *out_neg = bl;
     }
     return PDBEDA_OK;
@@ -1146,19 +1183,40 @@ extern "C" int pdbeda_full_blobs_pm(pdbeda_map *m, float cutoff_pos, float cutof
 }
 
 // ---- accessors ------------------------------------------------------------------------
+static pdbeda_bloblist *owner_of(pdbeda_bloblist *bl) { return bl->owns_arena ? bl : bl->sibling; }
 static int list_resolve_counts(pdbeda_bloblist *bl) {
     if (bl->have_counts) return 0;
     pdbeda_ctx *ctx = bl->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const Job &job = bl->job;
     // rank range of this list inside the job's blob table: a list is the whole job, or one plane of a fused whole-map job
     // (k_emit published the split)
     Counters ctr;
-    HIP_TRY(ctx, d2h(ctx, &ctr, job.ctr, sizeof ctr));
+    HIP_TRY(ctx, d2h(ctx, &ctr, bl->job.ctr, sizeof ctr));
     HIP_TRY(ctx, ctx_sync(ctx));
+    if (bl->whole_map && ctr.overflow != 0u) {
+        // the typical-size arena was too small for this map (see whole_map_enqueue): the job is run again, once, in a worst-case
+        // arena; both lists of a fused call move to the new job
+        pdbeda_bloblist *ow = owner_of(bl);
+        if (!ow || ow->tier != 0) return fail(ctx, PDBEDA_ERR_STATE, "whole-map labelling overflowed its worst-case arena");
+        if (ow->voxels_done || bl->voxels_done) return fail(ctx, PDBEDA_ERR_STATE, "whole-map labelling: overflow noticed after the voxel lists were made");
+        WholeMapJob wj;
+        arena_put(ctx, ow->arena);                         // (stream order: the first run's kernels are done -- ctx_sync above)
+        int rc = whole_map_enqueue(ow->map, ow->cut_pos, ow->cut_neg, ow->want_pos, ow->want_neg, ow->flags, 1, &wj);
+        if (rc) { ow->arena.base = nullptr; ow->arena.cap = 0; return rc; }
+        ow->arena = wj.arena;
+        pdbeda_bloblist *both[2] = {ow, ow->sibling};
+        for (pdbeda_bloblist *l : both) {
+            if (!l) continue;
+            l->job = wj.job; l->td = wj.td; l->labels_dev = wj.labels_dev; l->labels_done = wj.labels;
+            l->tier = 1; l->reruns += 1; l->have_counts = false;
+        }
+        HIP_TRY(ctx, d2h(ctx, &ctr, bl->job.ctr, sizeof ctr));
+        HIP_TRY(ctx, ctx_sync(ctx));
+        if (ctr.overflow != 0u) return fail(ctx, PDBEDA_ERR_STATE, "whole-map labelling overflowed its worst-case arena");
+    }
     if (bl->whole_map && ctr.unit_wait_failed) return fail(ctx, PDBEDA_ERR_DEVICE, "whole-map labelling: a tile waited in vain for the labels of a neighbour tile that overflowed LDS (k_face_merge)");
-    if (bl->vol_lo == 0 && bl->vol_hi == job.n_vols) { bl->rank_lo = 0; bl->rank_hi = ctr.n_blobs; }
-    else if (bl->whole_map && job.n_vols == 2 && bl->vol_hi == bl->vol_lo + 1) {
+    if (bl->vol_lo == 0 && bl->vol_hi == bl->job.n_vols) { bl->rank_lo = 0; bl->rank_hi = ctr.n_blobs; }
+    else if (bl->whole_map && bl->job.n_vols == 2 && bl->vol_hi == bl->vol_lo + 1) {
         bl->rank_lo = bl->vol_lo == 0 ? 0 : ctr.n_blobs_vol0;
         bl->rank_hi = bl->vol_lo == 0 ? ctr.n_blobs_vol0 : ctr.n_blobs;
     } else return fail(ctx, PDBEDA_ERR_STATE, "blob list covers an unexpected volume range");
@@ -1167,7 +1225,8 @@ static int list_resolve_counts(pdbeda_bloblist *bl) {
 }
 
 // Diagnostic: device counters of the labelling job behind a list:
-// out[0..7] = run ids, component ids, 0, blobs, unit tiles by cause (run slots, -, component table), 0.
+// out[0..7] = run ids, component ids, runs of the job (1 = the typical-size arena overflowed and the job ran again), blobs,
+// unit tiles by cause (run slots, -, component table), bytes of the job's arena.
 extern "C" int pdbeda_bloblist_counters(pdbeda_bloblist *bl, int64_t *out) {
     if (!bl || bl->freed || !out) return PDBEDA_ERR_ARGUMENT;
     pdbeda_ctx *ctx = bl->ctx;
@@ -1175,8 +1234,9 @@ extern "C" int pdbeda_bloblist_counters(pdbeda_bloblist *bl, int64_t *out) {
     Counters c;
     HIP_TRY(ctx, d2h(ctx, &c, bl->job.ctr, sizeof c));
     HIP_TRY(ctx, ctx_sync(ctx));
-    out[0] = c.n_runs; out[1] = c.n_comps; out[2] = 0; out[3] = c.n_blobs;
-    out[4] = out[5] = out[6] = out[7] = 0;
+    out[0] = c.n_runs; out[1] = c.n_comps; out[2] = bl->reruns; out[3] = c.n_blobs;
+    out[4] = out[5] = out[6] = 0;
+    out[7] = (int64_t)owner_of(bl)->arena.cap;      // bytes of device memory the job holds
     if (bl->whole_map && bl->job.tile_mode) {   // unit tiles by cause: tile_mode 1 = run slots / values, 3 = component table
         const int64_t n_tiles = (int64_t)bl->td.ctiles * bl->td.rtiles * bl->td.stiles;
         std::vector<uint8_t> mode(n_tiles);
@@ -1217,7 +1277,6 @@ extern "C" int pdbeda_bloblist_stats(pdbeda_bloblist *bl, int64_t *n, double *to
 
 // Voxel lists are materialised once per JOB (shared by the lists of a fused call through
 // the owning list).
-static pdbeda_bloblist *owner_of(pdbeda_bloblist *bl) { return bl->owns_arena ? bl : bl->sibling; }
 
 static int list_materialise_voxels(pdbeda_bloblist *bl) {
     pdbeda_bloblist *ow = owner_of(bl);

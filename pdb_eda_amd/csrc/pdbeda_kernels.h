@@ -91,6 +91,11 @@ struct Counters {
     unsigned int n_blobs_vol0;   // blobs whose first key lies in volume 0 (the split of a fused green / red job's table)
     unsigned int unit_wait_failed;   // k_face_merge: a unit tile waited a second for a neighbour's labels (see there): the job's results are void
     unsigned int unit_tiles[3];  // whole-map tiles that fell back to unit mode: run slots / edge buffer / component table full
+    // whole-map jobs are carved for what maps typically need, not for the worst case (round 4): bit 0 = the unit tiles asked for
+    // more run / component ids than the job has, bit 1 = more blobs than table rows.  Every kernel stays inside the arena (the
+    // unit work is skipped, rows beyond the table are dropped); the host sees the flag at its first read of the counters and
+    // runs the job again in a worst-case arena.
+    unsigned int overflow;
     unsigned long long n_voxels;
     long long total_words;
     long long total_keys;
@@ -164,6 +169,7 @@ struct Job {
     // fine_per_group is a power of two (>= 16): a key's group is a shift, and the number of groups comes with the job -- the
     // integer divisions they replace ran in the prologue of every wave of the label writer
     int32_t fine_shift, n_groups;
+    uint32_t run_cap, comp_cap, blob_cap;   // ids / table rows the arena holds (see Counters::overflow)
 };
 
 struct InboxEntry {           // 88 bytes: what a (tile, root) pair folds into the root's record (no key: the root holds the first voxel)
@@ -761,6 +767,7 @@ __device__ __forceinline__ void emit_row_ranked(const JobRef &job, const Geom &g
     if (whole_map) job.label_of_comp[id] = job.vol_sign[vi] > 0 ? 1 + (int32_t)rank : -1 - (int32_t)rank;
     const VolDesc vd = job.vols[vi];
     job.r_rank[id] = rank;
+    if (rank >= job.blob_cap) return;   // (more blobs than rows: the job is flagged and runs again with the worst-case table)
     const double n = (double)n_vox;
     double wc[3] = {rc / tot_q, rr / tot_q, rs / tot_q};   // (the quantum cancels)
     double cc[3] = {(double)ic / n, (double)ir / n, (double)is / n};
@@ -819,6 +826,7 @@ __global__ void __launch_bounds__(256) k_emit(Job job, const Geom *__restrict__ 
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         job.ctr->n_blobs = total;
         job.ctr->n_blobs_vol0 = total;
+        if (total > job.blob_cap) atomicOr(&job.ctr->overflow, 2u);
     }
 }
 
@@ -908,13 +916,14 @@ __global__ void __launch_bounds__(256) k_emit_tiles(Job job, const Geom *__restr
     }
     {   // unit components (every run of a tile that overflowed LDS its own component): none on ordinary maps
         const uint32_t n_comp = n_components(job), first = (uint32_t)n_tiles * (uint32_t)TILE_COMPS;
-        if (n_comp > first) emit_ids(job, g, s_pre, true, key_base1, first, n_comp, blockIdx.x, gridDim.x);
+        if (n_comp > first && job.ctr->overflow == 0u) emit_ids(job, g, s_pre, true, key_base1, first, n_comp, blockIdx.x, gridDim.x);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {   // the table's totals, for the host and for k_labels_tiles
         uint32_t below1 = total;                 // blobs before volume 1; every blob when there is one volume
         if (key_base1 != INT64_MAX) below1 = rank_of_key(job, s_pre, (unsigned long long)key_base1);
         job.ctr->n_blobs = total;
         job.ctr->n_blobs_vol0 = below1;
+        if (total > job.blob_cap) atomicOr(&job.ctr->overflow, 2u);
     }
 }
 

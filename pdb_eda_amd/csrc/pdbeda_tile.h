@@ -139,16 +139,16 @@ typedef const Job __attribute__((address_space(4))) *JobKernarg;
 // A kernel that reads its arguments late reads them in many small scalar loads, each behind a wait; the kernel-argument
 // segment is cold in the scalar cache at kernel start, so every new 64-byte line of it costs a trip to memory -- ten of them in
 // a row held the fused label writer's first loads back by ~5 us (stamps).  Touching all lines at once, at entry, makes that
-// one trip: the later loads hit the scalar cache.  (seven lines: Job + TileDims + the two pointers behind them)
-__device__ __forceinline__ void kernarg_prefetch7() {
+// one trip: the later loads hit the scalar cache.  (eight lines: Job + TileDims + the two pointers behind them)
+__device__ __forceinline__ void kernarg_prefetch() {
     JobKernarg ka = (JobKernarg)__builtin_amdgcn_kernarg_segment_ptr();
-    uint32_t d0, d1, d2, d3, d4, d5, d6;
-    asm volatile("s_load_dword %0, %7, 0x0\n\ts_load_dword %1, %7, 0x40\n\ts_load_dword %2, %7, 0x80\n\ts_load_dword %3, %7, 0xc0\n\t"
-                 "s_load_dword %4, %7, 0x100\n\ts_load_dword %5, %7, 0x140\n\ts_load_dword %6, %7, 0x180\n\t"
+    uint32_t d0, d1, d2, d3, d4, d5, d6, d7;
+    asm volatile("s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x40\n\ts_load_dword %2, %8, 0x80\n\ts_load_dword %3, %8, 0xc0\n\t"
+                 "s_load_dword %4, %8, 0x100\n\ts_load_dword %5, %8, 0x140\n\ts_load_dword %6, %8, 0x180\n\ts_load_dword %7, %8, 0x1c0\n\t"
                  "s_waitcnt lgkmcnt(0)"   // (inside the statement: the registers are the compiler's again behind it, and a load must not land later)
-                 : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6) : "s"(ka) : "memory");
+                 : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6), "=&s"(d7) : "s"(ka) : "memory");
 }
-static_assert(sizeof(Job) + sizeof(TileDims) + 16 > 0x180 && sizeof(Job) + sizeof(TileDims) + 16 <= 0x1c0, "seven 64-byte lines of kernel arguments");
+static_assert(sizeof(Job) + sizeof(TileDims) + 16 > 0x1c0 && sizeof(Job) + sizeof(TileDims) + 16 <= 0x200, "eight 64-byte lines of kernel arguments");
 
 // Lock-free union in an LDS parent table (parent[x] <= x, roots point at themselves): find both roots, hang the larger
 // under the smaller with an atomic min; if the larger was no root any more, carry on with its new parent.
@@ -189,7 +189,7 @@ __device__ void unit_label_tile(const JobRef &job, const float *__restrict__ den
     constexpr int QU = 16 * CW;   // units of a quarter tile
     uint64_t *s_m = reinterpret_cast<uint64_t *>(scratch);          // [64]
     uint32_t *s_off = reinterpret_cast<uint32_t *>(scratch + 512);  // [64]
-    uint32_t *s_base = reinterpret_cast<uint32_t *>(scratch + 768); // [2]
+    uint32_t *s_base = reinterpret_cast<uint32_t *>(scratch + 768); // [3]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n_waves = (int)(blockDim.x >> 6);
     const Geom &g = *gp;
     const int ur = td.ur, us = td.us, row_words = td.row_words;
@@ -215,11 +215,16 @@ __device__ void unit_label_tile(const JobRef &job, const float *__restrict__ den
             if (tid == 63) {
                 s_base[0] = x ? atomicAdd(&job.ctr->n_runs, x) : 0u;
                 s_base[1] = x ? atomicAdd(&job.ctr->n_comps, x) : 0u;
+                // the ids this job has may not cover a map this dense: nothing is written beyond them -- the job is flagged, the
+                // unit work of every later kernel is skipped, and the host runs the job again in a worst-case arena
+                s_base[2] = (s_base[0] + x > job.run_cap || s_base[1] + x > job.comp_cap) ? 1u : 0u;
+                if (s_base[2]) atomicOr(&job.ctr->overflow, 1u);
             }
             __syncthreads();
             const uint32_t run_first = s_base[0], comp_first = s_base[1];
-            if (my_valid) job.run_base[my_word] = run_first + s_off[tid];
-            for (int j = wv; j < QU; j += n_waves) {   // a wave per unit
+            const bool no_room = s_base[2] != 0u;   // block-uniform
+            if (my_valid) job.run_base[my_word] = no_room ? 0u : run_first + s_off[tid];
+            for (int j = wv; j < QU && !no_room; j += n_waves) {   // a wave per unit
                 const uint64_t mw = s_m[j];
                 if (mw == 0ull) continue;
                 const int uu = quarter * QU + j;
@@ -754,7 +759,7 @@ template <int CW, int NTH>
 __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job_arg, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td, int pair_slots) {
     // (the job is read from the kernel-argument segment where it is used: the ~45 pointers of a by-value Job sat in scalar registers
     //  -- and spilled into vector lanes -- through the whole kernel for the sake of its cold tail)
-    kernarg_prefetch7();
+    kernarg_prefetch();
     PDBEDA_LATE_JOB(lj);
     /*@F0*/
     const bool any_unit = *lj.unit_flag == lj.epoch;   // block-uniform: some tile of this job is a unit tile (rare)
@@ -1002,9 +1007,11 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job_arg, const float 
             __threadfence();
         }
         __syncthreads();
+        // (a unit tile that found no room for its ids raised the flag before its done flag: whoever waited for it sees it here)
+        const bool ids_ran_out = __hip_atomic_load(&lj.ctr->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
         const VolDesc v0 = lj.vols[0];
         constexpr int NU = 64 * CW;
-        for (int k = tid; k < td.n_planes * NU; k += NTH) {
+        for (int k = tid; k < td.n_planes * NU && !ids_ran_out; k += NTH) {
             const int plane = k / NU, u = k % NU, wl = u % CW, rowl = u / CW;
             const int r = rt * TILE_R + (rowl & 7), s = st * TILE_S + (rowl >> 3), wq = w0 + wl;
             if (r < ur && s < us && wq < row_words) unit_edges_word(lj, td, v0, plane, s, r, wq);
@@ -1063,6 +1070,7 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
         // a round that share a root are summed in the LDS table and folded with ONE set of atomics.  Folding them one by one put
         // hundreds of thousands of same-address atomics on the record of a map-spanning blob (a protein-like map at 0.5 sigma:
         // 2.3 ms in this kernel alone).
+        if (job.ctr->overflow != 0u) return;   // (the unit tiles ran out of ids: this job's results are void, the host runs it again)
         const uint32_t n_comp = n_components(job), stride = (gridDim.x - (uint32_t)n_tiles) * 256u;
         for (uint32_t base = (uint32_t)n_tiles * CCAP + (blockIdx.x - (uint32_t)n_tiles) * 256u; base < n_comp; base += stride) {   // block-uniform
             clear_table();
@@ -1155,7 +1163,7 @@ template <int CW, bool FUSED>
 __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS, FUSED ? 8 : 1) k_labels_tiles(Job job_arg, TileDims td, int32_t *__restrict__ labels, const Geom *__restrict__ gp) {
     // the job is read from the kernel-argument segment where it is used (see PDBEDA_LATE_JOB): its ~45 pointers do not fit the
     // scalar registers beside the row loop -- passed by value they were copied to scratch at entry
-    kernarg_prefetch7();
+    kernarg_prefetch();
     PDBEDA_LATE_JOB(lj);
     constexpr int NU = 64 * CW;
     constexpr int NTL = PDBEDA_LABELS_NT_THREADS, RPW = 64 / (NTL / 64);   // rows of the tile per wave
@@ -1370,6 +1378,7 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS, FUSED ? 8 : 1) k_lab
         if (bid == 0 && tid == 0) {   // the table's totals, for the host
             lj.ctr->n_blobs = total_blobs;
             lj.ctr->n_blobs_vol0 = blobs_vol0;
+            if (total_blobs > lj.blob_cap) atomicOr(&lj.ctr->overflow, 2u);
         }
         /*@L5*/
     }
@@ -1385,7 +1394,9 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS, FUSED ? 8 : 1) k_lab
     const int c = w0 * 64 + lane * 4;
     const bool inside = (r0 + TILE_R <= ur) && (s0 + TILE_S <= us) && ((w0 + CW) * 64 <= uc) && (uc & 3) == 0;   // block-uniform
     // the label of a run by its global id (unit tiles): through its component to the root; fused, the root's key is ranked here
+    const bool ids_ran_out = unit && lj.ctr->overflow != 0u;   // (block-uniform; read by unit tiles only: rare)
     auto label_of_run = [&](uint32_t run) -> int32_t {
+        if (ids_ran_out) return 0;                     // (void job: stay inside the arena, the host runs it again)
         const uint32_t comp = lj.comp_of_run[run];
         if (FUSED) return own_list(label_of_value(kuf_load(lj.kpar, comp)));
         return own_list(lj.label_of_comp[lj.parent[comp]]);
@@ -1451,7 +1462,7 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS, FUSED ? 8 : 1) k_lab
             __syncthreads();   // (everybody is done with the run -> component bytes: the prefix table comes back)
             rank_table_lds<NTL>(lj, s_pre, s_wave);
             const uint32_t n_comp = n_components(lj), first = (uint32_t)lj.n_tiles * (uint32_t)TILE_COMPS;
-            if (n_comp > first) emit_ids(lj, *gp, s_pre, true, key_base1, first, n_comp, bid, (uint32_t)lj.n_tiles);
+            if (n_comp > first && lj.ctr->overflow == 0u) emit_ids(lj, *gp, s_pre, true, key_base1, first, n_comp, bid, (uint32_t)lj.n_tiles);
         }
     }
 }

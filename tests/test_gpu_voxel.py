@@ -542,3 +542,89 @@ def test_six_times_full_size(gpu_ctx):
     g = synthetic.smooth_noise((512, 384, 512), 21, 1.5)
     n_green, n_red = _full_size_case(g, gpu_ctx, 1.5, spacing=0.4)
     assert n_green > 50000 and n_red > 50000
+
+
+def _equal_to_oracle(dm, grid, cut):
+    from oracle import oracle as ora
+    o = ora.Oracle(dm.header, grid)
+    green, red = dm._map.full_blobs_pm(cut, -cut, labels=True)
+    for bl, c in ((green, cut), (red, -cut)):
+        want = o.full_blobs(c, labels=True)
+        st = bl.stats()
+        assert np.array_equal(st["n"], want["n"]) and np.array_equal(st["firstKey"], want["firstKey"])
+        assert np.allclose(st["totalDensity"], want["totalDensity"], rtol=REL)
+        assert np.array_equal(bl.labels(dm._map.unique_shape), want["labels"])
+    return green, red
+
+
+def test_typical_size_arena_and_its_two_overflows(gpu_ctx):
+    """Whole-map jobs are carved for what maps need in practice, not for the worst case (round 4): a 256^3 job at +-1.5 sigma
+    holds well under 0.6 GB (2.9 GB worst case) and runs once.  A map whose unit tiles need more ids than the job has, and a
+    map with more blobs than the job has table rows, raise the device flag, stay inside their arena and are run again in a
+    worst-case arena by the first accessor -- same answers as the oracle, `reruns` = 1."""
+    from pdb_eda_amd import synthetic
+    # (1) the bench's configuration: one run, a small arena
+    g = synthetic.smooth_noise((256, 256, 256), 7, 1.5)
+    dm = _dm(g, gpu_ctx, spacing=0.4)
+    cut = dm.meanDensity + 1.5 * dm.stdDensity
+    green, red = dm._map.full_blobs_pm(cut, -cut, labels=True)
+    c = green.counters()
+    assert c["reruns"] == 0 and c["arena_bytes"] < 600e6, c
+    assert len(green) > 1000 and len(red) > 1000
+    green.free(); red.free()
+    # (2) every tile a unit tile, more word-runs than the typical arena has ids for (64 tiles' worth above the tiles' own ranges)
+    g = synthetic.smooth_noise((128, 128, 256), 3, 0.7)
+    dm = _dm(g, gpu_ctx)
+    cut = dm.meanDensity + 0.1 * dm.stdDensity
+    green, red = _equal_to_oracle(dm, g, cut)
+    c = green.counters()
+    assert c["reruns"] == 1 and c["unit_tiles_runs"] + c["unit_tiles_comps"] > 64, c
+    assert red.counters()["reruns"] == 1
+    green.free(); red.free()
+    # (3) a blob per 2 x 2 x 2 cell: more blobs than one table row per 128 keys
+    g = np.full((32, 40, 64), -1.0, dtype=np.float32)
+    g[::2, ::2, ::2] = 1.0
+    g[1::2, 1::2, 1::2] = -3.0
+    dm = _dm(g, gpu_ctx)
+    green, red = _equal_to_oracle(dm, g, 0.5)
+    assert len(green) == 16 * 20 * 32 and green.counters()["reruns"] == 1
+    green.free(); red.free()
+    # ... and the debug hook that carves the worst case at once gives the same lists in one run
+    import os
+    from pdb_eda_amd import _native
+    os.environ["PDBEDA_DEBUG_WORST_CASE_ARENA"] = "1"
+    try:
+        ctx = _native.Context(0)
+        dm2 = _dm(g, ctx)
+        green2, red2 = _equal_to_oracle(dm2, g, 0.5)
+        assert green2.counters()["reruns"] == 0
+        green2.free(); red2.free()
+        ctx.close()
+    finally:
+        del os.environ["PDBEDA_DEBUG_WORST_CASE_ARENA"]
+
+
+def test_many_contexts_under_a_small_pool_cap(monkeypatch):
+    """Eight contexts on one device, mixed 200^3 - 256^3 whole-map jobs, with the per-context arena pool capped far below what
+    the jobs park (PDBEDA_POOL_CAP_MB): freed arenas go back to the driver instead of piling up, every job still answers, and
+    the parked total stays bounded."""
+    from pdb_eda_amd import _native, ccp4, synthetic
+    monkeypatch.setenv("PDBEDA_POOL_CAP_MB", "96")
+    ctxs = [_native.Context(0) for _ in range(8)]
+    try:
+        grids = {n: synthetic.smooth_noise((n, n, n), 100 + n, 1.5) for n in (200, 224, 256)}
+        counts = {}
+        for rep in range(2):
+            for k, ctx in enumerate(ctxs):
+                n = (200, 224, 256)[(k + rep) % 3]
+                dm = _dm(grids[n], ctx, spacing=0.4)
+                cut = dm.meanDensity + 1.5 * dm.stdDensity
+                green, red = dm._map.full_blobs_pm(cut, -cut, labels=True)
+                got = (len(green), len(red), int(green.stats()["n"].sum()))
+                assert counts.setdefault(n, got) == got and got[0] > 100
+                assert green.counters()["arena_bytes"] < 600e6
+                green.free(); red.free()
+                dm._map.free()
+    finally:
+        for ctx in ctxs:
+            ctx.close()
