@@ -9,26 +9,26 @@ shutil.copytree(src, dst)
 inc = os.path.join(root, "include")
 t = open(os.path.join(dst, "pdbeda_tile.h")).read()
 a = t.index("__global__ void __launch_bounds__(512, 8) k_tile_label")
-b = t.index("// Generic labelling of the tiles k_tile_label could not hold in LDS")
+b = t.index("// Cross-tile pairs of one mask word.")
 body = t[a:b]
-ST = "((unsigned long long *)stamps_p)[(size_t)blockIdx.x * 64 + %s] = __builtin_amdgcn_s_memrealtime();"
+ST = "((unsigned long long *)stamps_p)[(size_t)bid * 64 + %s] = __builtin_amdgcn_s_memrealtime();"
 def once(old, new):
     global body
     assert body.count(old) == 1, old
     body = body.replace(old, new)
-once("    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;",
-     "    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;\n    unsigned long long *stamps_p = job.stamps;\n    if (tid == 0) " + ST % "0")
+once("    const uint32_t bid = ((uint32_t)st * (uint32_t)td.rtiles + (uint32_t)rt) * (uint32_t)td.ctiles + (uint32_t)ct;\n",
+     "    const uint32_t bid = ((uint32_t)st * (uint32_t)td.rtiles + (uint32_t)rt) * (uint32_t)td.ctiles + (uint32_t)ct;\n    unsigned long long *stamps_p = job.stamps;\n    if (tid == 0) " + ST % "0" + "\n")
 for k in (1, 2, 3, 4):
     once("    __syncthreads();   // ---- barrier %d" % k, "    __syncthreads();   if (tid == 0) " + (ST % str(k)) + "  // ---- barrier %d" % k)
 once("    __syncthreads();   if (tid == 0) " + (ST % "1"), "    if (lane == 0) " + (ST % "(8 + wv)") + "\n    __syncthreads();   if (tid == 0) " + (ST % "1"))
 once("    // ---- B: touching pairs -> unions.", "    if (lane == 0) " + (ST % "(16 + wv)") + "\n    // ---- B: touching pairs -> unions.")
 once("    __syncthreads();   if (tid == 0) " + (ST % "2"), "    if (lane == 0) " + (ST % "(24 + wv)") + "\n    __syncthreads();   if (tid == 0) " + (ST % "2"))
 once("    __syncthreads();   if (tid == 0) " + (ST % "4"), "    if (lane == 0) " + (ST % "(32 + wv)") + "\n    __syncthreads();   if (tid == 0) " + (ST % "4"))
-once("    if (tid == 0) lj.tile_runs[blockIdx.x] = n_runs;\n}", "    if (tid == 0) lj.tile_runs[blockIdx.x] = n_runs;\n    if (tid == 0) " + (ST % "5") + "\n}")
+once("    if (tid == 0) lj.tile_runs[bid] = n_runs;\n}", "    if (tid == 0) lj.tile_runs[bid] = n_runs;\n    if (tid == 0) " + (ST % "5") + "\n}")
 t = t[:a] + body + t[b:]
 open(os.path.join(dst, "pdbeda_tile.h"), "w").write(t)
 k = open(os.path.join(dst, "pdbeda_kernels.h")).read()
-k = k.replace("    uint64_t *root_mask;", "    unsigned long long *stamps;\n    uint64_t *root_mask;", 1)
+k = k.replace("    uint32_t run_cap, comp_cap, blob_cap;", "    uint32_t run_cap, comp_cap, blob_cap;\n    unsigned long long *stamps;", 1)
 open(os.path.join(dst, "pdbeda_kernels.h"), "w").write(k)
 h = open(os.path.join(dst, "pdbeda_hip.hip")).read()
 h = h.replace("    job.inbox = n_tiles ?", "    job.stamps = n_tiles ? cv.take<unsigned long long>(64 * n_tiles) : nullptr;\n    job.inbox = n_tiles ?", 1)

@@ -36,3 +36,15 @@ for name, lo, ref in (("wave: stream end - tile start", 8, t[:, 0:1]), ("wave: n
     w = t[:, lo:lo + 8]
     d = w - (t[:, 16:24] if ref is None else ref)
     print("%-40s median %5.1f  p90 %5.1f  max %5.1f us; slowest wave of a tile: median %5.1f us" % (name, us(np.median(d)), us(np.percentile(d, 90)), us(d.max()), us(np.median(d.max(axis=1)))))
+# where the late tiles are: by XCD group (workgroup id mod 8), by position along s (tile id // 32 at 256^3) and by CU slot order
+end = us(t[:, 5] - t0)
+b1 = us(t[:, 1] - t0)
+ids = np.arange(nt)
+print("end of tile by (id mod 8):", [round(float(np.median(end[ids % 8 == k])), 1) for k in range(8)], " max:", [round(float(end[ids % 8 == k].max()), 1) for k in range(8)])
+print("barrier 1 by (id mod 8):  ", [round(float(np.median(b1[ids % 8 == k])), 1) for k in range(8)])
+q = max(1, nt // 8)
+print("end of tile by id range (eighths):", [round(float(np.median(end[k * q:(k + 1) * q])), 1) for k in range(8)], " max:", [round(float(end[k * q:(k + 1) * q].max()), 1) for k in range(8)])
+print("barrier 1 by id range (eighths):  ", [round(float(np.median(b1[k * q:(k + 1) * q])), 1) for k in range(8)])
+late = np.argsort(end)[-16:]
+print("the 16 latest tiles:", sorted(late.tolist()), "ends", np.round(np.sort(end)[-16:], 1).tolist())
+print("corr(end, barrier1) = %.2f   corr(end - barrier1, barrier1) = %.2f" % (np.corrcoef(end, b1)[0, 1], np.corrcoef(end - b1, b1)[0, 1]))
