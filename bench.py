@@ -202,7 +202,7 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
             single = None
             for _ in range(3):                      # best of three short passes: a pool that has just started finds the GPU at idle clocks
                 t1 = time.perf_counter()
-                one.map(sample, chunk=8)            # (the chunk size the big pool works with: the worker pipelines inside a chunk)
+                one.map(sample, chunk=16)           # (the chunk size the big pool works with: the worker pipelines inside a chunk)
                 dt = (time.perf_counter() - t1) / len(sample)
                 single = dt if single is None else min(single, dt)
         finally:

@@ -242,7 +242,7 @@ def _worker_init(device, params, time_out, silent):
 
 
 def _worker_context(k=0):
-    ctxs = _worker_state.setdefault("ctxs", [None, None])
+    ctxs = _worker_state.setdefault("ctxs", [None] * N_WORKER_CONTEXTS)
     if ctxs[k] is None:
         ctxs[k] = _native.Context(_worker_state["device"])
         if _worker_state["time_out"] > 0:
@@ -255,20 +255,27 @@ def _worker_entry(entry):
     return _worker_chunk([entry])[0]
 
 
+N_WORKER_CONTEXTS = 3    # contexts (= HIP streams, arena pools, pinned rings) a pool worker rotates its entries over
+
+
 def _worker_chunk(entries):
-    """A few entries in a worker process, as a two-stage pipeline: while entry i is analysed (host-side table building: holds
-    the GIL) a helper thread brings the maps of entry i + 1 into HBM on the worker's OTHER context (file reads and PCIe copies
+    """A few entries in a worker process, as a pipeline: while entry i is analysed (host-side table building: holds the GIL)
+    helper threads bring the maps of the NEXT TWO entries into HBM on the worker's other contexts (file reads and PCIe copies
     happen inside the library, GIL released) -- a worker used to alternate between feeding the PCIe link and feeding the
-    interpreter, and four of them left the link idle 40 % of the time.  Entry i lives on context i % 2 from its upload to its
-    record.  Returns [(record or 0, failure reason or None)]; a time-out abandons the context it happened on."""
+    interpreter, and four of them left the link idle 40 % of the time; with one entry ahead the link still idled between a
+    worker's uploads (header parse, mean / std, the first chunk's read: tools/prof_pipeline2.py), with two there is always a
+    copy queued.  Entry i lives on context i % 3 from its upload to its record.  With a time-out the pipeline is one entry
+    deep (an entry's ONE deadline starts with its upload: it must not spend it queueing).  Returns [(record or 0, failure
+    reason or None)]; a time-out abandons the context it happened on."""
     silent = _worker_state["silent"]
 
     time_out = _worker_state["time_out"]
+    depth = 1 if time_out > 0 else N_WORKER_CONTEXTS - 1
     started = {}
 
     def load(i, box):
         try:
-            ctx = _worker_context(i % 2)
+            ctx = _worker_context(i % N_WORKER_CONTEXTS)
             started[i] = time.monotonic()
             if time_out > 0:
                 ctx.set_timeout(time_out)            # the entry's ONE deadline starts with its upload
@@ -283,24 +290,25 @@ def _worker_chunk(entries):
         return thread, box
 
     out = []
-    pending = start(0) if entries else None
+    pending = collections.deque(start(k) for k in range(min(depth, len(entries))))
     for i, entry in enumerate(entries):
-        thread, box = pending
+        thread, box = pending.popleft()
         thread.join()
-        pending = start(i + 1) if i + 1 < len(entries) else None
+        if i + depth < len(entries):
+            pending.append(start(i + depth))         # (its context is free: entry i + depth - 3 has returned its record)
         reasons = {}
         try:
-            record = analyzeEntry(entry, _worker_context(i % 2), reasons, silent, loaded=box[0])
+            record = analyzeEntry(entry, _worker_context(i % N_WORKER_CONTEXTS), reasons, silent, loaded=box[0])
             if time_out > 0 and record and time.monotonic() - started.get(i, time.monotonic()) > time_out:
                 _drop(entry.pdbid, "Timeout", reasons, silent)     # (host phases cannot be interrupted: judged when the entry returns)
                 record = 0
         except _native.PdbedaTimeout:
-            _worker_state["ctxs"][i % 2] = None
+            _worker_state["ctxs"][i % N_WORKER_CONTEXTS] = None
             _drop(entry.pdbid, "Timeout", reasons, silent)
             record = 0
         except BaseException:
-            if pending is not None:
-                pending[0].join()                    # (do not leave the helper running into a dying call)
+            for other, _ in pending:
+                other.join()                         # (do not leave the helpers running into a dying call)
             raise
         out.append((record, reasons.get(entry.pdbid)))
     return out
@@ -335,12 +343,13 @@ class ProcessPool(object):
 
     def map(self, entries, chunk=None):
         """Records of ``entries`` in order (0 for a failed entry, its reason in ``self.failures``).  The entries go to the
-        workers in chunks (default: at most 8 entries each, and a whole number of rounds over the workers -- 125 entries on 4
-        workers are 16 chunks of 8, not 18 of 7 with half a round left over) so that a worker can bring the next entry's maps
-        in while it analyses the current one (``_worker_chunk``)."""
+        workers in chunks (default: at most 16 entries each, and a whole number of rounds over the workers -- 125 entries on 4
+        workers are 8 chunks of 16, not 9 of 14 with a round left over) so that a worker can bring the next entries' maps in
+        while it analyses the current one (``_worker_chunk``); every chunk starts with an upload nothing overlaps, so chunks of
+        16 instead of 8 took the pool from 1.77 to 1.51 ms per entry (tools/prof_pipeline2.py)."""
         entries = list(entries)
         if chunk is None:
-            rounds = max(1, -(-len(entries) // (8 * self.n_workers)))
+            rounds = max(1, -(-len(entries) // (16 * self.n_workers)))
             chunk = max(1, -(-len(entries) // (rounds * self.n_workers)))
         chunks = [entries[k:k + chunk] for k in range(0, len(entries), chunk)]
         results = [pair for part in self.run(_worker_chunk, chunks) for pair in part]
