@@ -39,6 +39,7 @@ def parse_args():
     ap.add_argument("--no-labels", action="store_true", help="skip the dense label volume (not the headline configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-analysis", action="store_true", help="skip the informational densityAnalysis leg")
+    ap.add_argument("--no-sigma3", action="store_true", help="skip the informational +-3 sigma leg (a kernel trace of the headline configuration must not mix cutoffs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the bounded CPU-baseline sample")
     ap.add_argument("--windows", type=int, default=5, help="extra timed windows of --steps steps each (dispersion of ms_per_step)")
     ap.add_argument("--entries", type=int, default=125, help="multiple-structure leg (BASELINE configs[3]): entries per rank (1000 / 8 GPUs); 0 = skip")
@@ -474,7 +475,7 @@ def main():
 
     # ---- the same map at pdb_eda's own green / red default, +-(mean + 3 std) (densityAnalysis.py:148) -- informational, never `value`
     sigma3 = None
-    if args.nsd != 3.0:
+    if args.nsd != 3.0 and not args.no_sigma3:
         cut3 = mean + 3.0 * std
         for _ in range(max(args.warmup, 2)):
             keep3 = dmap.full_blobs_pm(cut3, -cut3, labels=labels)

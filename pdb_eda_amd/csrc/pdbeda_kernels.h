@@ -130,8 +130,8 @@ struct Job {
     uint32_t *tile_runs;      // per tile: number of word-runs (ids tile * runs_per_tile ...)
     // Scattered global atomics are the scarce resource of the merge (~20 G/s chip-wide: folding 9 fields per (tile, root) pair
     // took 12 of k_resolve_tiles' 22 us).  So a tile's members POST their summed record to the inbox of the tile that owns
-    // their root -- one returning atomic for the slot + plain stores -- and k_paint_tiles (a workgroup per tile) absorbs
-    // the inbox in LDS before it paints the final first keys.  A full inbox falls back to the atomics.
+    // their root -- one returning atomic for the slot + plain stores -- and whoever writes the blob table rows (the fused
+    // label writer, or k_emit_tiles) sums the tile's inbox in LDS first.  A full inbox falls back to the atomics.
     struct InboxEntry *inbox;     // [tile][INBOX_CAP]
     uint32_t *inbox_count;        // [tile * INBOX_STRIDE]: one counter per 128-B line (atomics on one line serialise); cleared by the
                                   // tile's own k_face_merge workgroup
@@ -155,7 +155,7 @@ struct Job {
     // (last: the tile kernel's scalar-register allocation is sensitive to the offsets of the fields above -- inserting these
     //  in the middle cost it 10 more SGPR spills and 1.6 us)
     uint64_t *root_mask;      // per tile: which of its TILE_COMPS component slots are blob roots (4 ballots, written by k_resolve_tiles):
-    int32_t n_tiles;          // k_emit visits the ~36 k roots of a 256^3 job, not its 262 k component ids
+    int32_t n_tiles;          // k_emit_tiles visits the ~36 k roots of a 256^3 job, not its 262 k component ids
     // Whole-map jobs unite by FIRST KEY, not by id (round 4): kpar[x] = key32(parent) << 32 | parent, key32 = plane << 31 | the
     // c-major key of the component's first voxel inside its plane (unique: a position).  The root of a blob is then the
     // component that holds the blob's first voxel, its own key IS the blob's first key as soon as the unions are done, and the

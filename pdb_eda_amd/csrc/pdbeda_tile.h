@@ -32,6 +32,13 @@
 // LDS pre-reduction per tile).  A tile whose run or component count exceeds the LDS capacity falls
 // back to "unit mode" (its workgroup of k_face_merge labels it run by run, every run its own component, and unites its pairs
 // globally): slower, same result.
+//
+// The step is FOUR launches (round 4; six in round 3): k_tile_label -> k_face_merge -> k_resolve_tiles -> k_labels_tiles<fused>.
+// The cross-tile unions hang by FIRST KEY (kpar[]: first key << 32 | id, the later first voxel under the earlier one), so the
+// root of a blob holds the blob's first key the moment the unions are done: k_resolve_tiles paints the keys while it finds the
+// roots (no fold of keys, no painting kernel), and the label writer -- every component's packed parent carries its root's
+// key -- ranks the keys of its own tile's components itself and writes the blob table rows of the tile's roots (no emit
+// kernel, no label table from another launch).
 #pragma once
 #include "pdbeda_kernels.h"
 #include <type_traits>

@@ -7,13 +7,13 @@
 # 3. bench.py alone (after the counters are condensed, so that its roofline.traffic is this round's) -> gpurun_out/prof_<tag>/bench.json
 # tools/make_profiles.py then condenses 1-3 into profiles/<tag>_*.  (Counter passes never carry --stats/traces.)
 set -e -o pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o bench -- python3 "$root/bench.py" --steps 30 --warmup 5 --windows 0 --entries 0 --sweep-entries 0 --no-cpu-baseline --no-analysis --streams 1 > "$out/bench_under_rocprof.json" 2> "$out/trace.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o bench -- python3 "$root/bench.py" --steps 30 --warmup 5 --windows 0 --entries 0 --sweep-entries 0 --no-cpu-baseline --no-analysis --no-sigma3 --streams 1 > "$out/bench_under_rocprof.json" 2> "$out/trace.err"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o p -- python3 "$root/tools/profile_step.py" > "$out/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o p -- python3 "$root/tools/profile_step.py" > "$out/pmc_write.log" 2>&1
 cd "$root"
