@@ -191,6 +191,32 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
             check_golden(records)
         n_done = passes * args.entries
         own_rate = 60.0 * n_done / elapsed
+        # ONE cold-cache data point: the pages of the bench's own files are dropped (fsync + POSIX_FADV_DONTNEED: an ordinary user may
+        # do that for files it owns; whether the kernel obeys is checked by timing) and one pass over the distinct entries is timed
+        cold = None
+        try:
+            dropped = 0
+            for l in loaders:
+                for path in (l.density_path, l.diff_path):
+                    fd = os.open(path, os.O_RDONLY)
+                    try:
+                        os.fsync(fd)
+                        os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+                        dropped += 1
+                    finally:
+                        os.close(fd)
+            barrier()
+            t0 = time.perf_counter()
+            cold_records = pool.map(entries[:distinct])
+            barrier()
+            cold_s = time.perf_counter() - t0
+            check_golden(cold_records)
+            cold = {"entries": distinct, "seconds": cold_s, "entries_per_min": 60.0 * distinct / cold_s, "files_dropped": dropped,
+                    "file_GBs": distinct * 2 * 4 * args.entry_size ** 3 / cold_s / 1e9,
+                    "note": "one pass over the distinct entries right after fsync + posix_fadvise(DONTNEED) on their files; a rate near the warm one means the "
+                            "kernel kept the pages (tmpfs / a busy page cache) -- read it beside file_GBs"}
+        except (OSError, AttributeError) as error:
+            cold = {"error": "%s: %s" % (type(error).__name__, error)}
         # ONE worker process of the same kind for comparison (the pool is closed first: few processes may share the GPU)
         pool.close()
         sample = entries[:min(16, len(entries))]
@@ -284,8 +310,9 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
                                   "note": "the same entry list with the product's default loader: the Fo-Fc file's header is read, its grid would follow on first use "
                                           "and nothing in the record of `pdb_eda multiple` uses it (32 MB per entry over PCIe instead of 64); same records"},
                 "cpu_baseline": cpu_pool,
-                "page_cache": "warm: the files were written by this process moments earlier and every one is read again on each pass (no O_DIRECT, no cache drop: "
-                              "an ordinary user cannot drop caches on the box); a cold first read of a 64 MB entry costs its disk time on top",
+                "cold_pass": cold,
+                "page_cache": "warm for `entries_per_min`: the files were written by this process moments earlier and every one is read again on each pass; "
+                              "`cold_pass` is one pass after the files' pages were dropped",
                 "note": "worker processes (spawn), one HIP stream each, sharing the GPU of the rank; sharding over ranks is one entry list per rank, no collective"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

@@ -176,6 +176,7 @@ struct pdbeda_bloblist {
     // resolved lazily
     bool have_counts = false;
     int64_t rank_lo = 0, rank_hi = 0;  // blob rank range of this list inside the job's table
+    int64_t job_blobs = -1;            // blobs of the whole job (known once the counters have been read)
     int64_t n_voxels = -1;
     int32_t *labels_dev = nullptr;     // inside arena when requested
     bool labels_done = false;
@@ -1220,6 +1221,7 @@ static int list_resolve_counts(pdbeda_bloblist *bl) {
         bl->rank_lo = bl->vol_lo == 0 ? 0 : ctr.n_blobs_vol0;
         bl->rank_hi = bl->vol_lo == 0 ? ctr.n_blobs_vol0 : ctr.n_blobs;
     } else return fail(ctx, PDBEDA_ERR_STATE, "blob list covers an unexpected volume range");
+    bl->job_blobs = ctr.n_blobs;
     bl->have_counts = true;
     return 0;
 }
@@ -1283,11 +1285,14 @@ static int list_materialise_voxels(pdbeda_bloblist *bl) {
     if (ow->voxels_done) return 0;
     pdbeda_ctx *ctx = bl->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    {   // the job's blob count: one read of the counters per list, not one more here (every caller has resolved its counts;
+        // a whole-map job that overflowed its typical-size arena has been run again by then)
+        const int rc_counts = list_resolve_counts(bl);
+        if (rc_counts) return rc_counts;
+        ow = owner_of(bl);
+    }
     Job &job = ow->job;
-    Counters ctr;
-    HIP_TRY(ctx, d2h(ctx, &ctr, job.ctr, sizeof ctr));
-    HIP_TRY(ctx, ctx_sync(ctx));
-    const int64_t nb = ctr.n_blobs;
+    const int64_t nb = bl->job_blobs;
     // total voxels unknown until the offsets scan; bound by key bits
     const int64_t max_vox = job.key_words * 64;
     size_t need = align_up(8 * (nb + 1)) + align_up(4 * std::max<int64_t>(nb, 1)) + align_up(12 * std::max<int64_t>(max_vox, 1));
@@ -1304,8 +1309,7 @@ static int list_materialise_voxels(pdbeda_bloblist *bl) {
         hipLaunchKernelGGL(k_voxel_lists, dim3(grid_for(job.total_words * 64, 256, 8192)), dim3(256), 0, st, job, ow->offsets_dev,
                            ow->cursor_dev, ow->crs_dev);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, ctx_sync(ctx));
-    ow->voxels_done = true;
+    ow->voxels_done = true;      // (enqueued: whatever reads the lists is ordered behind them on the stream, and waits there)
     return 0;
 }
 
