@@ -193,6 +193,7 @@ struct pdbeda_bloblist {
     bool want_pos = false, want_neg = false;
     uint32_t flags = 0;
     int tier = 0, reruns = 0;
+    size_t job_bytes = 0;              // bytes the job carved out of its arena (a recycled arena may be larger)
 };
 
 static const int N_PARTIAL = 2048;
@@ -1028,8 +1029,8 @@ static void launch_labels(pdbeda_ctx *ctx, const Job &job, const TileDims &td, i
     }
 }
 
-// Enqueue a whole-map job.  tier 0 carves the arena for what maps need in practice -- room for 64 unit tiles' worth of run /
-// component ids above the tiles' own ranges, a blob table of one row per 128 keys -- instead of the worst case (every other
+// Enqueue a whole-map job.  tier 0 carves the arena for what maps need in practice -- unit-tile run / component ids for a quarter of
+// the tiles' own run-id range above the tiles' ranges, a blob table of one row per 32 keys -- instead of the worst case (every other
 // voxel a run of a unit tile, a blob per 2x2x2 cell: 2.9 GB at 256^3, of which a job touches a few hundred MB).  A map that
 // needs more raises Counters::overflow on the device, stays inside its arena, and is run again at tier 1 (the worst case)
 // by the first accessor that reads the counters (list_resolve_counts): correct always, slower only where it was slow already.
@@ -1039,6 +1040,7 @@ struct WholeMapJob {
     TileDims td;
     int32_t *labels_dev = nullptr;
     bool labels = false;
+    size_t bytes = 0;
 };
 static int whole_map_enqueue(pdbeda_map *m, float cut_pos, float cut_neg, bool want_pos, bool want_neg, uint32_t flags, int tier, WholeMapJob *out) {
     pdbeda_ctx *ctx = m->ctx;
@@ -1076,8 +1078,10 @@ static int whole_map_enqueue(pdbeda_map *m, float cut_pos, float cut_neg, bool w
     if (tile_runs + worst_unit >= (1ll << 31))
         return fail(ctx, PDBEDA_ERR_ARGUMENT, "grid too large for whole-map labelling: %d x %d x %d voxels need %lld run ids (limit 2^31: about 1100^3 for a fused job)",
                     uc, ur, us, (long long)(tile_runs + worst_unit));
-    const int64_t unit_ids = tier == 0 ? std::min<int64_t>(worst_unit, std::max<int64_t>(65536, (int64_t)64 * td.cw * 64 * 32)) : worst_unit;
-    const int64_t max_blobs = tier == 0 ? std::min<int64_t>(worst_blobs, std::max<int64_t>(4096, total_keys / 128)) : worst_blobs;
+    // (tier 0: a quarter of the tiles' own run-id range -- every tile a unit tile of 2 048 word-runs, or a quarter of them at the
+    //  most a tile can hold: a protein-like map at 0.5 sigma, every tile over its LDS capacities, still runs once)
+    const int64_t unit_ids = tier == 0 ? std::min<int64_t>(worst_unit, std::max<int64_t>(65536, tile_runs / 4)) : worst_unit;
+    const int64_t max_blobs = tier == 0 ? std::min<int64_t>(worst_blobs, std::max<int64_t>(4096, total_keys / 32)) : worst_blobs;
     const int64_t max_runs = tile_runs + unit_ids, max_comps = tile_comps + unit_ids;
 
     int rc_fix = map_fix_mul(m);
@@ -1135,7 +1139,7 @@ static int whole_map_enqueue(pdbeda_map *m, float cut_pos, float cut_neg, bool w
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { arena_put(ctx, arena); return fail(ctx, PDBEDA_ERR_DEVICE, "whole-map labelling launch: %s", hipGetErrorString(e)); }
-    out->job = job; out->arena = arena; out->td = td; out->labels_dev = labels_dev; out->labels = labels;
+    out->job = job; out->arena = arena; out->td = td; out->labels_dev = labels_dev; out->labels = labels; out->bytes = need;
     return PDBEDA_OK;
 }
 
@@ -1161,6 +1165,7 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
         bl->labels_dev = wj.labels_dev;
         bl->labels_done = wj.labels;
         bl->cut_pos = cut_pos; bl->cut_neg = cut_neg; bl->want_pos = want_pos; bl->want_neg = want_neg; bl->flags = flags; bl->tier = tier;
+        bl->job_bytes = wj.bytes;
         if (bl->sign > 0) *out_pos = bl; else *out_neg = bl;
     }
     return PDBEDA_OK;
@@ -1209,7 +1214,7 @@ static int list_resolve_counts(pdbeda_bloblist *bl) {
         for (pdbeda_bloblist *l : both) {
             if (!l) continue;
             l->job = wj.job; l->td = wj.td; l->labels_dev = wj.labels_dev; l->labels_done = wj.labels;
-            l->tier = 1; l->reruns += 1; l->have_counts = false;
+            l->tier = 1; l->reruns += 1; l->have_counts = false; l->job_bytes = wj.bytes;
         }
         HIP_TRY(ctx, d2h(ctx, &ctr, bl->job.ctr, sizeof ctr));
         HIP_TRY(ctx, ctx_sync(ctx));
@@ -1238,7 +1243,7 @@ extern "C" int pdbeda_bloblist_counters(pdbeda_bloblist *bl, int64_t *out) {
     HIP_TRY(ctx, ctx_sync(ctx));
     out[0] = c.n_runs; out[1] = c.n_comps; out[2] = bl->reruns; out[3] = c.n_blobs;
     out[4] = out[5] = out[6] = 0;
-    out[7] = (int64_t)owner_of(bl)->arena.cap;      // bytes of device memory the job holds
+    out[7] = (int64_t)(bl->job_bytes ? bl->job_bytes : owner_of(bl)->arena.cap);   // bytes of device memory the job needs (its arena, if recycled, may be up to twice that)
     if (bl->whole_map && bl->job.tile_mode) {   // unit tiles by cause: tile_mode 1 = run slots / values, 3 = component table
         const int64_t n_tiles = (int64_t)bl->td.ctiles * bl->td.rtiles * bl->td.stiles;
         std::vector<uint8_t> mode(n_tiles);

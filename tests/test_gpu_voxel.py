@@ -581,7 +581,7 @@ def test_typical_size_arena_and_its_two_overflows(gpu_ctx):
     assert c["reruns"] == 1 and c["unit_tiles_runs"] + c["unit_tiles_comps"] > 64, c
     assert red.counters()["reruns"] == 1
     green.free(); red.free()
-    # (3) a blob per 2 x 2 x 2 cell: more blobs than one table row per 128 keys
+    # (3) a blob per 2 x 2 x 2 cell: more blobs than one table row per 32 keys
     g = np.full((32, 40, 64), -1.0, dtype=np.float32)
     g[::2, ::2, ::2] = 1.0
     g[1::2, 1::2, 1::2] = -3.0
