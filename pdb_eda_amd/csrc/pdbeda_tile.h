@@ -308,6 +308,7 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
 
     // the streaming phase runs at raised wave priority: a tile whose data arrives late shares its CU with tiles that are already
     // in their LDS phases, and it is the late tile that ends the kernel
+    const uint64_t t_in = __builtin_amdgcn_s_memrealtime();   // (100 MHz; see the priorities behind barrier 1)
     __builtin_amdgcn_s_setprio(3);
     // ---- A1: the wave streams its section: compare, ballot, park the significant values (lane order) in its LDS region.
     //      A tile that lies wholly inside the grid (all but the last ones along each axis) takes the unguarded path:
@@ -389,7 +390,17 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
         if (lane == 15) s_wtot[wvs] = rtot | (vcnt > (uint32_t)VREG ? 0x80000000u : 0u);
     }
     __syncthreads();   // ---- barrier 1 ----
-    __builtin_amdgcn_s_setprio(0);
+    {   // The tile whose data arrived LATE is the one that ends the kernel: HBM serves the workgroups in dispatch order (stamps by
+        // tile id: the first eighth of the tiles has its section after 5.9 us, the last after 10.7), every CU holds a tile of each
+        // quarter, and from 10 to 25 us all four are in the vector-bound phases below at once.  So the later a tile left the
+        // stream, the higher its priority from here on: the early tiles have the slack (r04 A/B: -1.8 us of 34; by tile id
+        // instead of by the clock: -1.3; two levels instead of four: -1.0).  Thresholds in 10 ns ticks, for MI355X's HBM.
+        const uint32_t dt = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_in);
+        if (dt > 1000u) __builtin_amdgcn_s_setprio(3);
+        else if (dt > 850u) __builtin_amdgcn_s_setprio(2);
+        else if (dt > 650u) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    }
 
     // ---- A2: lane = (sign q, row rl, word wl) of section wvs --------------------------------------------------------
     const int q = lane >> 5, usec = lane & 31;
