@@ -956,6 +956,12 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.tile_runs = n_tiles ? cv.take<uint32_t>(n_tiles) : nullptr;
     job.root_mask = n_tiles ? cv.take<uint64_t>((size_t)n_tiles * 4) : nullptr;
     job.n_tiles = (int32_t)n_tiles;
+    if (n_tiles) {   // (what a tile's k_face_merge workgroup clears)
+        const int64_t nt = n_tiles, nfc = job.n_fine_alloc / 2, nmid = (job.key_words + KEY_FINE - 1) / KEY_FINE * (KEY_FINE / 16);
+        job.clear_bits = (int32_t)((job.key_words + nt - 1) / nt);
+        job.clear_fine = (int32_t)((nfc + nt - 1) / nt);
+        job.clear_mid = (int32_t)((nmid + nt - 1) / nt);
+    }
     job.inbox = n_tiles ? cv.take<InboxEntry>((size_t)n_tiles * INBOX_CAP) : nullptr;
     job.inbox_count = n_tiles ? cv.take<uint32_t>((size_t)n_tiles * INBOX_STRIDE) : nullptr;
     job.vol_sign[0] = job.vol_sign[1] = 1;

@@ -170,6 +170,9 @@ struct Job {
     // integer divisions they replace ran in the prologue of every wave of the label writer
     int32_t fine_shift, n_groups;
     uint32_t run_cap, comp_cap, blob_cap;   // ids / table rows the arena holds (see Counters::overflow)
+    // words of the first-key bitmap / 16-bit counter words / byte counter words every tile's k_face_merge workgroup clears (the
+    // ceilings of the table sizes over the tile count: three 64-bit divisions per wave where the kernel computed them)
+    int32_t clear_bits, clear_fine, clear_mid;
 };
 
 struct InboxEntry {           // 88 bytes: what a (tile, root) pair folds into the root's record (no key: the root holds the first voxel)

@@ -122,6 +122,10 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// A workgroup barrier for LDS traffic only: __syncthreads() also waits for the wave's global stores to be acknowledged
+// (s_waitcnt vmcnt(0)), which is what a kernel that has fire-and-forget stores in flight must NOT do.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Tile t owns component ids [t * CCAP, (t+1) * CCAP) and run ids [t * runs_per_tile, ...): no
 // allocation atomics on the fast path.  Unused component ids are marked empty (r_n = 0).
 template <typename JobRef>
@@ -842,13 +846,28 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job_arg, const float 
         const uint32_t t5 = j == 0 ? tiles5[0] : (j == 1 ? tiles5[1] : (j == 2 ? tiles5[2] : (j == 3 ? tiles5[3] : tiles5[4])));
         kp_pre[k] = (e < 5 * CCAP && t5 != 0xffffffffu) ? kuf_load(lj.kpar, t5 * (uint32_t)CCAP + (uint32_t)(e % CCAP)) : KP_UNUSED;
     }
+    {   // every tile clears its slice of the first-key bitmap and of the rank counters (saves a memset launch; painted by the next
+        // kernel) and its inbox counter -- HERE, under the first trip: fire-and-forget stores, and the barriers of this kernel's hot
+        // path wait for LDS only (lds_barrier), so nothing ever waits for them (r03 had them behind the last barrier: 0.9 us at
+        // the end of every workgroup; in front of a __syncthreads() they cost 2 us)
+        const int64_t key_words = lj.key_words;
+        const int64_t lo = (int64_t)lj.clear_bits * tile, hi = lo + lj.clear_bits < key_words ? lo + lj.clear_bits : key_words;
+        for (int64_t i = lo + tid; i < hi; i += NTH) lj.key_bits[i] = 0ull;
+        const int64_t nfc = lj.n_fine_alloc / 2;   // (16-bit counters, two per word)
+        const int64_t clo = (int64_t)lj.clear_fine * tile, chi = clo + lj.clear_fine < nfc ? clo + lj.clear_fine : nfc;
+        for (int64_t i = clo + tid; i < chi; i += NTH) lj.fine_count[i] = 0u;
+        const int64_t nmid = (key_words + KEY_FINE - 1) / KEY_FINE * (KEY_FINE / 16);   // (a byte per 4 key words, four per word; whole buckets)
+        const int64_t mlo = (int64_t)lj.clear_mid * tile, mhi = mlo + lj.clear_mid < nmid ? mlo + lj.clear_mid : nmid;
+        for (int64_t i = mlo + tid; i < mhi; i += NTH) lj.mid_count[i] = 0u;
+        if (tid == 0) lj.inbox_count[(size_t)tile * INBOX_STRIDE] = 0u;
+    }
     for (int i = tid; i < pair_slots; i += NTH) s_set[i] = 0ull;   // 0 = empty: a pair (lo << 32 | hi) has hi > lo >= 0
 #pragma unroll
     for (int k = 0; k < KPL; ++k) {
         const int e = tid + k * NTH;
         if (e < 5 * CCAP) (&s_kp[0][0])[e] = kp_pre[k];
     }
-    __syncthreads();
+    lds_barrier();
     /*@F1*/
     auto val_of = [&](uint32_t id) -> kp_t {   // a value that names a node of id's set
         const uint32_t t = id / (uint32_t)CCAP;
@@ -930,7 +949,7 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job_arg, const float 
             if (cb != last_b) { add_pair(ca, cb); last_b = cb; }
         }
     }
-    __syncthreads();
+    lds_barrier();
     /*@F2*/
     // the distinct pairs of this tile: compacted (block prefix over the slots) so that thread k unites pair k, k + 512, ... --
     // a union is a chain of dependent memory round trips, and nobody should walk two chains while others walk none
@@ -953,13 +972,13 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job_arg, const float 
             if (lane >= d) x += y;
         }
         if (lane == 63) s_wsum[tid >> 6] = x;
-        __syncthreads();
+        lds_barrier();
         uint32_t at = x - cnt;
         for (int k = 0; k < (tid >> 6); ++k) at += s_wsum[k];
 #pragma unroll
         for (int k = 0; k < MAXPER; ++k)
             if (mine[k] != 0ull) s_pairs[at++] = mine[k];
-        __syncthreads();
+        lds_barrier();
     }
     /*@F3*/
     uint32_t n_pairs = 0;
@@ -970,22 +989,6 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job_arg, const float 
         kuf_hook_vals(lj.kpar, val_of((uint32_t)(key >> 32)), val_of((uint32_t)key));
     }
     /*@F4*/
-    {   // every tile clears its slice of the first-key bitmap and of the rank counters (saves a memset launch; painted two kernels
-        // later) and its inbox counter (used by the next kernel) -- here, behind the last barrier: a barrier waits for the stores
-        // before it to be acknowledged (2 us), the unions below do not
-        const int n_tiles = (int)(gridDim.x * gridDim.y * gridDim.z);
-        const int64_t key_words = lj.key_words;
-        const int64_t per = (key_words + n_tiles - 1) / n_tiles;
-        const int64_t lo = per * tile, hi = lo + per < key_words ? lo + per : key_words;
-        for (int64_t i = lo + tid; i < hi; i += NTH) lj.key_bits[i] = 0ull;
-        const int64_t nfc = lj.n_fine_alloc / 2;   // (16-bit counters, two per word)
-        const int64_t perc = (nfc + n_tiles - 1) / n_tiles, clo = perc * tile, chi = clo + perc < nfc ? clo + perc : nfc;
-        for (int64_t i = clo + tid; i < chi; i += NTH) lj.fine_count[i] = 0u;
-        const int64_t nmid = (key_words + KEY_FINE - 1) / KEY_FINE * (KEY_FINE / 16);   // (a byte per 4 key words, four per word; whole buckets)
-        const int64_t perm = (nmid + n_tiles - 1) / n_tiles, mlo = perm * tile, mhi = mlo + perm < nmid ? mlo + perm : nmid;
-        for (int64_t i = mlo + tid; i < mhi; i += NTH) lj.mid_count[i] = 0u;
-        if (tid == 0) lj.inbox_count[(size_t)tile * INBOX_STRIDE] = 0u;
-    }
     /*@F5*/
     if (any_unit) {
         // Some tile overflowed LDS in k_tile_label.  Its own workgroup labels it here, run by run (phase 1), and every pair with
@@ -1116,7 +1119,11 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
     const kp_t p0 = kuf_load(job.kpar, i);
     const FixSums v_sum = fix_load(job, i);
     const unsigned long long v_c = (unsigned long long)job.r_c[i], v_r = (unsigned long long)job.r_r[i], v_s = (unsigned long long)job.r_s[i], v_key = job.r_key[i];
+    __shared__ int s_any;
     clear_table();
+    if (tid == 0) s_any = 0;
+    lds_barrier();   // (early, and for LDS only: the table is clear before anybody has found anything -- a member adds itself as
+                     //  soon as ITS find is done, and no barrier of this kernel waits for the stores and atomics in flight)
     const bool used = n_i > 0u && p0 != KP_UNUSED;
     const bool is_root = used && kp_id(p0) == i;
     const bool member = used && !is_root;   // non-root component with voxels
@@ -1134,12 +1141,11 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
         if ((tid & 63) == 0) job.root_mask[(size_t)blockIdx.x * 4 + (tid >> 6)] = rbits;
     }
     if (is_root) paint(v_key);
-    __syncthreads();
     /*@R3*/
-    if (__syncthreads_or(member ? 1 : 0) == 0) return;   // nothing to fold in this tile
-    if (member) table_add(root, n_i, v_sum, v_c, v_r, v_s);
-    __syncthreads();
+    if (member) { table_add(root, n_i, v_sum, v_c, v_r, v_s); s_any = 1; }
+    lds_barrier();
     /*@R4*/
+    if (s_any == 0) return;   // nothing to fold in this tile
     for (int k = tid; k < RSLOTS; k += 256) {
         if (s_root[k] < 0) continue;
         const uint32_t root = (uint32_t)s_root[k], rtile = root / CCAP;
