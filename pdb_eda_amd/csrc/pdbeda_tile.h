@@ -791,7 +791,8 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job_arg, const float 
     // what kpar[] holds for the components of this tile and of the four tiles it meets across its r / s faces, fetched with
     // everything else: a union starts from two VALUES (an ancestor-or-self of either component, named by its first key), and
     // these are such values whatever the other workgroups have united meanwhile -- no trip for them in front of the first hook
-    __shared__ kp_t s_kp[5][CCAP];
+    constexpr int KPH = 128;   // ids of a tile whose packed parents ride in the first trip (a tile has ~100 components: the others are fetched on demand; r04 A/B: -0.6 us, -5 MB)
+    __shared__ kp_t s_kp[5][KPH];
     const int tid = threadIdx.x, lane = tid & 63;
     const int ur = td.ur, us = td.us, row_words = td.row_words;
     // (3-D grid: the tile coordinates come with the workgroup, x fastest = tile order)
@@ -838,13 +839,13 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job_arg, const float 
             tiles5[j] = (r5 >= 0 && r5 < td.rtiles && s5 >= 0) ? (uint32_t)((s5 * td.rtiles + r5) * td.ctiles + ct) : 0xffffffffu;
         }
     }
-    constexpr int KPL = (5 * CCAP + NTH - 1) / NTH;
+    constexpr int KPL = (5 * KPH + NTH - 1) / NTH;
     kp_t kp_pre[KPL];
 #pragma unroll
     for (int k = 0; k < KPL; ++k) {
-        const int e = tid + k * NTH, j = e / CCAP;
+        const int e = tid + k * NTH, j = e / KPH;
         const uint32_t t5 = j == 0 ? tiles5[0] : (j == 1 ? tiles5[1] : (j == 2 ? tiles5[2] : (j == 3 ? tiles5[3] : tiles5[4])));
-        kp_pre[k] = (e < 5 * CCAP && t5 != 0xffffffffu) ? kuf_load(lj.kpar, t5 * (uint32_t)CCAP + (uint32_t)(e % CCAP)) : KP_UNUSED;
+        kp_pre[k] = (e < 5 * KPH && t5 != 0xffffffffu) ? kuf_load(lj.kpar, t5 * (uint32_t)CCAP + (uint32_t)(e % KPH)) : KP_UNUSED;
     }
     {   // every tile clears its slice of the first-key bitmap and of the rank counters (saves a memset launch; painted by the next
         // kernel) and its inbox counter -- HERE, under the first trip: fire-and-forget stores, and the barriers of this kernel's hot
@@ -865,7 +866,7 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job_arg, const float 
 #pragma unroll
     for (int k = 0; k < KPL; ++k) {
         const int e = tid + k * NTH;
-        if (e < 5 * CCAP) (&s_kp[0][0])[e] = kp_pre[k];
+        if (e < 5 * KPH) (&s_kp[0][0])[e] = kp_pre[k];
     }
     lds_barrier();
     /*@F1*/
@@ -873,7 +874,7 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job_arg, const float 
         const uint32_t t = id / (uint32_t)CCAP;
 #pragma unroll
         for (int j = 0; j < 5; ++j)
-            if (t == tiles5[j]) return s_kp[j][id % (uint32_t)CCAP];
+            if (t == tiles5[j] && (id % (uint32_t)CCAP) < (uint32_t)KPH) return s_kp[j][id % (uint32_t)CCAP];
         return kuf_load(lj.kpar, id);   // (the c faces of a grid wider than one tile)
     };
     const uint32_t slot_mask = (uint32_t)pair_slots - 1u;
@@ -1114,11 +1115,18 @@ __global__ void __launch_bounds__(256) k_resolve_tiles(Job job, int n_tiles) {
     }
     /*@R0*/
     const uint32_t i = (uint32_t)blockIdx.x * CCAP + tid;
-    // everything this thread may need, in flight at once (unused ids hold stale bytes: loaded, never used)
-    const uint32_t n_i = job.r_n[i];
+    // everything this thread may need, in flight at once -- for the lower half of the tile's ids (unused ones hold stale bytes:
+    // loaded, never used).  A tile has ~100 components: ids 128 .. 255 are rarely in use, and their records (100 bytes each)
+    // were 13 MB of reads per step for nothing: those threads load theirs once kpar[] says the id is in use (r04 A/B: -1.1 us)
     const kp_t p0 = kuf_load(job.kpar, i);
-    const FixSums v_sum = fix_load(job, i);
-    const unsigned long long v_c = (unsigned long long)job.r_c[i], v_r = (unsigned long long)job.r_r[i], v_s = (unsigned long long)job.r_s[i], v_key = job.r_key[i];
+    uint32_t n_i = 0;
+    FixSums v_sum = fix_zero();
+    unsigned long long v_c = 0, v_r = 0, v_s = 0, v_key = 0;
+    if (tid < 128 || p0 != KP_UNUSED) {
+        n_i = job.r_n[i];
+        v_sum = fix_load(job, i);
+        v_c = (unsigned long long)job.r_c[i]; v_r = (unsigned long long)job.r_r[i]; v_s = (unsigned long long)job.r_s[i]; v_key = job.r_key[i];
+    }
     __shared__ int s_any;
     clear_table();
     if (tid == 0) s_any = 0;
