@@ -594,6 +594,28 @@ __global__ void __launch_bounds__(256) k_paint_keys(Job job) {
     }
 }
 
+// x of another lane through the DPP network (no LDS crossbar trip); lanes without a source read 0
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp0(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, true);
+}
+constexpr int DPP_ROW_SHR = 0x110, DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+// inclusive prefix sums inside each HALF of the wave (lanes 0..31 and 32..63 separately): five DPP adds
+__device__ __forceinline__ uint32_t half_scan(uint32_t x) {
+    x += dpp0<DPP_ROW_SHR + 1>(x);
+    x += dpp0<DPP_ROW_SHR + 2>(x);
+    x += dpp0<DPP_ROW_SHR + 4>(x);
+    x += dpp0<DPP_ROW_SHR + 8>(x);
+    x += dpp0<DPP_ROW_BCAST15, 0xa>(x);   // rows 1 and 3 add the totals of rows 0 and 2
+    return x;
+}
+
+// inclusive prefix sums over the whole wave: six DPP adds
+__device__ __forceinline__ uint32_t wave_scan(uint32_t x) {
+    x = half_scan(x);
+    x += dpp0<DPP_ROW_BCAST31, 0xc>(x);   // rows 2 and 3 add the total of rows 0 and 1
+    return x;
+}
 // sum of the eight 16-bit counters of a quad, and of its first `take` (0..8) ones
 __device__ __forceinline__ uint32_t sum_u16x8(const uint4 q) {
     const uint32_t a = (q.x & 0xffffu) + (q.x >> 16), b = (q.y & 0xffffu) + (q.y >> 16), c = (q.z & 0xffffu) + (q.z >> 16), d = (q.w & 0xffffu) + (q.w >> 16);
@@ -657,12 +679,7 @@ __device__ __forceinline__ uint32_t rank_table_finish(RankTableLoads<NT> &ld, ui
     uint32_t mine = 0;
 #pragma unroll
     for (int k = 0; k < PER; ++k) mine += ld.v[k];
-    uint32_t x = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d);
-        if (lane >= d) x += y;
-    }
+    const uint32_t x = wave_scan(mine);   // (six DPP adds: the shuffle form went through the LDS crossbar six times, one after the other)
     if (lane == 63) s_wave[wv] = x;
     __syncthreads();
     uint32_t pre = x - mine, total = 0;

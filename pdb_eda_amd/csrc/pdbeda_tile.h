@@ -92,28 +92,6 @@ __device__ __forceinline__ uint32_t wave_writelane(uint32_t old, uint32_t sval, 
     return old;
 }
 
-// x of another lane through the DPP network (no LDS crossbar trip); lanes without a source read 0
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ uint32_t dpp0(uint32_t x) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, true);
-}
-constexpr int DPP_ROW_SHR = 0x110, DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
-// inclusive prefix sums inside each HALF of the wave (lanes 0..31 and 32..63 separately): five DPP adds
-__device__ __forceinline__ uint32_t half_scan(uint32_t x) {
-    x += dpp0<DPP_ROW_SHR + 1>(x);
-    x += dpp0<DPP_ROW_SHR + 2>(x);
-    x += dpp0<DPP_ROW_SHR + 4>(x);
-    x += dpp0<DPP_ROW_SHR + 8>(x);
-    x += dpp0<DPP_ROW_BCAST15, 0xa>(x);   // rows 1 and 3 add the totals of rows 0 and 2
-    return x;
-}
-
-// inclusive prefix sums over the whole wave: six DPP adds
-__device__ __forceinline__ uint32_t wave_scan(uint32_t x) {
-    x = half_scan(x);
-    x += dpp0<DPP_ROW_BCAST31, 0xc>(x);   // rows 2 and 3 add the total of rows 0 and 1
-    return x;
-}
 // orders this wave's LDS accesses for its own lanes (LDS executes a wave's instructions in order: nothing to wait for,
 // the fences only pin the compiler)
 __device__ __forceinline__ void wave_lds_sync() {
@@ -893,7 +871,7 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job_arg, const float 
         const uint64_t SA = mA & ~(mA << 1), SB = mB & ~(mB << 1);   // word-local run starts
         // what the next word of the row needs of me: do my rows end set, and the components of the runs that end them
         const uint32_t pack = (uint32_t)(mA >> 63) | ((uint32_t)(mB >> 63) << 1) | ((uint32_t)(cA >> 56) << 8) | ((uint32_t)(cB >> 56) << 16);
-        uint32_t prev = (uint32_t)__shfl_up((int)pack, 1);   // (the four word slots of a pair of rows are four lanes of one wave)
+        uint32_t prev = dpp0<DPP_WAVE_SHR1>(pack);   // (the four word slots of a pair of rows are four lanes of one wave; lane 0 reads 0)
         if (fwl == 0) prev = 0u;
         const uint64_t carA = prev & 1u, carB = (prev >> 1) & 1u;
         uint64_t todo = (SA & (mB | (mB << 1) | carB)) | (SB & ((mA << 1) | carA));
@@ -966,12 +944,7 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job_arg, const float 
             mine[k] = (k < per && slot < pair_slots) ? s_set[slot] : 0ull;
             cnt += mine[k] != 0ull ? 1u : 0u;
         }
-        uint32_t x = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t y = __shfl_up(x, d);
-            if (lane >= d) x += y;
-        }
+        const uint32_t x = wave_scan(cnt);   // (DPP: six adds; the shuffle form is six trips through the LDS crossbar)
         if (lane == 63) s_wsum[tid >> 6] = x;
         lds_barrier();
         uint32_t at = x - cnt;
