@@ -1288,6 +1288,39 @@ extern "C" int pdbeda_bloblist_stats(pdbeda_bloblist *bl, int64_t *n, double *to
     return PDBEDA_OK;
 }
 
+// Counters AND the first `guess` rows of a batch job's blob table in ONE host round trip (the batches of pdbeda_aggregate_cloud:
+// a count and then the table were two waits each; under four workers on one GPU a wait costs a quarter of a millisecond).
+// Rows beyond the blob count are stale arena bytes, copied and dropped.  Falls back to the two-step path when the guess was
+// too small (or the list is not a whole batch job).
+static int list_stats_one_trip(pdbeda_bloblist *bl, int64_t guess, std::vector<int64_t> &n, std::vector<double> &tot, std::vector<double> &cen,
+                               std::vector<int32_t> &grp) {
+    pdbeda_ctx *ctx = bl->ctx;
+    const Job &job = bl->job;
+    guess = std::min<int64_t>(guess, (int64_t)job.blob_cap);
+    const bool whole_job = !bl->whole_map && bl->vol_lo == 0 && bl->vol_hi == job.n_vols;
+    if (!bl->have_counts && whole_job && guess > 0 && 44 * guess + 4096 < (int64_t)ctx->pinned_cap - (int64_t)ctx->pinned_used) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        n.resize((size_t)guess); tot.resize((size_t)guess); cen.resize(3 * (size_t)guess); grp.resize((size_t)guess);
+        Counters ctr;
+        HIP_TRY(ctx, d2h(ctx, &ctr, job.ctr, sizeof ctr));
+        HIP_TRY(ctx, d2h(ctx, n.data(), job.b_n, 8 * guess));
+        HIP_TRY(ctx, d2h(ctx, tot.data(), job.b_total, 8 * guess));
+        HIP_TRY(ctx, d2h(ctx, cen.data(), job.b_centroid, 24 * guess));
+        HIP_TRY(ctx, d2h(ctx, grp.data(), job.b_group, 4 * guess));
+        HIP_TRY(ctx, ctx_sync(ctx));
+        bl->rank_lo = 0; bl->rank_hi = ctr.n_blobs; bl->job_blobs = ctr.n_blobs; bl->have_counts = true;
+        if ((int64_t)ctr.n_blobs <= guess) {
+            const size_t nb = ctr.n_blobs;
+            n.resize(nb); tot.resize(nb); cen.resize(3 * nb); grp.resize(nb);
+            return PDBEDA_OK;
+        }
+    }
+    const int64_t nb = pdbeda_bloblist_count(bl);
+    if (nb < 0) return (int)nb;
+    n.resize((size_t)nb); tot.resize((size_t)nb); cen.resize(3 * (size_t)nb); grp.resize((size_t)nb);
+    return pdbeda_bloblist_stats(bl, n.data(), tot.data(), cen.data(), nullptr, nullptr, nullptr, grp.data());
+}
+
 // Voxel lists are materialised once per JOB (shared by the lists of a fused call through
 // the owning list).
 
@@ -1829,13 +1862,12 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
         if (rc) { delete res; *out = nullptr; return rc; }
     }
     auto bail = [&](int rc, pdbeda_bloblist *a, pdbeda_bloblist *b) { if (a) pdbeda_bloblist_free(a); if (b) pdbeda_bloblist_free(b); delete res; *out = nullptr; return rc; };
-    const int64_t nb = pdbeda_bloblist_count(clouds);
-    if (nb < 0) return bail((int)nb, clouds, nullptr);
-    std::vector<int64_t> c_n((size_t)nb);
-    std::vector<double> c_tot((size_t)nb), c_cen(3 * (size_t)nb);
-    std::vector<int32_t> c_grp((size_t)nb);
-    int rc = pdbeda_bloblist_stats(clouds, c_n.data(), c_tot.data(), c_cen.data(), nullptr, nullptr, nullptr, c_grp.data());
+    std::vector<int64_t> c_n;
+    std::vector<double> c_tot, c_cen;
+    std::vector<int32_t> c_grp;
+    int rc = list_stats_one_trip(clouds, 4 * n + 64, c_n, c_tot, c_cen, c_grp);   // (an atom has one to three clouds: the count and the table in one wait)
     if (rc) return bail(rc, clouds, nullptr);
+    const int64_t nb = (int64_t)c_n.size();
 
     // ---- 2. host: centroid-distance cut-off, best cloud, pool (604-642) ----
     std::vector<int64_t> first((size_t)n + 1, 0);       // clouds of atom a: [first[a], first[a + 1])  (sorted by group)
@@ -1953,13 +1985,13 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
     e = d2h(ctx, comp.data(), d_comp, 8 * n_pool);
     if (e == hipSuccess && n_pairs > 0) e = d2h(ctx, touch.data(), d_touch, 4 * n_pairs);
     if (e != hipSuccess) return fail_dev(e, uni);
-    const int64_t nu = pdbeda_bloblist_count(uni);          // (synchronises: comp / touch have landed)
-    if (nu < 0) { arena_put(ctx, aux); return bail((int)nu, clouds, uni); }
+    std::vector<int64_t> u_n;
+    std::vector<double> u_tot, u_cen;
+    std::vector<int32_t> u_grp;
+    rc = list_stats_one_trip(uni, 2 * n_pool + 64, u_n, u_tot, u_cen, u_grp);   // (synchronises: comp / touch have landed too; a union component holds at least one pooled cloud)
     arena_put(ctx, aux);
-    std::vector<int64_t> u_n((size_t)nu);
-    std::vector<double> u_tot((size_t)nu), u_cen(3 * (size_t)nu);
-    std::vector<int32_t> u_grp((size_t)nu);
-    rc = pdbeda_bloblist_stats(uni, u_n.data(), u_tot.data(), u_cen.data(), nullptr, nullptr, nullptr, u_grp.data());
+    if (rc) return bail(rc, clouds, uni);
+    const int64_t nu = (int64_t)u_n.size();
     pdbeda_bloblist_free(uni);
     pdbeda_bloblist_free(clouds);
     if (rc) { delete res; *out = nullptr; return rc; }

@@ -136,3 +136,38 @@ def test_bench_gpus_flag_refuses_to_measure_fewer_devices():
     env["WORLD_SIZE"] = "3"
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode != 0 and "does not match WORLD_SIZE" in p.stderr, (p.returncode, p.stderr[-500:])
+
+
+def test_type_regressions_equal_scipy_linregress():
+    """The per-atom-type b-factor regression of the statistics tail (ref densityAnalysis.py:752-757: one scipy.stats.linregress
+    per type) is computed for all types at once; slopes, p-values and the decision to fit must be scipy's."""
+    import warnings
+    import numpy as np
+    from scipy import stats
+    from pdb_eda_amd import densityAnalysis as da
+    rng = np.random.default_rng(5)
+    for trial in range(40):
+        n_types = int(rng.integers(1, 7))
+        n = int(rng.integers(n_types, 400))
+        group = np.concatenate([np.arange(n_types), rng.integers(0, n_types, n - n_types)])
+        rng.shuffle(group)
+        b = np.round(rng.uniform(5.0, 60.0, n), 2)
+        if trial % 4 == 0:
+            b[group == 0] = 20.0                      # a type whose b-factors are all equal: no fit
+        if trial % 5 == 0 and n_types > 1:
+            keep = np.ones(n, dtype=bool)
+            keep[np.nonzero(group == 1)[0][2:]] = False   # a type with two rows: no fit
+            group, b = group[keep], b[keep]
+        x = np.log(b)
+        y = 0.02 * x * rng.uniform(-1, 1) + rng.normal(0, 0.05, len(x))
+        slope, p, fitted = da._typeRegressions(x, y, b, group, n_types)
+        for k in range(n_types):
+            sel = group == k
+            want_fit = sel.sum() > 2 and len(np.unique(b[sel])) != 1
+            assert bool(fitted[k]) == bool(want_fit)
+            if want_fit:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    fit = stats.linregress(x[sel], y[sel])
+                assert slope[k] == pytest.approx(fit.slope, rel=1e-10, abs=1e-14)
+                assert p[k] == pytest.approx(fit.pvalue, rel=1e-8, abs=1e-14)
