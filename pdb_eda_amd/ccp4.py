@@ -11,6 +11,7 @@ the unit-cell basis to :func:`pdb_eda_amd._native.map_upload`.
 There is no CPU fallback: constructing a ``DensityMatrix`` without the HIP library /
 a GPU raises.
 """
+import collections.abc
 import os
 import sys
 
@@ -399,6 +400,85 @@ class DensityMatrix(object):
         return DensityBlob.listFromDevice(self._map.list_blobs(crs), self)
 
 
+class _DeviceBlobSegment(object):
+    """One device blob list behind a ``DeviceBlobs`` sequence: its statistics columns and, once somebody asked, its objects."""
+
+    def __init__(self, bl, densityMatrix):
+        self.bl, self.densityMatrix = bl, densityMatrix
+        self.stats = bl.stats()
+        self.blobs = None
+
+    def __len__(self):
+        return len(self.stats["n"])
+
+    def made(self):
+        if self.blobs is None:
+            st, bl, densityMatrix = self.stats, self.bl, self.densityMatrix
+            columns = zip(st["centroid"].tolist(), st["coordCenter"].tolist(), st["totalDensity"].tolist(), st["volume"].tolist(), st["n"].tolist(),
+                          st["firstKey"].tolist())
+            new = DensityBlob.__new__
+            out = []
+            for i, (centroid, center, total, volume, n, key) in enumerate(columns):
+                blob = new(DensityBlob)                          # same fields as __init__ sets, without a call per field
+                blob.__dict__ = {"centroid": centroid, "coordCenter": center, "totalDensity": total, "volume": volume, "_crsList": None, "_numVoxels": n,
+                                 "_list": bl, "_index": i, "densityMatrix": densityMatrix, "firstKey": key}
+                out.append(blob)
+            self.blobs = out
+        return self.blobs
+
+
+class DeviceBlobs(collections.abc.Sequence):
+    """What ``createFullBlobList`` / ``findAberrantBlobs`` / ``createBlobList`` return (a list of DensityBlob in the reference,
+    ccp4.py:463-485): the same blobs in the same order, as a read-only sequence whose objects are made on first access, one
+    device list at a time.  ``a + b`` of two of them is again one (the objects are shared with ``a`` and ``b``); ``+`` with a
+    plain list and ``==`` against one behave as a list's."""
+
+    def __init__(self, segments):
+        self._segments = list(segments)
+
+    def __len__(self):
+        return sum(len(seg) for seg in self._segments)
+
+    def _all(self):
+        if len(self._segments) == 1:
+            return self._segments[0].made()
+        return [blob for seg in self._segments for blob in seg.made()]
+
+    def __getitem__(self, i):
+        return self._all()[i]
+
+    def __iter__(self):
+        return iter(self._all())
+
+    def __add__(self, other):
+        if isinstance(other, DeviceBlobs):
+            return DeviceBlobs(self._segments + other._segments)
+        return self._all() + other if isinstance(other, list) else NotImplemented
+
+    def __radd__(self, other):
+        return other + self._all() if isinstance(other, list) else NotImplemented
+
+    def __eq__(self, other):
+        if not isinstance(other, (list, DeviceBlobs)):
+            return NotImplemented
+        return len(self) == len(other) and all(a == b for a, b in zip(self, other))
+
+    __hash__ = None
+
+    def __repr__(self):
+        return "DeviceBlobs(%d blobs)" % len(self)
+
+    def columns(self):
+        """{"centroid", "totalDensity", "n", "volume"} of all blobs as arrays -- or None once any of the objects exists (they
+        are ordinary mutable objects: from then on they are the truth)."""
+        if any(seg.blobs is not None for seg in self._segments):
+            return None
+        if not self._segments:
+            return {"centroid": np.zeros((0, 3)), "totalDensity": np.zeros(0), "n": np.zeros(0, dtype=np.int64), "volume": np.zeros(0)}
+        return {k: np.concatenate([seg.stats[k] for seg in self._segments]) if len(self._segments) > 1 else self._segments[0].stats[k]
+                for k in ("centroid", "totalDensity", "n", "volume")}
+
+
 class DensityBlob(object):
     """A connected set of voxels with its fp64 statistics (ref ccp4.py:488-594).
 
@@ -421,17 +501,9 @@ class DensityBlob(object):
 
     @classmethod
     def listFromDevice(cls, bl, densityMatrix):
-        st = bl.stats()
-        out = []
-        columns = zip(st["centroid"].tolist(), st["coordCenter"].tolist(), st["totalDensity"].tolist(), st["volume"].tolist(), st["n"].tolist(),
-                      st["firstKey"].tolist())
-        new = cls.__new__
-        for i, (centroid, center, total, volume, n, key) in enumerate(columns):
-            blob = new(cls)                                  # same fields as __init__ sets, without a call per field
-            blob.__dict__ = {"centroid": centroid, "coordCenter": center, "totalDensity": total, "volume": volume, "_crsList": None, "_numVoxels": n,
-                             "_list": bl, "_index": i, "densityMatrix": densityMatrix, "firstKey": key}
-            out.append(blob)
-        return out
+        """The blobs of a device list, in its order: a sequence that makes the DensityBlob objects when somebody reads one
+        (``DeviceBlobs``) -- the tables over thousands of blobs read the list's columns and never touch an object."""
+        return DeviceBlobs([_DeviceBlobSegment(bl, densityMatrix)])
 
     @property
     def crsList(self):

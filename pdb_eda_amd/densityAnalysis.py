@@ -418,7 +418,7 @@ class DensityAnalysis(object):
                 "electrons": pair_electrons[pair_of], "used_pairs": sorted(used), "pair": pair_of, "pair_type": pair_type,
                 "residue": residue_of.astype(np.int32), "alias": alias.astype(np.int32), "key": key_of.astype(np.int32),
                 "bonded_off": bonded_off, "bonded": bonded.astype(np.int32), "owner_key": owner_key.astype(np.int32),
-                "owner_type_id": pair_type_id[child_pair[found]], "type_names": type_names}
+                "owner_type_id": pair_type_id[child_pair[found]], "type_names": type_names, "pair_type_id": pair_type_id}
 
     def aggregateCloud(self, minCloudElectrons=25.0, minTotalElectrons=400.0):
         """Aggregate the 2Fo-Fc clouds by atom, residue and domain; sets ``densityElectronRatio``,
@@ -481,6 +481,11 @@ class DensityAnalysis(object):
         """The host-side statistics over the atom table (what densityAnalysis.py:734-767 computes), on whole columns: the
         per-atom-type medians come from ONE sort per column instead of a masked nanmedian per (column, type)."""
         idx = res["atom"]
+        dist = res["atom_distance"]
+        total, count, centroid = res["atom_total"], res["atom_n"], res["atom_centroid"]
+        if not np.isnan(dist).all():
+            near = dist < np.nanmedian(dist) + np.nanstd(dist) * 2              # (the reference filters the finished table: same rows)
+            idx, dist, total, count, centroid = idx[near], dist[near], total[near], count[near], centroid[near]
         n = len(idx)
         table = np.zeros(n, dtype=np.dtype([
             ('chain', 'U20'), ('residue_number', int), ('residue_name', 'U10'), ('atom_name', 'U10'), ('atom_type', 'U%d' % atomTypeLengthGlobal),
@@ -489,49 +494,57 @@ class DensityAnalysis(object):
             ('corrected_density_electron_ratio', float), ('volume', float)]))
         cols, rows = inp["cols"], inp["rows"][idx]
         of_residue = cols.res_of_atom[rows]
+        # atom types as numbers: inp["type_names"] is sorted, so the types present, in np.unique's order, are the ids present
+        type_id = inp["pair_type_id"][inp["pair"][idx]]
+        present = np.flatnonzero(np.bincount(type_id, minlength=len(inp["type_names"])))
+        atom_types = np.asarray(inp["type_names"])[present] if len(present) else np.zeros(0, dtype='U1')
+        n_types = len(atom_types)
+        group = np.searchsorted(present, type_id)
         table['chain'] = np.asarray(cols.res_chain)[of_residue]
         table['residue_number'] = np.asarray(cols.res_number)[of_residue]
         table['residue_name'] = np.asarray(cols.res_name)[of_residue]
-        table['atom_name'] = np.asarray(cols.name)[rows]
-        table['atom_type'] = np.asarray([t if t is not None else '' for t in inp["pair_type"]])[inp["pair"][idx]]
-        table['density_electron_ratio'] = res["atom_total"] / inp["electrons"][idx] / inp["occupancy"][idx]
-        table['num_voxels'] = res["atom_n"]
+        table['atom_name'] = np.asarray(cols.atom_names)[cols.name_of_atom[rows]] if n else ''
+        table['atom_type'] = atom_types[group] if n else ''
+        table['density_electron_ratio'] = total / inp["electrons"][idx] / inp["occupancy"][idx]
+        table['num_voxels'] = count
         table['electrons'] = inp["electrons"][idx]
         table['bfactor'] = cols.bfactor[rows]
-        table['centroid_distance'] = res["atom_distance"]
-        table['centroid_xyz'] = res["atom_centroid"]
-        dist = table['centroid_distance']
-        if not np.isnan(dist).all():
-            table = table[dist < np.nanmedian(dist) + np.nanstd(dist) * 2]
-        atom_types, group = np.unique(table['atom_type'], return_inverse=True)
-        n_types = len(atom_types)
+        table['centroid_distance'] = dist
+        table['centroid_xyz'] = centroid
 
-        group16 = group.astype(np.int16 if n_types < 32768 else np.int64)       # (16-bit keys: numpy's stable sort is a radix sort)
-        start = np.searchsorted(np.sort(group), np.arange(n_types))
+        # rows in type order, once: every median below sorts the values of one type at a time, in place
+        by_type = np.argsort(group.astype(np.int16 if n_types < 32768 else np.int64), kind="stable")
+        start = np.searchsorted(group[by_type], np.arange(n_types + 1))
+        runs = list(zip(start[:-1].tolist(), start[1:].tolist()))
 
-        def typeMedians(values, keep=None):
-            """np.nanmedian of ``values`` per atom type: order by value, then stably by type -- NaNs and dropped rows last in every
-            type's run -- and take the middle one or the mean of the middle two of every run."""
+        def typeMedians(values, keep=None, also=()):
+            """np.nanmedian of ``values`` per atom type (NaNs and dropped rows sort last within a type; the middle one or the mean of
+            the middle two of what is left).  ``also``: weakly monotone functions of the values whose per-type medians are wanted as
+            well -- the median of f(values) is the mean of f at the same one or two order statistics, so no second sort."""
             v = np.asarray(values, dtype=np.float64)
             if keep is not None:
                 v = np.where(keep, v, np.nan)
-            by_value = np.argsort(v)
-            sv = v[by_value[np.argsort(group16[by_value], kind="stable")]]
+            sv = v[by_type]
+            for lo, hi in runs:
+                sv[lo:hi].sort()
             count = np.bincount(group, weights=~np.isnan(v), minlength=n_types).astype(np.int64)
-            lo, hi = start + np.maximum(count - 1, 0) // 2, start + count // 2
-            safe = np.minimum(np.stack([lo, hi]), max(len(sv) - 1, 0))
-            med = (sv[safe[0]] + sv[safe[1]]) / 2.0 if len(sv) else np.full(n_types, np.nan)
-            return np.where(count > 0, med, np.nan)
+            safe = np.minimum(np.stack([start[:-1] + np.maximum(count - 1, 0) // 2, start[:-1] + count // 2]), max(n - 1, 0))
+            middle = sv[safe] if n else np.full((2, n_types), np.nan)
+            out = [np.where(count > 0, (f(middle[0]) + f(middle[1])) / 2.0, np.nan) for f in (lambda x: x,) + tuple(also)]
+            return out[0] if not also else out
 
         def asDict(per_type):
             return dict(zip(atom_types.tolist(), per_type))
         medians = {}
-        m_vox = typeMedians(table['num_voxels'])
+        m_vox, m_volume = typeMedians(table['num_voxels'], also=(lambda nv: nv * unitVolume,))
         medians['num_voxels'] = asDict(m_vox)
         table['adj_density_electron_ratio'] = table['density_electron_ratio'] / table['num_voxels'] * m_vox[group]
         table['volume'] = table['num_voxels'] * unitVolume
-        for column in ('density_electron_ratio', 'centroid_distance', 'adj_density_electron_ratio', 'volume'):
-            medians[column] = asDict(typeMedians(table[column]))
+        medians['density_electron_ratio'] = asDict(typeMedians(table['density_electron_ratio']))
+        medians['centroid_distance'] = asDict(typeMedians(table['centroid_distance']))
+        m_adj, m_fraction = typeMedians(table['adj_density_electron_ratio'], also=(lambda adj: (adj - ratio) / ratio,))
+        medians['adj_density_electron_ratio'] = asDict(m_adj)
+        medians['volume'] = asDict(m_volume)
         m_b = typeMedians(table['bfactor'], table['bfactor'] > 0)
         medians['bfactor'] = asDict(m_b)
         missing = table['bfactor'] <= 0
@@ -546,8 +559,10 @@ class DensityAnalysis(object):
         table['domain_fraction'] = fraction
         table['corrected_fraction'] = fraction - (log_b - np.log(m_b[group])) * slopes[group]
         table['corrected_density_electron_ratio'] = table['corrected_fraction'] * ratio + ratio
-        for column in ('domain_fraction', 'corrected_fraction', 'corrected_density_electron_ratio'):
-            medians[column] = asDict(typeMedians(table[column]))
+        medians['domain_fraction'] = asDict(m_fraction)
+        m_corrected, m_corrected_ratio = typeMedians(table['corrected_fraction'], also=(lambda c: c * ratio + ratio,))
+        medians['corrected_fraction'] = asDict(m_corrected)
+        medians['corrected_density_electron_ratio'] = asDict(m_corrected_ratio)
         return table, medians
 
     # ---- symmetry atoms (ref densityAnalysis.py:885-912 + cutils.pyx:73-103) -------------------
@@ -586,17 +601,26 @@ class DensityAnalysis(object):
             # no symmetry atoms (a file without REMARK 290 has no operators): the reference's cdist() of a centroid against an
             # empty coordinate array raises this ValueError (densityAnalysis.py:933) -- an ordinary per-entry failure, not a device error
             raise ValueError("XB must be a 2-dimensional array.")
-        centroid = [blob.centroid for blob in blobList]
-        total = np.array([blob.totalDensity for blob in blobList], dtype=np.float64)
-        idx, dist = self.densityObj._ctx.nearest_atom(np.array(centroid, dtype=np.float64), np.asarray(symmetryAtomCoords, dtype=np.float64))
+        listed = blobList.columns() if isinstance(blobList, ccp4.DeviceBlobs) else None
+        if listed is not None:                   # straight from the device list's columns: no blob object is made for the table
+            centroid_xyz = listed["centroid"]
+            centroid = centroid_xyz.tolist()
+            total = listed["totalDensity"]
+            num_voxels, volume = listed["n"].tolist(), listed["volume"].tolist()
+        else:
+            centroid = [blob.centroid for blob in blobList]
+            centroid_xyz = np.array(centroid, dtype=np.float64)
+            total = np.array([blob.totalDensity for blob in blobList], dtype=np.float64)
+            num_voxels, volume = [blob.numVoxels for blob in blobList], [blob.volume for blob in blobList]
+        idx, dist = self.densityObj._ctx.nearest_atom(centroid_xyz, np.asarray(symmetryAtomCoords, dtype=np.float64))
         rows, symmetry, coords = symmetryAtoms.columns(idx)
         cols = _structure.columns(self.biopdbObj)
         rows = rows.tolist()
         chain, number, resname = (cols.atom_lists(which) for which in ("chain", "number", "resname"))
         sign = np.where(total >= 0, '+', '-').tolist()
-        return [list(row) for row in zip(list(dist), sign, np.abs(total / ratio).tolist(), [blob.numVoxels for blob in blobList], [blob.volume for blob in blobList],
-                                         [chain[r] for r in rows], [number[r] for r in rows], [resname[r] for r in rows], [cols.name[r] for r in rows],
-                                         symmetry, coords, centroid)]
+        return self._rows(list(dist), sign, np.abs(total / ratio).tolist(), num_voxels, volume,
+                          [chain[r] for r in rows], [number[r] for r in rows], [resname[r] for r in rows], [cols.name[r] for r in rows],
+                          symmetry, coords, centroid)
 
     # ---- Fo / Fc maps, RSCC / RSR (ref densityAnalysis.py:426-446, 783-882) -------------------
     @property
@@ -756,7 +780,7 @@ class DensityAnalysis(object):
 
     @staticmethod
     def _rows(*columns):
-        return [list(row) for row in zip(*columns)]
+        return list(map(list, zip(*columns)))
 
     def _atomPick(self, type):
         """Rows of the structure columns of the atoms named ``type`` (all when empty) and their leading table columns (model,

@@ -14,6 +14,7 @@ preparation, not part of the accelerated path.
 """
 import re
 
+import itertools
 import numpy as np
 
 __all__ = ["Structure", "Model", "Chain", "Residue", "Atom", "PDBHeader", "PDBEntry", "read_pdb", "columns", "Columns"]
@@ -131,6 +132,14 @@ class PDBEntry(object):
         self.atoms = atoms or []
 
 
+def _first_appearance_ids(values):
+    """(distinct values in order of first appearance, int64 id of every value)."""
+    ids = dict.fromkeys(values)
+    for k, value in enumerate(ids):
+        ids[value] = k
+    return list(ids), np.fromiter(map(ids.__getitem__, values), dtype=np.int64, count=len(values))
+
+
 class Columns(object):
     """A columnar snapshot of a structure: what the analysis reads from the object tree (see the module text), gathered in
     ONE walk so that the per-entry host work runs on arrays instead of on 10^3..10^4 Python objects.
@@ -138,7 +147,7 @@ class Columns(object):
     Order is the order of ``structure.get_residues()`` / ``get_atoms()`` (the atoms of a residue are contiguous).
     Per residue: ``residues`` (the objects), ``res_model``, ``res_chain``, ``res_number``, ``res_name`` (lists),
     ``res_het`` (bool array: ``id[0] != ' '``), ``res_start`` (int64[n_res + 1], atom range of every residue).
-    Per atom: ``atoms`` (the objects), ``name`` (list), ``res_of_atom`` (int64), ``coord32`` (float32[n, 3], the stored
+    Per atom: ``atoms`` (the objects), ``name`` (list; ``atom_names`` the distinct ones and ``name_of_atom`` the int64 index into them), ``res_of_atom`` (int64), ``coord32`` (float32[n, 3], the stored
     coordinates), ``coord`` (float64, promoted exactly), ``occupancy``, ``bfactor`` (float64; ``occupancy_raw``: the objects as read), ``pair_of_atom`` (int64 index
     into ``pair_names``, the distinct 'RES_ATOM' names of densityAnalysis.residueAtomName).
     The snapshot is cached on the structure object: edit the tree and call ``columns(structure, refresh=True)``."""
@@ -153,32 +162,43 @@ class Columns(object):
         res_name = [residue.resname for residue in residues]
         res_het = [rid[0] != ' ' for rid in ids]
         children = [residue.child_list for residue in residues]
-        res_start = [0]
-        pair_of_atom = []
-        pairs = {}
-        for resname, child_list in zip(res_name, children):
-            prefix = resname.strip() + '_'
-            pair_of_atom.extend([pairs.setdefault(prefix + atom.name, len(pairs)) for atom in child_list])
-            res_start.append(len(pair_of_atom))
-        atoms = [atom for child_list in children for atom in child_list]
-        name = [atom.name for atom in atoms]
-        occupancy = [atom.get_occupancy() for atom in atoms]
-        bfactor = [atom.get_bfactor() for atom in atoms]
-        coord = [atom.coord for atom in atoms]
+        atoms = list(itertools.chain.from_iterable(children))
         n = len(atoms)
+        res_start = np.zeros(len(residues) + 1, dtype=np.int64)
+        np.cumsum(np.fromiter(map(len, children), dtype=np.int64, count=len(residues)), out=res_start[1:])
+        res_of_atom = np.repeat(np.arange(len(residues), dtype=np.int64), np.diff(res_start))
+        name = [atom.name for atom in atoms]
+        # the distinct 'RES_ATOM' names, numbered by first appearance: ids of the (stripped) residue names and of the atom names
+        # through C-level dict lookups, then one np.unique over the combined code -- no string is built per atom
+        res_names = _first_appearance_ids([resname.strip() for resname in res_name])
+        atom_names = _first_appearance_ids(name)
+        code = res_names[1][res_of_atom] * max(len(atom_names[0]), 1) + atom_names[1]
+        distinct, first, inverse = np.unique(code, return_index=True, return_inverse=True)
+        by_first = np.argsort(first, kind="stable")
+        rank = np.empty(len(distinct), dtype=np.int64)
+        rank[by_first] = np.arange(len(distinct))
+        pair_names = [res_names[0][c // max(len(atom_names[0]), 1)] + '_' + atom_names[0][c % max(len(atom_names[0]), 1)] for c in distinct[by_first].tolist()]
+        try:                                       # (the accessors of our atoms and of Bio.PDB's return these attributes)
+            occupancy = [atom.occupancy for atom in atoms]
+            bfactor = [atom.bfactor for atom in atoms]
+        except AttributeError:
+            occupancy = [atom.get_occupancy() for atom in atoms]
+            bfactor = [atom.get_bfactor() for atom in atoms]
+        coord = [atom.coord for atom in atoms]
         self.residues, self.atoms = residues, atoms
         self.res_model, self.res_chain, self.res_number, self.res_name = res_model, res_chain, res_number, res_name
         self.res_het = np.asarray(res_het, dtype=bool)
-        self.res_start = np.asarray(res_start, dtype=np.int64)
-        self.res_of_atom = np.repeat(np.arange(len(residues), dtype=np.int64), np.diff(self.res_start))
+        self.res_start = res_start
+        self.res_of_atom = res_of_atom
         self.name = name
+        self.atom_names, self.name_of_atom = atom_names
         self.occupancy_raw = occupancy
         self.occupancy = np.asarray(occupancy, dtype=np.float64)
         self.bfactor = np.asarray(bfactor, dtype=np.float64)
-        self.coord32 = np.asarray(coord, dtype=np.float32).reshape(n, 3)
+        self.coord32 = (np.concatenate(coord).astype(np.float32, copy=False) if n else np.zeros(0, dtype=np.float32)).reshape(n, 3)
         self.coord = self.coord32.astype(np.float64)
-        self.pair_of_atom = np.asarray(pair_of_atom, dtype=np.int64)
-        self.pair_names = list(pairs)
+        self.pair_of_atom = rank[inverse.reshape(-1)] if n else np.zeros(0, dtype=np.int64)
+        self.pair_names = pair_names
 
     def atom_lists(self, which):
         """Per-atom Python lists of residue-level columns ('model', 'chain', 'number', 'resname'), made on first use."""
