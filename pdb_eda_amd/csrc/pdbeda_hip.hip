@@ -993,8 +993,13 @@ static int engine_enqueue(pdbeda_ctx *ctx, pdbeda_map *m, Job &job, int64_t max_
     // per-run kernels are grid-stride over the ACTUAL run count (read on the device)
     const unsigned run_grid = grid_for(max_runs, 256, 2048);
     if (job.total_words > 0) {
-        { PROF(ctx, "k_run_index"); hipLaunchKernelGGL(k_run_index, dim3(grid_for(job.total_words, 256, 1ll << 30)), dim3(256), 0, st, job, m->dens, m->geom_dev); }
-        { PROF(ctx, "k_union"); hipLaunchKernelGGL(k_union, dim3(grid_for(job.total_words, 256, 1ll << 30)), dim3(256), 0, st, job); }
+        {   // few words in large volumes: a quarter of the words a block, four times the blocks (the loop over a wave's words is
+            // serial; the rows of many small volumes -- atom spheres -- are mostly narrow: a thread each, 256 to the block)
+            PROF(ctx, "k_run_index");
+            if (job.total_words < 256ll * 2048 && job.total_words > 64ll * job.n_vols) hipLaunchKernelGGL(k_run_index<64>, dim3(grid_for(job.total_words, 64, 1ll << 30)), dim3(256), 0, st, job, m->dens, m->geom_dev);
+            else hipLaunchKernelGGL(k_run_index<256>, dim3(grid_for(job.total_words, 256, 1ll << 30)), dim3(256), 0, st, job, m->dens, m->geom_dev);
+        }
+        { PROF(ctx, "k_union"); hipLaunchKernelGGL(k_union, dim3(grid_for(job.total_words * 4, 256, 1ll << 30)), dim3(256), 0, st, job); }
         { PROF(ctx, "k_resolve"); hipLaunchKernelGGL(k_resolve, dim3(run_grid), dim3(256), 0, st, job); }
         { PROF(ctx, "k_paint_keys"); hipLaunchKernelGGL(k_paint_keys, dim3(run_grid), dim3(256), 0, st, job); }
     }
@@ -1502,7 +1507,7 @@ static int group_bounds(pdbeda_map *m, GroupSetup *gs, int64_t n_items, int64_t 
             { PROF(ctx, "k_atom_boxes"); hipLaunchKernelGGL(k_atom_boxes, dim3(grid_for(n_items, 256)), dim3(256), 0, st, m->geom_dev, gs->d_xyz, gs->d_radii,
                                gs->d_item_group, n_items, gs->d_boxes, gs->g_lo, gs->g_hi); }
         else
-            { PROF(ctx, "k_list_boxes"); hipLaunchKernelGGL(k_list_boxes, dim3(grid_for(n_items, 256)), dim3(256), 0, st, gs->d_crs, gs->d_item_group, n_items,
+            { PROF(ctx, "k_list_boxes"); hipLaunchKernelGGL(k_list_boxes, dim3(grid_for(n_items, 256 * 4, 256)), dim3(256), 0, st, gs->d_crs, gs->d_item_group, n_items,
                                gs->g_lo, gs->g_hi); }
     }
     { PROF(ctx, "k_make_vols"); hipLaunchKernelGGL(k_make_vols, dim3(1), dim3(1024), 0, st, gs->g_lo, gs->g_hi, (int)n_groups, gs->d_vols, gs->d_ctr); }

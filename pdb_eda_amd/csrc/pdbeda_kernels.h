@@ -222,10 +222,19 @@ __device__ inline double wave_incl_scan(double x, int lane) {
 // run's first lane; writes one record per run at index rec0 + (run number inside the word).
 // (cl0, rl, sl) = volume-local coordinates of lane 0, (rawc0, rawr, raws) = raw crs of lane 0.
 template <typename JobRef>
+__device__ inline void word_run_records_of(const JobRef &job, const VolDesc &vd, uint64_t mw, int lane, double rho, int cl0, int rl, int sl,
+                                           int rawc0, int rawr, int raws, uint32_t rec0);
+template <typename JobRef>
 __device__ inline void word_run_records(const JobRef &job, const Geom &g, const float *__restrict__ dens, const VolDesc &vd, uint64_t mw,
                                         int lane, int cl0, int rl, int sl, int rawc0, int rawr, int raws, uint32_t rec0) {
     const bool bit = (mw >> lane) & 1ull;
     const double rho = bit ? (double)fetch_wrapped(g, dens, rawc0 + lane, rawr, raws) : 0.0;
+    word_run_records_of(job, vd, mw, lane, rho, cl0, rl, sl, rawc0, rawr, raws, rec0);
+}
+// ... the same with the lane's density already in hand (0 where the lane's bit is clear)
+template <typename JobRef>
+__device__ inline void word_run_records_of(const JobRef &job, const VolDesc &vd, uint64_t mw, int lane, double rho, int cl0, int rl, int sl,
+                                           int rawc0, int rawr, int raws, uint32_t rec0) {
     const double rl_ = rho * (double)lane;
     const double p1 = wave_incl_scan(rho, lane);
     const double p2 = wave_incl_scan(rl_, lane);
@@ -254,24 +263,68 @@ __device__ inline void word_run_records(const JobRef &job, const Geom &g, const 
     }
 }
 
+// The same records for a NARROW word -- a row of at most 16 voxels, which is every row of an atom's sphere box at the grid
+// spacings of real maps -- by ONE thread: its (at most 16) densities are fetched together, the sums of a run are plain
+// sequential fp64 sums.  k_run_index's wave-per-word loop spends a memory round trip or two per word and uses 10 of its 64
+// lanes on such rows (2 x 71 us of an aggregateCloud's 0.55 ms of kernels, round 4); here 256 words of a block go at once.
+constexpr int NARROW_ROW = 16;
+template <typename JobRef>
+__device__ inline void narrow_run_records(const JobRef &job, const Geom &g, const float *__restrict__ dens, const VolDesc &vd, uint64_t mw,
+                                          int rl, int sl, uint32_t rec0) {
+    const int rawc0 = vd.org[0], rawr = vd.org[1] + rl, raws = vd.org[2] + sl;
+    float v[NARROW_ROW];
+#pragma unroll
+    for (int k = 0; k < NARROW_ROW; ++k) v[k] = ((mw >> k) & 1ull) ? fetch_wrapped(g, dens, rawc0 + k, rawr, raws) : 0.0f;
+    uint64_t todo = run_starts(mw);
+    uint32_t idx = rec0;
+    while (todo) {
+        const int a = ctz64(todo);
+        todo &= todo - 1;
+        const int b = run_end_of(mw, a), len = b - a + 1;
+        double s_rho = 0.0, s_rl = 0.0;
+#pragma unroll
+        for (int k = 0; k < NARROW_ROW; ++k)
+            if (k >= a && k <= b) { s_rho += (double)v[k]; s_rl += (double)v[k] * (double)k; }
+        job.parent[idx] = (int32_t)idx;
+        job.r_n[idx] = (uint32_t)len;
+        fix_store(job, idx, fix_sums(fix_of(s_rho, job.fix_mul), fix_of(s_rl, job.fix_mul), 0, 0, rawc0, rawr, raws));
+        const long long first = (long long)rawc0 + a;
+        job.r_c[idx] = (long long)len * first + (long long)len * (len - 1) / 2;
+        job.r_r[idx] = (long long)len * rawr;
+        job.r_s[idx] = (long long)len * raws;
+        const int64_t key_in = ((int64_t)a * vd.dim[1] + rl) * vd.dim[2] + sl;
+        job.r_key[idx] = (unsigned long long)(vd.key_base + key_in);
+        if (job.kpar) job.kpar[idx] = ((unsigned long long)(((uint32_t)vd.group << 31) | (uint32_t)key_in) << 32) | idx;
+        ++idx;
+    }
+}
+
 // ------------------------------------------------------------------------------------
-// Run indexing + per-run statistics.  Block = 256 threads = one chunk of 256 words.
-// Phase 1 (thread per word): count runs, block scan, one atomicAdd per block -> run_base.
-// Phase 2 (wave per non-empty word, lane per voxel): wrapped density fetch
-// (getPointDensityFromCrs), two wave prefix sums (rho, rho*lane), run sums by difference
+// Run indexing + per-run statistics.  Block = 256 threads = one chunk of WPB words (256, or 64 for a job of few words:
+// the union job of an aggregateCloud has 40 k wide, sparse words -- 164 blocks of 256 words left a third of the chip idle
+// behind four waves a block that walked 64 words each, one or two memory round trips a word: 92 us, round 4).
+// Phase 1 (thread per word): count runs, block scan, one atomicAdd per block -> run_base; the word's volume and its place
+// in it go to LDS.  Narrow words (narrow_run_records) are finished by their own thread.
+// Phase 2 (wave per remaining word, lane per voxel): wrapped density fetch (getPointDensityFromCrs) -- the NEXT word's
+// fetch is in flight while this one's records are made --, two wave prefix sums (rho, rho*lane), run sums by difference
 // at the run's first lane.  fromCrsList's sums (ccp4.py:534-545) become per-run partials.
 // ------------------------------------------------------------------------------------
+template <int WPB>
 __global__ void __launch_bounds__(256) k_run_index(Job job, const float *__restrict__ dens, const Geom *__restrict__ gp) {
-    __shared__ uint64_t s_mask[256];
-    __shared__ uint32_t s_off[256];
-    __shared__ int s_vol[256];
+    static_assert(WPB == 256 || WPB == 64, "a word per thread of the block, or of its first wave");
+    constexpr int SCAN_WAVES = WPB / 64, PER_WAVE = WPB / 4;
+    __shared__ uint64_t s_mask[WPB];
+    __shared__ uint32_t s_off[WPB];
+    __shared__ VolDesc s_vd[WPB];
+    __shared__ int s_row[WPB][3];        // wq, rl, sl of the word
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t chunk0 = (int64_t)blockIdx.x * 256;
+    const int64_t chunk0 = (int64_t)blockIdx.x * WPB;
     const int64_t w = chunk0 + tid;
-    uint64_t m = (w < job.total_words) ? job.mask[w] : 0ull;
-    uint32_t cnt = (uint32_t)popc64(run_starts(m));
+    const bool mine = tid < WPB && w < job.total_words;
+    const uint64_t m = mine ? job.mask[w] : 0ull;
+    const uint32_t cnt = (uint32_t)popc64(run_starts(m));
     // block exclusive scan of cnt
     uint32_t x = cnt;
 #pragma unroll
@@ -280,34 +333,57 @@ __global__ void __launch_bounds__(256) k_run_index(Job job, const float *__restr
         if (lane >= d) x += y;
     }
     if (lane == 63) s_wsum[wv] = x;
-    s_mask[tid] = m;
+    if (tid < WPB) s_mask[tid] = m;
     __syncthreads();
     if (tid == 0) {
-        uint32_t tot = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        uint32_t tot = 0;
+        for (int k = 0; k < SCAN_WAVES; ++k) tot += s_wsum[k];
         s_base = tot ? atomicAdd(&job.ctr->n_runs, tot) : 0u;
     }
     __syncthreads();
     uint32_t wpre = 0;
-    for (int k = 0; k < wv; ++k) wpre += s_wsum[k];
-    uint32_t off = s_base + wpre + x - cnt;
-    s_off[tid] = off;
-    s_vol[tid] = m ? find_vol(job.vols, job.n_vols, w) : 0;      // (every thread searches for its own word: the per-word loop below is serial)
-    if (w < job.total_words) job.run_base[w] = off;
+    for (int k = 0; k < wv && k < SCAN_WAVES; ++k) wpre += s_wsum[k];
+    const uint32_t off = s_base + wpre + x - cnt;
+    if (mine) job.run_base[w] = off;
+    // (every thread searches for its own word's volume: the per-word loop below is serial)
+    VolDesc my_vd;
+    int wq = 0, rl = 0, sl = 0;
+    bool narrow = false;
+    if (m != 0ull) {
+        my_vd = job.vols[find_vol(job.vols, job.n_vols, w)];
+        const int64_t rem = w - my_vd.word_base;
+        wq = (int)(rem % my_vd.row_words);
+        const int64_t row = rem / my_vd.row_words;
+        rl = (int)(row % my_vd.dim[1]);
+        sl = (int)(row / my_vd.dim[1]);
+        narrow = my_vd.dim[0] <= NARROW_ROW;
+        if (narrow) s_mask[tid] = 0ull;      // the thread's own work; the wave-per-word loop below skips it
+        else { s_off[tid] = off; s_vd[tid] = my_vd; s_row[tid][0] = wq; s_row[tid][1] = rl; s_row[tid][2] = sl; }
+    }
     __syncthreads();
 
     const Geom &g = *gp;
-    for (int j = 0; j < 64; ++j) {
-        const int slot = wv * 64 + j;
+    if (narrow) narrow_run_records(job, g, dens, my_vd, m, rl, sl, off);
+    // the words of my wave that are left, as a bit per slot
+    uint64_t todo = 0ull;
+    {
+        const bool live = lane < PER_WAVE && s_mask[wv * PER_WAVE + lane] != 0ull;
+        todo = __ballot(live);
+    }
+    auto fetch = [&](int slot) -> double {
         const uint64_t mw = s_mask[slot];
-        if (mw == 0ull) continue;
-        const int64_t word = chunk0 + slot;
-        const VolDesc vd = job.vols[s_vol[slot]];
-        const int64_t rem = word - vd.word_base;
-        const int wq = (int)(rem % vd.row_words);
-        const int64_t row = rem / vd.row_words;
-        const int rl = (int)(row % vd.dim[1]);
-        const int sl = (int)(row / vd.dim[1]);
-        word_run_records(job, g, dens, vd, mw, lane, wq * 64, rl, sl, vd.org[0] + wq * 64, vd.org[1] + rl, vd.org[2] + sl, s_off[slot]);
+        const VolDesc &vd = s_vd[slot];
+        return ((mw >> lane) & 1ull) ? (double)fetch_wrapped(g, dens, vd.org[0] + s_row[slot][0] * 64 + lane, vd.org[1] + s_row[slot][1], vd.org[2] + s_row[slot][2]) : 0.0;
+    };
+    double rho_next = todo ? fetch(wv * PER_WAVE + ctz64(todo)) : 0.0;
+    while (todo) {
+        const int slot = wv * PER_WAVE + ctz64(todo);
+        todo &= todo - 1;
+        const double rho = rho_next;
+        if (todo) rho_next = fetch(wv * PER_WAVE + ctz64(todo));
+        const VolDesc &vd = s_vd[slot];
+        const int q = s_row[slot][0], r = s_row[slot][1], t = s_row[slot][2];
+        word_run_records_of(job, vd, s_mask[slot], lane, rho, q * 64, r, t, vd.org[0] + q * 64, vd.org[1] + r, vd.org[2] + t, s_off[slot]);
     }
 }
 
@@ -444,12 +520,18 @@ __device__ inline uint32_t run_of_bit(uint64_t nm, uint32_t base, int p, int *st
     return base + (uint32_t)popc64(run_starts(nm) & bits_below(st));
 }
 
-// Thread per word: unite each run with the touching runs of (a) the previous word of the
-// same row, (b) words w-1, w, w+1 of the rows (r-1,s), (r-1,s-1), (r,s-1), (r+1,s-1).
+// Four threads per word, one per neighbour ROW -- (r-1,s), (r-1,s-1), (r,s-1), (r+1,s-1) -- : each unites the runs of the
+// word with the touching runs of words w-1, w, w+1 of its row; the first also with the previous word of the word's own row.
 // Two runs [a,b] and [a',b'] in adjacent rows touch iff [a-1,b+1] meets [a',b']
 // (Chebyshev distance <= 1 == cdist <= sqrt(3) on integer coordinates, cutils.pyx:43,62).
+// The neighbour words and their run bases are loaded up front and unconditionally (a clamped address where there is no such
+// word): one memory round trip before the unions instead of one or two per neighbour; a union is a chain of dependent
+// trips, so the rows of a word go side by side (round 4: a thread per word with loads on demand was 2 x 65-80 us of an
+// aggregateCloud, most of it in a union job of 40 k words = 164 blocks).
 __global__ void __launch_bounds__(256) k_union(Job job) {
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t w = t >> 2;
+    const int nb = (int)(t & 3);
     if (w >= job.total_words) return;
     const uint64_t m = job.mask[w];
     if (m == 0ull) return;
@@ -459,9 +541,29 @@ __global__ void __launch_bounds__(256) k_union(Job job) {
     const int64_t row = rem / vd.row_words;
     const int rl = (int)(row % vd.dim[1]);
     const int sl = (int)(row / vd.dim[1]);
+    uint64_t nmask[3];
+    uint32_t nbase[3];
+    {
+        const int dr = nb == 3 ? 1 : (nb == 2 ? 0 : -1), ds = nb == 0 ? 0 : -1;
+        const int r2 = rl + dr, s2 = sl + ds;
+        const bool row_ok = r2 >= 0 && r2 < vd.dim[1] && s2 >= 0;
+        const int64_t rowbase = vd.word_base + ((int64_t)(row_ok ? s2 : sl) * vd.dim[1] + (row_ok ? r2 : rl)) * vd.row_words;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int w2 = wq + d - 1;
+            const bool ok = row_ok && w2 >= 0 && w2 < vd.row_words;
+            const int64_t at = ok ? rowbase + w2 : w;
+            const uint64_t v = job.mask[at];
+            nbase[d] = job.run_base[at];
+            nmask[d] = ok ? v : 0ull;
+        }
+    }
+    const bool with_prev = nb == 0 && wq > 0;
+    const uint64_t pm = with_prev ? job.mask[w - 1] : 0ull;
+    const uint32_t pbase = job.run_base[with_prev ? w - 1 : w];
     const uint32_t base = job.run_base[w];
-    const uint64_t starts = run_starts(m);
-    uint64_t todo = starts;
+    if (!(nmask[0] | nmask[1] | nmask[2] | (pm >> 63))) return;
+    uint64_t todo = run_starts(m);
     uint32_t k = 0;
     while (todo) {
         const int a = ctz64(todo);
@@ -469,40 +571,24 @@ __global__ void __launch_bounds__(256) k_union(Job job) {
         const int b = run_end_of(m, a);
         const int me = (int)(base + k);
         ++k;
-        if (a == 0 && wq > 0) {
-            const uint64_t pm = job.mask[w - 1];
-            if (pm >> 63) {
-                int st;
-                uint32_t other = run_of_bit(pm, job.run_base[w - 1], 63, &st);
-                uf_unite(job.parent, me, (int)other);
-            }
+        if (a == 0 && (pm >> 63)) {
+            int st;
+            uf_unite2(job.parent, me, (int)run_of_bit(pm, pbase, 63, &st));
         }
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            const int dr = nb == 0 ? -1 : (nb == 1 ? -1 : (nb == 2 ? 0 : 1));
-            const int ds = nb == 0 ? 0 : -1;
-            const int r2 = rl + dr, s2 = sl + ds;
-            if (r2 < 0 || r2 >= vd.dim[1] || s2 < 0) continue;
-            const int64_t rowbase = vd.word_base + ((int64_t)s2 * vd.dim[1] + r2) * vd.row_words;
-            for (int dw = -1; dw <= 1; ++dw) {
-                const int w2 = wq + dw;
-                if (w2 < 0 || w2 >= vd.row_words) continue;
-                int lo = a - 1 - 64 * dw, hi = b + 1 - 64 * dw;
-                if (hi < 0 || lo > 63) continue;
-                if (lo < 0) lo = 0;
-                if (hi > 63) hi = 63;
-                const uint64_t nm = job.mask[rowbase + w2];
-                uint64_t hit = nm & (bits_below(hi + 1) & ~bits_below(lo));
-                if (!hit) continue;
-                const uint32_t nbase = job.run_base[rowbase + w2];
-                while (hit) {
-                    const int p = ctz64(hit);
-                    int st;
-                    const uint32_t other = run_of_bit(nm, nbase, p, &st);
-                    uf_unite(job.parent, me, (int)other);
-                    const int en = run_end_of(nm, st);
-                    hit &= ~bits_below(en + 1);
-                }
+        for (int d = 0; d < 3; ++d) {
+            const uint64_t nm = nmask[d];
+            int lo = a - 1 - 64 * (d - 1), hi = b + 1 - 64 * (d - 1);
+            if (nm == 0ull || hi < 0 || lo > 63) continue;
+            if (lo < 0) lo = 0;
+            if (hi > 63) hi = 63;
+            uint64_t hit = nm & (bits_below(hi + 1) & ~bits_below(lo));
+            while (hit) {
+                const int p = ctz64(hit);
+                int st;
+                const uint32_t other = run_of_bit(nm, nbase[d], p, &st);
+                uf_unite2(job.parent, me, (int)other);
+                hit &= ~bits_below(run_end_of(nm, st) + 1);
             }
         }
     }
@@ -985,16 +1071,28 @@ __global__ void __launch_bounds__(256) k_voxel_lists(Job job, const int64_t *__r
     for (int64_t w = wave; w < job.total_words; w += n_waves) {
         const uint64_t m = job.mask[w];
         if (m == 0ull) continue;
-        if (!((m >> lane) & 1ull)) continue;
+        const bool bit = (m >> lane) & 1ull;
         const VolDesc vd = job.vols[find_vol(job.vols, job.n_vols, w)];
         const int64_t rem = w - vd.word_base;
         const int wq = (int)(rem % vd.row_words);
         const int64_t row = rem / vd.row_words;
-        const uint32_t run = job.run_base[w] + run_ordinal(run_starts(m), lane);
+        const uint64_t starts = run_starts(m);
+        const int at_bit = bit ? lane : ctz64(m);        // (a lane without a voxel follows the word's first one: valid indices, nothing stored)
+        const uint32_t run = job.run_base[w] + run_ordinal(starts, at_bit);
         const uint32_t comp = job.comp_of_run ? job.comp_of_run[run] : run;
         const uint32_t root = (uint32_t)job.parent[comp];
         const uint32_t rank = job.r_rank[root];
-        const int64_t pos = offsets[rank] + atomicAdd(&cursor[rank], 1u);
+        // one cursor bump per RUN, or per word when all its voxels belong to one blob (a domain union is 10^5 voxels of a
+        // single blob: a bump per voxel was 10^5 atomics on one address, 33 us of an aggregateCloud in round 4)
+        const uint32_t rank0 = __shfl(rank, ctz64(m));
+        const bool one_blob = __all(!bit || rank == rank0);
+        const int first = one_blob ? ctz64(m) : run_start_of(m, at_bit);
+        const uint32_t count = one_blob ? (uint32_t)popc64(m) : (uint32_t)(run_end_of(m, first) - first + 1);
+        uint32_t at = 0;
+        if (bit && lane == first) at = atomicAdd(&cursor[rank], count);
+        at = __shfl(at, first);
+        if (!bit) continue;
+        const int64_t pos = offsets[rank] + at + (one_blob ? (uint32_t)popc64(m & bits_below(lane)) : (uint32_t)(lane - first));
         crs_out[3 * pos + 0] = vd.org[0] + wq * 64 + lane;
         crs_out[3 * pos + 1] = vd.org[1] + (int)(row % vd.dim[1]);
         crs_out[3 * pos + 2] = vd.org[2] + (int)(row / vd.dim[1]);
@@ -1040,18 +1138,36 @@ __global__ void k_atom_boxes(const Geom *__restrict__ gp, const double *__restri
     }
 }
 
-// Thread per explicit voxel: group bounding boxes for list jobs.
-__global__ void k_list_boxes(const int32_t *__restrict__ crs, const int32_t *__restrict__ vox_group, int64_t n,
-                             int32_t *__restrict__ g_lo, int32_t *__restrict__ g_hi) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = i < n;
-    const int gidx = in ? vox_group[i] : -1;
-    int lo[3], hi[3];
-    for (int k = 0; k < 3; ++k) { lo[k] = in ? crs[3 * i + k] : INT32_MAX; hi[k] = in ? crs[3 * i + k] : INT32_MIN; }
-    // voxels arrive grouped: a wave usually holds ONE group (a domain union is a single group of 10^5 voxels) -> reduce in
-    // the wave and send six atomics instead of 6 x 64 to the same six addresses
-    const int g0 = __builtin_amdgcn_readfirstlane(gidx);
-    if (__all(gidx == g0 || !in) && g0 >= 0) {
+// Explicit voxels: group bounding boxes for list jobs.  A thread takes a contiguous share of the list; voxels arrive
+// grouped (a domain union is a single group of 10^5 voxels), so a thread keeps the box of its current group in registers and
+// sends it when the group changes; at the end a wave -- and then the block -- whose threads all hold the same group reduce
+// first and send six atomics (a wave per 64 voxels sent 6 x 1000 atomics to the same six addresses: 33 us, round 4).
+__global__ void __launch_bounds__(256) k_list_boxes(const int32_t *__restrict__ crs, const int32_t *__restrict__ vox_group, int64_t n,
+                                                    int32_t *__restrict__ g_lo, int32_t *__restrict__ g_hi) {
+    __shared__ int s_box[4][7];
+    const int64_t n_threads = (int64_t)gridDim.x * blockDim.x, t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t share = (n + n_threads - 1) / n_threads, i0 = t * share, i1 = i0 + share < n ? i0 + share : n;
+    int gidx = -1;
+    int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    for (int64_t i = i0; i < i1; ++i) {
+        const int gi = vox_group[i];
+        if (gi != gidx) {
+            if (gidx >= 0)
+                for (int k = 0; k < 3; ++k) { atomicMin(&g_lo[3 * gidx + k], lo[k]); atomicMax(&g_hi[3 * gidx + k], hi[k]); }
+            gidx = gi;
+            for (int k = 0; k < 3; ++k) { lo[k] = INT32_MAX; hi[k] = INT32_MIN; }
+        }
+        for (int k = 0; k < 3; ++k) {
+            const int v = crs[3 * i + k];
+            lo[k] = v < lo[k] ? v : lo[k];
+            hi[k] = v > hi[k] ? v : hi[k];
+        }
+    }
+    // the wave: one group among the lanes that hold one?
+    const unsigned long long have = __ballot(gidx >= 0);
+    const int g0 = have ? __shfl(gidx, ctz64(have)) : -1;
+    const bool wave_one = __all(gidx < 0 || gidx == g0);
+    if (wave_one) {
         for (int k = 0; k < 3; ++k) {
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) {
@@ -1060,14 +1176,29 @@ __global__ void k_list_boxes(const int32_t *__restrict__ crs, const int32_t *__r
                 hi[k] = c > hi[k] ? c : hi[k];
             }
         }
-        if (lane_id() == 0)
-            for (int k = 0; k < 3; ++k) { atomicMin(&g_lo[3 * g0 + k], lo[k]); atomicMax(&g_hi[3 * g0 + k], hi[k]); }
-        return;
+    } else if (gidx >= 0) {
+        for (int k = 0; k < 3; ++k) { atomicMin(&g_lo[3 * gidx + k], lo[k]); atomicMax(&g_hi[3 * gidx + k], hi[k]); }
     }
-    if (!in) return;
-    for (int k = 0; k < 3; ++k) {
-        atomicMin(&g_lo[3 * gidx + k], lo[k]);
-        atomicMax(&g_hi[3 * gidx + k], hi[k]);
+    const int wv = threadIdx.x >> 6;
+    if (lane_id() == 0) {
+        s_box[wv][0] = wave_one ? g0 : -1;
+        for (int k = 0; k < 3; ++k) { s_box[wv][1 + k] = lo[k]; s_box[wv][4 + k] = hi[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {   // waves of one group each: merge neighbours of the same group, send the rest
+        int cur = -1, clo[3] = {0, 0, 0}, chi[3] = {0, 0, 0};
+        for (int q = 0; q <= 4; ++q) {
+            const int gq = q < 4 ? s_box[q][0] : -1;
+            if (q < 4 && gq >= 0 && gq == cur) {
+                for (int k = 0; k < 3; ++k) { clo[k] = s_box[q][1 + k] < clo[k] ? s_box[q][1 + k] : clo[k]; chi[k] = s_box[q][4 + k] > chi[k] ? s_box[q][4 + k] : chi[k]; }
+                continue;
+            }
+            if (cur >= 0)
+                for (int k = 0; k < 3; ++k) { atomicMin(&g_lo[3 * cur + k], clo[k]); atomicMax(&g_hi[3 * cur + k], chi[k]); }
+            cur = gq;
+            if (q < 4 && gq >= 0)
+                for (int k = 0; k < 3; ++k) { clo[k] = s_box[q][1 + k]; chi[k] = s_box[q][4 + k]; }
+        }
     }
 }
 
