@@ -160,6 +160,31 @@ def _typeRegressions(x, y, bfactor, group, n_types):
     return slope, p, fitted
 
 
+def _lastWithSameCoord(coord32):
+    """For every row of float32 coordinates, the index of the LAST row with an equal triple (``allAtomClouds[tuple(atom.coord)]``
+    keeps the last atom of a coordinate, ref densityAnalysis.py:604; equal as floats: -0.0 is 0.0).  One 64-bit sort of a mixed
+    key instead of a sort of 12-byte records; rows whose keys collide without being equal send the call to the slow exact path."""
+    n = len(coord32)
+    if n == 0:
+        return np.zeros(0, dtype=np.int64)
+    bits = np.ascontiguousarray(coord32 + np.float32(0.0)).view(np.uint32).astype(np.uint64)     # (+0.0: -0.0 becomes 0.0)
+    key = ((bits[:, 0] << np.uint64(32)) | bits[:, 1]) * np.uint64(0x9E3779B97F4A7C15) ^ (bits[:, 2] * np.uint64(0xC2B2AE3D27D4EB4F))
+    order = np.argsort(key, kind="stable")
+    sorted_bits, sorted_key = bits[order], key[order]
+    same_row = (sorted_bits[1:] == sorted_bits[:-1]).all(axis=1)
+    if ((sorted_key[1:] == sorted_key[:-1]) & ~same_row).any():
+        triple = np.ascontiguousarray(bits.astype(np.uint32)).view(np.dtype((np.void, 12))).ravel()
+        _, same = np.unique(triple, return_inverse=True)
+        last = np.full(int(same.max()) + 1, -1, dtype=np.int64)
+        np.maximum.at(last, same.reshape(-1), np.arange(n))
+        return last[same.reshape(-1)]
+    starts = np.flatnonzero(np.concatenate([[True], ~same_row]))
+    group = np.cumsum(np.concatenate([[0], (~same_row).astype(np.int64)]))
+    alias = np.empty(n, dtype=np.int64)
+    alias[order] = np.maximum.reduceat(order, starts)[group]
+    return alias
+
+
 class _SymAtomList(object):
     """The list of SymAtom objects createSymmetryAtoms returns (cutils.pyx:73-103), materialised item by item; the tables that
     list thousands of them read whole columns instead (``columns``)."""
@@ -379,11 +404,7 @@ class DensityAnalysis(object):
             found = distinct[pos] == codes if len(distinct) else np.zeros(len(codes), dtype=bool)
             return found, rank[pos[found]]
         # allAtomClouds is keyed by the coordinate: the last atom with the same float32 triple wins (604)
-        triple = np.ascontiguousarray(cols.coord32[sel]).view(np.dtype((np.void, 12))).ravel()
-        _, same = np.unique(triple, return_inverse=True)
-        last = np.full(int(same.max()) + 1 if n else 0, -1, dtype=np.int64)
-        np.maximum.at(last, same, np.arange(n))
-        alias = last[same]
+        alias = _lastWithSameCoord(cols.coord32[sel])
         # the pair tables: type, electrons, radius, and the bonded names that exist in this structure
         used = set(np.unique(pair_of).tolist())
         pair_id = {name: k for k, name in enumerate(names)}

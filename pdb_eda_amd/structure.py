@@ -140,6 +140,20 @@ def _first_appearance_ids(values):
     return list(ids), np.fromiter(map(ids.__getitem__, values), dtype=np.int64, count=len(values))
 
 
+_hostwalk_module = [False]
+
+
+def _hostwalk():
+    """The C walk of the object tree (pdb_eda_amd/_hostwalk.so, csrc/hostwalk.c), or None when it is not built."""
+    if _hostwalk_module[0] is False:
+        try:
+            from . import _hostwalk as module
+        except ImportError:
+            module = None
+        _hostwalk_module[0] = module
+    return _hostwalk_module[0]
+
+
 class Columns(object):
     """A columnar snapshot of a structure: what the analysis reads from the object tree (see the module text), gathered in
     ONE walk so that the per-entry host work runs on arrays instead of on 10^3..10^4 Python objects.
@@ -152,50 +166,77 @@ class Columns(object):
     into ``pair_names``, the distinct 'RES_ATOM' names of densityAnalysis.residueAtomName).
     The snapshot is cached on the structure object: edit the tree and call ``columns(structure, refresh=True)``."""
 
-    def __init__(self, structure):
+    def __init__(self, structure, native=None):
+        """``native``: None = use the C walk (``_hostwalk``) when it is built and understands the tree, else the Python loops;
+        True / False force one of them (tests)."""
         residues = list(structure.get_residues())
-        chains = [residue.parent for residue in residues]
-        ids = [residue.id for residue in residues]
-        res_model = [chain.parent.id for chain in chains]
-        res_chain = [chain.id for chain in chains]
-        res_number = [rid[1] for rid in ids]
-        res_name = [residue.resname for residue in residues]
-        res_het = [rid[0] != ' ' for rid in ids]
-        children = [residue.child_list for residue in residues]
-        atoms = list(itertools.chain.from_iterable(children))
-        n = len(atoms)
+        walked = None
+        if native is not False:
+            walk = _hostwalk()
+            if walk is None and native:
+                raise ImportError("pdb_eda_amd/_hostwalk.so is not built (python __graft_entry__.py)")
+            if walk is not None:
+                try:
+                    res_model, res_chain, res_number, res_name, het, children = walk.residue_columns(residues)
+                    walked = walk.atom_columns(children)
+                except Exception:
+                    if native:
+                        raise
+                    walked = None                      # an object tree the C walk does not read: the loops below do
+        if walked is not None:
+            atoms, name, occupancy, counts, occ, bfac, xyz, name_id, distinct = walked
+            n = len(atoms)
+            res_het = np.frombuffer(het, dtype=np.uint8).astype(bool)
+            counts = np.frombuffer(counts, dtype=np.int64)
+            atom_names = (distinct, np.frombuffer(name_id, dtype=np.int64))
+            occupancy_f, bfactor_f = np.frombuffer(occ, dtype=np.float64), np.frombuffer(bfac, dtype=np.float64)
+            coord32 = np.frombuffer(xyz, dtype=np.float32).reshape(n, 3)
+        else:
+            chains = [residue.parent for residue in residues]
+            ids = [residue.id for residue in residues]
+            res_model = [chain.parent.id for chain in chains]
+            res_chain = [chain.id for chain in chains]
+            res_number = [rid[1] for rid in ids]
+            res_name = [residue.resname for residue in residues]
+            res_het = np.asarray([rid[0] != ' ' for rid in ids], dtype=bool)
+            children = [residue.child_list for residue in residues]
+            atoms = list(itertools.chain.from_iterable(children))
+            n = len(atoms)
+            counts = np.fromiter(map(len, children), dtype=np.int64, count=len(residues))
+            name = [atom.name for atom in atoms]
+            atom_names = _first_appearance_ids(name)
+            try:                                       # (the accessors of our atoms and of Bio.PDB's return these attributes)
+                occupancy = [atom.occupancy for atom in atoms]
+                bfactor = [atom.bfactor for atom in atoms]
+            except AttributeError:
+                occupancy = [atom.get_occupancy() for atom in atoms]
+                bfactor = [atom.get_bfactor() for atom in atoms]
+            occupancy_f, bfactor_f = np.asarray(occupancy, dtype=np.float64), np.asarray(bfactor, dtype=np.float64)
+            coord = [atom.coord for atom in atoms]
+            coord32 = (np.concatenate(coord).astype(np.float32, copy=False) if n else np.zeros(0, dtype=np.float32)).reshape(n, 3)
         res_start = np.zeros(len(residues) + 1, dtype=np.int64)
-        np.cumsum(np.fromiter(map(len, children), dtype=np.int64, count=len(residues)), out=res_start[1:])
-        res_of_atom = np.repeat(np.arange(len(residues), dtype=np.int64), np.diff(res_start))
-        name = [atom.name for atom in atoms]
+        np.cumsum(counts, out=res_start[1:])
+        res_of_atom = np.repeat(np.arange(len(residues), dtype=np.int64), counts)
         # the distinct 'RES_ATOM' names, numbered by first appearance: ids of the (stripped) residue names and of the atom names
         # through C-level dict lookups, then one np.unique over the combined code -- no string is built per atom
         res_names = _first_appearance_ids([resname.strip() for resname in res_name])
-        atom_names = _first_appearance_ids(name)
         code = res_names[1][res_of_atom] * max(len(atom_names[0]), 1) + atom_names[1]
         distinct, first, inverse = np.unique(code, return_index=True, return_inverse=True)
         by_first = np.argsort(first, kind="stable")
         rank = np.empty(len(distinct), dtype=np.int64)
         rank[by_first] = np.arange(len(distinct))
         pair_names = [res_names[0][c // max(len(atom_names[0]), 1)] + '_' + atom_names[0][c % max(len(atom_names[0]), 1)] for c in distinct[by_first].tolist()]
-        try:                                       # (the accessors of our atoms and of Bio.PDB's return these attributes)
-            occupancy = [atom.occupancy for atom in atoms]
-            bfactor = [atom.bfactor for atom in atoms]
-        except AttributeError:
-            occupancy = [atom.get_occupancy() for atom in atoms]
-            bfactor = [atom.get_bfactor() for atom in atoms]
-        coord = [atom.coord for atom in atoms]
         self.residues, self.atoms = residues, atoms
         self.res_model, self.res_chain, self.res_number, self.res_name = res_model, res_chain, res_number, res_name
-        self.res_het = np.asarray(res_het, dtype=bool)
+        self.res_het = res_het
         self.res_start = res_start
         self.res_of_atom = res_of_atom
         self.name = name
         self.atom_names, self.name_of_atom = atom_names
         self.occupancy_raw = occupancy
-        self.occupancy = np.asarray(occupancy, dtype=np.float64)
-        self.bfactor = np.asarray(bfactor, dtype=np.float64)
-        self.coord32 = (np.concatenate(coord).astype(np.float32, copy=False) if n else np.zeros(0, dtype=np.float32)).reshape(n, 3)
+        self.occupancy = occupancy_f
+        self.bfactor = bfactor_f
+        self.coord32 = coord32
         self.coord = self.coord32.astype(np.float64)
         self.pair_of_atom = rank[inverse.reshape(-1)] if n else np.zeros(0, dtype=np.int64)
         self.pair_names = pair_names

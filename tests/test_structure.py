@@ -171,3 +171,49 @@ def test_type_regressions_equal_scipy_linregress():
                     fit = stats.linregress(x[sel], y[sel])
                 assert slope[k] == pytest.approx(fit.slope, rel=1e-10, abs=1e-14)
                 assert p[k] == pytest.approx(fit.pvalue, rel=1e-8, abs=1e-14)
+
+
+def test_columns_c_walk_equals_python_walk():
+    """structure.Columns reads the object tree once per entry: the C walk (pdb_eda_amd/_hostwalk.so) and the Python loops it
+    replaces must give the same snapshot -- on our own tree, with float64 coordinates and a missing occupancy (Bio.PDB has
+    both), and an object the C walk does not read falls back to the loops."""
+    import numpy as np
+    import __graft_entry__
+    __graft_entry__.build()
+    from pdb_eda_amd import structure, synthetic
+    lo, hi = np.zeros(3), np.full(3, 40.0)
+    st = synthetic.chain_structure(60, 3, lo, hi, hetero_every=7, zero_occupancy_every=11)
+    atoms = list(st.get_atoms())
+    atoms[5].coord = atoms[5].coord.astype(np.float64)
+    atoms[9].occupancy = None
+    atoms[12].coord = np.asarray([1.0, 2.0, 3.0, 4.0], dtype=np.float32)[::1][:3][::-1][::-1]      # a view with the same layout
+    fast, slow = structure.Columns(st, native=True), structure.Columns(st, native=False)
+    for field in ("res_model", "res_chain", "res_number", "res_name", "name", "atom_names", "occupancy_raw", "pair_names"):
+        assert getattr(fast, field) == getattr(slow, field), field
+    assert all(a is b for a, b in zip(fast.atoms, slow.atoms)) and all(a is b for a, b in zip(fast.residues, slow.residues))
+    for field in ("res_het", "res_start", "res_of_atom", "name_of_atom", "occupancy", "bfactor", "coord32", "coord", "pair_of_atom"):
+        a, b = getattr(fast, field), getattr(slow, field)
+        assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b, equal_nan=True), field
+    assert np.isnan(fast.occupancy[9])
+    atoms[3].coord = [1.0, 2.0, 3.0]                     # a plain list: not a buffer
+    with pytest.raises(TypeError):
+        structure.Columns(st, native=True)
+    assert np.array_equal(structure.Columns(st).coord32, structure.Columns(st, native=False).coord32)
+
+
+def test_last_atom_with_the_same_coordinate():
+    """The alias rule's index column (the last atom of a float32 coordinate triple, ref densityAnalysis.py:604-605) against a dict
+    keyed the way the reference keys allAtomClouds, duplicates, -0.0 and all."""
+    import numpy as np
+    from pdb_eda_amd import densityAnalysis as da
+    rng = np.random.default_rng(11)
+    for n in (0, 1, 7, 500):
+        xyz = rng.normal(0, 10, (n, 3)).astype(np.float32)
+        if n >= 7:
+            xyz[3] = xyz[1]; xyz[6] = xyz[1]; xyz[5] = xyz[0]
+            xyz[2] = [0.0, 1.0, 2.0]; xyz[4] = [-0.0, 1.0, 2.0]
+        last = {}
+        for i in range(n):
+            last[tuple(xyz[i])] = i
+        want = np.array([last[tuple(xyz[i])] for i in range(n)], dtype=np.int64)
+        assert np.array_equal(da._lastWithSameCoord(xyz), want)
