@@ -190,8 +190,9 @@ int pdbeda_bloblist_labels(pdbeda_bloblist *bl, int32_t *labels_host);
 int pdbeda_bloblist_free(pdbeda_bloblist *bl);
 /* Diagnostic (no reference counterpart): counters of the labelling job behind a list,
  * out[8] = run ids, component ids, runs of the job beyond the first (1 = the typical-size arena was too small for this map and
- * the job ran again in a worst-case one), blobs, tiles that fell back to the generic "unit tile" path by cause (run slots
- * full, -, component table full), bytes of device memory the job holds. */
+ * the job ran again in a worst-case one), blobs, tiles off the fast path by kind (unit tiles: run slots full; wide tiles: more
+ * components than the LDS tables hold, united in LDS all the same; unit tiles: no ids left for a wide tile), bytes of device memory
+ * the job holds. */
 int pdbeda_bloblist_counters(pdbeda_bloblist *bl, int64_t *out);
 
 /* ---- regional sums ---------------------------------------------------------------- */

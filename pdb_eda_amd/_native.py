@@ -342,7 +342,7 @@ class BlobList(object):
     def counters(self):
         out = np.zeros(8, dtype=np.int64)
         self._ctx.check(self._ctx._lib.pdbeda_bloblist_counters(self._h, _ptr(out)), "pdbeda_bloblist_counters")
-        return {"run_ids": int(out[0]), "component_ids": int(out[1]), "blobs": int(out[3]), "unit_tiles_runs": int(out[4]), "unit_tiles_comps": int(out[6]),
+        return {"run_ids": int(out[0]), "component_ids": int(out[1]), "blobs": int(out[3]), "unit_tiles_runs": int(out[4]), "wide_tiles": int(out[5]), "unit_tiles_comps": int(out[6]),
                 "reruns": int(out[2]), "arena_bytes": int(out[7])}
 
     def free(self):

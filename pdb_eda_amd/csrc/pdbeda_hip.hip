@@ -951,7 +951,7 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.label_of_comp = n_tiles ? cv.take<int32_t>(max_comps) : nullptr;
     job.word_comps = n_tiles ? cv.take<uint8_t>((size_t)n_tiles * 2 * 256 * 8) : nullptr;
     job.unit_done = n_tiles ? cv.take<uint32_t>((size_t)n_tiles) : nullptr;
-    job.unit_flag = n_tiles ? cv.take<uint32_t>(1) : nullptr;
+    job.unit_flag = n_tiles ? cv.take<uint32_t>(2) : nullptr;
     job.tile_mode = n_tiles ? cv.take<uint8_t>(n_tiles) : nullptr;
     job.tile_runs = n_tiles ? cv.take<uint32_t>(n_tiles) : nullptr;
     job.root_mask = n_tiles ? cv.take<uint64_t>((size_t)n_tiles * 4) : nullptr;
@@ -1255,12 +1255,12 @@ extern "C" int pdbeda_bloblist_counters(pdbeda_bloblist *bl, int64_t *out) {
     out[0] = c.n_runs; out[1] = c.n_comps; out[2] = bl->reruns; out[3] = c.n_blobs;
     out[4] = out[5] = out[6] = 0;
     out[7] = (int64_t)(bl->job_bytes ? bl->job_bytes : owner_of(bl)->arena.cap);   // bytes of device memory the job needs (its arena, if recycled, may be up to twice that)
-    if (bl->whole_map && bl->job.tile_mode) {   // unit tiles by cause: tile_mode 1 = run slots / values, 3 = component table
+    if (bl->whole_map && bl->job.tile_mode) {   // tiles off the fast path by kind: tile_mode 1 = unit tile (run slots / values), 2 = wide tile (more than CCAP components, united in LDS all the same), 3 = unit tile (no ids left for a wide tile's components)
         const int64_t n_tiles = (int64_t)bl->td.ctiles * bl->td.rtiles * bl->td.stiles;
         std::vector<uint8_t> mode(n_tiles);
         HIP_TRY(ctx, d2h(ctx, mode.data(), bl->job.tile_mode, n_tiles));
         HIP_TRY(ctx, ctx_sync(ctx));
-        for (uint8_t v : mode) { if (v == 1) ++out[4]; else if (v == 3) ++out[6]; }
+        for (uint8_t v : mode) { if (v == 1) ++out[4]; else if (v == 2) ++out[5]; else if (v == 3) ++out[6]; }
     }
     return PDBEDA_OK;
 }

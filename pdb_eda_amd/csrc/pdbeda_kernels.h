@@ -124,9 +124,9 @@ struct Job {
     // a byte each -- k_face_merge unites across tile faces from the mask words and these records alone (one round trip)
     uint8_t *word_comps;               // [tile][2][256][8]
     uint32_t *unit_done;               // [tile]: == epoch once the tile's workgroup of k_face_merge has labelled it (unit tiles) or has nothing to label
-    uint32_t *unit_flag;      // == epoch iff some tile of THIS job fell back to unit mode (stale values of a recycled arena never match)
+    uint32_t *unit_flag;      // [0] == epoch iff some tile of THIS job fell back to unit mode (stale values of a recycled arena never match); [1] == epoch once k_tile_label's workgroup 0 has initialised the counters
     uint32_t epoch;           // job number of the context (never 0)
-    uint8_t *tile_mode;       // per tile: 0 = united in LDS, 1 = unit tile
+    uint8_t *tile_mode;       // per tile: 0 = united in LDS; 1 / 3 = unit tile (too many runs / no ids for its components); 2 = wide tile (united in LDS, components above the tiles' id ranges)
     uint32_t *tile_runs;      // per tile: number of word-runs (ids tile * runs_per_tile ...)
     // Scattered global atomics are the scarce resource of the merge (~20 G/s chip-wide: folding 9 fields per (tile, root) pair
     // took 12 of k_resolve_tiles' 22 us).  So a tile's members POST their summed record to the inbox of the tile that owns

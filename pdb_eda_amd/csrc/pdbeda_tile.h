@@ -282,6 +282,9 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
             c.n_runs = init.runs0;
             c.n_comps = init.comps0;
             *pj.ctr = c;
+            // a tile with more than CCAP components takes ids from c.n_comps further down (the wide tiles): not before this
+            // flag says that the counters are this job's (epoch: stale values of a recycled arena never match)
+            __hip_atomic_store(&pj.unit_flag[1], pj.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
         // (the first-key bitmap, the rank counters and the inbox counters are cleared by k_face_merge: this kernel is bound by
         //  instruction issue, that one by memory round trips -- its issue slots are free)
@@ -537,83 +540,127 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
     }
     __syncthreads();   // ---- barrier 3 ----
     const uint32_t n_comp = s_ncomp;
-    if (n_comp > CCAP) {  // block-uniform: too many components for LDS -> unit tile
-        if (my_valid) lj.run_base[my_word] = 0u;
-        if (tid == 0) { lj.tile_mode[tile_id] = 3; lj.tile_runs[bid] = 0u; *lj.unit_flag = lj.epoch; }
-        mark_comps_unused(lj, (uint32_t)bid * CCAP, 0u, tid, NT);
-        return;
-    }
-    // ---- C2: a thread per run: sums over the parked values, fold into the component ----
-    {
-        uint32_t *comp_of_run = lj.comp_of_run + rb;
-        // k_face_merge reads, per word, the tile-local components of its first FACE_K word-runs and (byte 7) of the run that
-        // reaches the word's last bit, as the bytes of one 64-bit load
-        uint8_t *word_comps = lj.word_comps + (size_t)bid * (2 * 256 * 8);
-        const int ctile = w0 * 64;
-        const uint32_t urus = (uint32_t)ur * (uint32_t)us;
-        const double fix_mul = lj.fix_mul;
-        for (uint32_t i = tid; i < n_runs; i += NT) {
-            const uint32_t pd = s_parent[i], desc = pd >> 16;
-            uint32_t x = pd & 0xffffu;
-            while (!(x & ROOT16)) x = s_half[2 * x];
-            const uint32_t comp = x & 0x7fffu;
-            const int ru = (int)(desc & 0xffu), rq = (int)((desc >> 8) & 1u), a = (int)(desc >> 9);
-            const int rsl = ru / USEC, rrl = (ru % USEC) / CW, rwl = ru % CW;
-            const uint64_t rm = s_mask[rq][ru];
-            const uint32_t ub = s_ub[rq][ru];
-            const uint64_t inv = ~(rm >> a);
-            const int len = inv ? ctz64(inv) : 64;   // (a run that fills bits a..63: rm >> a has 64 - a ones and zeros above)
-            // exact sequential fp64 sums: S = sum v_i, T = sum of the running S = sum (len - i) v_i, so sum i v_i = len S - T
-            double S = 0.0, T = 0.0;
-            if (!from_global) {
-                const uint32_t off = (ub & 0xffffu) + (uint32_t)popc64((rm | s_mask[rq ^ 1][ru]) & bits_below(a));
-                int k = 0;
-                for (; k + 2 <= len; k += 2) {   // two parked values in flight
-                    const float v0 = s_val[off + k], v1 = s_val[off + k + 1];
-                    S += (double)v0; T += S;
-                    S += (double)v1; T += S;
-                }
-                if (k < len) { S += (double)s_val[off + k]; T += S; }
-            } else {   // dense tile: the values were not parked; re-read from L2
-                const float *rowptr = dens + ((int64_t)(s0 + rsl) * nr + (r0 + rrl)) * nc + ctile + rwl * 64;
-                for (int k = 0; k < len; ++k) { S += (double)rowptr[a + k]; T += S; }
+    // More components than the accumulators hold (CCAP): a WIDE tile.  Its unions are done all the same -- in LDS, above --, so
+    // it keeps them: the components take ids from the job's counter (above the tiles' own ranges, where the unit tiles' runs take
+    // theirs), and the sums below are made CCAP components at a time (round 4; before, such a tile fell back to run-by-run
+    // labelling and global unions of ALL its pairs in k_face_merge -- a protein-like map at 0.5 sigma, every tile of it: 1.2 ms
+    // a step).  For everybody else it is a unit tile (tile_mode 2: look the component up by run id) whose in-tile pairs are done.
+    const bool wide = n_comp > (uint32_t)CCAP;   // block-uniform
+    uint32_t gb = cb;
+    if (wide) {
+        uint32_t *s_gb = s_wtot;   // (free since A2)
+        if (tid == 0) {
+            // the counters are written by workgroup 0 at its very start, some 15 us before any tile gets here; the flag makes that
+            // order a fact instead of a habit of the dispatcher (bounded: a flag that does not come up sends the tile the old way)
+            unsigned spins = 0;
+            bool ready = true;
+            while (__hip_atomic_load(&lj.unit_flag[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != lj.epoch) {
+                if (++spins > (1u << 16)) { ready = false; break; }
+                __builtin_amdgcn_s_sleep(8);
             }
-            const int p0 = rwl * 64 + a;
-            // the run's sums become integers here (rounded once to the job's quantum); moments relative to the tile origin
-            const long long F = fix_of(S, fix_mul), Fc = fix_of((double)p0 * S + ((double)len * S - T), fix_mul);
-            atomicAdd(&s_rho[comp], (unsigned long long)F);
-            atomicAdd(&s_rho_c[comp], (unsigned long long)Fc);
-            atomicAdd(&s_rho_r[comp], (unsigned long long)(F * rrl));
-            atomicAdd(&s_rho_s[comp], (unsigned long long)(F * rsl));
-            // (keys of a plane are below 2^31: the host checks)
-            atomicMin(&s_key[comp], ((uint32_t)rq << 31) | ((uint32_t)(ctile + p0) * urus + (uint32_t)(r0 + rrl) * (uint32_t)us + (uint32_t)(s0 + rsl)));
-            const uint32_t ulen = (uint32_t)len;
-            atomicAdd(&s_pk[comp], (unsigned long long)ulen | ((unsigned long long)(ulen * (uint32_t)rrl) << 20) | ((unsigned long long)(ulen * (uint32_t)rsl) << 40));
-            atomicAdd(&s_crel[comp], ulen * (uint32_t)p0 + ulen * (ulen - 1u) / 2u);
-            comp_of_run[i] = cb + comp;
-            const uint32_t kw = i - (ub >> 16);   // my place among the word-runs of my word
-            uint8_t *rec = word_comps + ((desc & 0x1ffu) << 3);
-            if (kw < (uint32_t)FACE_K) rec[kw] = (uint8_t)comp;
-            if (a + len == 64) rec[7] = (uint8_t)comp;
+            uint32_t first = 0xffffffffu;
+            if (ready) {
+                first = atomicAdd(&lj.ctr->n_comps, n_comp);
+                if (first + n_comp > lj.comp_cap) { atomicOr(&lj.ctr->overflow, 1u); first = 0xffffffffu; }   // (no ids left: flagged; the host runs the job again in the worst-case arena)
+            }
+            s_gb[0] = first;
         }
-        if (tid == 0) lj.tile_mode[tile_id] = 0;
+        __syncthreads();
+        gb = s_gb[0];
+        if (gb == 0xffffffffu) {   // block-uniform: a unit tile, labelled run by run by its workgroup of k_face_merge
+            if (my_valid) lj.run_base[my_word] = 0u;
+            if (tid == 0) { lj.tile_mode[tile_id] = 3; lj.tile_runs[bid] = 0u; *lj.unit_flag = lj.epoch; }
+            mark_comps_unused(lj, cb, 0u, tid, NT);
+            return;
+        }
     }
-    __syncthreads();   // ---- barrier 4 ----
+    uint32_t *comp_of_run = lj.comp_of_run + rb;
+    // k_face_merge reads, per word, the tile-local components of its first FACE_K word-runs and (byte 7) of the run that
+    // reaches the word's last bit, as the bytes of one 64-bit load (a wide tile's are not read: tile_mode)
+    uint8_t *word_comps = lj.word_comps + (size_t)bid * (2 * 256 * 8);
     const int64_t keys_pp = (int64_t)uc * ur * us;
-    for (uint32_t i = tid; i < n_comp; i += NT) {
-        const uint32_t g = cb + i;
-        const unsigned long long pk = s_pk[i];
-        const long long n = (long long)(pk & 0xfffffull);
-        lj.r_n[g] = (uint32_t)n;
-        fix_store(lj, g, fix_sums((long long)s_rho[i], (long long)s_rho_c[i], (long long)s_rho_r[i], (long long)s_rho_s[i], w0 * 64, r0, s0));
-        lj.r_c[g] = (long long)s_crel[i] + n * (w0 * 64);
-        lj.r_r[g] = (long long)((pk >> 20) & 0xfffffull) + n * r0;
-        lj.r_s[g] = (long long)(pk >> 40) + n * s0;
-        const uint32_t key = s_key[i];
-        lj.r_key[g] = (unsigned long long)((key >> 31) ? keys_pp : 0) + (key & 0x7fffffffu);
-        lj.kpar[g] = ((unsigned long long)key << 32) | g;   // a root, named by its first key: the cross-tile unions hang the later first voxel under the earlier
+    for (uint32_t pass0 = 0;; pass0 += (uint32_t)CCAP) {   // (one pass unless the tile is wide)
+        // ---- C2: a thread per run: sums over the parked values, fold into the component ----
+        {
+            const int ctile = w0 * 64;
+            const uint32_t urus = (uint32_t)ur * (uint32_t)us;
+            const double fix_mul = lj.fix_mul;
+            for (uint32_t i = tid; i < n_runs; i += NT) {
+                const uint32_t pd = s_parent[i], desc = pd >> 16;
+                uint32_t x = pd & 0xffffu;
+                while (!(x & ROOT16)) x = s_half[2 * x];
+                const uint32_t comp_all = x & 0x7fffu;
+                if (wide && comp_all - pass0 >= (uint32_t)CCAP) continue;   // (not this pass's)
+                const uint32_t comp = comp_all - pass0;
+                const int ru = (int)(desc & 0xffu), rq = (int)((desc >> 8) & 1u), a = (int)(desc >> 9);
+                const int rsl = ru / USEC, rrl = (ru % USEC) / CW, rwl = ru % CW;
+                const uint64_t rm = s_mask[rq][ru];
+                const uint32_t ub = s_ub[rq][ru];
+                const uint64_t inv = ~(rm >> a);
+                const int len = inv ? ctz64(inv) : 64;   // (a run that fills bits a..63: rm >> a has 64 - a ones and zeros above)
+                // exact sequential fp64 sums: S = sum v_i, T = sum of the running S = sum (len - i) v_i, so sum i v_i = len S - T
+                double S = 0.0, T = 0.0;
+                if (!from_global) {
+                    const uint32_t off = (ub & 0xffffu) + (uint32_t)popc64((rm | s_mask[rq ^ 1][ru]) & bits_below(a));
+                    int k = 0;
+                    for (; k + 2 <= len; k += 2) {   // two parked values in flight
+                        const float v0 = s_val[off + k], v1 = s_val[off + k + 1];
+                        S += (double)v0; T += S;
+                        S += (double)v1; T += S;
+                    }
+                    if (k < len) { S += (double)s_val[off + k]; T += S; }
+                } else {   // dense tile: the values were not parked; re-read from L2
+                    const float *rowptr = dens + ((int64_t)(s0 + rsl) * nr + (r0 + rrl)) * nc + ctile + rwl * 64;
+                    for (int k = 0; k < len; ++k) { S += (double)rowptr[a + k]; T += S; }
+                }
+                const int p0 = rwl * 64 + a;
+                // the run's sums become integers here (rounded once to the job's quantum); moments relative to the tile origin
+                const long long F = fix_of(S, fix_mul), Fc = fix_of((double)p0 * S + ((double)len * S - T), fix_mul);
+                atomicAdd(&s_rho[comp], (unsigned long long)F);
+                atomicAdd(&s_rho_c[comp], (unsigned long long)Fc);
+                atomicAdd(&s_rho_r[comp], (unsigned long long)(F * rrl));
+                atomicAdd(&s_rho_s[comp], (unsigned long long)(F * rsl));
+                // (keys of a plane are below 2^31: the host checks)
+                atomicMin(&s_key[comp], ((uint32_t)rq << 31) | ((uint32_t)(ctile + p0) * urus + (uint32_t)(r0 + rrl) * (uint32_t)us + (uint32_t)(s0 + rsl)));
+                const uint32_t ulen = (uint32_t)len;
+                atomicAdd(&s_pk[comp], (unsigned long long)ulen | ((unsigned long long)(ulen * (uint32_t)rrl) << 20) | ((unsigned long long)(ulen * (uint32_t)rsl) << 40));
+                atomicAdd(&s_crel[comp], ulen * (uint32_t)p0 + ulen * (ulen - 1u) / 2u);
+                comp_of_run[i] = gb + comp_all;
+                const uint32_t kw = i - (ub >> 16);   // my place among the word-runs of my word
+                uint8_t *rec = word_comps + ((desc & 0x1ffu) << 3);
+                if (kw < (uint32_t)FACE_K) rec[kw] = (uint8_t)comp;
+                if (a + len == 64) rec[7] = (uint8_t)comp;
+            }
+            if (tid == 0 && pass0 == 0u) {
+                lj.tile_mode[tile_id] = wide ? 2 : 0;
+                if (wide) *lj.unit_flag = lj.epoch;
+            }
+        }
+        __syncthreads();   // ---- barrier 4 ----
+        const uint32_t n_here = n_comp - pass0 < (uint32_t)CCAP ? n_comp - pass0 : (uint32_t)CCAP;
+        for (uint32_t i = tid; i < n_here; i += NT) {
+            const uint32_t g = gb + pass0 + i;
+            const unsigned long long pk = s_pk[i];
+            const long long n = (long long)(pk & 0xfffffull);
+            lj.r_n[g] = (uint32_t)n;
+            fix_store(lj, g, fix_sums((long long)s_rho[i], (long long)s_rho_c[i], (long long)s_rho_r[i], (long long)s_rho_s[i], w0 * 64, r0, s0));
+            lj.r_c[g] = (long long)s_crel[i] + n * (w0 * 64);
+            lj.r_r[g] = (long long)((pk >> 20) & 0xfffffull) + n * r0;
+            lj.r_s[g] = (long long)(pk >> 40) + n * s0;
+            const uint32_t key = s_key[i];
+            lj.r_key[g] = (unsigned long long)((key >> 31) ? keys_pp : 0) + (key & 0x7fffffffu);
+            lj.kpar[g] = ((unsigned long long)key << 32) | g;   // a root, named by its first key: the cross-tile unions hang the later first voxel under the earlier
+            if (wide) lj.parent[g] = (int32_t)g;                 // (ids above the tiles' ranges: k_resolve_tiles writes parent[] of non-roots only)
+        }
+        if (pass0 + (uint32_t)CCAP >= n_comp) break;
+        __syncthreads();   // (the accumulators have been read)
+        for (uint32_t i = tid; i < (uint32_t)CCAP; i += NT) {
+            s_rho[i] = 0ull; s_rho_c[i] = 0ull; s_rho_r[i] = 0ull; s_rho_s[i] = 0ull;
+            s_pk[i] = 0ull; s_crel[i] = 0u; s_key[i] = 0xffffffffu;
+        }
+        __syncthreads();
     }
-    mark_comps_unused(lj, cb, n_comp, tid, NT);
+    mark_comps_unused(lj, cb, wide ? 0u : n_comp, tid, NT);
     if (tid == 0) lj.tile_runs[bid] = n_runs;
 }
 
@@ -637,15 +684,17 @@ __device__ inline bool load_cross_tile(const JobRef &job, const TileDims &td, in
     const int64_t row = rem / vd.row_words;
     const int rl = (int)(row % vd.dim[1]);
     const int sl = (int)(row / vd.dim[1]);
-    const bool my_unit = job.tile_mode[tile_index(td, 0, wq, rl, sl)] != 0;
+    const uint32_t my_mode = job.tile_mode[tile_index(td, 0, wq, rl, sl)];
+    const bool my_unit = my_mode != 0u;            // components by run id; its pairs belong to the unit path
+    const bool in_lds = my_mode == 0u || my_mode == 2u;   // ... but a WIDE tile (2) united its own pairs in LDS, like a normal one
     // does any of the 13 earlier neighbours live in ANOTHER tile?
     const bool edge = ((rl & 7) == 0 && rl > 0) || ((sl & 7) == 0 && sl > 0) || ((rl & 7) == 7 && rl + 1 < vd.dim[1] && sl > 0) ||
                       (wq % td.cw == 0 && wq > 0) || (wq % td.cw == td.cw - 1 && wq + 1 < vd.row_words && (rl > 0 || sl > 0));
-    if (!edge && !my_unit) return false;
+    if (!edge && in_lds) return false;
     const bool all_nb = !unit_only || my_unit;   // otherwise a neighbour counts only if ITS tile is a unit tile
     bool want[13];
     int64_t at[13];
-    want[0] = (m & 1ull) && wq > 0 && (my_unit || (wq % td.cw == 0));
+    want[0] = (m & 1ull) && wq > 0 && (!in_lds || (wq % td.cw == 0));
     if (want[0] && !all_nb) want[0] = job.tile_mode[tile_index(td, 0, wq - 1, rl, sl)] != 0;
     at[0] = w - 1;
 #pragma unroll
@@ -661,7 +710,7 @@ __device__ inline bool load_cross_tile(const JobRef &job, const TileDims &td, in
             const int w2 = wq + dw;
             const int i = 1 + nb * 3 + (dw + 1);
             bool ok = row_ok && w2 >= 0 && w2 < vd.row_words;
-            if (ok && !my_unit && row_same_tile && (w2 / td.cw == wq / td.cw)) ok = false;  // united in LDS
+            if (ok && in_lds && row_same_tile && (w2 / td.cw == wq / td.cw)) ok = false;  // united in LDS
             if (dw < 0 && !(m & 1ull)) ok = false;
             if (dw > 0 && !(m >> 63)) ok = false;
             if (ok && !all_nb) ok = job.tile_mode[tile_index(td, 0, w2, r2, s2)] != 0;
@@ -976,7 +1025,7 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job_arg, const float 
         // as that many consecutive workgroups are resident -- no grid barrier, nothing that needs the whole grid at once
         // (the 128 fallback workgroups this replaces had to be co-resident, all of them).
         __syncthreads();   // (everybody is done with the pair tables: their LDS is the scratch below)
-        const bool mine_unit = lj.tile_mode[tile] != 0;   // block-uniform
+        const bool mine_unit = (lj.tile_mode[tile] & 1) != 0;   // block-uniform: 1 / 3 (a wide tile, 2, was labelled by k_tile_label)
         if (mine_unit) {
             unit_label_tile<CW>(lj, dens, gp, td, w0, rt * TILE_R, st * TILE_S, reinterpret_cast<unsigned char *>(s_set));
             __threadfence();   // publish run bases / records / run -> component ids to the other XCDs

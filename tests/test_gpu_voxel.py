@@ -628,3 +628,36 @@ def test_many_contexts_under_a_small_pool_cap(monkeypatch):
     finally:
         for ctx in ctxs:
             ctx.close()
+
+
+def test_wide_tiles_beside_normal_and_unit_tiles(gpu_ctx):
+    """A tile with more components than the LDS accumulators hold (256) but few enough word-runs keeps its in-LDS unions (round
+    4: a WIDE tile, tile_mode 2 -- its components take ids above the tiles' own ranges and its sums are made 256 components at
+    a time); before, it was relabelled run by run.  Here wide tiles (a lattice of isolated voxels: 1 024 components a tile),
+    unit tiles (a denser lattice: more word-runs than LDS holds) and ordinary tiles (smooth noise) share faces, and lines
+    along c, r, s and a diagonal tie blobs together across all three kinds -- against the oracle, labels included, both signs."""
+    from pdb_eda_amd import synthetic
+    ns, nr, nc = 24, 24, 512
+    g = (0.3 * synthetic.smooth_noise((ns, nr, nc), 17, 1.5)).astype(np.float32)
+    g = np.clip(g, -0.45, 0.45)                                     # nothing significant yet
+    noise = synthetic.smooth_noise((ns, nr, nc), 18, 1.5)
+    g[:8, :, :] = np.where(np.abs(noise[:8]) > 1.2, np.sign(noise[:8]), g[:8]).astype(np.float32)      # ordinary tiles (s < 8)
+    g[8:16, :, :] = 0.0
+    g[8:13:2, ::2, ::4] = 1.0                                       # wide tiles: 3 x 4 x 64 isolated voxels a tile
+    g[9:12:2, 1::2, 2::8] = -1.0                                    # ... and a red lattice between them (both signs share the run slots)
+    g[16:, :, :256] = 0.0
+    g[16::2, ::2, 0:256:2] = 1.0                                    # unit tiles: 4 x 4 x 128 word-runs a tile (> RCAP)
+    g[16::2, 1::2, 256::4] = 1.0                                    # wide again, beside the unit tiles along c
+    g[:, 11, 100] = 1.0                                             # a line along s through all three kinds
+    g[12, :, 301] = 1.0                                             # ... along r inside the wide band
+    g[10, 5, :] = 1.0                                               # ... along c across the c face
+    for k in range(24):
+        g[k, k, 200 + k] = 1.0                                      # a diagonal: corner contacts across faces
+        g[k, 23 - k, 280 + 2 * k] = -1.0
+    dm = _dm(g, gpu_ctx)
+    green, red = _equal_to_oracle(dm, g, 0.5)
+    c = green.counters()
+    assert c["wide_tiles"] >= 8 and c["unit_tiles_runs"] >= 3, c      # (a map this small may need the second, worst-case arena for its unit tiles)
+    one = dm._map.full_blobs(0.5, labels=True)                      # the one-sign job takes the same paths
+    assert np.array_equal(one.stats()["n"], green.stats()["n"]) and one.counters()["wide_tiles"] >= 8
+    green.free(); red.free(); one.free()
