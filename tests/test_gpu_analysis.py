@@ -110,6 +110,35 @@ def test_blob_statistics(analysis):
         assert np.allclose(np.array([list(s[11]) for s in stats]).reshape(-1, 3), z["blob_%s_centroid" % tag], rtol=1e-8, atol=1e-9)
 
 
+def test_blob_lists_are_lazy_sequences(analysis):
+    """createFullBlobList & co. return the blobs as a sequence that makes its DensityBlob objects on first access
+    (ccp4.DeviceBlobs): the statistics table straight from the device list's columns must be the table built from the objects,
+    `+` / `==` / indexing behave as a list's, and the objects of `a + b` are those of `a` and `b`."""
+    from pdb_eda_amd import ccp4
+    z, an = analysis
+
+    def same(a, b):          # tables of rows whose cells are numbers, strings, tuples and coordinate arrays
+        return len(a) == len(b) and all(len(r) == len(q) and all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(r, q)) for r, q in zip(a, b))
+    cut = an.diffDensityObj.diffDensityCutoff
+    green, red = an.diffDensityObj.createFullBlobLists(cut)
+    assert isinstance(green, ccp4.DeviceBlobs) and green.columns() is not None
+    both = green + red
+    assert isinstance(both, ccp4.DeviceBlobs) and len(both) == len(green) + len(red)
+    from_columns = an.calculateAtomSpecificBlobStatistics(both)
+    assert both.columns() is not None                       # ... and still no object was made
+    objects = list(both)                                    # now they are
+    assert green.columns() is None and both.columns() is None
+    assert objects[0] is green[0] and objects[len(green)] is red[0] and both[-1] is red[len(red) - 1]
+    from_objects = an.calculateAtomSpecificBlobStatistics(both)
+    assert same(from_objects, from_columns)
+    assert same(an.calculateAtomSpecificBlobStatistics(objects), from_columns)       # a plain list of the same blobs
+    assert green == list(green) and list(green) == green and green[:2] == [green[0], green[1]]
+    assert green + [] == list(green) and [] + green == list(green)
+    assert [b.numVoxels for b in both] == [row[3] for row in from_columns]
+    empty = an.diffDensityObj.createFullBlobList(1e30)
+    assert empty == [] and len(empty) == 0 and not empty and an.calculateAtomSpecificBlobStatistics(empty) == []
+
+
 def test_rscc_rsr_metrics(analysis):
     """RSCC / RSR per residue and per atom, the Fo / Fc scale check and the Fc map quirk (densityAnalysis.py:426-435, 783-882)."""
     z, an = analysis
