@@ -46,7 +46,8 @@
 namespace pdbeda {
 
 constexpr int TILE_R = 8, TILE_S = 8;
-constexpr int RCAP = 1408;  // word-runs of a tile (both signs) handled in LDS
+constexpr int RCAP = 1408;  // word-runs of a tile (both signs) whose parents fit the parent table proper
+constexpr int RCAP_DENSE = 4096;   // ... and with the parked values' LDS as more of the same table (a tile that dense re-reads its values from L2 anyway)
 constexpr int CCAP = 256;   // tile-local components (both signs together) handled in LDS
 static_assert(CCAP == TILE_COMPS, "k_emit walks the tiles' component ranges");
 constexpr int VCAP = 3584;  // significant values of a tile parked in LDS: one private region of VCAP / 8 per wave (= section)
@@ -245,8 +246,14 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
     const int wvs = __builtin_amdgcn_readfirstlane(wv);
     const int wvs_edge_base = wvs * ECAPW;
     __shared__ uint64_t s_mask[2][256];
-    __shared__ float s_val[VCAP];
-    __shared__ uint32_t s_parent[RCAP];
+    // one block: the parent table and, behind it, the parked values.  A tile with more than RCAP word-runs (noise below ~1.1
+    // sigma: 1 500-2 700 a tile) has sections far too dense to park (VREG values each) and reads its values from L2 in C2
+    // whatever happens -- so the values' 14 KiB are its parent slots RCAP .. RCAP_DENSE - 1 (round 4: such a tile was a unit
+    // tile before, labelled run by run and united through global atomics -- 1.6 ms a step for noise at 1 sigma against 0.09 at 1.5)
+    __shared__ __attribute__((aligned(16))) uint32_t s_pv[RCAP + VCAP];
+    static_assert(RCAP_DENSE <= RCAP + VCAP && RCAP_DENSE <= 32768 && RCAP_DENSE <= 64 * 4 * 32, "parent slots of a dense tile; 15-bit component numbers; the tile's own run id range");
+    uint32_t *s_parent = s_pv;
+    float *s_val = reinterpret_cast<float *>(s_pv + RCAP);
     // phase B: the waves' edge lists; phase C: the component accumulators (sums relative to the tile origin)
     __shared__ __attribute__((aligned(16))) unsigned char s_blob[CCAP * 48];
     static_assert(NW * ECAPW * 4 <= CCAP * 48, "the edge lists fit the accumulator block");
@@ -416,7 +423,12 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
     const int64_t my_word = (int64_t)q * plane_words + ((int64_t)(s0 + wvs) * ur + (r0 + rl)) * row_words + (w0 + wl);
     const int64_t tile_id = (int64_t)bid;
 
-    if (n_runs == 0 || n_runs > (uint32_t)RCAP) {   // block-uniform
+    if (n_runs > (uint32_t)RCAP && n_runs <= (uint32_t)RCAP_DENSE) {   // block-uniform: a dense tile (see s_pv)
+        from_global = true;
+        for (uint32_t i = (uint32_t)RCAP + tid; i < n_runs; i += NT) s_parent[i] = i;
+        __syncthreads();
+    }
+    if (n_runs == 0 || n_runs > (uint32_t)RCAP_DENSE) {   // block-uniform
         PDBEDA_LATE_JOB(lj);
         // nothing significant, or too many runs for LDS: publish the masks; an overflowing tile is labelled run by run
         // (every run its own component) by its workgroup of k_face_merge

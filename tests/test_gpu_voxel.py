@@ -634,7 +634,7 @@ def test_wide_tiles_beside_normal_and_unit_tiles(gpu_ctx):
     """A tile with more components than the LDS accumulators hold (256) but few enough word-runs keeps its in-LDS unions (round
     4: a WIDE tile, tile_mode 2 -- its components take ids above the tiles' own ranges and its sums are made 256 components at
     a time); before, it was relabelled run by run.  Here wide tiles (a lattice of isolated voxels: 1 024 components a tile),
-    unit tiles (a denser lattice: more word-runs than LDS holds) and ordinary tiles (smooth noise) share faces, and lines
+    unit tiles (columns on a checkerboard, both signs: more word-runs than LDS holds) and ordinary tiles (smooth noise) share faces, and lines
     along c, r, s and a diagonal tie blobs together across all three kinds -- against the oracle, labels included, both signs."""
     from pdb_eda_amd import synthetic
     ns, nr, nc = 24, 24, 512
@@ -646,7 +646,8 @@ def test_wide_tiles_beside_normal_and_unit_tiles(gpu_ctx):
     g[8:13:2, ::2, ::4] = 1.0                                       # wide tiles: 3 x 4 x 64 isolated voxels a tile
     g[9:12:2, 1::2, 2::8] = -1.0                                    # ... and a red lattice between them (both signs share the run slots)
     g[16:, :, :256] = 0.0
-    g[16::2, ::2, 0:256:2] = 1.0                                    # unit tiles: 4 x 4 x 128 word-runs a tile (> RCAP)
+    g[16:, ::2, 0:256:2] = 1.0                                      # unit tiles: 8 x 4 x 128 word-runs a tile and sign (more than the
+    g[16:, 1::2, 1:256:2] = -1.0                                    # 4 096 run slots even a dense tile has in LDS)
     g[16::2, 1::2, 256::4] = 1.0                                    # wide again, beside the unit tiles along c
     g[:, 11, 100] = 1.0                                             # a line along s through all three kinds
     g[12, :, 301] = 1.0                                             # ... along r inside the wide band
@@ -661,3 +662,20 @@ def test_wide_tiles_beside_normal_and_unit_tiles(gpu_ctx):
     one = dm._map.full_blobs(0.5, labels=True)                      # the one-sign job takes the same paths
     assert np.array_equal(one.stats()["n"], green.stats()["n"]) and one.counters()["wide_tiles"] >= 8
     green.free(); red.free(); one.free()
+
+
+@pytest.mark.parametrize("nsd", [1.0, 0.6, 0.2])
+def test_dense_noise_stays_in_lds(gpu_ctx, nsd):
+    """Smooth noise below ~1.1 sigma has 1 500 - 2 700 word-runs a tile: more than the parent table proper (1 408), and its
+    sections are far too dense to park their values -- such a tile uses the parked values' LDS as parent slots (up to 4 096
+    word-runs) and reads its values from L2 (round 4; a unit tile before: 1.6 ms a step at 1 sigma against 0.14 now).  Against the
+    oracle, labels included; no tile may leave the LDS path."""
+    from pdb_eda_amd import synthetic
+    g = synthetic.smooth_noise((40, 48, 512), 31, 1.5)
+    dm = _dm(g, gpu_ctx)
+    cut = dm.meanDensity + nsd * dm.stdDensity
+    green, red = _equal_to_oracle(dm, g, cut)
+    c = green.counters()
+    assert c["unit_tiles_runs"] == 0 and c["unit_tiles_comps"] == 0 and c["reruns"] == 0, c
+    assert c["run_ids"] > 0
+    green.free(); red.free()
