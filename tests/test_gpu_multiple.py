@@ -59,7 +59,7 @@ def test_unit_fallback_on_many_streams(shape):
     import io
     from oracle import oracle as ora
     from pdb_eda_amd import ccp4, synthetic, multipleStructures
-    g = synthetic.smooth_noise(shape, 9, 1.5)
+    g = synthetic.smooth_noise(shape, 9, 0.5)       # nearly white: ~30 word-runs a mask word, far beyond the 4 096 a tile holds in LDS
     spec = synthetic.MapSpec(ncrs=shape[::-1])
     blob = synthetic.ccp4_bytes(spec, g)
     header = ccp4.DensityHeader.fromFileHeader(blob[:1024])
