@@ -10,7 +10,7 @@ header = ccp4.DensityHeader.fromFileHeader(synthetic.ccp4_header_bytes(spec))
 ctx = _native.Context(0)
 dmap = _native.DeviceMap(ctx, grid, header.geometry())
 mean, std = dmap.stats()
-for nsd in (1.5, 1.0, 0.75, 0.5, 0.25):
+for nsd in (1.5, 1.35, 1.25, 1.15, 1.0, 0.75, 0.5, 0.25):
     cut = mean + nsd * std
     for _ in range(3):
         g, r = dmap.full_blobs_pm(cut, -cut, labels=True)
