@@ -1,6 +1,7 @@
 """Bridge for the CPU baseline: the reference's Cython path and the CPU restatement (oracle) timed HERE, in the
 build container, on the same grids.  The reference never travels to the GPU box, so bench.py times the restatement there
-("port") and this ratio, measured where both run, links the two.  Build container only:  python tests/golden/ref_bridge.py"""
+("port") and this ratio, measured where both run, links the two.  Build container only:  python tests/golden/ref_bridge.py [tag]
+(-> profiles/<tag>_reference_vs_restatement_cpu.json; default r04)"""
 import io
 import json
 import os
@@ -44,7 +45,8 @@ for edge, nsd in ((64, 3.0), (100, 3.0), (128, 3.0), (200, 3.0), (48, 1.5), (64,
     rows.append({"grid": edge, "cutoff_sigma": nsd, "significant_voxels": int(a["n"].sum() + b["n"].sum()), "reference_s": t_ref,
                  "reference_Mvoxels_per_s": n / t_ref / 1e6, "restatement_s": t_ora, "restatement_Mvoxels_per_s": n / t_ora / 1e6, "ratio": t_ref / t_ora})
     print(rows[-1], flush=True)
-with open(os.path.join(ROOT, "profiles", "r01_reference_vs_restatement_cpu.json"), "w") as fh:
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+with open(os.path.join(ROOT, "profiles", "%s_reference_vs_restatement_cpu.json" % tag), "w") as fh:
     json.dump({"note": "build container (8 vCPU Xeon 2.1 GHz), one core, threshold + clustering + blob statistics of both signs; reference = pdb_eda Cython path "
                        "(cutils built -O3), restatement = oracle/pdbeda_oracle.c ora_full_blobs", "rows": rows}, fh, indent=1)
     fh.write("\n")
