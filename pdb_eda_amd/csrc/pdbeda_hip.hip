@@ -945,6 +945,7 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.n_fine_alloc = (int32_t)((job.n_fine + job.fine_per_group - 1) / job.fine_per_group * job.fine_per_group);
     job.fine_count = cv.take<uint32_t>((size_t)std::max(job.n_fine_alloc / 2, 8));   // 16-bit counters, two per word
     job.mid_count = cv.take<uint32_t>((size_t)(job.key_words + KEY_FINE - 1) / KEY_FINE * (KEY_FINE / 16));   // a byte per 4 key words: 8 per bucket
+    job.group_count = (n_tiles && job.fine_shift > 5) ? cv.take<uint32_t>(KEY_GROUPS) : nullptr;   // (groups of 64 counters or more: maps beyond ~320^3 fused)
     job.run_base = cv.take<uint32_t>(total_words);
     job.comps_are_runs = n_tiles ? 0 : 1;
     job.comp_of_run = n_tiles ? cv.take<uint32_t>(max_runs) : nullptr;
@@ -1141,6 +1142,7 @@ static int whole_map_enqueue(pdbeda_map *m, float cut_pos, float cut_neg, bool w
         default: launch_tile_label<4>(ctx, (unsigned)tiles_pp, job, m->dens, m->geom_dev, td, init, pair_slots); break;
     }
     { PROF(ctx, "k_resolve_tiles"); hipLaunchKernelGGL(k_resolve_tiles, dim3((unsigned)tiles_pp + 64u), dim3(256), 0, st, job, (int)tiles_pp); }
+    if (job.group_count) { PROF(ctx, "k_group_counts"); hipLaunchKernelGGL(k_group_counts, dim3((unsigned)(job.n_groups + 255) / 256u), dim3(256), 0, st, job); }
     if (labels) {   // the label writer ranks the roots and writes the blob table itself: one launch
         PROF(ctx, "k_labels_tiles");
         launch_labels<true>(ctx, job, td, labels_dev, m->geom_dev);

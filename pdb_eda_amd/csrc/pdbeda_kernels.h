@@ -173,6 +173,11 @@ struct Job {
     // words of the first-key bitmap / 16-bit counter words / byte counter words every tile's k_face_merge workgroup clears (the
     // ceilings of the table sizes over the tile count: three 64-bit divisions per wave where the kernel computed them)
     int32_t clear_bits, clear_fine, clear_mid;
+    // whole-map jobs of more than 2^25 keys (groups of more than 16 counters): the groups' totals, summed ONCE by k_group_counts
+    // behind k_resolve_tiles.  Every workgroup that ranks builds its prefix table from these n_groups words; summing the 16-bit
+    // counters itself it read the whole counter array -- 32 KiB at 256^3, but 256 KiB at 512^3, by each of 8 192 workgroups
+    // (round 4: the fused label writer took 557 us at 512^3 for that reason, 3.3 x what eight 256^3 maps take).  nullptr otherwise.
+    uint32_t *group_count;
 };
 
 struct InboxEntry {           // 88 bytes: what a (tile, root) pair folds into the root's record (no key: the root holds the first voxel)
@@ -743,6 +748,13 @@ __device__ __forceinline__ void rank_table_issue(const JobRef &job, RankTableLoa
             ld.q[2 * k] = e < n_groups ? fine4[(size_t)e * 2] : make_uint4(0, 0, 0, 0);
             ld.q[2 * k + 1] = e < n_groups ? fine4[(size_t)e * 2 + 1] : make_uint4(0, 0, 0, 0);
         }
+    } else if (job.group_count) {   // (larger whole-map jobs: the groups' totals are there, k_group_counts)
+        const uint32_t *gc = job.group_count;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int e = tid * PER + k;
+            ld.v[k] = e < n_groups ? gc[e] : 0u;
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
@@ -785,6 +797,20 @@ __device__ inline uint32_t rank_table_lds(const JobRef &job, uint32_t *s_pre /* 
     RankTableLoads<NT> ld;
     rank_table_issue<NT>(job, ld);
     return rank_table_finish<NT>(ld, s_pre, s_wave);
+}
+
+// Totals of the groups of 16-bit counters (Job::group_count): a thread per group, behind k_resolve_tiles (which paints).
+__global__ void __launch_bounds__(256) k_group_counts(Job job) {
+    const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (e >= job.n_groups) return;
+    const int Q = job.fine_per_group / 8;
+    const uint4 *fine4 = reinterpret_cast<const uint4 *>(job.fine_count) + (size_t)e * Q;
+    uint32_t acc = 0;
+    for (int j = 0; j < Q; j += 4) {   // (Q is a power of two >= 4 here: groups of 32 counters or more)
+        const uint4 a = fine4[j], b = fine4[j + 1], c = fine4[j + 2], d = fine4[j + 3];
+        acc += (sum_u16x8(a) + sum_u16x8(b)) + (sum_u16x8(c) + sum_u16x8(d));
+    }
+    job.group_count[e] = acc;
 }
 
 // Number of painted keys below `key` (s_pre: this block's rank_table_lds) = table entry + the 16-bit counters of the key's group

@@ -679,3 +679,18 @@ def test_dense_noise_stays_in_lds(gpu_ctx, nsd):
     assert c["unit_tiles_runs"] == 0 and c["unit_tiles_comps"] == 0 and c["reruns"] == 0, c
     assert c["run_ids"] > 0
     green.free(); red.free()
+
+
+def test_map_beyond_the_one_trip_rank_table(gpu_ctx):
+    """A fused job of more than 2^26 keys (here 336 x 330 x 344 = 38 M voxels a sign) has rank-counter groups of 64 counters: the
+    groups' totals are summed once (k_group_counts) and every ranking workgroup reads those instead of the whole counter array
+    (round 4: 512^3 took 0.94 ms a step without them, 0.62 with).  Counts, keys, totals and the label volume against the oracle."""
+    from pdb_eda_amd import synthetic
+    g = synthetic.smooth_noise((344, 330, 336), 41, 1.5)
+    dm = _dm(g, gpu_ctx)
+    cut = dm.meanDensity + 2.0 * dm.stdDensity
+    green, red = _equal_to_oracle(dm, g, cut)
+    assert len(green) > 5000 and len(red) > 5000 and green.counters()["reruns"] == 0
+    g2, r2 = dm._map.full_blobs_pm(cut, -cut)           # no labels: k_emit_tiles ranks through the same totals
+    assert np.array_equal(g2.stats()["firstKey"], green.stats()["firstKey"]) and np.array_equal(r2.stats()["n"], red.stats()["n"])
+    green.free(); red.free(); g2.free(); r2.free()

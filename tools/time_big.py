@@ -23,6 +23,11 @@ for _ in range(n):
 ctx.synchronize()
 dt = (time.perf_counter() - t0) / n
 print("%d^3: %.3f ms/step = %.1f Gvoxel/s; blobs %d / %d" % (edge, 1e3 * dt, edge ** 3 / dt / 1e9, len(green), len(red)), flush=True)
+ctx.profile_begin()
+green, red = dmap.full_blobs_pm(cut, -cut, labels=True)
+len(green)
+prof = ctx.profile_end()
+print("kernels (us):", {k: round(1e3 * ms, 1) for k, (_, ms) in sorted(prof.items())}, green.counters(), flush=True)
 o = ora.Oracle(header, g)
 t0 = time.perf_counter()
 want = o.full_blobs(cut, labels=True)
