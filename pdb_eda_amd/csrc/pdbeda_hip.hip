@@ -945,7 +945,7 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.n_fine_alloc = (int32_t)((job.n_fine + job.fine_per_group - 1) / job.fine_per_group * job.fine_per_group);
     job.fine_count = cv.take<uint32_t>((size_t)std::max(job.n_fine_alloc / 2, 8));   // 16-bit counters, two per word
     job.mid_count = cv.take<uint32_t>((size_t)(job.key_words + KEY_FINE - 1) / KEY_FINE * (KEY_FINE / 16));   // a byte per 4 key words: 8 per bucket
-    job.group_count = (n_tiles && job.fine_shift > 5) ? cv.take<uint32_t>(KEY_GROUPS) : nullptr;   // (groups of 64 counters or more: maps beyond ~320^3 fused)
+    job.group_count = (n_tiles && job.fine_shift > 4) ? cv.take<uint32_t>(KEY_GROUPS) : nullptr;   // (groups of 32 counters or more: maps beyond 2^25 keys = 256^3 fused)
     job.run_base = cv.take<uint32_t>(total_words);
     job.comps_are_runs = n_tiles ? 0 : 1;
     job.comp_of_run = n_tiles ? cv.take<uint32_t>(max_runs) : nullptr;

@@ -681,12 +681,13 @@ def test_dense_noise_stays_in_lds(gpu_ctx, nsd):
     green.free(); red.free()
 
 
-def test_map_beyond_the_one_trip_rank_table(gpu_ctx):
-    """A fused job of more than 2^26 keys (here 336 x 330 x 344 = 38 M voxels a sign) has rank-counter groups of 64 counters: the
+@pytest.mark.parametrize("shape", [(264, 256, 256), (344, 330, 336)])      # groups of 32 and of 64 rank counters
+def test_map_beyond_the_one_trip_rank_table(gpu_ctx, shape):
+    """A fused job of more than 2^25 keys (more than 256^3 voxels a sign) has rank-counter groups of more than 16 counters: the
     groups' totals are summed once (k_group_counts) and every ranking workgroup reads those instead of the whole counter array
     (round 4: 512^3 took 0.94 ms a step without them, 0.62 with).  Counts, keys, totals and the label volume against the oracle."""
     from pdb_eda_amd import synthetic
-    g = synthetic.smooth_noise((344, 330, 336), 41, 1.5)
+    g = synthetic.smooth_noise(shape, 41, 1.5)
     dm = _dm(g, gpu_ctx)
     cut = dm.meanDensity + 2.0 * dm.stdDensity
     green, red = _equal_to_oracle(dm, g, cut)
