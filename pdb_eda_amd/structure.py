@@ -246,11 +246,8 @@ class Columns(object):
         cache = self.__dict__.setdefault("_atom_lists", {})
         if which not in cache:
             source = {"model": self.res_model, "chain": self.res_chain, "number": self.res_number, "resname": self.res_name}[which]
-            counts = np.diff(self.res_start).tolist()
-            out = []
-            for value, count in zip(source, counts):
-                out.extend([value] * count)
-            cache[which] = out
+            column = np.fromiter(source, dtype=object, count=len(source))      # (the very objects, repeated by numpy)
+            cache[which] = np.repeat(column, np.diff(self.res_start)).tolist()
         return cache[which]
 
 
