@@ -162,6 +162,7 @@ struct pdbeda_map {
     Geom *geom_dev = nullptr;
     int64_t n_vox = 0;
     double fix_mul = 0.0;             // 2^S of the order-independent blob sums (FixSums); 0 = not yet derived from the map's range
+    bool fix_refused = false;         // the range pass found a NaN / infinity: labelling calls refuse the map (map_fix_mul)
 };
 
 struct pdbeda_bloblist {
@@ -763,20 +764,23 @@ static int reduce_launch(pdbeda_map *m, int mode, const double *mean_dev, double
 // sum |rho| over the whole map nor the first moment of one tile / one run (<= 2^22 max |rho|) can leave 62 bits.  Two
 // deterministic reductions over the map, once per map (the result is cached; a borrowed device pointer is taken to hold the
 // same grid for the life of the map).
-static int map_fix_mul(pdbeda_map *m) {
-    if (m->fix_mul != 0.0) return 0;
+// The quantum of a map's integer blob sums from its range (sum |x|, max |x|: fixed reduction order, so the quantum is the same in
+// every run).  range_enqueue + range_apply: the pass rides in the same wait as the map's mean / std when those are asked for
+// first (pdbeda_map_stats: every DensityMatrix asks at once) -- a wait of its own in front of the map's first labelling job was
+// one of an entry's ~17 host round trips (round 4).
+static int range_enqueue(pdbeda_map *m, double *range_host /* [2], filled at the next ctx_sync */) {
     pdbeda_ctx *ctx = m->ctx;
     double *res = ctx->partials + 2 * N_PARTIAL + 4;
     { PROF(ctx, "k_range_partials"); hipLaunchKernelGGL(k_range_partials, dim3(N_PARTIAL), dim3(256), 0, ctx->stream, m->dens, m->n_vox, ctx->partials, ctx->partials + N_PARTIAL); }
     hipLaunchKernelGGL(k_range_final, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, ctx->partials + N_PARTIAL, N_PARTIAL, res);
     HIP_TRY(ctx, hipGetLastError());
-    double range[2] = {0.0, 0.0};   // sum |x|, max |x|: fixed reduction order, so the quantum is the same in every run
-    HIP_TRY(ctx, d2h(ctx, range, res, 2 * sizeof(double)));
-    HIP_TRY(ctx, ctx_sync(ctx));
-    // the integer sums cannot hold a NaN or an infinity (fix_of would saturate without a word): such a map is refused here,
-    // once, instead of producing wrong blob totals (the reference's sums would be NaN / inf for every blob that holds one)
-    if (!std::isfinite(range[0]) || !std::isfinite(range[1]))
-        return fail(ctx, PDBEDA_ERR_ARGUMENT, "the map holds non-finite density values: blob sums are undefined");
+    HIP_TRY(ctx, d2h(ctx, range_host, res, 2 * sizeof(double)));
+    return 0;
+}
+static void range_apply(pdbeda_map *m, const double range[2]) {
+    // the integer sums cannot hold a NaN or an infinity (fix_of would saturate without a word): such a map is refused by the
+    // labelling calls instead of producing wrong blob totals (the reference's sums would be NaN / inf for every blob that holds one)
+    if (!std::isfinite(range[0]) || !std::isfinite(range[1])) { m->fix_refused = true; return; }
     const double bound = std::max(range[0], 4194304.0 * range[1]);
     int S = 40;
     if (bound > 0.0 && std::isfinite(bound)) {
@@ -786,6 +790,17 @@ static int map_fix_mul(pdbeda_map *m) {
     }
     S = std::max(-900, std::min(S, 900));
     m->fix_mul = ldexp(1.0, S);
+}
+static int map_fix_mul(pdbeda_map *m) {
+    pdbeda_ctx *ctx = m->ctx;
+    if (m->fix_mul == 0.0 && !m->fix_refused) {
+        double range[2] = {0.0, 0.0};
+        const int rc = range_enqueue(m, range);
+        if (rc) return rc;
+        HIP_TRY(ctx, ctx_sync(ctx));
+        range_apply(m, range);
+    }
+    if (m->fix_refused) return fail(ctx, PDBEDA_ERR_ARGUMENT, "the map holds non-finite density values: blob sums are undefined");
     return 0;
 }
 
@@ -795,6 +810,7 @@ static int map_fix_mul(pdbeda_map *m) {
 extern "C" int pdbeda_map_invalidate(pdbeda_map *m) {
     if (!m) return PDBEDA_ERR_ARGUMENT;
     m->fix_mul = 0.0;
+    m->fix_refused = false;
     return PDBEDA_OK;
 }
 
@@ -805,7 +821,8 @@ extern "C" int pdbeda_map_stats(pdbeda_map *m, double *mean, double *std) {
     double *res = ctx->partials + N_PARTIAL;
     // numpy's own summation tree (k_np_chunk_sums / k_np_final): == np.mean / np.std, not merely close
     const int64_t n_full = m->n_vox / NP_CHUNK;
-    double host[2];
+    double host[2], range[2] = {0.0, 0.0};
+    const bool want_range = m->fix_mul == 0.0 && !m->fix_refused;   // the quantum of the map's blob sums, in the same wait
     int rc = with_scratch(ctx, 8 * (size_t)std::max<int64_t>(n_full, 1), [&](char *base) -> int {
         double *chunk_sums = reinterpret_cast<double *>(base);
         hipStream_t st = ctx->stream;
@@ -815,9 +832,12 @@ extern "C" int pdbeda_map_stats(pdbeda_map *m, double *mean, double *std) {
         }
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, d2h(ctx, host, res, 2 * sizeof(double)));
+        // (behind the copy of the two results: the range pass reuses the partial sums' memory)
+        if (want_range) { const int rc_range = range_enqueue(m, range); if (rc_range) return rc_range; }
         return 0;
     });
     if (rc) return rc;
+    if (want_range) range_apply(m, range);
     if (mean) *mean = host[0];
     if (std) *std = host[1];
     return PDBEDA_OK;
@@ -1817,11 +1837,14 @@ static double np_sum_h(const double *a, int64_t n, int mode, double shift) {
     for (int64_t off = 0; off < n; off += 8192) out += np_pairwise_h(a, off, std::min<int64_t>(8192, n - off), mode, shift);
     return out;
 }
-static double np_median_h(std::vector<double> v) {   // np.median of a NaN-free 1-D array
+static double np_median_h(std::vector<double> v) {   // np.median of a NaN-free 1-D array (the middle order statistics: a selection, not a sort)
     const size_t n = v.size();
     if (n == 0) return NAN;
-    std::sort(v.begin(), v.end());
-    return (n & 1) ? v[n / 2] : (v[n / 2 - 1] + v[n / 2]) / 2.0;
+    std::nth_element(v.begin(), v.begin() + n / 2, v.end());
+    const double hi = v[n / 2];
+    if (n & 1) return hi;
+    const double lo = *std::max_element(v.begin(), v.begin() + n / 2);   // (the largest of what was put below the middle)
+    return (lo + hi) / 2.0;
 }
 static double np_std_h(const std::vector<double> &v) {   // np.std (population) of a NaN-free 1-D array
     const int64_t n = (int64_t)v.size();
@@ -1875,6 +1898,10 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
     int rc = list_stats_one_trip(clouds, 4 * n + 64, c_n, c_tot, c_cen, c_grp);   // (an atom has one to three clouds: the count and the table in one wait)
     if (rc) return bail(rc, clouds, nullptr);
     const int64_t nb = (int64_t)c_n.size();
+    // the voxel lists of the clouds (what the pooled voxels and the overlap tests are gathered from) are made by the device
+    // while the host decides what to pool
+    rc = list_materialise_voxels(clouds);
+    if (rc) return bail(rc, clouds, nullptr);
 
     // ---- 2. host: centroid-distance cut-off, best cloud, pool (604-642) ----
     std::vector<int64_t> first((size_t)n + 1, 0);       // clouds of atom a: [first[a], first[a + 1])  (sorted by group)
@@ -1882,6 +1909,7 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
     for (int64_t a = 0; a < n; ++a) first[(size_t)a + 1] += first[(size_t)a];
     std::vector<double> c_dist((size_t)nb), min_dist((size_t)n, NAN);
     std::vector<double> centroidDistances;
+    centroidDistances.reserve((size_t)n);
     for (int64_t a = 0; a < n; ++a) {
         double mn = NAN;
         for (int64_t c = first[(size_t)a]; c < first[(size_t)a + 1]; ++c) {
@@ -1894,6 +1922,9 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
     const double cutoff = np_median_h(centroidDistances) + 2.5 * np_std_h(centroidDistances);
     res->totals[3] = cutoff;
     std::vector<int32_t> pool_cloud, pool_atom;
+    pool_cloud.reserve((size_t)nb); pool_atom.reserve((size_t)nb);
+    res->atom_idx.reserve((size_t)n); res->atom_total.reserve((size_t)n); res->atom_nvox.reserve((size_t)n);
+    res->atom_centroid.reserve(3 * (size_t)n); res->atom_dist.reserve((size_t)n);
     std::vector<int32_t> pooled_of_key((size_t)at->n_keys, -1);
     for (int64_t i = 0; i < n; ++i) {
         const int64_t s = at->alias[i], lo = first[(size_t)s], hi = first[(size_t)s + 1];
@@ -1915,9 +1946,7 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
     const int64_t n_pool = (int64_t)pool_cloud.size();
     if (n_pool == 0) { pdbeda_bloblist_free(clouds); return PDBEDA_OK; }
 
-    // ---- 3. device: voxel lists of the clouds; pooled voxels -> union job (a group per residue + the domain group) ----
-    rc = list_materialise_voxels(clouds);
-    if (rc) return bail(rc, clouds, nullptr);
+    // ---- 3. device: pooled voxels -> union job (a group per residue + the domain group) ----
     pdbeda_bloblist *cow = owner_of(clouds);
     std::vector<int32_t> pool_group((size_t)n_pool), group_res;     // compact residue groups in increasing order
     for (int64_t p = 0; p < n_pool; ++p) {
