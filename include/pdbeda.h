@@ -109,6 +109,11 @@ int pdbeda_map_invalidate(pdbeda_map *map);
  * their PCIe copies queued on two streams; the context's stream is ordered behind both); byteswap != 0 when the file has the other endianness (swapped on the device).  No host copy
  * of the map exists afterwards (pdbeda_map_download fetches one on demand). */
 int pdbeda_map_upload_file(pdbeda_ctx *ctx, const char *path, int64_t offset, int byteswap, const pdbeda_geometry *geom, pdbeda_map **out);
+/* The same with the map's mean and standard deviation (pdbeda_map_stats: DensityMatrix.meanDensity / stdDensity, ccp4.py:343-361)
+ * computed behind the copies and returned from the SAME wait: every cutoff of the analysis is mean + k std, so the statistics are
+ * what a caller asks for next.  mean / std may be NULL. */
+int pdbeda_map_upload_file_stats(pdbeda_ctx *ctx, const char *path, int64_t offset, int byteswap, const pdbeda_geometry *geom, pdbeda_map **out,
+                                 double *mean, double *std);
 int pdbeda_map_free(pdbeda_map *map);
 /* A new map on the geometry of `a` with density  float32( double(a) + alpha * double(b) )  per voxel -- the Fc map of
  * DensityAnalysis.fc is (2Fo-Fc) - 2 (Fo-Fc), densityAnalysis.py:426-435 (alpha = -2).  Same grid shape required. */

@@ -83,6 +83,7 @@ _SIGS = {
     "pdbeda_ctx_profile_end": (C.c_int, [_p, C.c_char_p, _i64]),
     "pdbeda_map_upload": (C.c_int, [_p, _p, C.POINTER(Geometry), C.POINTER(_p)]),
     "pdbeda_map_upload_file": (C.c_int, [_p, C.c_char_p, _i64, C.c_int, C.POINTER(Geometry), C.POINTER(_p)]),
+    "pdbeda_map_upload_file_stats": (C.c_int, [_p, C.c_char_p, _i64, C.c_int, C.POINTER(Geometry), C.POINTER(_p), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pdbeda_map_from_device": (C.c_int, [_p, _p, C.POINTER(Geometry), C.POINTER(_p)]),
     "pdbeda_map_invalidate": (C.c_int, [_p]),
     "pdbeda_map_free": (C.c_int, [_p]),
@@ -379,6 +380,7 @@ class DeviceMap(object):
     def invalidate(self):
         """The caller rewrote a borrowed device buffer in place: drop what the library cached about its contents."""
         self._ctx.check(self._ctx._lib.pdbeda_map_invalidate(self._h), "pdbeda_map_invalidate")
+        self.__dict__.pop("_file_stats", None)
 
     @classmethod
     def from_file(cls, ctx, path, offset, byteswap, geometry):
@@ -387,9 +389,12 @@ class DeviceMap(object):
         self = cls.__new__(cls)
         self._ctx, self._geom, self._keep = ctx, geometry, None
         h = C.c_void_p()
+        mean, std = C.c_double(), C.c_double()
         try:
-            ctx.check(ctx._lib.pdbeda_map_upload_file(ctx._h, os.fsencode(path), int(offset), 1 if byteswap else 0, C.byref(geometry), C.byref(h)),
-                      "pdbeda_map_upload_file")
+            # (with the map's mean / std from the same wait: every caller asks for them next)
+            ctx.check(ctx._lib.pdbeda_map_upload_file_stats(ctx._h, os.fsencode(path), int(offset), 1 if byteswap else 0, C.byref(geometry), C.byref(h),
+                                                            C.byref(mean), C.byref(std)), "pdbeda_map_upload_file")
+            self._file_stats = (mean.value, std.value)
         except PdbedaError as error:
             if getattr(error, "code", 0) == PDBEDA_ERR_ARGUMENT:       # the FILE is at fault (unreadable, truncated): an entry-level condition
                 raise OSError(str(error))
@@ -443,6 +448,9 @@ class DeviceMap(object):
 
     # -- reductions ------------------------------------------------------------------
     def stats(self):
+        known = self.__dict__.get("_file_stats")           # (a map uploaded from a file brought them along)
+        if known is not None:
+            return known
         mean, std = C.c_double(), C.c_double()
         self._ctx.check(self._ctx._lib.pdbeda_map_stats(self._h, C.byref(mean), C.byref(std)), "pdbeda_map_stats")
         return mean.value, std.value

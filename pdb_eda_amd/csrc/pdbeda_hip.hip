@@ -576,7 +576,10 @@ static hipError_t event_wait(pdbeda_ctx *ctx, hipEvent_t ev) {
 // page faults per 32 MB before the first byte moves).  byteswap: the file has the other endianness.
 static const size_t FILE_CHUNK = (size_t)4 << 20;
 static const int FILE_READERS = 2;
-extern "C" int pdbeda_map_upload_file(pdbeda_ctx *ctx, const char *path, int64_t offset, int byteswap, const pdbeda_geometry *geom, pdbeda_map **out) {
+static int stats_enqueue(pdbeda_map *m, double *chunk_sums, double host[2], double range[2], bool want_range);
+static void range_apply(pdbeda_map *m, const double range[2]);
+
+static int upload_file_impl(pdbeda_ctx *ctx, const char *path, int64_t offset, int byteswap, const pdbeda_geometry *geom, pdbeda_map **out, double *mean, double *std) {
     if (!ctx || !path || !geom || !out || offset < 0) return PDBEDA_ERR_ARGUMENT;
     *out = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -682,16 +685,44 @@ extern "C" int pdbeda_map_upload_file(pdbeda_ctx *ctx, const char *path, int64_t
         hipLaunchKernelGGL(k_byteswap32, dim3(grid_for(n_vox, 256, 8192)), dim3(256), 0, ctx->stream, (uint32_t *)d, n_vox);
         e = hipGetLastError();
     }
+    // mean / std (and the range of the blob sums' quantum) queued behind the copies: ONE wait for the map and its statistics -- every
+    // caller asks for them next (cutoffs are mean + k std), and a wait of their own was one of a pool entry's host round trips
+    const bool with_stats = (mean || std) && e == hipSuccess && !why;
+    double host[2] = {0.0, 0.0}, range[2] = {0.0, 0.0};
+    Arena scratch;
+    bool have_scratch = false;
+    if (with_stats) {
+        if (arena_get(ctx, 8 * (size_t)std::max<int64_t>(n_vox / NP_CHUNK, 1), &scratch) == 0) {
+            have_scratch = true;
+            if (stats_enqueue(m, reinterpret_cast<double *>(scratch.base), host, range, true) != 0) e = hipErrorUnknown;
+        } else {
+            e = hipErrorOutOfMemory;
+        }
+    }
     const hipError_t e2 = ctx_sync(ctx);      // (the ring and &m->geom are free again)
+    if (have_scratch) arena_put(ctx, scratch);
     if (e == hipSuccess) e = e2;
     if (e != hipSuccess || why) {
         arena_put(ctx, m->arena);
         delete m;
         return why ? fail(ctx, PDBEDA_ERR_ARGUMENT, "reading %s: %s", path, why) : fail(ctx, PDBEDA_ERR_DEVICE, "map upload from file: %s", hipGetErrorString(e));
     }
+    if (with_stats) {
+        range_apply(m, range);
+        if (mean) *mean = host[0];
+        if (std) *std = host[1];
+    }
     ctx->live_handles++;
     *out = m;
     return PDBEDA_OK;
+}
+
+extern "C" int pdbeda_map_upload_file(pdbeda_ctx *ctx, const char *path, int64_t offset, int byteswap, const pdbeda_geometry *geom, pdbeda_map **out) {
+    return upload_file_impl(ctx, path, offset, byteswap, geom, out, nullptr, nullptr);
+}
+extern "C" int pdbeda_map_upload_file_stats(pdbeda_ctx *ctx, const char *path, int64_t offset, int byteswap, const pdbeda_geometry *geom, pdbeda_map **out,
+                                            double *mean, double *std) {
+    return upload_file_impl(ctx, path, offset, byteswap, geom, out, mean, std);
 }
 
 extern "C" int pdbeda_map_combine(pdbeda_map *a, pdbeda_map *b, double alpha, pdbeda_map **out) {
@@ -814,27 +845,34 @@ extern "C" int pdbeda_map_invalidate(pdbeda_map *m) {
     return PDBEDA_OK;
 }
 
+// mean and std in numpy's own summation tree (k_np_chunk_sums / k_np_final): == np.mean / np.std, not merely close -- and, while
+// the map's range is not known yet, the range pass behind them (range_enqueue): everything queued, nothing waited for.
+// chunk_sums: 8 * max(n_vox / NP_CHUNK, 1) bytes of device scratch; host[2] / range[2] are filled at the next ctx_sync.
+static int stats_enqueue(pdbeda_map *m, double *chunk_sums, double host[2], double range[2], bool want_range) {
+    pdbeda_ctx *ctx = m->ctx;
+    double *res = ctx->partials + N_PARTIAL;
+    const int64_t n_full = m->n_vox / NP_CHUNK;
+    hipStream_t st = ctx->stream;
+    for (int mode = 0; mode < 2; ++mode) {
+        if (n_full > 0) { PROF(ctx, "k_np_chunk_sums"); hipLaunchKernelGGL(k_np_chunk_sums, dim3((unsigned)std::min<int64_t>(n_full, 1 << 16)), dim3(256), 0, st, m->dens, n_full, mode, res, chunk_sums); }
+        { PROF(ctx, "k_np_final"); hipLaunchKernelGGL(k_np_final, dim3(1), dim3(256), 0, st, m->dens, m->n_vox, n_full, mode, res, chunk_sums, mode, res + mode); }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, d2h(ctx, host, res, 2 * sizeof(double)));
+    // (behind the copy of the two results: the range pass reuses the partial sums' memory)
+    if (want_range) { const int rc_range = range_enqueue(m, range); if (rc_range) return rc_range; }
+    return 0;
+}
+
 extern "C" int pdbeda_map_stats(pdbeda_map *m, double *mean, double *std) {
     if (!m) return PDBEDA_ERR_ARGUMENT;
     pdbeda_ctx *ctx = m->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    double *res = ctx->partials + N_PARTIAL;
-    // numpy's own summation tree (k_np_chunk_sums / k_np_final): == np.mean / np.std, not merely close
     const int64_t n_full = m->n_vox / NP_CHUNK;
     double host[2], range[2] = {0.0, 0.0};
     const bool want_range = m->fix_mul == 0.0 && !m->fix_refused;   // the quantum of the map's blob sums, in the same wait
     int rc = with_scratch(ctx, 8 * (size_t)std::max<int64_t>(n_full, 1), [&](char *base) -> int {
-        double *chunk_sums = reinterpret_cast<double *>(base);
-        hipStream_t st = ctx->stream;
-        for (int mode = 0; mode < 2; ++mode) {
-            if (n_full > 0) { PROF(ctx, "k_np_chunk_sums"); hipLaunchKernelGGL(k_np_chunk_sums, dim3((unsigned)std::min<int64_t>(n_full, 1 << 16)), dim3(256), 0, st, m->dens, n_full, mode, res, chunk_sums); }
-            { PROF(ctx, "k_np_final"); hipLaunchKernelGGL(k_np_final, dim3(1), dim3(256), 0, st, m->dens, m->n_vox, n_full, mode, res, chunk_sums, mode, res + mode); }
-        }
-        HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, d2h(ctx, host, res, 2 * sizeof(double)));
-        // (behind the copy of the two results: the range pass reuses the partial sums' memory)
-        if (want_range) { const int rc_range = range_enqueue(m, range); if (rc_range) return rc_range; }
-        return 0;
+        return stats_enqueue(m, reinterpret_cast<double *>(base), host, range, want_range);
     });
     if (rc) return rc;
     if (want_range) range_apply(m, range);

@@ -300,3 +300,21 @@ def test_file_upload_into_a_recycled_arena(tmp_path, monkeypatch):
         assert np.array_equal(got.download().reshape(grid.shape), grid), rep
         got.free()
     ctx.close()
+
+
+def test_file_upload_brings_the_statistics_along(gpu_ctx, tmp_path):
+    """pdbeda_map_upload_file_stats: a map read from a file comes with its mean / std from the same wait (and the quantum of
+    its blob sums): exactly the numbers pdbeda_map_stats gives on the same grid uploaded from memory (== np.mean / np.std)."""
+    import io
+    from pdb_eda_amd import ccp4, synthetic
+    g = synthetic.smooth_noise((37, 50, 71), 12, 1.5)
+    spec = synthetic.MapSpec(ncrs=(71, 50, 37))
+    path = tmp_path / "stats.ccp4"
+    path.write_bytes(synthetic.ccp4_bytes(spec, g))
+    from_file = ccp4.read(str(path), ctx=gpu_ctx)
+    assert from_file._map.__dict__.get("_file_stats") is not None
+    from_memory = ccp4.parse(io.BytesIO(path.read_bytes()), "m", ctx=gpu_ctx)
+    assert (from_file.meanDensity, from_file.stdDensity) == (from_memory.meanDensity, from_memory.stdDensity)
+    assert from_file.meanDensity == float(np.mean(g, dtype=np.float64)) and from_file.stdDensity == float(np.std(g.astype(np.float64)))
+    a, b = from_file.createFullBlobList(from_file.meanDensity + 1.5 * from_file.stdDensity), from_memory.createFullBlobList(from_memory.meanDensity + 1.5 * from_memory.stdDensity)
+    assert len(a) == len(b) and [x.totalDensity for x in a] == [y.totalDensity for y in b]      # (the same quantum: bit-equal sums)
