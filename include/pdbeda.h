@@ -98,6 +98,8 @@ int pdbeda_ctx_profile_end(pdbeda_ctx *ctx, char *buf, int64_t cap);
 /* ---- map residency: replaces DensityMatrix.__init__ (ccp4.py:322-341) ------------- */
 /* density: host float32 [ns][nr][nc] (c fastest); copied to HBM. */
 int pdbeda_map_upload(pdbeda_ctx *ctx, const float *density, const pdbeda_geometry *geom, pdbeda_map **out);
+/* ... with the map's mean / std from the same wait (see pdbeda_map_upload_file_stats); mean / std may be NULL. */
+int pdbeda_map_upload_stats(pdbeda_ctx *ctx, const float *density, const pdbeda_geometry *geom, pdbeda_map **out, double *mean, double *std);
 /* density_dev: a device pointer the caller keeps alive (zero-copy, e.g. a torch tensor). */
 int pdbeda_map_from_device(pdbeda_ctx *ctx, const float *density_dev, const pdbeda_geometry *geom, pdbeda_map **out);
 /* The caller has rewritten a borrowed buffer in place: drop what the library cached about the map's contents (the quantum of

@@ -82,6 +82,7 @@ _SIGS = {
     "pdbeda_ctx_profile_begin": (C.c_int, [_p]),
     "pdbeda_ctx_profile_end": (C.c_int, [_p, C.c_char_p, _i64]),
     "pdbeda_map_upload": (C.c_int, [_p, _p, C.POINTER(Geometry), C.POINTER(_p)]),
+    "pdbeda_map_upload_stats": (C.c_int, [_p, _p, C.POINTER(Geometry), C.POINTER(_p), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pdbeda_map_upload_file": (C.c_int, [_p, C.c_char_p, _i64, C.c_int, C.POINTER(Geometry), C.POINTER(_p)]),
     "pdbeda_map_upload_file_stats": (C.c_int, [_p, C.c_char_p, _i64, C.c_int, C.POINTER(Geometry), C.POINTER(_p), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pdbeda_map_from_device": (C.c_int, [_p, _p, C.POINTER(Geometry), C.POINTER(_p)]),
@@ -371,7 +372,10 @@ class DeviceMap(object):
         else:
             grid = np.ascontiguousarray(density, dtype=np.float32)
             assert grid.size == geometry.ncrs[0] * geometry.ncrs[1] * geometry.ncrs[2], "grid size does not match header ncrs"
-            rc = ctx._lib.pdbeda_map_upload(ctx._h, _ptr(grid), C.byref(geometry), C.byref(h))
+            mean, std = C.c_double(), C.c_double()      # (with the map's mean / std from the same wait: every caller asks for them next)
+            rc = ctx._lib.pdbeda_map_upload_stats(ctx._h, _ptr(grid), C.byref(geometry), C.byref(h), C.byref(mean), C.byref(std))
+            if rc == 0:
+                self._file_stats = (mean.value, std.value)
             self._keep = None
         ctx.check(rc, "pdbeda_map_upload")
         self._h = h

@@ -507,7 +507,10 @@ static int fill_geom(pdbeda_ctx *ctx, const pdbeda_geometry *in, Geom *g) {
     return 0;
 }
 
-static int map_create(pdbeda_ctx *ctx, const float *host, const float *dev, const pdbeda_geometry *geom, pdbeda_map **out) {
+static int stats_enqueue(pdbeda_map *m, double *chunk_sums, double host[2], double range[2], bool want_range);
+static void range_apply(pdbeda_map *m, const double range[2]);
+
+static int map_create(pdbeda_ctx *ctx, const float *host, const float *dev, const pdbeda_geometry *geom, pdbeda_map **out, double *mean = nullptr, double *std = nullptr) {
     if (!ctx || !geom || !out || (!host && !dev)) return PDBEDA_ERR_ARGUMENT;
     *out = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -531,11 +534,33 @@ static int map_create(pdbeda_ctx *ctx, const float *host, const float *dev, cons
     } else {
         m->dens = dev;
     }
-    if (e == hipSuccess) e = ctx_sync(ctx);  // host buffers may be released on return
+    // (an uploaded map with its statistics from the same wait: see upload_file_impl)
+    const bool with_stats = (mean || std) && host && e == hipSuccess;
+    double st_host[2] = {0.0, 0.0}, range[2] = {0.0, 0.0};
+    Arena scratch;
+    bool have_scratch = false;
+    if (with_stats) {
+        if (arena_get(ctx, 8 * (size_t)std::max<int64_t>(m->n_vox / NP_CHUNK, 1), &scratch) == 0) {
+            have_scratch = true;
+            if (stats_enqueue(m, reinterpret_cast<double *>(scratch.base), st_host, range, true) != 0) e = hipErrorUnknown;
+        } else {
+            e = hipErrorOutOfMemory;
+        }
+    }
+    {
+        const hipError_t e2 = ctx_sync(ctx);  // host buffers may be released on return
+        if (e == hipSuccess) e = e2;
+    }
+    if (have_scratch) arena_put(ctx, scratch);
     if (e != hipSuccess) {
         arena_put(ctx, m->arena);
         delete m;
         return fail(ctx, PDBEDA_ERR_DEVICE, "map upload: %s", hipGetErrorString(e));
+    }
+    if (with_stats) {
+        range_apply(m, range);
+        if (mean) *mean = st_host[0];
+        if (std) *std = st_host[1];
     }
     ctx->live_handles++;
     *out = m;
@@ -544,6 +569,9 @@ static int map_create(pdbeda_ctx *ctx, const float *host, const float *dev, cons
 
 extern "C" int pdbeda_map_upload(pdbeda_ctx *ctx, const float *density, const pdbeda_geometry *geom, pdbeda_map **out) {
     return map_create(ctx, density, nullptr, geom, out);
+}
+extern "C" int pdbeda_map_upload_stats(pdbeda_ctx *ctx, const float *density, const pdbeda_geometry *geom, pdbeda_map **out, double *mean, double *std) {
+    return map_create(ctx, density, nullptr, geom, out, mean, std);
 }
 extern "C" int pdbeda_map_from_device(pdbeda_ctx *ctx, const float *density_dev, const pdbeda_geometry *geom, pdbeda_map **out) {
     return map_create(ctx, nullptr, density_dev, geom, out);
@@ -576,9 +604,6 @@ static hipError_t event_wait(pdbeda_ctx *ctx, hipEvent_t ev) {
 // page faults per 32 MB before the first byte moves).  byteswap: the file has the other endianness.
 static const size_t FILE_CHUNK = (size_t)4 << 20;
 static const int FILE_READERS = 2;
-static int stats_enqueue(pdbeda_map *m, double *chunk_sums, double host[2], double range[2], bool want_range);
-static void range_apply(pdbeda_map *m, const double range[2]);
-
 static int upload_file_impl(pdbeda_ctx *ctx, const char *path, int64_t offset, int byteswap, const pdbeda_geometry *geom, pdbeda_map **out, double *mean, double *std) {
     if (!ctx || !path || !geom || !out || offset < 0) return PDBEDA_ERR_ARGUMENT;
     *out = nullptr;
