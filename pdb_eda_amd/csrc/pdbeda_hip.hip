@@ -11,6 +11,7 @@
 #include <thread>
 #include <atomic>
 #include <random>
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -261,6 +262,19 @@ static hipError_t d2h(pdbeda_ctx *ctx, void *dst, const void *src, size_t bytes)
     return e;
 }
 
+// Host -> device copy of a small input that the caller may free as soon as the call returns, WITHOUT a wait: staged through the
+// same pinned buffer (its regions are handed out until the next ctx_sync).  false: it does not fit -- copy directly and wait.
+static bool h2d_staged(pdbeda_ctx *ctx, void *dst, const void *src, size_t bytes, hipError_t *e) {
+    *e = hipSuccess;
+    if (bytes == 0) return true;
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (!ctx->pinned || ctx->pinned_used + need > ctx->pinned_cap) return false;
+    memcpy(ctx->pinned + ctx->pinned_used, src, bytes);
+    *e = hipMemcpyAsync(dst, ctx->pinned + ctx->pinned_used, bytes, hipMemcpyHostToDevice, ctx->stream);
+    ctx->pinned_used += need;
+    return true;
+}
+
 static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 static int arena_get_raw(pdbeda_ctx *ctx, size_t bytes, Arena *out);
@@ -393,7 +407,7 @@ extern "C" int pdbeda_ctx_create_on_stream(int device_id, void *hip_stream, pdbe
         delete ctx;
         return PDBEDA_ERR_MEMORY;
     }
-    if (hipHostMalloc((void **)&ctx->pinned, 1 << 20, hipHostMallocDefault) == hipSuccess) ctx->pinned_cap = 1 << 20;   // (without it results are copied directly)
+    if (hipHostMalloc((void **)&ctx->pinned, 4 << 20, hipHostMallocDefault) == hipSuccess) ctx->pinned_cap = 4 << 20;   // (without it results are copied directly)
     if (const char *v = getenv("PDBEDA_DEBUG_POISON")) ctx->debug_poison = v[0] && v[0] != '0';
     if (const char *v = getenv("PDBEDA_DEBUG_EDGE_CAP")) ctx->debug_edge_cap = atoll(v);
     if (const char *v = getenv("PDBEDA_DEBUG_WORST_CASE_ARENA")) ctx->debug_worst_case_arena = v[0] && v[0] != '0';
@@ -1317,6 +1331,7 @@ static int list_resolve_counts(pdbeda_bloblist *bl) {
         if (ctr.overflow != 0u) return fail(ctx, PDBEDA_ERR_STATE, "whole-map labelling overflowed its worst-case arena");
     }
     if (bl->whole_map && ctr.unit_wait_failed) return fail(ctx, PDBEDA_ERR_DEVICE, "whole-map labelling: a tile waited in vain for the labels of a neighbour tile that overflowed LDS (k_face_merge)");
+    if (!bl->whole_map && ctr.unit_wait_failed) return fail(ctx, PDBEDA_ERR_DEVICE, "sphere batch: the device's volumes outgrew what the host sized the job for");
     if (bl->vol_lo == 0 && bl->vol_hi == bl->job.n_vols) { bl->rank_lo = 0; bl->rank_hi = ctr.n_blobs; }
     else if (bl->whole_map && bl->job.n_vols == 2 && bl->vol_hi == bl->vol_lo + 1) {
         bl->rank_lo = bl->vol_lo == 0 ? 0 : ctr.n_blobs_vol0;
@@ -1398,6 +1413,7 @@ static int list_stats_one_trip(pdbeda_bloblist *bl, int64_t guess, std::vector<i
         HIP_TRY(ctx, d2h(ctx, cen.data(), job.b_centroid, 24 * guess));
         HIP_TRY(ctx, d2h(ctx, grp.data(), job.b_group, 4 * guess));
         HIP_TRY(ctx, ctx_sync(ctx));
+        if (ctr.unit_wait_failed) return fail(ctx, PDBEDA_ERR_DEVICE, "sphere batch: the device's volumes outgrew what the host sized the job for");
         bl->rank_lo = 0; bl->rank_hi = ctr.n_blobs; bl->job_blobs = ctr.n_blobs; bl->have_counts = true;
         if ((int64_t)ctr.n_blobs <= guess) {
             const size_t nb = ctr.n_blobs;
@@ -1546,6 +1562,7 @@ struct GroupSetup {
     VolDesc *d_vols = nullptr;
     Counters *d_ctr = nullptr;
     int64_t total_words = 0, total_keys = 0;
+    bool host_totals = false;   // the totals are the host's (per-atom spheres): nobody waited for the device's -- k_make_vols checks them
 };
 
 static int expand_groups(const int64_t *group_offsets, int64_t n_groups, int64_t n_items, std::vector<int32_t> &item_group) {
@@ -1581,7 +1598,7 @@ static int group_alloc(pdbeda_ctx *ctx, int64_t n_items, int64_t n_groups, Group
 
 // Inputs are on the device (d_xyz + d_radii, or d_crs; d_item_group): group bounding volumes, volume descriptors, and the
 // totals read back (the one host round trip of a sphere / list batch).
-static int group_bounds(pdbeda_map *m, GroupSetup *gs, int64_t n_items, int64_t n_groups, bool spheres) {
+static int group_bounds(pdbeda_map *m, GroupSetup *gs, int64_t n_items, int64_t n_groups, bool spheres, const int64_t *host_totals = nullptr) {
     pdbeda_ctx *ctx = m->ctx;
     hipStream_t st = ctx->stream;
     const int64_t ng = std::max<int64_t>(n_groups, 1);
@@ -1595,8 +1612,16 @@ static int group_bounds(pdbeda_map *m, GroupSetup *gs, int64_t n_items, int64_t 
             { PROF(ctx, "k_list_boxes"); hipLaunchKernelGGL(k_list_boxes, dim3(grid_for(n_items, 256 * 4, 256)), dim3(256), 0, st, gs->d_crs, gs->d_item_group, n_items,
                                gs->g_lo, gs->g_hi); }
     }
-    { PROF(ctx, "k_make_vols"); hipLaunchKernelGGL(k_make_vols, dim3(1), dim3(1024), 0, st, gs->g_lo, gs->g_hi, (int)n_groups, gs->d_vols, gs->d_ctr); }
+    { PROF(ctx, "k_make_vols"); hipLaunchKernelGGL(k_make_vols, dim3(1), dim3(1024), 0, st, gs->g_lo, gs->g_hi, (int)n_groups, gs->d_vols, gs->d_ctr,
+                                                   host_totals ? (long long)host_totals[0] : LLONG_MAX, host_totals ? (long long)host_totals[1] : LLONG_MAX); }
     HIP_TRY(ctx, hipGetLastError());
+    if (host_totals) {   // sized by the host: no round trip (the kernel holds the device's totals against these)
+        gs->total_words = host_totals[0];
+        gs->total_keys = host_totals[1];
+        gs->host_totals = true;
+        if (gs->total_words >= (1ll << 31) * 2) return fail(ctx, PDBEDA_ERR_ARGUMENT, "sphere batch too large (%lld mask words)", (long long)gs->total_words);
+        return 0;
+    }
     Counters ctr;
     HIP_TRY(ctx, d2h(ctx, &ctr, gs->d_ctr, sizeof ctr));
     HIP_TRY(ctx, ctx_sync(ctx));  // (host-side staging vectors of the caller are also safe to drop now)
@@ -1615,6 +1640,42 @@ static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, con
     int rc = group_alloc(ctx, n_items, n_groups, gs);
     if (rc) return rc;
     hipStream_t st = ctx->stream;
+    // Per-atom spheres (a group per atom: the clouds of aggregateCloud, the per-atom region tables): an atom's box is
+    // [C - R - 1, C + R] with R = xyz2crs(origin + radius) -- its SIZE follows from the radius alone, so the host knows the
+    // job's mask words and keys without asking the device (the round trip for the totals was one of an entry's host waits).
+    // The inputs go through the pinned staging buffer, so nothing here needs the caller's arrays after the call returns.
+    if (xyz && n_items > 0 && n_groups == n_items) {
+        bool per_atom = true;
+        for (int64_t g = 0; g <= n_groups && per_atom; ++g) per_atom = group_offsets[g] == g;
+        int64_t totals[2] = {0, 0};
+        float last_rad = NAN;
+        int64_t last_words = 0, last_keys = 0;
+        for (int64_t a = 0; a < n_items && per_atom; ++a) {
+            const float rad = radii[a];
+            if (!(rad >= 0.0f) || !std::isfinite(rad)) { per_atom = false; break; }
+            if (!(rad == last_rad)) {   // (a handful of distinct radii: one per atom type)
+                const double o[3] = {m->geom.origin[0] + (double)rad, m->geom.origin[1] + (double)rad, m->geom.origin[2] + (double)rad};
+                int32_t R[3];
+                xyz2crs(m->geom, o, R);
+                int64_t dim[3];
+                bool empty = false;
+                for (int k = 0; k < 3; ++k) { dim[k] = 2 * (int64_t)R[k] + 2; empty = empty || dim[k] <= 0; }
+                last_words = empty ? 0 : (dim[0] + 63) / 64 * dim[1] * dim[2];
+                last_keys = empty ? 0 : dim[0] * dim[1] * dim[2];
+                last_rad = rad;
+            }
+            totals[0] += last_words;
+            totals[1] += last_keys;
+            if (totals[0] >= (1ll << 40) || totals[1] >= (1ll << 46)) per_atom = false;   // (absurd: let the waiting path report it)
+        }
+        hipError_t e1 = hipSuccess, e2 = hipSuccess, e3 = hipSuccess;
+        if (per_atom && 32 * (size_t)n_items + 256 <= ctx->pinned_cap - ctx->pinned_used &&
+            h2d_staged(ctx, gs->d_xyz, xyz, 24 * (size_t)n_items, &e1) && h2d_staged(ctx, gs->d_radii, radii, 4 * (size_t)n_items, &e2) &&
+            h2d_staged(ctx, gs->d_item_group, item_group.data(), 4 * (size_t)n_items, &e3)) {
+            HIP_TRY(ctx, e1); HIP_TRY(ctx, e2); HIP_TRY(ctx, e3);
+            return group_bounds(m, gs, n_items, n_groups, true, totals);
+        }
+    }
     if (n_items > 0) {
         if (xyz) {
             HIP_TRY(ctx, hipMemcpyAsync(gs->d_xyz, xyz, 24 * n_items, hipMemcpyHostToDevice, st));
@@ -1651,7 +1712,7 @@ static int grouped_job(pdbeda_map *m, GroupSetup &gs, int64_t n_items, int64_t n
     if (e == hipSuccess && n_items > 0) {
         if (spheres)
             { PROF(ctx, "k_sphere_paint"); hipLaunchKernelGGL(k_sphere_paint, dim3((unsigned)n_items), dim3(256), 0, st, m->geom_dev, m->dens, gs.d_xyz, gs.d_radii,
-                               gs.d_item_group, gs.d_boxes, job.vols, job.mask, cutoff); }
+                               gs.d_item_group, gs.d_boxes, job.vols, job.mask, cutoff, gs.d_ctr, job.ctr); }
         else
             { PROF(ctx, "k_list_paint"); hipLaunchKernelGGL(k_list_paint, dim3(grid_for(n_items, 256)), dim3(256), 0, st, gs.d_crs, gs.d_item_group, n_items, job.vols, job.mask); }
         e = hipGetLastError();
@@ -1719,7 +1780,7 @@ extern "C" int pdbeda_region_sums(pdbeda_map *m, const double *xyz, const float 
     hipError_t e = hipMemsetAsync(a.base, 0, cv.off, st);
     if (e == hipSuccess && n_atoms > 0) {
         { PROF(ctx, "k_sphere_paint"); hipLaunchKernelGGL(k_sphere_paint, dim3((unsigned)n_atoms), dim3(256), 0, st, m->geom_dev, m->dens, gs.d_xyz, gs.d_radii,
-                           gs.d_item_group, gs.d_boxes, gs.d_vols, mask, 0.0f); }
+                           gs.d_item_group, gs.d_boxes, gs.d_vols, mask, 0.0f, gs.d_ctr, (Counters *)nullptr); }
         { PROF(ctx, "k_region_reduce"); hipLaunchKernelGGL(k_region_reduce, dim3((unsigned)std::min<int64_t>(n_groups, 65536)), dim3(256), 0, st, m->geom_dev, m->dens, gs.d_vols,
                            (int)n_groups, mask, gs.total_words, cutoff, d_pos, d_neg, d_cnt, d_inv); }
         e = hipGetLastError();
@@ -1730,10 +1791,14 @@ extern "C" int pdbeda_region_sums(pdbeda_map *m, const double *xyz, const float 
     if (e == hipSuccess && neg) e = d2h(ctx, neg, d_neg, 8 * n_groups);
     if (e == hipSuccess) e = d2h(ctx, h_cnt.data(), d_cnt, 8 * n_groups);
     if (e == hipSuccess) e = d2h(ctx, h_inv.data(), d_inv, 4 * n_groups);
+    Counters setup;
+    memset(&setup, 0, sizeof setup);
+    if (e == hipSuccess && gs.host_totals) e = d2h(ctx, &setup, gs.d_ctr, sizeof setup);
     if (e == hipSuccess) e = ctx_sync(ctx);
     arena_put(ctx, a);
     arena_put(ctx, gs.in_arena);
     if (e != hipSuccess) return fail(ctx, PDBEDA_ERR_DEVICE, "region sums: %s", hipGetErrorString(e));
+    if (setup.overflow != 0u) return fail(ctx, PDBEDA_ERR_DEVICE, "region sums: the device's volumes outgrew what the host sized the batch for");
     for (int64_t g = 0; g < n_groups; ++g) {
         if (n_region) n_region[g] = (int64_t)h_cnt[g];
         if (valid) valid[g] = h_inv[g] ? 0 : 1;

@@ -1236,8 +1236,12 @@ __global__ void k_init_bounds(int32_t *g_lo, int32_t *g_hi, int64_t n3) {
 }
 
 // Single block: group bounding boxes -> volume descriptors with word / key offsets.
+// cap_words / cap_keys: what the HOST sized the job for when it did not wait for these totals (group_setup: per-atom spheres, whose
+// box sizes follow from the radius alone).  The two agree by construction (the same IEEE arithmetic on both sides); should they
+// ever not, every volume is emptied before anything is painted and the flag makes the call fail -- nothing is written out of bounds.
 __global__ void __launch_bounds__(1024) k_make_vols(const int32_t *__restrict__ g_lo, const int32_t *__restrict__ g_hi,
-                                                     int n_groups, VolDesc *__restrict__ vols, Counters *__restrict__ ctr) {
+                                                     int n_groups, VolDesc *__restrict__ vols, Counters *__restrict__ ctr,
+                                                     long long cap_words, long long cap_keys) {
     __shared__ long long s_w[16], s_k[16];
     __shared__ long long s_cw, s_ck;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1281,6 +1285,14 @@ __global__ void __launch_bounds__(1024) k_make_vols(const int32_t *__restrict__ 
         __syncthreads();
     }
     if (tid == 0) { ctr->total_words = s_cw; ctr->total_keys = s_ck; }
+    if (s_cw > cap_words || s_ck > cap_keys) {   // block-uniform
+        if (tid == 0) ctr->overflow = 1u;
+        for (int i = tid; i < n_groups; i += 1024) {
+            VolDesc vd = vols[i];
+            vd.dim[0] = vd.dim[1] = vd.dim[2] = 0; vd.row_words = 0; vd.word_base = 0; vd.key_base = 0;
+            vols[i] = vd;
+        }
+    }
 }
 
 // Block per atom, thread per 16-voxel piece of a box row: wrapped fetch, strict density filter (Q2), fp64 distance
@@ -1290,7 +1302,12 @@ __global__ void __launch_bounds__(1024) k_make_vols(const int32_t *__restrict__ 
 __global__ void __launch_bounds__(256) k_sphere_paint(const Geom *__restrict__ gp, const float *__restrict__ dens,
                                                       const double *__restrict__ xyz, const float *__restrict__ radii,
                                                       const int32_t *__restrict__ atom_group, const AtomBox *__restrict__ boxes,
-                                                      const VolDesc *__restrict__ vols, uint64_t *__restrict__ mask, float cutoff) {
+                                                      const VolDesc *__restrict__ vols, uint64_t *__restrict__ mask, float cutoff,
+                                                      const Counters *__restrict__ setup_ctr, Counters *__restrict__ job_ctr) {
+    if (setup_ctr->overflow != 0u) {   // (k_make_vols: the volumes outgrew what the host sized the job for -- cannot happen; fails the call)
+        if (blockIdx.x == 0 && threadIdx.x == 0 && job_ctr) job_ctr->unit_wait_failed = 1u;
+        return;
+    }
     const int64_t a = blockIdx.x;
     const AtomBox bx = boxes[a];
     const int dc = bx.hi[0] - bx.lo[0] + 1, dr = bx.hi[1] - bx.lo[1] + 1, dsz = bx.hi[2] - bx.lo[2] + 1;
