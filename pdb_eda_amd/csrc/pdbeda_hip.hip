@@ -66,6 +66,7 @@ struct pdbeda_ctx {
     // is handed out (a kernel that trusts recycled memory shows up at once); PDBEDA_DEBUG_EDGE_CAP=n shrinks the
     // cross-tile pair buffer so the shard-overflow path runs on small inputs.
     bool debug_poison = false;
+    bool debug_shrink_totals = false;   // PDBEDA_DEBUG_SHRINK_TOTALS=1: the host sizes per-atom sphere batches for HALF their mask words -- what k_make_vols' check of the device's totals is there to catch (tests)
     int64_t debug_edge_cap = 0;
     bool debug_worst_case_arena = false;   // PDBEDA_DEBUG_WORST_CASE_ARENA=1: whole-map jobs are carved for the worst case at once (no second run)
     // per-entry watchdog (multipleStructures.py:359-377 wraps every entry in a SIGALRM timeout; threads cannot): when
@@ -409,6 +410,7 @@ extern "C" int pdbeda_ctx_create_on_stream(int device_id, void *hip_stream, pdbe
     }
     if (hipHostMalloc((void **)&ctx->pinned, 4 << 20, hipHostMallocDefault) == hipSuccess) ctx->pinned_cap = 4 << 20;   // (without it results are copied directly)
     if (const char *v = getenv("PDBEDA_DEBUG_POISON")) ctx->debug_poison = v[0] && v[0] != '0';
+    if (const char *v = getenv("PDBEDA_DEBUG_SHRINK_TOTALS")) ctx->debug_shrink_totals = v[0] && v[0] != '0';
     if (const char *v = getenv("PDBEDA_DEBUG_EDGE_CAP")) ctx->debug_edge_cap = atoll(v);
     if (const char *v = getenv("PDBEDA_DEBUG_WORST_CASE_ARENA")) ctx->debug_worst_case_arena = v[0] && v[0] != '0';
     if (const char *v = getenv("PDBEDA_POOL_CAP_MB")) ctx->pool_cap = (size_t)std::max<long long>(atoll(v), 0) << 20;
@@ -1668,6 +1670,7 @@ static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, con
             totals[1] += last_keys;
             if (totals[0] >= (1ll << 40) || totals[1] >= (1ll << 46)) per_atom = false;   // (absurd: let the waiting path report it)
         }
+        if (ctx->debug_shrink_totals) { totals[0] /= 2; totals[1] /= 2; }
         hipError_t e1 = hipSuccess, e2 = hipSuccess, e3 = hipSuccess;
         if (per_atom && 32 * (size_t)n_items + 256 <= ctx->pinned_cap - ctx->pinned_used &&
             h2d_staged(ctx, gs->d_xyz, xyz, 24 * (size_t)n_items, &e1) && h2d_staged(ctx, gs->d_radii, radii, 4 * (size_t)n_items, &e2) &&

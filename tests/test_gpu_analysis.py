@@ -205,3 +205,30 @@ def test_structure_without_symmetry_operators(gpu_ctx):
     # the raw C entry point with zero operators is an empty result, not an argument error
     idx, sym, xyz = gpu_ctx.symmetry_atoms(np.zeros((3, 3)), np.zeros((0, 12)), np.eye(3), np.zeros(3), np.ones(3))
     assert len(idx) == 0 and len(sym) == 0 and len(xyz) == 0
+
+
+def test_host_sized_sphere_batches_are_checked_on_the_device(monkeypatch):
+    """Per-atom sphere batches are sized by the HOST (an atom's box size follows from its radius) and nobody waits for the
+    device's totals; k_make_vols holds its own totals against the host's and, should they ever be larger, empties the volumes
+    before anything is painted and fails the call -- no write out of bounds.  The debug hook halves the host's totals."""
+    from pdb_eda_amd import _native, ccp4, synthetic
+    import io
+    spec = synthetic.MapSpec(ncrs=(48, 40, 36), spacing=0.5)
+    g = synthetic.smooth_noise((36, 40, 48), 5, 1.5)
+    xyz = np.array([[8.0, 9.0, 7.0], [12.0, 10.5, 9.0], [15.0, 6.0, 11.0]])
+    radii = np.array([1.5, 2.0, 1.5], dtype=np.float32)
+    good = _native.Context(0)
+    dm = ccp4.parse(io.BytesIO(synthetic.ccp4_bytes(spec, g)), "ok", ctx=good)
+    want = dm._map.sphere_blobs(xyz, radii, np.arange(4), 0.0).stats()["n"]
+    assert len(want) >= 3
+    monkeypatch.setenv("PDBEDA_DEBUG_SHRINK_TOTALS", "1")
+    bad = _native.Context(0)                                   # (debug hooks are read when a context is made)
+    monkeypatch.delenv("PDBEDA_DEBUG_SHRINK_TOTALS")
+    dm2 = ccp4.parse(io.BytesIO(synthetic.ccp4_bytes(spec, g)), "shrunk", ctx=bad)
+    with pytest.raises(_native.PdbedaError):
+        dm2._map.sphere_blobs(xyz, radii, np.arange(4), 0.0).stats()
+    with pytest.raises(_native.PdbedaError):
+        dm2._map.region_sums(xyz, radii, np.arange(4), 0.1)
+    # groups of several atoms wait for the device's totals as before: not affected by the hook, and the context is still good
+    assert np.array_equal(dm2._map.sphere_blobs(xyz, radii, np.array([0, 3]), 0.0).stats()["n"], dm._map.sphere_blobs(xyz, radii, np.array([0, 3]), 0.0).stats()["n"])
+    assert np.array_equal(dm._map.sphere_blobs(xyz, radii, np.arange(4), 0.0).stats()["n"], want)
