@@ -217,3 +217,34 @@ def test_last_atom_with_the_same_coordinate():
             last[tuple(xyz[i])] = i
         want = np.array([last[tuple(xyz[i])] for i in range(n)], dtype=np.int64)
         assert np.array_equal(da._lastWithSameCoord(xyz), want)
+
+
+def test_device_blobs_sequence_semantics_without_a_device():
+    """ccp4.DeviceBlobs over a stand-in for a device list: objects on first access only, `+` of two is one (sharing the
+    objects), list semantics for ==, + with a plain list, indexing and slices; columns() until an object exists."""
+    import numpy as np
+    from pdb_eda_amd import ccp4
+
+    class FakeList(object):
+        def __init__(self, n, base):
+            self.calls = 0
+            self._st = {"centroid": np.arange(3 * n, dtype=np.float64).reshape(n, 3) + base, "coordCenter": np.zeros((n, 3)),
+                        "totalDensity": np.linspace(1.0, 2.0, n) + base, "volume": np.full(n, 0.125), "n": np.arange(1, n + 1), "firstKey": np.arange(n) * 7}
+
+        def stats(self):
+            self.calls += 1
+            return self._st
+    a_list, b_list = FakeList(4, 0.0), FakeList(3, 100.0)
+    a, b = ccp4.DensityBlob.listFromDevice(a_list, None), ccp4.DensityBlob.listFromDevice(b_list, None)
+    assert isinstance(a, ccp4.DeviceBlobs) and len(a) == 4 and len(b) == 3 and a_list.calls == 1
+    both = a + b
+    cols = both.columns()
+    assert cols is not None and cols["n"].tolist() == [1, 2, 3, 4, 1, 2, 3] and cols["centroid"].shape == (7, 3)
+    assert a.columns() is not None                      # nothing materialised yet
+    first = both[0]
+    assert isinstance(first, ccp4.DensityBlob) and first.numVoxels == 1 and first is a[0]
+    assert both.columns() is None and a.columns() is None      # (objects exist: they are the truth from now on)
+    assert [blob.numVoxels for blob in both] == [1, 2, 3, 4, 1, 2, 3] and both[-1] is b[2]
+    assert both[1:3] == [a[1], a[2]] and a == list(a) and list(b) == b and a != b
+    assert (a + [1])[-1] == 1 and ([0] + b)[0] == 0
+    assert ccp4.DeviceBlobs([]) == [] and not ccp4.DeviceBlobs([]) and ccp4.DeviceBlobs([]).columns()["n"].size == 0
