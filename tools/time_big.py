@@ -1,5 +1,5 @@
 # A 512^3 map (8x BASELINE configs[1]): correctness against the oracle (counts, keys, totals) and throughput.
-#   python tools/time_big.py [edge]
+#   python tools/time_big.py [edge [nsd]]
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,7 +12,7 @@ header = ccp4.DensityHeader.fromFileHeader(synthetic.ccp4_header_bytes(spec))
 ctx = _native.Context(0)
 dmap = _native.DeviceMap(ctx, g, header.geometry())
 mean, std = dmap.stats()
-cut = mean + 1.5 * std
+cut = mean + (float(sys.argv[2]) if len(sys.argv) > 2 else 1.5) * std
 for _ in range(2):
     green, red = dmap.full_blobs_pm(cut, -cut, labels=True)
 ctx.synchronize()
