@@ -29,8 +29,11 @@
 // pairs and runs are handed out one per lane instead of being walked word by word.
 // Only component pairs that touch across a tile face are united globally (k_face_merge, after an LDS
 // de-duplication per tile), and only non-root tile components cost global atomics (k_resolve_tiles, after an
-// LDS pre-reduction per tile).  A tile whose run or component count exceeds the LDS capacity falls
-// back to "unit mode" (its workgroup of k_face_merge labels it run by run, every run its own component, and unites its pairs
+// LDS pre-reduction per tile).  Tiles beyond the LDS tables (round 4): more than CCAP components -> a WIDE tile (tile_mode 2: its
+// components take ids above the tiles' own ranges, its sums are made CCAP components at a time); more than RCAP word-runs -> a
+// DENSE tile (the parked values' LDS becomes parent slots RCAP .. RCAP_DENSE - 1, the values are re-read from L2); both keep
+// their in-LDS unions.  Only a tile with more than RCAP_DENSE word-runs, or one that finds no ids, falls back to "unit mode"
+// (tile_mode 1 / 3: its workgroup of k_face_merge labels it run by run, every run its own component, and unites its pairs
 // globally): slower, same result.
 //
 // The step is FOUR launches (round 4; six in round 3): k_tile_label -> k_face_merge -> k_resolve_tiles -> k_labels_tiles<fused>.
