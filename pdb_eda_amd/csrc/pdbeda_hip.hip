@@ -1036,8 +1036,10 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     while (((int64_t)KEY_GROUPS << job.fine_shift) < job.n_fine) job.fine_shift++;
     job.fine_per_group = 1 << job.fine_shift;
     job.n_groups = (job.n_fine + job.fine_per_group - 1) / job.fine_per_group;
-    job.ctr = cv.take<Counters>(1);
     job.vols = cv.take<VolDesc>(std::max(n_vols, 1));
+    // counters, masks, first-key bitmap and rank counters in a row: a sphere / list job clears them with ONE fill (grouped_job;
+    // whole-map jobs clear theirs in kernels)
+    job.ctr = cv.take<Counters>(1);
     job.mask = cv.take<uint64_t>(total_words);
     job.key_bits = cv.take<uint64_t>((size_t)(job.key_words + KEY_FINE - 1) / KEY_FINE * KEY_FINE);   // whole fine buckets (rank_of_key loads a bucket whole)
     // the rank counters sit right behind the bitmap (ONE clear covers both), padded to whole groups
@@ -1604,8 +1606,7 @@ static int group_bounds(pdbeda_map *m, GroupSetup *gs, int64_t n_items, int64_t 
     pdbeda_ctx *ctx = m->ctx;
     hipStream_t st = ctx->stream;
     const int64_t ng = std::max<int64_t>(n_groups, 1);
-    HIP_TRY(ctx, hipMemsetAsync(gs->d_ctr, 0, sizeof(Counters), st));
-    { PROF(ctx, "k_init_bounds"); hipLaunchKernelGGL(k_init_bounds, dim3(grid_for(3 * ng, 256)), dim3(256), 0, st, gs->g_lo, gs->g_hi, 3 * ng); }
+    { PROF(ctx, "k_init_bounds"); hipLaunchKernelGGL(k_init_bounds, dim3(grid_for(3 * ng, 256)), dim3(256), 0, st, gs->g_lo, gs->g_hi, 3 * ng, gs->d_ctr); }
     if (n_items > 0) {
         if (spheres)
             { PROF(ctx, "k_atom_boxes"); hipLaunchKernelGGL(k_atom_boxes, dim3(grid_for(n_items, 256)), dim3(256), 0, st, m->geom_dev, gs->d_xyz, gs->d_radii,
@@ -1708,10 +1709,8 @@ static int grouped_job(pdbeda_map *m, GroupSetup &gs, int64_t n_items, int64_t n
     hipStream_t st = ctx->stream;
     hipError_t e = hipSuccess;
     if (n_groups > 0) e = hipMemcpyAsync(job.vols, gs.d_vols, sizeof(VolDesc) * n_groups, hipMemcpyDeviceToDevice, st);
-    if (e == hipSuccess) e = hipMemsetAsync(job.ctr, 0, sizeof(Counters), st);
-    if (e == hipSuccess)   // first-key bitmap + both levels of rank counters (adjacent in the arena)
-        e = hipMemsetAsync(job.key_bits, 0, (size_t)((char *)(job.mid_count + (job.key_words + KEY_FINE - 1) / KEY_FINE * (KEY_FINE / 16)) - (char *)job.key_bits), st);
-    if (e == hipSuccess && job.total_words > 0) e = hipMemsetAsync(job.mask, 0, 8 * job.total_words, st);
+    if (e == hipSuccess)   // counters + masks + first-key bitmap + both levels of rank counters (adjacent in the arena: job_carve): one fill
+        e = hipMemsetAsync(job.ctr, 0, (size_t)((char *)(job.mid_count + (job.key_words + KEY_FINE - 1) / KEY_FINE * (KEY_FINE / 16)) - (char *)job.ctr), st);
     if (e == hipSuccess && n_items > 0) {
         if (spheres)
             { PROF(ctx, "k_sphere_paint"); hipLaunchKernelGGL(k_sphere_paint, dim3((unsigned)n_items), dim3(256), 0, st, m->geom_dev, m->dens, gs.d_xyz, gs.d_radii,
@@ -2116,24 +2115,33 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
     Arena aux;
     rc = arena_get(ctx, 2 * align_up(4 * n_pool) + align_up(8 * (n_pool + 1)) + align_up(8 * n_pool) + align_up(8 * (n + 1)) + 3 * align_up(4 * std::max<int64_t>(n_pairs, 1)), &aux);
     if (rc) { arena_put(ctx, gs.in_arena); return bail(rc, clouds, nullptr); }
+    // what the device needs of the host's decisions, in ONE copy: pooled clouds, their groups, voxel offsets, the atoms' voxel
+    // slices, the bonded pairs and the pairs' (zeroed) touch flags sit in a row in the scratch arena and in one host block
+    // (six copies and a fill were seven launches on the stream, 6-8 us apart each: round 4, tools/exp/trace_cloud.sh)
     Carver cv(aux.base);
+    const int64_t np1 = std::max<int64_t>(n_pairs, 1);
     int32_t *d_pool_cloud = cv.take<int32_t>(n_pool), *d_pool_group = cv.take<int32_t>(n_pool);
     int64_t *d_pool_voff = cv.take<int64_t>(n_pool + 1);
-    int32_t *d_comp = cv.take<int32_t>(2 * n_pool);
     int64_t *d_set_off = cv.take<int64_t>(n + 1);
-    int32_t *d_pa = cv.take<int32_t>(std::max<int64_t>(n_pairs, 1)), *d_pb = cv.take<int32_t>(std::max<int64_t>(n_pairs, 1));
-    unsigned int *d_touch = cv.take<unsigned int>(std::max<int64_t>(n_pairs, 1));
+    int32_t *d_pa = cv.take<int32_t>(np1), *d_pb = cv.take<int32_t>(np1);
+    unsigned int *d_touch = cv.take<unsigned int>(np1);
+    const size_t upload_bytes = cv.off;
+    int32_t *d_comp = cv.take<int32_t>(2 * n_pool);
     auto fail_dev = [&](hipError_t e, pdbeda_bloblist *u) {
         arena_put(ctx, aux);
         return bail(fail(ctx, PDBEDA_ERR_DEVICE, "aggregate cloud: %s", hipGetErrorString(e)), clouds, u);
     };
-    hipError_t e = hipMemcpyAsync(d_pool_cloud, pool_cloud.data(), 4 * n_pool, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_pool_group, pool_group.data(), 4 * n_pool, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_pool_voff, pool_voff.data(), 8 * (n_pool + 1), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_set_off, set_off.data(), 8 * (n + 1), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && n_pairs > 0) e = hipMemcpyAsync(d_pa, pair_a.data(), 4 * n_pairs, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && n_pairs > 0) e = hipMemcpyAsync(d_pb, pair_b.data(), 4 * n_pairs, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && n_pairs > 0) e = hipMemsetAsync(d_touch, 0, 4 * n_pairs, st);
+    std::vector<char> block(upload_bytes, 0);      // (stays alive until group_bounds has waited for the stream)
+    {
+        auto put = [&](const void *dev, const void *src, size_t bytes) { if (bytes) memcpy(block.data() + ((const char *)dev - aux.base), src, bytes); };
+        put(d_pool_cloud, pool_cloud.data(), 4 * (size_t)n_pool);
+        put(d_pool_group, pool_group.data(), 4 * (size_t)n_pool);
+        put(d_pool_voff, pool_voff.data(), 8 * (size_t)(n_pool + 1));
+        put(d_set_off, set_off.data(), 8 * (size_t)(n + 1));
+        put(d_pa, pair_a.data(), 4 * (size_t)n_pairs);
+        put(d_pb, pair_b.data(), 4 * (size_t)n_pairs);
+    }
+    hipError_t e = hipMemcpyAsync(aux.base, block.data(), upload_bytes, hipMemcpyHostToDevice, st);
     if (e != hipSuccess) { arena_put(ctx, gs.in_arena); return fail_dev(e, nullptr); }
     { PROF(ctx, "k_pool_gather"); hipLaunchKernelGGL(k_pool_gather, dim3(grid_for(2 * V, 256)), dim3(256), 0, st, cow->crs_dev, cow->offsets_dev, d_pool_cloud, d_pool_voff,
                                                      d_pool_group, (int)n_pool, V, n_rg, gs.d_crs, gs.d_item_group); }

@@ -1228,8 +1228,13 @@ __global__ void __launch_bounds__(256) k_list_boxes(const int32_t *__restrict__ 
     }
 }
 
-__global__ void k_init_bounds(int32_t *g_lo, int32_t *g_hi, int64_t n3) {
+__global__ void k_init_bounds(int32_t *g_lo, int32_t *g_hi, int64_t n3, Counters *ctr) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {   // (the batch's counters: k_make_vols fills the totals, raises the flag -- saves a fill launch)
+        Counters c;
+        memset(&c, 0, sizeof c);
+        *ctr = c;
+    }
     if (i >= n3) return;
     g_lo[i] = INT32_MAX;
     g_hi[i] = INT32_MIN;
