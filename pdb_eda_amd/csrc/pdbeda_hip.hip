@@ -1672,11 +1672,16 @@ static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, con
             if (totals[0] >= (1ll << 40) || totals[1] >= (1ll << 46)) per_atom = false;   // (absurd: let the waiting path report it)
         }
         if (ctx->debug_shrink_totals) { totals[0] /= 2; totals[1] /= 2; }
-        hipError_t e1 = hipSuccess, e2 = hipSuccess, e3 = hipSuccess;
-        if (per_atom && 32 * (size_t)n_items + 256 <= ctx->pinned_cap - ctx->pinned_used &&
-            h2d_staged(ctx, gs->d_xyz, xyz, 24 * (size_t)n_items, &e1) && h2d_staged(ctx, gs->d_radii, radii, 4 * (size_t)n_items, &e2) &&
-            h2d_staged(ctx, gs->d_item_group, item_group.data(), 4 * (size_t)n_items, &e3)) {
-            HIP_TRY(ctx, e1); HIP_TRY(ctx, e2); HIP_TRY(ctx, e3);
+        // (coordinates, radii and groups sit in a row at the head of the scratch arena: one staged block, one copy)
+        const size_t block = (size_t)((char *)(gs->d_item_group + n_items) - gs->in_arena.base);
+        const size_t need = (block + 63) & ~(size_t)63;
+        if (per_atom && (char *)gs->d_xyz == gs->in_arena.base && ctx->pinned && ctx->pinned_used + need <= ctx->pinned_cap) {
+            char *stage = ctx->pinned + ctx->pinned_used;
+            memcpy(stage + ((char *)gs->d_xyz - gs->in_arena.base), xyz, 24 * (size_t)n_items);
+            memcpy(stage + ((char *)gs->d_radii - gs->in_arena.base), radii, 4 * (size_t)n_items);
+            memcpy(stage + ((char *)gs->d_item_group - gs->in_arena.base), item_group.data(), 4 * (size_t)n_items);
+            HIP_TRY(ctx, hipMemcpyAsync(gs->in_arena.base, stage, block, hipMemcpyHostToDevice, st));
+            ctx->pinned_used += need;
             return group_bounds(m, gs, n_items, n_groups, true, totals);
         }
     }
