@@ -44,6 +44,8 @@ struct pdbeda_ctx {
     size_t pool_cap = (size_t)24 << 30; // ... trimmed (largest first) beyond this (PDBEDA_POOL_CAP_MB): streams x live lists x multi-GB
                                         // whole-map arenas must not creep up on the 288 GB until hipMalloc fails
     double *partials = nullptr;         // reduction partials (N_PARTIAL doubles) + 4 result slots
+    char *dev_stage = nullptr;          // device staging block of d2h_many (results packed by k_pack, one copy to the host); handed out until the next ctx_sync
+    size_t dev_stage_cap = 0, dev_stage_used = 0;
     // device -> host results are staged through pinned memory: the copies are truly asynchronous (a copy into pageable
     // memory blocks inside the runtime, where no watchdog can see it) and land in the caller's buffers when ctx_sync()
     // has seen the stream drain
@@ -98,6 +100,7 @@ static void ctx_release_device(pdbeda_ctx *ctx, bool lent_too) {
         ctx->lent.clear();
     }
     if (ctx->partials) (void)hipFree(ctx->partials);
+    if (ctx->dev_stage) (void)hipFree(ctx->dev_stage);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->ring_stream) (void)hipStreamDestroy(ctx->ring_stream);
     if (ctx->ring_joined) (void)hipEventDestroy(ctx->ring_joined);
@@ -207,7 +210,7 @@ static int fail(pdbeda_ctx *ctx, int code, const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (ctx) { ctx->pending.clear(); ctx->pinned_used = 0; }   // results of a failed call are never delivered
+    if (ctx) { ctx->pending.clear(); ctx->pinned_used = 0; ctx->dev_stage_used = 0; }   // results of a failed call are never delivered
     if (ctx && ctx->timed_out) return PDBEDA_ERR_TIMEOUT;   // (the watchdog's message stays)
     if (ctx) ctx->err = buf;
     return code;
@@ -245,6 +248,7 @@ static hipError_t ctx_sync(pdbeda_ctx *ctx) {
         for (const auto &p : ctx->pending) memcpy(p.dst, ctx->pinned + p.off, p.bytes);
     ctx->pending.clear();
     ctx->pinned_used = 0;
+    ctx->dev_stage_used = 0;
     return e;
 }
 
@@ -355,6 +359,50 @@ static inline unsigned grid_for(int64_t n, int block, int64_t cap = 1 << 20) {
     return (unsigned)g;
 }
 
+// Several results of one call, complete after the next ctx_sync(): packed on the device (k_pack) and brought over in ONE copy
+// when they fit the staging blocks, else one by one (d2h).  Items with a null destination or no bytes are skipped.
+struct D2HItem { void *dst; const void *src; size_t bytes; };
+static hipError_t d2h_many(pdbeda_ctx *ctx, const D2HItem *items, int n_items) {
+    int live[8], n = 0;
+    size_t total = 0;
+    bool packable = ctx->dev_stage != nullptr && ctx->pinned != nullptr;
+    for (int k = 0; k < n_items; ++k) {
+        if (!items[k].dst || items[k].bytes == 0) continue;
+        if (n == 8 || (items[k].bytes & 3u) || ((uintptr_t)items[k].src & 3u)) { packable = false; break; }
+        live[n++] = k;
+        total += (items[k].bytes + 63) & ~(size_t)63;
+    }
+    if (packable && n >= 2 && ctx->dev_stage_used + total <= ctx->dev_stage_cap && ctx->pinned_used + total <= ctx->pinned_cap) {
+        PackArgs a;
+        memset(&a, 0, sizeof a);
+        a.n = n;
+        size_t off = 0, words = 0;
+        for (int j = 0; j < n; ++j) {
+            const D2HItem &it = items[live[j]];
+            a.seg[j].src = reinterpret_cast<const uint32_t *>(it.src);
+            a.seg[j].words = it.bytes / 4;
+            a.seg[j].dst_word = off / 4;
+            ctx->pending.push_back({it.dst, ctx->pinned_used + off, it.bytes});
+            off += (it.bytes + 63) & ~(size_t)63;
+            words = std::max<size_t>(words, it.bytes / 4);
+        }
+        char *block = ctx->dev_stage + ctx->dev_stage_used;
+        hipLaunchKernelGGL(k_pack, dim3(grid_for((int64_t)words, 256, 256)), dim3(256), 0, ctx->stream, a, reinterpret_cast<uint32_t *>(block));
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + ctx->pinned_used, block, total, hipMemcpyDeviceToHost, ctx->stream);
+        if (e != hipSuccess) { for (int j = 0; j < n; ++j) ctx->pending.pop_back(); return e; }
+        ctx->dev_stage_used += total;
+        ctx->pinned_used += total;
+        return hipSuccess;
+    }
+    for (int k = 0; k < n_items; ++k) {
+        if (!items[k].dst || items[k].bytes == 0) continue;
+        const hipError_t e = d2h(ctx, items[k].dst, items[k].src, items[k].bytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 // ------------------------------------------------------------------------------------
 // Small batched helpers: stage host arrays through a scratch arena
 // ------------------------------------------------------------------------------------
@@ -409,6 +457,7 @@ extern "C" int pdbeda_ctx_create_on_stream(int device_id, void *hip_stream, pdbe
         return PDBEDA_ERR_MEMORY;
     }
     if (hipHostMalloc((void **)&ctx->pinned, 4 << 20, hipHostMallocDefault) == hipSuccess) ctx->pinned_cap = 4 << 20;   // (without it results are copied directly)
+    if (ctx->pinned_cap && hipMalloc((void **)&ctx->dev_stage, 2 << 20) == hipSuccess) ctx->dev_stage_cap = 2 << 20; else { ctx->dev_stage = nullptr; (void)hipGetLastError(); }
     if (const char *v = getenv("PDBEDA_DEBUG_POISON")) ctx->debug_poison = v[0] && v[0] != '0';
     if (const char *v = getenv("PDBEDA_DEBUG_SHRINK_TOTALS")) ctx->debug_shrink_totals = v[0] && v[0] != '0';
     if (const char *v = getenv("PDBEDA_DEBUG_EDGE_CAP")) ctx->debug_edge_cap = atoll(v);
@@ -1386,13 +1435,11 @@ extern "C" int pdbeda_bloblist_stats(pdbeda_bloblist *bl, int64_t *n, double *to
     const Job &job = bl->job;
     const int64_t lo = bl->rank_lo, cnt = bl->rank_hi - bl->rank_lo;
     if (cnt == 0) return PDBEDA_OK;
-    if (n) HIP_TRY(ctx, d2h(ctx, n, job.b_n + lo, 8 * cnt));
-    if (total_density) HIP_TRY(ctx, d2h(ctx, total_density, job.b_total + lo, 8 * cnt));
-    if (centroid) HIP_TRY(ctx, d2h(ctx, centroid, job.b_centroid + 3 * lo, 24 * cnt));
-    if (coord_center) HIP_TRY(ctx, d2h(ctx, coord_center, job.b_center + 3 * lo, 24 * cnt));
-    if (volume) HIP_TRY(ctx, d2h(ctx, volume, job.b_volume + lo, 8 * cnt));
-    if (first_key) HIP_TRY(ctx, d2h(ctx, first_key, job.b_key + lo, 8 * cnt));
-    if (group) HIP_TRY(ctx, d2h(ctx, group, job.b_group + lo, 4 * cnt));
+    const D2HItem columns[7] = {{n, job.b_n + lo, (size_t)(8 * cnt)}, {total_density, job.b_total + lo, (size_t)(8 * cnt)},
+                                {centroid, job.b_centroid + 3 * lo, (size_t)(24 * cnt)}, {coord_center, job.b_center + 3 * lo, (size_t)(24 * cnt)},
+                                {volume, job.b_volume + lo, (size_t)(8 * cnt)}, {first_key, job.b_key + lo, (size_t)(8 * cnt)},
+                                {group, job.b_group + lo, (size_t)(4 * cnt)}};
+    HIP_TRY(ctx, d2h_many(ctx, columns, 7));      // (packed on the device: one copy instead of seven)
     HIP_TRY(ctx, ctx_sync(ctx));
     return PDBEDA_OK;
 }
@@ -1411,11 +1458,9 @@ static int list_stats_one_trip(pdbeda_bloblist *bl, int64_t guess, std::vector<i
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         n.resize((size_t)guess); tot.resize((size_t)guess); cen.resize(3 * (size_t)guess); grp.resize((size_t)guess);
         Counters ctr;
-        HIP_TRY(ctx, d2h(ctx, &ctr, job.ctr, sizeof ctr));
-        HIP_TRY(ctx, d2h(ctx, n.data(), job.b_n, 8 * guess));
-        HIP_TRY(ctx, d2h(ctx, tot.data(), job.b_total, 8 * guess));
-        HIP_TRY(ctx, d2h(ctx, cen.data(), job.b_centroid, 24 * guess));
-        HIP_TRY(ctx, d2h(ctx, grp.data(), job.b_group, 4 * guess));
+        const D2HItem parts[5] = {{&ctr, job.ctr, sizeof ctr}, {n.data(), job.b_n, (size_t)(8 * guess)}, {tot.data(), job.b_total, (size_t)(8 * guess)},
+                                  {cen.data(), job.b_centroid, (size_t)(24 * guess)}, {grp.data(), job.b_group, (size_t)(4 * guess)}};
+        HIP_TRY(ctx, d2h_many(ctx, parts, 5));
         HIP_TRY(ctx, ctx_sync(ctx));
         if (ctr.unit_wait_failed) return fail(ctx, PDBEDA_ERR_DEVICE, "sphere batch: the device's volumes outgrew what the host sized the job for");
         bl->rank_lo = 0; bl->rank_hi = ctr.n_blobs; bl->job_blobs = ctr.n_blobs; bl->have_counts = true;
@@ -1794,13 +1839,13 @@ extern "C" int pdbeda_region_sums(pdbeda_map *m, const double *xyz, const float 
     }
     std::vector<unsigned long long> h_cnt(n_groups);
     std::vector<unsigned int> h_inv(n_groups);
-    if (e == hipSuccess && pos) e = d2h(ctx, pos, d_pos, 8 * n_groups);
-    if (e == hipSuccess && neg) e = d2h(ctx, neg, d_neg, 8 * n_groups);
-    if (e == hipSuccess) e = d2h(ctx, h_cnt.data(), d_cnt, 8 * n_groups);
-    if (e == hipSuccess) e = d2h(ctx, h_inv.data(), d_inv, 4 * n_groups);
     Counters setup;
     memset(&setup, 0, sizeof setup);
-    if (e == hipSuccess && gs.host_totals) e = d2h(ctx, &setup, gs.d_ctr, sizeof setup);
+    if (e == hipSuccess) {
+        const D2HItem parts[5] = {{pos, d_pos, (size_t)(8 * n_groups)}, {neg, d_neg, (size_t)(8 * n_groups)}, {h_cnt.data(), d_cnt, (size_t)(8 * n_groups)},
+                                  {h_inv.data(), d_inv, (size_t)(4 * n_groups)}, {gs.host_totals ? &setup : nullptr, gs.d_ctr, sizeof setup}};
+        e = d2h_many(ctx, parts, 5);
+    }
     if (e == hipSuccess) e = ctx_sync(ctx);
     arena_put(ctx, a);
     arena_put(ctx, gs.in_arena);

@@ -1125,6 +1125,20 @@ __global__ void __launch_bounds__(256) k_voxel_lists(Job job, const int64_t *__r
     }
 }
 
+// Several small result arrays packed into one block of a device staging buffer, so that ONE copy brings them to the host: every
+// device -> host copy is a launch of the runtime's own on the stream (~5 us + the gap), and an accessor that returns seven columns
+// of a blob table paid seven of them (round 4: 52 of an analysis entry's 114 launches were such copies).  Sizes and offsets are
+// multiples of 4 bytes.
+struct PackSeg { const uint32_t *src; unsigned long long words, dst_word; };
+struct PackArgs { PackSeg seg[8]; int n; };
+__global__ void __launch_bounds__(256) k_pack(PackArgs a, uint32_t *__restrict__ dst) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x, t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int s = 0; s < a.n; ++s) {
+        const PackSeg sg = a.seg[s];
+        for (unsigned long long i = t; i < sg.words; i += stride) dst[sg.dst_word + i] = sg.src[i];
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // Sphere batches (getSphereCrsFromXyz, cutils.pyx:220-248).
 // ------------------------------------------------------------------------------------
