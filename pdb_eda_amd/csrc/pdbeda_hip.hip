@@ -359,6 +359,36 @@ static inline unsigned grid_for(int64_t n, int block, int64_t cap = 1 << 20) {
     return (unsigned)g;
 }
 
+// Several small inputs that sit in a row in device scratch (consecutive Carver takes), in ONE copy: laid out in the pinned
+// staging block as on the device; one by one from the caller's memory when the block has no room (the caller waits before it
+// returns either way).
+struct H2DItem { void *dst; const void *src; size_t bytes; };
+static hipError_t h2d_row(pdbeda_ctx *ctx, const H2DItem *items, int n) {
+    char *lo = nullptr, *hi = nullptr;
+    for (int k = 0; k < n; ++k) {
+        if (items[k].bytes == 0) continue;
+        char *d = (char *)items[k].dst;
+        if (!lo || d < lo) lo = d;
+        if (!hi || d + items[k].bytes > hi) hi = d + items[k].bytes;
+    }
+    if (!lo) return hipSuccess;
+    const size_t span = (size_t)(hi - lo), need = (span + 63) & ~(size_t)63;
+    if (ctx->pinned && span <= (256u << 10) && ctx->pinned_used + need <= ctx->pinned_cap) {
+        char *stage = ctx->pinned + ctx->pinned_used;
+        for (int k = 0; k < n; ++k)
+            if (items[k].bytes) memcpy(stage + ((char *)items[k].dst - lo), items[k].src, items[k].bytes);
+        const hipError_t e = hipMemcpyAsync(lo, stage, span, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) ctx->pinned_used += need;
+        return e;
+    }
+    for (int k = 0; k < n; ++k) {
+        if (items[k].bytes == 0) continue;
+        const hipError_t e = hipMemcpyAsync(items[k].dst, items[k].src, items[k].bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 // Several results of one call, complete after the next ctx_sync(): packed on the device (k_pack) and brought over in ONE copy
 // when they fit the staging blocks, else one by one (d2h).  Items with a null destination or no bytes are skipped.
 struct D2HItem { void *dst; const void *src; size_t bytes; };
@@ -889,13 +919,13 @@ static int reduce_launch(pdbeda_map *m, int mode, const double *mean_dev, double
 // every run).  range_enqueue + range_apply: the pass rides in the same wait as the map's mean / std when those are asked for
 // first (pdbeda_map_stats: every DensityMatrix asks at once) -- a wait of its own in front of the map's first labelling job was
 // one of an entry's ~17 host round trips (round 4).
-static int range_enqueue(pdbeda_map *m, double *range_host /* [2], filled at the next ctx_sync */) {
+static int range_enqueue(pdbeda_map *m, double *range_host /* [2], filled at the next ctx_sync; nullptr: the caller copies the result slots itself */) {
     pdbeda_ctx *ctx = m->ctx;
     double *res = ctx->partials + 2 * N_PARTIAL + 4;
     { PROF(ctx, "k_range_partials"); hipLaunchKernelGGL(k_range_partials, dim3(N_PARTIAL), dim3(256), 0, ctx->stream, m->dens, m->n_vox, ctx->partials, ctx->partials + N_PARTIAL); }
     hipLaunchKernelGGL(k_range_final, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, ctx->partials + N_PARTIAL, N_PARTIAL, res);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, d2h(ctx, range_host, res, 2 * sizeof(double)));
+    if (range_host) HIP_TRY(ctx, d2h(ctx, range_host, res, 2 * sizeof(double)));
     return 0;
 }
 static void range_apply(pdbeda_map *m, const double range[2]) {
@@ -940,7 +970,9 @@ extern "C" int pdbeda_map_invalidate(pdbeda_map *m) {
 // chunk_sums: 8 * max(n_vox / NP_CHUNK, 1) bytes of device scratch; host[2] / range[2] are filled at the next ctx_sync.
 static int stats_enqueue(pdbeda_map *m, double *chunk_sums, double host[2], double range[2], bool want_range) {
     pdbeda_ctx *ctx = m->ctx;
-    double *res = ctx->partials + N_PARTIAL;
+    // (mean / std in the first two of the eight result slots behind the partial sums, the range in slots 4 / 5: with the range
+    //  pass behind them, ONE copy of six doubles brings both)
+    double *res = ctx->partials + 2 * N_PARTIAL;
     const int64_t n_full = m->n_vox / NP_CHUNK;
     hipStream_t st = ctx->stream;
     for (int mode = 0; mode < 2; ++mode) {
@@ -948,9 +980,22 @@ static int stats_enqueue(pdbeda_map *m, double *chunk_sums, double host[2], doub
         { PROF(ctx, "k_np_final"); hipLaunchKernelGGL(k_np_final, dim3(1), dim3(256), 0, st, m->dens, m->n_vox, n_full, mode, res, chunk_sums, mode, res + mode); }
     }
     HIP_TRY(ctx, hipGetLastError());
+    if (!want_range) {
+        HIP_TRY(ctx, d2h(ctx, host, res, 2 * sizeof(double)));
+        return 0;
+    }
+    const int rc_range = range_enqueue(m, nullptr);
+    if (rc_range) return rc_range;
+    // one copy of the six doubles into the staging block, delivered to the caller's two arrays at the next ctx_sync
+    if (ctx->pinned && ctx->pinned_used + 64 <= ctx->pinned_cap) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + ctx->pinned_used, res, 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        ctx->pending.push_back({host, ctx->pinned_used, 2 * sizeof(double)});
+        ctx->pending.push_back({range, ctx->pinned_used + 4 * sizeof(double), 2 * sizeof(double)});
+        ctx->pinned_used += 64;
+        return 0;
+    }
     HIP_TRY(ctx, d2h(ctx, host, res, 2 * sizeof(double)));
-    // (behind the copy of the two results: the range pass reuses the partial sums' memory)
-    if (want_range) { const int rc_range = range_enqueue(m, range); if (rc_range) return rc_range; }
+    HIP_TRY(ctx, d2h(ctx, range, res + 4, 2 * sizeof(double)));
     return 0;
 }
 
@@ -1732,12 +1777,12 @@ static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, con
     }
     if (n_items > 0) {
         if (xyz) {
-            HIP_TRY(ctx, hipMemcpyAsync(gs->d_xyz, xyz, 24 * n_items, hipMemcpyHostToDevice, st));
-            HIP_TRY(ctx, hipMemcpyAsync(gs->d_radii, radii, 4 * n_items, hipMemcpyHostToDevice, st));
+            const H2DItem in[3] = {{gs->d_xyz, xyz, (size_t)(24 * n_items)}, {gs->d_radii, radii, (size_t)(4 * n_items)}, {gs->d_item_group, item_group.data(), (size_t)(4 * n_items)}};
+            HIP_TRY(ctx, h2d_row(ctx, in, 3));       // (a row at the head of the scratch arena: one copy)
         } else {
             HIP_TRY(ctx, hipMemcpyAsync(gs->d_crs, crs, 12 * n_items, hipMemcpyHostToDevice, st));
+            HIP_TRY(ctx, hipMemcpyAsync(gs->d_item_group, item_group.data(), 4 * n_items, hipMemcpyHostToDevice, st));
         }
-        HIP_TRY(ctx, hipMemcpyAsync(gs->d_item_group, item_group.data(), 4 * n_items, hipMemcpyHostToDevice, st));
     }
     return group_bounds(m, gs, n_items, n_groups, xyz != nullptr);   // (synchronises: item_group may go)
 }
@@ -1917,11 +1962,10 @@ extern "C" int pdbeda_symmetry_atoms(pdbeda_ctx *ctx, const double *xyz, int64_t
         int64_t *d_picked = cv.take<int64_t>(total);
         double *d_out = cv.take<double>(3 * total);
         hipStream_t st = ctx->stream;
-        HIP_TRY(ctx, hipMemcpyAsync(d_xyz, xyz, 24 * n_atoms, hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(d_rot, rot, 96 * n_ops, hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(d_ortho, ortho, 72, hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(d_lo, bbox_lo, 24, hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(d_hi, bbox_hi, 24, hipMemcpyHostToDevice, st));
+        {
+            const H2DItem in[5] = {{d_xyz, xyz, (size_t)(24 * n_atoms)}, {d_rot, rot, (size_t)(96 * n_ops)}, {d_ortho, ortho, 72}, {d_lo, bbox_lo, 24}, {d_hi, bbox_hi, 24}};
+            HIP_TRY(ctx, h2d_row(ctx, in, 5));      // (one copy: the five sit in a row)
+        }
         { PROF(ctx, "k_symmetry_keep"); hipLaunchKernelGGL(k_symmetry_keep, dim3(grid_for(total, 256)), dim3(256), 0, st, d_xyz, n_atoms, d_rot, (int)n_ops, d_ortho, d_lo, d_hi, d_keep); }
         HIP_TRY(ctx, d2h(ctx, h_keep.data(), d_keep, 8 * n_words));
         HIP_TRY(ctx, ctx_sync(ctx));
@@ -1961,8 +2005,10 @@ extern "C" int pdbeda_nearest_atom(pdbeda_ctx *ctx, const double *centroids, int
         int64_t *d_i = cv.take<int64_t>(n_centroids);
         double *d_d = cv.take<double>(n_centroids);
         hipStream_t st = ctx->stream;
-        HIP_TRY(ctx, hipMemcpyAsync(d_c, centroids, 24 * n_centroids, hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(d_a, atom_xyz, 24 * n_atoms, hipMemcpyHostToDevice, st));
+        {
+            const H2DItem in[2] = {{d_c, centroids, (size_t)(24 * n_centroids)}, {d_a, atom_xyz, (size_t)(24 * n_atoms)}};
+            HIP_TRY(ctx, h2d_row(ctx, in, 2));
+        }
         hipLaunchKernelGGL(k_nearest_atom, dim3((unsigned)n_centroids), dim3(256), 0, st, d_c, d_a, n_atoms, d_i, d_d);
         HIP_TRY(ctx, d2h(ctx, index, d_i, 8 * n_centroids));
         HIP_TRY(ctx, d2h(ctx, distance, d_d, 8 * n_centroids));
