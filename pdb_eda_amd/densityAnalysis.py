@@ -185,6 +185,44 @@ def _lastWithSameCoord(coord32):
     return alias
 
 
+_pairTableCache = collections.OrderedDict()
+
+
+def _pairTables(names, n_pairs):
+    """What the parameter tables say about a structure's distinct 'RES_ATOM' names (``structure.Columns.pair_names``): atom type,
+    electrons, and the bonded names that exist among them (densityAnalysis.py:617-621, 653-656), as arrays over the names.
+    Entries of one run share their names (the same residues with the same atoms, met in the same order) and the tables are the
+    same objects from entry to entry, so the answer is kept per (names, tables): a few dict look-ups per entry instead of a
+    Python loop over ~160 names and their bonded lists."""
+    typeMap, electronsMap, bonded = fullAtomNameMapAtomTypeGlobal, fullAtomNameMapElectronsGlobal, bondedAtomsGlobal
+    key = (tuple(names), id(typeMap), id(electronsMap), id(bonded))
+    hit = _pairTableCache.get(key)
+    if hit is not None and hit["tables"][0] is typeMap and hit["tables"][1] is electronsMap and hit["tables"][2] is bonded:
+        _pairTableCache.move_to_end(key)
+        return hit
+    known = np.fromiter((name in typeMap for name in names), dtype=bool, count=len(names))
+    pair_id = {name: k for k, name in enumerate(names)}
+    pair_type = [typeMap[name] if name in typeMap else None for name in names] + [None] * (n_pairs - len(names))
+    electrons = np.full(n_pairs, np.nan)
+    nb_off = np.zeros(n_pairs + 1, dtype=np.int64)
+    nb = []
+    for k, name in enumerate(names):
+        if name in electronsMap:
+            electrons[k] = electronsMap[name]
+        nb.extend(pair_id[other] for other in bonded.get(name, ()) if other in pair_id)
+        nb_off[k + 1] = len(nb)
+    nb_off[len(names) + 1:] = len(nb)
+    type_names = sorted({t for t in pair_type if t is not None})
+    type_id = {t: k for k, t in enumerate(type_names)}
+    pair_type_id = np.asarray([type_id[t] if t is not None else -1 for t in pair_type], dtype=np.int64)
+    hit = {"tables": (typeMap, electronsMap, bonded), "known": known, "pair_type": pair_type, "pair_type_id": pair_type_id, "type_names": type_names,
+           "electrons": electrons, "nb_off": nb_off, "nb": np.asarray(nb, dtype=np.int64)}
+    _pairTableCache[key] = hit
+    while len(_pairTableCache) > 32:
+        _pairTableCache.popitem(last=False)
+    return hit
+
+
 class _SymAtomList(object):
     """The list of SymAtom objects createSymmetryAtoms returns (cutils.pyx:73-103), materialised item by item; the tables that
     list thousands of them read whole columns instead (``columns``)."""
@@ -381,7 +419,7 @@ class DensityAnalysis(object):
         typeMap, electronsMap = fullAtomNameMapAtomTypeGlobal, fullAtomNameMapElectronsGlobal
         names = cols.pair_names
         n_pairs = max(len(names), 1)
-        known = np.fromiter((name in typeMap for name in names), dtype=bool, count=len(names))
+        known = _pairTables(names, n_pairs)["known"]
         plain = ~cols.res_het                                                      # residues with id[0] == ' ' (596)
         ordinal = np.cumsum(plain) - 1                                             # their running number
         child = np.nonzero(plain[cols.res_of_atom])[0]                             # EVERY child atom of those residues, in order
@@ -406,22 +444,12 @@ class DensityAnalysis(object):
         # allAtomClouds is keyed by the coordinate: the last atom with the same float32 triple wins (604)
         alias = _lastWithSameCoord(cols.coord32[sel])
         # the pair tables: type, electrons, radius, and the bonded names that exist in this structure
-        used = set(np.unique(pair_of).tolist())
-        pair_id = {name: k for k, name in enumerate(names)}
-        pair_electrons = np.zeros(n_pairs)
-        pair_type = [None] * n_pairs
-        nb_off = np.zeros(n_pairs + 1, dtype=np.int64)
-        nb = []
-        for k in range(len(names)):
-            if known[k]:
-                pair_type[k] = typeMap[names[k]]
-        for k in used:
-            pair_electrons[k] = electronsMap[names[k]]
-        for k in range(len(names)):
-            if k in used:
-                nb.extend(pair_id[other] for other in bondedAtomsGlobal[names[k]] if other in pair_id)
-            nb_off[k + 1] = len(nb)
-        nb = np.asarray(nb, dtype=np.int64)
+        used = np.unique(pair_of)
+        tables = _pairTables(names, n_pairs)
+        pair_type, pair_type_id, type_names, nb_off, nb = tables["pair_type"], tables["pair_type_id"], tables["type_names"], tables["nb_off"], tables["nb"]
+        pair_electrons = tables["electrons"]
+        if len(used) and np.isnan(pair_electrons[used]).any():     # (the reference's electronsMap[name] raises the same KeyError)
+            raise KeyError(names[int(used[np.isnan(pair_electrons[used])][0])])
         # bonded keys of every key, in key order then table order
         key_code = distinct[by_first]
         key_res, key_pair = key_code // n_pairs, key_code % n_pairs
@@ -432,11 +460,8 @@ class DensityAnalysis(object):
         bonded_off = np.concatenate([[0], np.cumsum(np.bincount(owner[found], minlength=len(key_code)))]).astype(np.int64)
         # owners of the completeness count: every child atom whose (residue, name) has a key (653-656)
         found, owner_key = key_lookup(child_res * n_pairs + child_pair)
-        type_names = sorted({t for t in pair_type if t is not None})
-        type_id = {t: k for k, t in enumerate(type_names)}
-        pair_type_id = np.asarray([type_id[t] if t is not None else -1 for t in pair_type] + [-1] * (n_pairs - len(pair_type)), dtype=np.int64)
         return {"cols": cols, "rows": sel, "plain_residues": np.nonzero(plain)[0], "xyz": cols.coord[sel], "occupancy": cols.occupancy[sel],
-                "electrons": pair_electrons[pair_of], "used_pairs": sorted(used), "pair": pair_of, "pair_type": pair_type,
+                "electrons": pair_electrons[pair_of], "used_pairs": used.tolist(), "pair": pair_of, "pair_type": pair_type,
                 "residue": residue_of.astype(np.int32), "alias": alias.astype(np.int32), "key": key_of.astype(np.int32),
                 "bonded_off": bonded_off, "bonded": bonded.astype(np.int32), "owner_key": owner_key.astype(np.int32),
                 "owner_type_id": pair_type_id[child_pair[found]], "type_names": type_names, "pair_type_id": pair_type_id}
