@@ -10,6 +10,7 @@
 #include <Python.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 static PyObject *s_parent, *s_id, *s_resname, *s_child_list, *s_name, *s_occupancy, *s_bfactor, *s_coord, *s_space;
@@ -161,9 +162,146 @@ fail:
     return NULL;
 }
 
+/* ---- cloud_inputs: the index work of densityAnalysis._cloudInputsFixed (ref densityAnalysis.py:596-604, 617-621, 653-656) ----
+ * In: res_of_atom int64[n], pair_of_atom int64[n], res_plain uint8[n_res] (residue.id[0] == ' '), known uint8[n_pairs] (the name has
+ * an atom type), occupancy float64[n], coord32 float32[3 n], nb_off int64[n_pairs + 1] / nb int64[] (bonded names of a name, as
+ * pair ids).  Out (bytearrays): rows int64 (the eligible atoms, in order), residue int32 (running number of the plain residue),
+ * pair int64, key int32 ((residue, name) numbered by first appearance), alias int32 (last eligible atom with the same float32
+ * coordinate), bonded_off int64[n_keys + 1], bonded int32, owner_key int32 / owner_pair int64 (every child atom of a plain
+ * residue whose (residue, name) has a key), plain_residues int64.  tests/test_cloud_inputs.py holds it against the plain walk. */
+typedef struct { int64_t *key; int32_t *val; size_t cap; } Map64;
+static int map_init(Map64 *m, size_t n) {
+    size_t cap = 16;
+    while (cap < 2 * n + 8) cap <<= 1;
+    m->cap = cap;
+    m->key = (int64_t *)malloc(cap * sizeof(int64_t));
+    m->val = (int32_t *)malloc(cap * sizeof(int32_t));
+    if (!m->key || !m->val) { free(m->key); free(m->val); m->key = NULL; m->val = NULL; return -1; }
+    for (size_t i = 0; i < cap; ++i) m->key[i] = INT64_MIN;
+    return 0;
+}
+static void map_free(Map64 *m) { free(m->key); free(m->val); }
+static inline size_t map_slot(const Map64 *m, int64_t k) {
+    size_t h = (size_t)((uint64_t)k * 0x9E3779B97F4A7C15ull) & (m->cap - 1);
+    while (m->key[h] != INT64_MIN && m->key[h] != k) h = (h + 1) & (m->cap - 1);
+    return h;
+}
+typedef struct { float c[3]; } Tri;
+static inline uint64_t tri_hash(const float *c) {
+    uint32_t b[3];
+    for (int q = 0; q < 3; ++q) { float v = c[q] + 0.0f; memcpy(&b[q], &v, 4); }      /* (+0.0: -0.0 and 0.0 are one key, as for a tuple of floats) */
+    return (((uint64_t)b[0] << 32) | b[1]) * 0x9E3779B97F4A7C15ull ^ ((uint64_t)b[2] * 0xC2B2AE3D27D4EB4Full);
+}
+static inline int tri_equal(const float *a, const float *b) { return a[0] == b[0] && a[1] == b[1] && a[2] == b[2]; }
+
+static int view_of(PyObject *o, Py_buffer *v, Py_ssize_t itemsize, const char *what) {
+    if (PyObject_GetBuffer(o, v, PyBUF_C_CONTIGUOUS) < 0) return -1;
+    if (v->itemsize != itemsize && v->len != 0) { PyBuffer_Release(v); PyErr_Format(PyExc_TypeError, "%s: item size %zd expected", what, itemsize); return -1; }
+    return 0;
+}
+static PyObject *bytes_of(const void *p, size_t n) { return PyByteArray_FromStringAndSize((const char *)p, (Py_ssize_t)n); }
+
+static PyObject *cloud_inputs(PyObject *self, PyObject *args) {
+    (void)self;
+    PyObject *o[8];
+    if (!PyArg_ParseTuple(args, "OOOOOOOO", &o[0], &o[1], &o[2], &o[3], &o[4], &o[5], &o[6], &o[7])) return NULL;
+    Py_buffer v[8];
+    const Py_ssize_t sizes[8] = {8, 8, 1, 1, 8, 4, 8, 8};
+    const char *names[8] = {"res_of_atom", "pair_of_atom", "res_plain", "known", "occupancy", "coord32", "nb_off", "nb"};
+    int got = 0;
+    for (; got < 8; ++got)
+        if (view_of(o[got], &v[got], sizes[got], names[got]) < 0) { for (int k = 0; k < got; ++k) PyBuffer_Release(&v[k]); return NULL; }
+    PyObject *out = NULL;
+    const int64_t n = v[0].len / 8, n_res = v[2].len, n_pairs = v[3].len;
+    const int64_t *res_of = (const int64_t *)v[0].buf, *pair_of_atom = (const int64_t *)v[1].buf, *nb_off = (const int64_t *)v[6].buf, *nb = (const int64_t *)v[7].buf;
+    const uint8_t *plain = (const uint8_t *)v[2].buf, *known = (const uint8_t *)v[3].buf;
+    const double *occ = (const double *)v[4].buf;
+    const float *xyz = (const float *)v[5].buf;
+    const int64_t np_ = n_pairs > 0 ? n_pairs : 1;
+    int64_t *ordinal = NULL, *rows = NULL, *pair = NULL, *key_code = NULL, *bonded_off = NULL, *owner_pair = NULL, *child_code = NULL, *child_pair = NULL, *plain_res = NULL;
+    int32_t *residue = NULL, *key = NULL, *alias = NULL, *bonded = NULL, *owner_key = NULL;
+    Map64 keys = {NULL, NULL, 0}, coords = {NULL, NULL, 0};
+    if (v[1].len / 8 != n || v[4].len / 8 != n || v[5].len / 12 != n || v[6].len / 8 != n_pairs + 1) { PyErr_SetString(PyExc_ValueError, "cloud_inputs: array lengths do not agree"); goto done; }
+    for (int64_t a = 0; a < n; ++a)
+        if (res_of[a] < 0 || res_of[a] >= n_res || pair_of_atom[a] < 0 || pair_of_atom[a] >= n_pairs) { PyErr_SetString(PyExc_ValueError, "cloud_inputs: index out of range"); goto done; }
+    ordinal = (int64_t *)malloc((size_t)(n_res + 1) * 8); plain_res = (int64_t *)malloc((size_t)(n_res + 1) * 8);
+    rows = (int64_t *)malloc((size_t)(n + 1) * 8); pair = (int64_t *)malloc((size_t)(n + 1) * 8); key_code = (int64_t *)malloc((size_t)(n + 1) * 8);
+    child_code = (int64_t *)malloc((size_t)(n + 1) * 8); child_pair = (int64_t *)malloc((size_t)(n + 1) * 8); owner_pair = (int64_t *)malloc((size_t)(n + 1) * 8);
+    residue = (int32_t *)malloc((size_t)(n + 1) * 4); key = (int32_t *)malloc((size_t)(n + 1) * 4); alias = (int32_t *)malloc((size_t)(n + 1) * 4);
+    owner_key = (int32_t *)malloc((size_t)(n + 1) * 4);
+    if (!ordinal || !plain_res || !rows || !pair || !key_code || !child_code || !child_pair || !owner_pair || !residue || !key || !alias || !owner_key ||
+        map_init(&keys, (size_t)n) < 0 || map_init(&coords, (size_t)n) < 0) { PyErr_NoMemory(); goto done; }
+    {
+        int64_t n_plain = 0, m = 0, n_child = 0, n_keys = 0, n_owner = 0, n_bonded = 0;
+        for (int64_t r = 0; r < n_res; ++r) { ordinal[r] = plain[r] ? n_plain : -1; if (plain[r]) plain_res[n_plain++] = r; }
+        for (int64_t a = 0; a < n; ++a) {
+            const int64_t ri = ordinal[res_of[a]], p = pair_of_atom[a];
+            if (ri < 0) continue;
+            const int64_t code = ri * np_ + p;
+            child_code[n_child] = code; child_pair[n_child] = p; ++n_child;
+            if (!known[p] || occ[a] == 0.0) continue;
+            rows[m] = a; residue[m] = (int32_t)ri; pair[m] = p;
+            const size_t h = map_slot(&keys, code);
+            if (keys.key[h] == INT64_MIN) { keys.key[h] = code; keys.val[h] = (int32_t)n_keys; key_code[n_keys++] = code; }
+            key[m] = keys.val[h];
+            ++m;
+        }
+        /* the last eligible atom of every coordinate: a second table keyed by a hash of the triple, collisions told apart by the values */
+        for (int64_t i = 0; i < m; ++i) {
+            const float *c = xyz + 3 * rows[i];
+            int64_t hk = (int64_t)(tri_hash(c) >> 1);            /* (never INT64_MIN) */
+            for (;; ++hk) {                                        /* linear re-keying on a collision of different triples */
+                const size_t h = map_slot(&coords, hk);
+                if (coords.key[h] == INT64_MIN) { coords.key[h] = hk; coords.val[h] = (int32_t)i; break; }
+                if (tri_equal(xyz + 3 * rows[coords.val[h]], c)) { coords.val[h] = (int32_t)i; break; }
+            }
+        }
+        for (int64_t i = 0; i < m; ++i) {
+            const float *c = xyz + 3 * rows[i];
+            int64_t hk = (int64_t)(tri_hash(c) >> 1);
+            for (;; ++hk) {
+                const size_t h = map_slot(&coords, hk);
+                if (coords.key[h] == INT64_MIN) { alias[i] = (int32_t)i; break; }      /* (cannot happen: the triple was entered above) */
+                if (tri_equal(xyz + 3 * rows[coords.val[h]], c)) { alias[i] = coords.val[h]; break; }
+            }
+        }
+        /* bonded keys of every key, in key order then table order */
+        bonded_off = (int64_t *)malloc((size_t)(n_keys + 1) * 8);
+        if (!bonded_off) { PyErr_NoMemory(); goto done; }
+        int64_t cap_b = 0;
+        for (int64_t k = 0; k < n_keys; ++k) { const int64_t p = key_code[k] % np_; cap_b += nb_off[p + 1] - nb_off[p]; }
+        bonded = (int32_t *)malloc((size_t)(cap_b + 1) * 4);
+        if (!bonded) { PyErr_NoMemory(); goto done; }
+        bonded_off[0] = 0;
+        for (int64_t k = 0; k < n_keys; ++k) {
+            const int64_t ri = key_code[k] / np_, p = key_code[k] % np_;
+            for (int64_t q = nb_off[p]; q < nb_off[p + 1]; ++q) {
+                if (nb[q] < 0 || nb[q] >= n_pairs) { PyErr_SetString(PyExc_ValueError, "cloud_inputs: bonded name out of range"); goto done; }
+                const size_t h = map_slot(&keys, ri * np_ + nb[q]);
+                if (keys.key[h] != INT64_MIN) bonded[n_bonded++] = keys.val[h];
+            }
+            bonded_off[k + 1] = n_bonded;
+        }
+        for (int64_t c = 0; c < n_child; ++c) {
+            const size_t h = map_slot(&keys, child_code[c]);
+            if (keys.key[h] != INT64_MIN) { owner_key[n_owner] = keys.val[h]; owner_pair[n_owner] = child_pair[c]; ++n_owner; }
+        }
+        out = Py_BuildValue("(NNNNNNNNNN)", bytes_of(rows, (size_t)m * 8), bytes_of(residue, (size_t)m * 4), bytes_of(pair, (size_t)m * 8), bytes_of(key, (size_t)m * 4),
+                            bytes_of(alias, (size_t)m * 4), bytes_of(bonded_off, (size_t)(n_keys + 1) * 8), bytes_of(bonded, (size_t)n_bonded * 4),
+                            bytes_of(owner_key, (size_t)n_owner * 4), bytes_of(owner_pair, (size_t)n_owner * 8), bytes_of(plain_res, (size_t)n_plain * 8));
+    }
+done:
+    free(ordinal); free(plain_res); free(rows); free(pair); free(key_code); free(child_code); free(child_pair); free(owner_pair);
+    free(residue); free(key); free(alias); free(owner_key); free(bonded_off); free(bonded);
+    map_free(&keys); map_free(&coords);
+    for (int k = 0; k < 8; ++k) PyBuffer_Release(&v[k]);
+    return out;
+}
+
 static PyMethodDef methods[] = {
     {"residue_columns", residue_columns, METH_O, "residue_columns(residues) -> (model ids, chain ids, numbers, names, hetero flags, child lists)"},
     {"atom_columns", atom_columns, METH_O, "atom_columns(child lists) -> the per-atom columns of structure.Columns"},
+    {"cloud_inputs", cloud_inputs, METH_VARARGS, "cloud_inputs(res_of_atom, pair_of_atom, res_plain, known, occupancy, coord32, nb_off, nb) -> the index arrays of pdbeda_cloud_atoms"},
     {NULL, NULL, 0, NULL}};
 
 static struct PyModuleDef module = {PyModuleDef_HEAD_INIT, "_hostwalk", "one-pass walk of a structure's object tree", -1, methods, NULL, NULL, NULL, NULL};

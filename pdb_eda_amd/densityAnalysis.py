@@ -411,13 +411,34 @@ class DensityAnalysis(object):
         return inp
 
     @staticmethod
-    def _cloudInputsFixed(cols):
+    def _cloudInputsFixed(cols, native=None):
         """Flatten what aggregateCloud reads from the structure (densityAnalysis.py:596-603, 617-621, 653-656) into the arrays
         of ``pdbeda_cloud_atoms``: the eligible atoms in the reference's iteration order, a key per (residue, residue_atom
         name), the bonded-name table restricted to each residue, and the 'owners' of the completeness count.  Works on the
-        columnar snapshot of the structure (``structure.columns``): no per-atom Python."""
-        typeMap, electronsMap = fullAtomNameMapAtomTypeGlobal, fullAtomNameMapElectronsGlobal
+        columnar snapshot of the structure (``structure.columns``): no per-atom Python.  The index work is one pass in C
+        (``_hostwalk.cloud_inputs``: fifty small numpy calls were 0.3 ms of a 2 000-atom entry) with the numpy form below as
+        its fallback and its check (``native``: None = C when built, True / False force one; tests/test_cloud_inputs.py)."""
         names = cols.pair_names
+        walk = _structure._hostwalk() if native is not False else None
+        if walk is None and native:
+            raise ImportError("pdb_eda_amd/_hostwalk.so is not built (python __graft_entry__.py)")
+        if walk is not None and hasattr(walk, "cloud_inputs"):
+            n_pairs = max(len(names), 1)
+            tables = _pairTables(names, n_pairs)
+            known = np.zeros(n_pairs, dtype=np.uint8)
+            known[:len(names)] = tables["known"]
+            out = walk.cloud_inputs(cols.res_of_atom, cols.pair_of_atom, (~cols.res_het).astype(np.uint8), known, cols.occupancy,
+                                    np.ascontiguousarray(cols.coord32), tables["nb_off"], tables["nb"])
+            sel, residue_of, pair_of, key_of, alias, bonded_off, bonded, owner_key, owner_pair, plain_residues = (
+                np.frombuffer(b, dtype=t) for b, t in zip(out, (np.int64, np.int32, np.int64, np.int32, np.int32, np.int64, np.int32, np.int32, np.int64, np.int64)))
+            used = np.unique(pair_of)
+            electrons = tables["electrons"]
+            if len(used) and np.isnan(electrons[used]).any():     # (the reference's electronsMap[name] raises the same KeyError)
+                raise KeyError(names[int(used[np.isnan(electrons[used])][0])])
+            return {"cols": cols, "rows": sel, "plain_residues": plain_residues, "xyz": cols.coord[sel], "occupancy": cols.occupancy[sel],
+                    "electrons": electrons[pair_of], "used_pairs": used.tolist(), "pair": pair_of, "pair_type": tables["pair_type"],
+                    "residue": residue_of, "alias": alias, "key": key_of, "bonded_off": bonded_off, "bonded": bonded, "owner_key": owner_key,
+                    "owner_type_id": tables["pair_type_id"][owner_pair], "type_names": tables["type_names"], "pair_type_id": tables["pair_type_id"]}
         n_pairs = max(len(names), 1)
         known = _pairTables(names, n_pairs)["known"]
         plain = ~cols.res_het                                                      # residues with id[0] == ' ' (596)

@@ -53,11 +53,22 @@ def make_structure(seed, n_res):
     return st
 
 
+@pytest.mark.parametrize("native", [True, False])       # the one pass in C (pdb_eda_amd/_hostwalk.so) and the numpy form it replaces
 @pytest.mark.parametrize("seed,n_res", [(1, 1), (2, 7), (3, 60), (4, 211)])
-def test_cloud_inputs_match_the_plain_walk(seed, n_res):
+def test_cloud_inputs_match_the_plain_walk(seed, n_res, native):
+    import __graft_entry__
+    __graft_entry__.build()
     da.setGlobals(synthetic.synthetic_params())
     st = make_structure(seed, n_res)
+    fixed = da.DensityAnalysis._cloudInputsFixed(structure.columns(st), native=native)
+    if native:          # what the analysis itself takes is the C pass when it is built
+        structure.columns(st).__dict__.pop("_cloud_inputs", None)
     inp = da.DensityAnalysis("t", None, None, st, None)._cloudInputs()
+    for name in ("rows", "residue", "alias", "key", "bonded_off", "bonded", "owner_key", "owner_type_id", "pair", "electrons", "plain_residues"):
+        a, b = np.asarray(fixed[name]), np.asarray(inp[name])
+        assert a.shape == b.shape and (a == b).all(), name
+    inp = dict(inp)
+    inp.update({k: fixed[k] for k in ("rows", "residue", "alias", "key", "bonded_off", "bonded", "owner_key", "owner_type_id", "plain_residues")})
     ref = walk(st)
     cols = inp["cols"]
     assert [cols.atoms[i] for i in inp["rows"].tolist()] == ref["atoms"]
