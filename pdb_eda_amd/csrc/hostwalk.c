@@ -1,5 +1,5 @@
-/* _hostwalk: the walk over a structure's object tree (Bio.PDB's or pdb_eda_amd.structure's) that structure.Columns makes once
- * per entry, as one pass in C.  Host-side plumbing of the analysis (what densityAnalysis.py reads per atom at 596-603, 617-621,
+/* _hostwalk: host-side passes of an entry in C.  (1) The walk over a structure's object tree (Bio.PDB's or pdb_eda_amd.structure's)
+ * that structure.Columns makes once per entry; (2) cloud_inputs, the index work of densityAnalysis._cloudInputsFixed (further down).  Host-side plumbing of the analysis (what densityAnalysis.py reads per atom at 596-603, 617-621,
  * 653-656, 966-971: residue.parent / .id / .resname / .child_list, atom.name / .occupancy / .bfactor / .coord) -- no arithmetic
  * of the path happens here.  structure.Columns falls back to its Python loops when this module is not built or meets an
  * object it does not understand (any exception raised here); tests/test_structure.py holds the two against each other.
