@@ -51,15 +51,16 @@ def test_stream_pool_matches_sequential(gpu_ctx):
 
 
 @pytest.mark.timeout(240)
-@pytest.mark.parametrize("shape", [(40, 48, 256), (24, 40, 600)])       # one tile column; three (the last one partial)
-def test_unit_fallback_on_many_streams(shape):
+@pytest.mark.parametrize("shape,roughness", [((40, 48, 256), 0.5), ((24, 40, 600), 0.5),      # one tile column; three (the last one partial)
+                                             ((40, 48, 256), 1.5)])                                # smooth: dense and wide tiles instead of unit tiles
+def test_unit_fallback_on_many_streams(shape, roughness):
     """Dense maps (tiles overflow LDS -> their workgroups of k_face_merge label them run by run and wait for each other's
     flags, later tiles along r and c included) labelled concurrently on six streams: every stream gets the oracle's answer
     (counts, keys and the label volume) and nobody starves the others of workgroup slots."""
     import io
     from oracle import oracle as ora
     from pdb_eda_amd import ccp4, synthetic, multipleStructures
-    g = synthetic.smooth_noise(shape, 9, 0.5)       # nearly white: ~30 word-runs a mask word, far beyond the 4 096 a tile holds in LDS
+    g = synthetic.smooth_noise(shape, 9, roughness)  # 0.5 = nearly white: ~30 word-runs a mask word, far beyond the 4 096 a tile holds in LDS
     spec = synthetic.MapSpec(ncrs=shape[::-1])
     blob = synthetic.ccp4_bytes(spec, g)
     header = ccp4.DensityHeader.fromFileHeader(blob[:1024])
@@ -75,7 +76,8 @@ def test_unit_fallback_on_many_streams(shape):
             st = green.stats()
             same = np.array_equal(st["n"], want["n"]) and np.array_equal(st["firstKey"], want["firstKey"]) and \
                 np.array_equal(green.labels(dm._map.unique_shape), want["labels"])
-            out.append((same, green.counters()["unit_tiles_runs"] + green.counters()["unit_tiles_comps"]))
+            c = green.counters()
+            out.append((same, c["unit_tiles_runs"] + c["unit_tiles_comps"] if roughness < 1.0 else c["run_ids"]))
         return out
     res = multipleStructures.StreamPool(device=0, n_streams=6).map(work, list(range(12)))
     assert all(r != 0 for r in res)
