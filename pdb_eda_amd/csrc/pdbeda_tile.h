@@ -55,7 +55,6 @@ constexpr int CCAP = 256;   // tile-local components (both signs together) handl
 static_assert(CCAP == TILE_COMPS, "k_emit walks the tiles' component ranges");
 constexpr int VCAP = 3584;  // significant values of a tile parked in LDS: one private region of VCAP / 8 per wave (= section)
 constexpr int FACE_K = 7;    // word-runs of a word whose components k_face_merge finds in the word's byte record (the 8th: by run id)
-constexpr int ECAPW = 384;  // touching run pairs a wave lists before it unites them (the list lives where the component sums go later)
 
 struct TileDims {
     int cw;                       // words per tile along c (1..4)
@@ -247,7 +246,6 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
     static_assert(USEC % CHU == 0 && CHU % CW == 0, "chunks are whole rows");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wvs = __builtin_amdgcn_readfirstlane(wv);
-    const int wvs_edge_base = wvs * ECAPW;
     __shared__ uint64_t s_mask[2][256];
     // one block: the parent table and, behind it, the parked values.  A tile with more than RCAP word-runs (noise below ~1.1
     // sigma: 1 500-2 700 a tile) has sections far too dense to park (VREG values each) and reads its values from L2 in C2
@@ -259,17 +257,20 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
     float *s_val = reinterpret_cast<float *>(s_pv + RCAP);
     // phase B: the waves' edge lists; phase C: the component accumulators (sums relative to the tile origin)
     __shared__ __attribute__((aligned(16))) unsigned char s_blob[CCAP * 48];
-    static_assert(NW * ECAPW * 4 <= CCAP * 48, "the edge lists fit the accumulator block");
     // (integers: multiples of the job's quantum, see FixSums -- LDS atomics fold them in whatever order, the result is the same)
     unsigned long long *s_rho = reinterpret_cast<unsigned long long *>(s_blob), *s_rho_c = s_rho + CCAP, *s_rho_r = s_rho + 2 * CCAP, *s_rho_s = s_rho + 3 * CCAP;
     // integer sums of a component, relative to the tile origin, packed so that a run costs two LDS atomics, not four:
     // s_pk = voxels (20 bits) | sum (r - r0) << 20 (20 bits) | sum (s - s0) << 40;  s_crel = sum (c - c_tile)
     unsigned long long *s_pk = reinterpret_cast<unsigned long long *>(s_rho + 4 * CCAP);
     uint32_t *s_crel = reinterpret_cast<uint32_t *>(s_pk + CCAP), *s_key = s_crel + CCAP;   // s_key: plane << 31 | c-major key inside the plane (min = first voxel)
-    uint32_t *s_edge = reinterpret_cast<uint32_t *>(s_blob) + wvs_edge_base;
     __shared__ __attribute__((aligned(16))) uint32_t s_wtot[NW];   // word-runs of section w (both signs); bit 31: it could not park all its values
     __shared__ uint32_t s_ub[2][256];  // per sign and unit: first parked value of the unit | first word-run of the word << 16
     __shared__ uint32_t s_ncomp;
+    // the union-find NODES (round 5): per sign, 2 x 2 (row, section) group and word, the starts of the word-runs of the OR of the
+    // group's four row masks, and the id of the first of them; s_gtot: nodes of either sign
+    __shared__ uint64_t s_sg[2][64];
+    __shared__ uint16_t s_nb[2][64];
+    __shared__ uint32_t s_gtot[2];
 
     const int uc = td.uc, ur = td.ur, us = td.us;   // (kernel arguments: no dependent load through gp before the stream can start)
     const int nc = td.nc, nr = td.nr;
@@ -397,12 +398,13 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
         else __builtin_amdgcn_s_setprio(0);
     }
 
-    // ---- A2: lane = (sign q, row rl, word wl) of section wvs --------------------------------------------------------
+    // ---- A2: lane = (sign q, row rl, word wl) of section wvs: the word-runs of the ROWS are numbered (ids follow wave, sign, row,
+    //      word): they are what the later kernels look voxels up by, and what C2 sums; the unions no longer run on them ----
     const int q = lane >> 5, usec = lane & 31;
     const bool act = usec < USEC;
     const int rl = usec / CW, wl = usec % CW;
     const int u = wvs * USEC + (act ? usec : 0);
-    uint32_t wbase = 0, n_runs = 0, wprev = 0;
+    uint32_t wbase = 0, n_runs = 0;
     bool from_global = false;
     {   // lanes 0..7 hold the sections' totals: count | overflow << 16 (a tile has < 2^16 word-runs), scanned inside the DPP row
         const uint32_t raw = lane < NW ? s_wtot[lane] : 0u;
@@ -413,11 +415,9 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
         x += dpp0<DPP_ROW_SHR + 4>(x);
         const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)x, NW - 1);
         const uint32_t upto = (uint32_t)__builtin_amdgcn_readlane((int)x, wvs), mine = (uint32_t)__builtin_amdgcn_readlane((int)v, wvs);
-        const uint32_t below = (uint32_t)__builtin_amdgcn_readlane((int)v, wvs > 0 ? wvs - 1 : 0);
         n_runs = all & 0xffffu;
         from_global = (all >> 16) != 0u;
         wbase = (upto - mine) & 0xffffu;
-        wprev = wvs > 0 ? (below & 0xffffu) : 0u;
     }
     const uint64_t m = act ? s_mask[q][u] : 0ull, mo = act ? s_mask[q ^ 1][u] : 0ull;
     // my word
@@ -441,89 +441,101 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
         return;
     }
 
-    // the same word one section below (wave wvs - 1 owns it), and its three neighbours in my own numbering of that section:
-    // every wave numbers the section below exactly as its owner does, so ids never travel between waves
-    const bool sec = wvs > 0;
-    const uint64_t B2 = (act && sec) ? s_mask[q][u - USEC] : 0ull;
-    const uint64_t B0 = (act && rl > 0) ? s_mask[q][u - CW] : 0ull;
-    const uint64_t B1 = (act && sec && rl > 0) ? s_mask[q][u - USEC - CW] : 0ull;
-    const uint64_t B3 = (act && sec && rl < 7) ? s_mask[q][u - USEC + CW] : 0ull;
     const uint64_t SA = run_starts(m);
-    const uint32_t cnt = (uint32_t)popc64(SA), cnt2 = (uint32_t)popc64(run_starts(B2));
-    // one packed scan per half wave: word-runs of my section [0, 11), of the section below [11, 22), parked values [22, 32)
-    const uint32_t packed = cnt | (cnt2 << 11) | ((uint32_t)popc64(m | mo) << 22);
+    // one packed scan per half wave: word-runs of my section [0, 11), parked values [22, 32)
+    const uint32_t packed = (uint32_t)popc64(SA) | ((uint32_t)popc64(m | mo) << 22);
     const uint32_t incl = half_scan(packed), excl = incl - packed;
     const uint32_t half0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);   // totals of the sign-0 lanes
     const uint32_t my_base = wbase + (q ? (half0 & 0x7ffu) : 0u) + (excl & 0x7ffu);                         // id of my first run
-    const uint32_t base2 = wbase - wprev + (q ? ((half0 >> 11) & 0x7ffu) : 0u) + ((excl >> 11) & 0x7ffu);   // ... of B2's first run
     const uint32_t vb = (uint32_t)wvs * VREG + (excl >> 22);   // my unit's first parked value (both sign lanes of a unit agree)
-    const uint32_t base0 = (uint32_t)__shfl((int)my_base, lane - CW), base1 = (uint32_t)__shfl((int)base2, lane - CW),
-                   base3 = (uint32_t)__shfl((int)base2, lane + CW);
 
-    // ---- B: touching pairs -> unions.  Between my word A and a neighbour row's word B (same word index; the bit
-    // below bit 0 comes from the words to the left), a pair of runs is charged to the later of its two starts:
-    //   EA = starts(A) & (B | B << 1): my run starts at p and B covers p or p - 1 (that run started no later than p)
-    //   EB = starts(B) & (A << 1):     B's run starts at p and my row covers p - 1 (my run started earlier)
-    // -- every touching pair of ROW runs appears exactly once; word-runs that continue across a word boundary add
-    // harmless repeats.  Ids of a row are consecutive, so "the run to the left of bit 0" is simply base - 1.
-    {
-        // (cross-lane reads sit outside every conditional: a masked-off source lane would read as zero)
-        const uint32_t upA = dpp0<DPP_WAVE_SHR1>((uint32_t)(m >> 32));
-        const uint32_t cA = wl > 0 ? upA >> 31 : 0u;   // bit 63 of the word to my left
-        const uint64_t A1s = (m << 1) | cA;
-        const uint32_t up0 = dpp0<DPP_WAVE_SHR1>((uint32_t)(B0 >> 32)), up1 = dpp0<DPP_WAVE_SHR1>((uint32_t)(B1 >> 32)),
-                       up2 = dpp0<DPP_WAVE_SHR1>((uint32_t)(B2 >> 32)), up3 = dpp0<DPP_WAVE_SHR1>((uint32_t)(B3 >> 32));
-        const uint64_t SB0 = run_starts(B0), SB1 = run_starts(B1), SB2 = run_starts(B2), SB3 = run_starts(B3);
-        auto pairs = [&](uint64_t B, uint64_t SB, uint32_t up) { return (SA & (B | (B << 1) | (wl > 0 ? up >> 31 : 0u))) | (SB & A1s); };   // EA and EB are disjoint
-        // A pair with the row diagonally below (B1, B3) is implied wherever the row straight below (B2) has a voxel at p or p - 1:
-        // that voxel touches both runs of the pair, and its own pairs with them are of the kinds that are never dropped.
-        const uint64_t keep = ~(B2 | (B2 << 1) | (wl > 0 ? up2 >> 31 : 0u));
-        const uint64_t E0 = pairs(B0, SB0, up0), E1 = pairs(B1, SB1, up1) & keep, E2 = pairs(B2, SB2, up2), E3 = pairs(B3, SB3, up3) & keep;
-        const bool same_row = (m & 1ull) && cA;   // my row continues across the word boundary
-        // The lanes list their pairs (mine << 16 | earlier: ids of earlier rows are smaller), then lane k unites pair k, k + 64, ...:
-        // a union is a chain of dependent LDS trips, and a lane with six pairs must not keep 63 others waiting -- instruction issue,
-        // not LDS, bounds this kernel, and a divergent loop issues for its slowest lane.
-        const uint32_t ecount = (uint32_t)popc64(E0) + (uint32_t)popc64(E1) + (uint32_t)popc64(E2) + (uint32_t)popc64(E3) + (same_row ? 1u : 0u);
+    // ---- B: 26-connected components inside the tile, on BLOCK nodes (round 5).  Under 26-connectivity every voxel of a 2 x 2
+    // group of rows (rows 2R, 2R + 1 of sections 2S, 2S + 1) at column p touches every voxel of the group at p - 1, p, p + 1: the
+    // runs of the OR of the group's four row masks are connected sets, and they are the union-find nodes -- 16 groups a tile
+    // instead of 64 rows, a third of the nodes, no pairs inside a group (the block-based idea of the GPU labelling literature
+    // on this kernel's bit masks; rounds 1-4 united the word-runs of single rows: 2.3 pairs per word and sign).
+    // Lane = (group, word).  A group meets four earlier groups -- (R - 1, S)
+    // across its r face, (R, S - 1) across its s face, (R - 1, S - 1) and (R + 1, S - 1) across an edge -- and only the rows on
+    // that face can touch: with FA / FB the OR of the face rows of either side, a touching pair of face runs is charged to the
+    // later of its two starts, as before --
+    //     EA = starts(FA) & (FB | FB << 1 | carry FB)      EB = starts(FB) & (FA << 1 | carry FA)
+    // and at a set bit p either side's NODE is the last start <= p of its group's OR mask (a face run lies inside one node:
+    // repeats are harmless).  Node ids: sign 0 counts up from 0, sign 1 ends at n_runs - 1 (a node holds at least one whole
+    // word-run of a row: there are never more nodes than those) -- the signs do not wait for each other.
+    // Wave = (sign, which of the four earlier groups): all eight waves work, each lists and unites the pairs of ONE relation
+    // (r05 A/B: one wave per sign doing all four took 5.4 us per tile on the critical path, the other six waiting at the barrier).
+    // Every wave of a sign numbers the nodes for itself -- the same scan over the same masks -- so nobody waits for ids.
+    const int gq = wvs >> 2, grel = wvs & 3;   // wave-uniform
+    if (gq < n_planes) {
+        constexpr int ECAPW = CCAP * 48 / 4 / NW;   // pairs a wave lists before it unites them (the lists live where the component sums go later)
+        uint32_t *g_edge = reinterpret_cast<uint32_t *>(s_blob) + wvs * ECAPW;
+        const int gi = lane / CW, gwl = lane % CW;
+        const bool gact = gi < 16;
+        const int R = gi & 3, S = (gi >> 2) & 3;
+        auto MK = [&](int sec, int row) -> uint64_t { return s_mask[gq][sec * USEC + row * CW + gwl]; };
+        const uint64_t a = gact ? MK(2 * S, 2 * R) : 0ull, b = gact ? MK(2 * S, 2 * R + 1) : 0ull;
+        const uint64_t c = gact ? MK(2 * S + 1, 2 * R) : 0ull, d = gact ? MK(2 * S + 1, 2 * R + 1) : 0ull;
+        const uint64_t G = (a | b) | (c | d);
+        const uint64_t SG = run_starts(G);
+        const uint32_t gcnt = (uint32_t)popc64(SG);
+        const uint32_t gincl = wave_scan(gcnt);
+        const uint32_t gtot = (uint32_t)__builtin_amdgcn_readlane((int)gincl, 63);
+        const uint32_t nbase = (gq ? n_runs - gtot : 0u) + gincl - gcnt;
+        if (grel == 0) {   // for C1 / C2
+            s_sg[gq][lane] = SG;
+            s_nb[gq][lane] = (uint16_t)nbase;
+            if (lane == 0) s_gtot[gq] = gtot;
+        }
+        // my relation: the earlier group (R + dR, S + dS), my face rows towards it and its face rows towards me
+        const int dR = grel == 1 ? 0 : (grel == 3 ? 1 : -1), dS = grel == 0 ? 0 : -1;
+        const int R2 = R + dR, S2 = S + dS;
+        const bool has = gact && R2 >= 0 && R2 < 4 && S2 >= 0;   // (else: in another tile -- k_face_merge's pairs)
+        const int R2c = has ? R2 : R, S2c = has ? S2 : S;
+        uint64_t a2 = MK(2 * S2c, 2 * R2c), b2 = MK(2 * S2c, 2 * R2c + 1), c2 = MK(2 * S2c + 1, 2 * R2c), d2 = MK(2 * S2c + 1, 2 * R2c + 1);
+        if (!has) { a2 = 0ull; b2 = 0ull; c2 = 0ull; d2 = 0ull; }
+        const uint64_t SG2 = run_starts((a2 | b2) | (c2 | d2));
+        const uint32_t nbase2 = (uint32_t)__shfl((int)nbase, lane + (dS * 4 + dR) * CW);
+        //                            (R - 1, S)        (R, S - 1)        (R - 1, S - 1)   (R + 1, S - 1)
+        const uint64_t FA = grel == 0 ? (a | c) : (grel == 1 ? (a | b) : (grel == 2 ? a : b));
+        const uint64_t FB = grel == 0 ? (b2 | d2) : (grel == 1 ? (c2 | d2) : (grel == 2 ? d2 : c2));
+        // bit 63 of the word to the left, for every mask that takes part (cross-lane reads sit outside every conditional)
+        const uint32_t hbits = (uint32_t)(G >> 63) | ((uint32_t)(FA >> 63) << 1) | ((uint32_t)(FB >> 63) << 2);
+        const uint32_t upb = dpp0<DPP_WAVE_SHR1>(hbits);
+        const uint32_t car = gwl > 0 ? upb : 0u;
+        const uint64_t E = (run_starts(FA) & (FB | (FB << 1) | (uint64_t)((car >> 2) & 1u))) | (run_starts(FB) & ((FA << 1) | (uint64_t)((car >> 1) & 1u)));   // EA and EB are disjoint
+        const bool same_row = grel == 3 && (G & 1ull) && (car & 1u);   // my group's run continues across the word boundary
+        const uint32_t ecount = (uint32_t)popc64(E) + (same_row ? 1u : 0u);
         const uint32_t eincl = wave_scan(ecount);
         const uint32_t etot = (uint32_t)__builtin_amdgcn_readlane((int)eincl, 63);
-        const uint32_t mb1 = my_base - 1u;
+        const uint32_t mb1 = nbase - 1u, bb1 = nbase2 - 1u;
         if (etot <= (uint32_t)ECAPW) {   // wave-uniform
+            // The lanes list their pairs (mine << 16 | earlier: ids of earlier groups are smaller), then lane k unites pair k, k + 64, ...:
+            // a union is a chain of dependent LDS trips, and a lane with six pairs must not keep 63 others waiting
             uint32_t epos = eincl - ecount;
-            if (same_row) s_edge[epos++] = (my_base << 16) | mb1;
-            // bit p of E: my run is the one that covers p or p - 1 (the last start <= p), and so is the neighbour's
-            auto list = [&](uint64_t E, uint64_t SB, uint32_t baseB) {
-                const uint32_t bb1 = baseB - 1u;
-                while (E) {
-                    const uint64_t below = E - 1, upto = E ^ below;   // bits <= p
-                    E &= below;
-                    s_edge[epos++] = ((mb1 + (uint32_t)popc64(SA & upto)) << 16) | (bb1 + (uint32_t)popc64(SB & upto));
-                }
-            };
-            list(E0, SB0, base0);
-            list(E1, SB1, base1);
-            list(E2, SB2, base2);
-            list(E3, SB3, base3);
+            if (same_row) g_edge[epos++] = (nbase << 16) | mb1;
+            uint64_t todo = E;
+            while (todo) {
+                const uint64_t below = todo - 1, upto = todo ^ below;   // bits <= p
+                todo &= below;
+                g_edge[epos++] = ((mb1 + (uint32_t)popc64(SG & upto)) << 16) | (bb1 + (uint32_t)popc64(SG2 & upto));
+            }
             wave_lds_sync();
             for (uint32_t e = lane; e < etot; e += 64) {
-                const uint32_t pk = s_edge[e], a = pk >> 16, b = pk & 0xffffu;
-                const uint32_t old = atomicMin(&s_parent[a], b);   // optimistic: most runs are still roots when their first pair arrives
-                if (old != a) lds_unite(s_parent, old, b);         // a hung under `old` already: unite that tree with b's
+                const uint32_t pk = g_edge[e], x = pk >> 16, y = pk & 0xffffu;
+                const uint32_t old = atomicMin(&s_parent[x], y);   // optimistic: most nodes are still roots when their first pair arrives
+                if (old != x) lds_unite(s_parent, old, y);         // x hung under `old` already: unite that tree with y's
             }
-        } else {   // a very dense section: unite on the spot
-            if (same_row) lds_unite(s_parent, my_base, mb1);
-            auto direct = [&](uint64_t E, uint64_t SB, uint32_t baseB) {
-                const uint32_t bb1 = baseB - 1u;
-                while (E) {
-                    const uint64_t below = E - 1, upto = E ^ below;
-                    E &= below;
-                    lds_unite(s_parent, mb1 + (uint32_t)popc64(SA & upto), bb1 + (uint32_t)popc64(SB & upto));
-                }
-            };
-            direct(E0, SB0, base0);
-            direct(E1, SB1, base1);
-            direct(E2, SB2, base2);
-            direct(E3, SB3, base3);
+        } else {   // a very dense tile: unite on the spot
+            if (same_row) lds_unite(s_parent, nbase, mb1);
+            uint64_t todo = E;
+            while (todo) {
+                const uint64_t below = todo - 1, upto = todo ^ below;
+                todo &= below;
+                lds_unite(s_parent, mb1 + (uint32_t)popc64(SG & upto), bb1 + (uint32_t)popc64(SG2 & upto));
+            }
         }
+    } else if (grel == 0 && lane == 0) {
+        s_gtot[1] = 0u;
     }
     __syncthreads();   // ---- barrier 2: all unions done ----
     // ---- C1: the accumulators take the place of the edge lists; roots take component numbers; every lane describes the
@@ -534,8 +546,11 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
         s_pk[i] = 0ull; s_crel[i] = 0u; s_key[i] = 0xffffffffu;
     }
     uint16_t *s_half = reinterpret_cast<uint16_t *>(s_parent);   // [2 i]: parent / ROOT16 | component, [2 i + 1]: descriptor of run i
-    for (uint32_t i = tid; i < n_runs; i += NT)   // (one LDS atomic per wave: the compiler aggregates)
-        if (s_half[2 * i] == i) s_half[2 * i] = (uint16_t)(ROOT16 | atomicAdd(&s_ncomp, 1u));
+    const uint32_t n_node0 = s_gtot[0], n_nodes = n_node0 + s_gtot[1], node_skip = n_runs - n_nodes;   // (sign 1's nodes end at n_runs - 1)
+    for (uint32_t i = tid; i < n_nodes; i += NT) {   // (one LDS atomic per wave: the compiler aggregates)
+        const uint32_t id = i < n_node0 ? i : i + node_skip;
+        if (s_half[2 * id] == id) s_half[2 * id] = (uint16_t)(ROOT16 | atomicAdd(&s_ncomp, 1u));
+    }
     {
         const uint32_t dw = (uint32_t)u | ((uint32_t)q << 8);
         uint64_t todo = SA;
@@ -601,14 +616,16 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
             const uint32_t urus = (uint32_t)ur * (uint32_t)us;
             const double fix_mul = lj.fix_mul;
             for (uint32_t i = tid; i < n_runs; i += NT) {
-                const uint32_t pd = s_parent[i], desc = pd >> 16;
-                uint32_t x = pd & 0xffffu;
-                while (!(x & ROOT16)) x = s_half[2 * x];
+                const uint32_t desc = s_half[2 * i + 1];
+                const int ru = (int)(desc & 0xffu), rq = (int)((desc >> 8) & 1u), a = (int)(desc >> 9);
+                const int rsl = ru / USEC, rrl = (ru % USEC) / CW, rwl = ru % CW;
+                // my node: the run of my group's OR mask that covers my first bit (the last start <= a)
+                const int gl = ((rsl >> 1) * 4 + (rrl >> 1)) * CW + rwl;
+                uint32_t x = (uint32_t)s_nb[rq][gl] + (uint32_t)popc64(s_sg[rq][gl] & ((2ull << a) - 1ull)) - 1u;
+                do x = s_half[2 * x]; while (!(x & ROOT16));
                 const uint32_t comp_all = x & 0x7fffu;
                 if (wide && comp_all - pass0 >= (uint32_t)CCAP) continue;   // (not this pass's)
                 const uint32_t comp = comp_all - pass0;
-                const int ru = (int)(desc & 0xffu), rq = (int)((desc >> 8) & 1u), a = (int)(desc >> 9);
-                const int rsl = ru / USEC, rrl = (ru % USEC) / CW, rwl = ru % CW;
                 const uint64_t rm = s_mask[rq][ru];
                 const uint32_t ub = s_ub[rq][ru];
                 const uint64_t inv = ~(rm >> a);

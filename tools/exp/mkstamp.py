@@ -1,9 +1,11 @@
 # Diagnostic build (never shipped): a COPY of csrc with s_memrealtime stamps in k_tile_label -- after every barrier (thread 0) and,
 # per wave, at the end of the stream (A1), of the numbering (A2), of the unions (B) and of the folds (C2).
 #   python tools/exp/mkstamp.py  -> abl/libSTAMP.so ;  on the GPU box: PDBEDA_LIB=abl/libSTAMP.so python tools/exp/stamps.py
-import os, shutil, subprocess
+#   python tools/exp/mkstamp.py [NAME [csrc-dir]]  (another source tree, e.g. last round's, for a side-by-side)
+import os, shutil, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-src, dst = os.path.join(root, "pdb_eda_amd", "csrc"), "/tmp/csrc_stamp"
+name = sys.argv[1] if len(sys.argv) > 1 else "STAMP"
+src, dst = (sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "pdb_eda_amd", "csrc")), "/tmp/csrc_stamp_" + name
 shutil.rmtree(dst, ignore_errors=True)
 shutil.copytree(src, dst)
 inc = os.path.join(root, "include")
@@ -21,7 +23,8 @@ once("    const uint32_t bid = ((uint32_t)st * (uint32_t)td.rtiles + (uint32_t)r
 for k in (1, 2, 3, 4):
     once("    __syncthreads();   // ---- barrier %d" % k, "    __syncthreads();   if (tid == 0) " + (ST % str(k)) + "  // ---- barrier %d" % k)
 once("    __syncthreads();   if (tid == 0) " + (ST % "1"), "    if (lane == 0) " + (ST % "(8 + wv)") + "\n    __syncthreads();   if (tid == 0) " + (ST % "1"))
-once("    // ---- B: touching pairs -> unions.", "    if (lane == 0) " + (ST % "(16 + wv)") + "\n    // ---- B: touching pairs -> unions.")
+bmark = "    // ---- B: touching pairs -> unions." if "    // ---- B: touching pairs -> unions." in body else "    // ---- B: 26-connected components inside the tile"
+once(bmark, "    if (lane == 0) " + (ST % "(16 + wv)") + "\n" + bmark)
 once("    __syncthreads();   if (tid == 0) " + (ST % "2"), "    if (lane == 0) " + (ST % "(24 + wv)") + "\n    __syncthreads();   if (tid == 0) " + (ST % "2"))
 once("    __syncthreads();   if (tid == 0) " + (ST % "4"), "    if (lane == 0) " + (ST % "(32 + wv)") + "\n    __syncthreads();   if (tid == 0) " + (ST % "4"))
 once("    if (tid == 0) lj.tile_runs[bid] = n_runs;\n}", "    if (tid == 0) lj.tile_runs[bid] = n_runs;\n    if (tid == 0) " + (ST % "5") + "\n}")
@@ -41,8 +44,8 @@ extern "C" int pdbeda_bloblist_stamps(pdbeda_bloblist *bl, unsigned long long *o
 }
 '''
 for f, txt in (("pdbeda_hip.hip", h), ("pdbeda_device.h", open(os.path.join(dst, "pdbeda_device.h")).read())):
-    open(os.path.join(dst, f), "w").write(txt.replace('#include "../../include/pdbeda.h"', '#include "%s/pdbeda.h"' % inc))
+    open(os.path.join(dst, f), "w").write(txt.replace('#include "../../include/pdbeda.h"', '#include "%s/pdbeda.h"' % inc).replace('#include "/root/repo/include/pdbeda.h"', '#include "%s/pdbeda.h"' % inc))
 os.makedirs(os.path.join(root, "abl"), exist_ok=True)
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off", "-std=c++17", "-Wno-unused-function",
-                       "-o", os.path.join(root, "abl", "libSTAMP.so"), os.path.join(dst, "pdbeda_hip.hip")])
-print("built abl/libSTAMP.so")
+                       "-o", os.path.join(root, "abl", "lib%s.so" % name), os.path.join(dst, "pdbeda_hip.hip")])
+print("built abl/lib%s.so" % name)
