@@ -435,6 +435,7 @@ class DeviceBlobs(collections.abc.Sequence):
 
     def __init__(self, segments):
         self._segments = list(segments)
+        self._flat = None
 
     def __len__(self):
         return sum(len(seg) for seg in self._segments)
@@ -442,7 +443,9 @@ class DeviceBlobs(collections.abc.Sequence):
     def _all(self):
         if len(self._segments) == 1:
             return self._segments[0].made()
-        return [blob for seg in self._segments for blob in seg.made()]
+        if self._flat is None:       # (kept: the segments never change once the sequence exists, and an index loop must not rebuild it per access)
+            self._flat = [blob for seg in self._segments for blob in seg.made()]
+        return self._flat
 
     def __getitem__(self, i):
         return self._all()[i]

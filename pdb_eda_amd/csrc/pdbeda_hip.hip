@@ -210,7 +210,9 @@ static int fail(pdbeda_ctx *ctx, int code, const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (ctx) { ctx->pending.clear(); ctx->pinned_used = 0; ctx->dev_stage_used = 0; }   // results of a failed call are never delivered
+    // results of a failed call are never delivered.  The staging regions are NOT handed out again here: copies queued by an
+    // earlier call (a sphere batch's staged inputs) may still read them -- only ctx_sync(), which has drained the stream, rewinds
+    if (ctx) ctx->pending.clear();
     if (ctx && ctx->timed_out) return PDBEDA_ERR_TIMEOUT;   // (the watchdog's message stays)
     if (ctx) ctx->err = buf;
     return code;
@@ -265,19 +267,6 @@ static hipError_t d2h(pdbeda_ctx *ctx, void *dst, const void *src, size_t bytes)
     hipError_t e = ctx_sync(ctx);
     if (e == hipSuccess) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
     return e;
-}
-
-// Host -> device copy of a small input that the caller may free as soon as the call returns, WITHOUT a wait: staged through the
-// same pinned buffer (its regions are handed out until the next ctx_sync).  false: it does not fit -- copy directly and wait.
-static bool h2d_staged(pdbeda_ctx *ctx, void *dst, const void *src, size_t bytes, hipError_t *e) {
-    *e = hipSuccess;
-    if (bytes == 0) return true;
-    const size_t need = (bytes + 63) & ~(size_t)63;
-    if (!ctx->pinned || ctx->pinned_used + need > ctx->pinned_cap) return false;
-    memcpy(ctx->pinned + ctx->pinned_used, src, bytes);
-    *e = hipMemcpyAsync(dst, ctx->pinned + ctx->pinned_used, bytes, hipMemcpyHostToDevice, ctx->stream);
-    ctx->pinned_used += need;
-    return true;
 }
 
 static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }

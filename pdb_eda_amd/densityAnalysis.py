@@ -147,9 +147,13 @@ def _typeRegressions(x, y, bfactor, group, n_types):
     first = np.searchsorted(group[order], np.arange(n_types))
     present = n > 0
     b_sorted = bfactor[order]
-    b_lo = np.where(present, np.minimum.reduceat(b_sorted, np.minimum(first, max(len(b_sorted) - 1, 0))), 0.0) if len(b_sorted) else np.zeros(n_types)
-    b_hi = np.where(present, np.maximum.reduceat(b_sorted, np.minimum(first, max(len(b_sorted) - 1, 0))), 0.0) if len(b_sorted) else np.zeros(n_types)
-    fitted = (n > 2) & (b_lo != b_hi)
+    # the reference's test is `len(np.unique(bfactor)) == 1` (densityAnalysis.py:752), and np.unique counts all NaNs as ONE value:
+    # a type whose b-factors are all NaN (no positive B: its median is NaN, and so is every normalised value) is NOT fitted
+    b_lo = np.where(present, np.fmin.reduceat(b_sorted, np.minimum(first, max(len(b_sorted) - 1, 0))), 0.0) if len(b_sorted) else np.zeros(n_types)
+    b_hi = np.where(present, np.fmax.reduceat(b_sorted, np.minimum(first, max(len(b_sorted) - 1, 0))), 0.0) if len(b_sorted) else np.zeros(n_types)
+    n_nan = np.bincount(group, weights=np.isnan(bfactor), minlength=n_types)
+    one_value = (n_nan == n) | ((n_nan == 0) & (b_lo == b_hi))
+    fitted = (n > 2) & ~one_value
     with np.errstate(divide="ignore", invalid="ignore"):
         r = np.where((ssxm == 0.0) | (ssym == 0.0), 0.0, ssxym / np.sqrt(ssxm * ssym))
         r = np.clip(r, -1.0, 1.0)
