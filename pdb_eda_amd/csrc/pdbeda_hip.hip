@@ -2,6 +2,7 @@
 // extern "C" entry points declared in include/pdbeda.h.  gfx950 only, no CPU fallback.
 #include <hip/hip_runtime.h>
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <cerrno>
@@ -16,6 +17,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
@@ -53,12 +56,11 @@ struct pdbeda_ctx {
     size_t pinned_cap = 0, pinned_used = 0;
     struct Pending { void *dst; size_t off, bytes; };
     std::vector<Pending> pending;
-    // file -> device uploads (pdbeda_map_upload_file): pinned chunks filled by pread() while others are in flight
-    static constexpr int RING = 4;
-    char *ring[RING] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ring_done[RING] = {nullptr, nullptr, nullptr, nullptr};
-    hipStream_t ring_stream = nullptr;   // the second reader's copies: two streams keep the link busy across the gap between two copies of one
-    hipEvent_t ring_joined = nullptr;
+    // file -> device uploads (pdbeda_map_upload_file): the chunks of a map go through the process's upload engine (reader threads
+    // with pinned chunks and copy streams of their own); what a context keeps is one event per reader, recorded
+    // behind the reader's copies of the map and waited for by the context's stream
+    static constexpr int MAX_READERS = 8;
+    hipEvent_t reader_ev[MAX_READERS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int live_handles = 0;
     // optional per-kernel timing with HIP events on ctx->stream (bench.py's roofline leg)
     bool profiling = false;
@@ -102,12 +104,8 @@ static void ctx_release_device(pdbeda_ctx *ctx, bool lent_too) {
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->dev_stage) (void)hipFree(ctx->dev_stage);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-    if (ctx->ring_stream) (void)hipStreamDestroy(ctx->ring_stream);
-    if (ctx->ring_joined) (void)hipEventDestroy(ctx->ring_joined);
-    for (int k = 0; k < pdbeda_ctx::RING; ++k) {
-        if (ctx->ring[k]) (void)hipHostFree(ctx->ring[k]);
-        if (ctx->ring_done[k]) (void)hipEventDestroy(ctx->ring_done[k]);
-    }
+    for (int k = 0; k < pdbeda_ctx::MAX_READERS; ++k)
+        if (ctx->reader_ev[k]) (void)hipEventDestroy(ctx->reader_ev[k]);
     for (auto &r : ctx->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
 }
@@ -121,8 +119,11 @@ static size_t reap_abandoned() {
     for (size_t i = 0; i < g_abandoned.size();) {
         pdbeda_ctx *ctx = g_abandoned[i];
         (void)hipSetDevice(ctx->device);
-        // still running (or hung) on either of its streams -- the file upload queues copies on the second one: try again later
-        if (hipStreamQuery(ctx->stream) == hipErrorNotReady || (ctx->ring_stream && hipStreamQuery(ctx->ring_stream) == hipErrorNotReady)) { ++i; continue; }
+        // still running (or hung) on its stream, or the upload engine still copies into one of its maps: try again later
+        bool busy = hipStreamQuery(ctx->stream) == hipErrorNotReady;
+        for (int k = 0; k < pdbeda_ctx::MAX_READERS && !busy; ++k)      // (the readers' copies of its last map: behind these events)
+            if (ctx->reader_ev[k] && hipEventQuery(ctx->reader_ev[k]) == hipErrorNotReady) busy = true;
+        if (busy) { ++i; continue; }
         ctx_release_device(ctx, true);
         delete ctx;
         g_abandoned.erase(g_abandoned.begin() + i);
@@ -467,6 +468,8 @@ extern "C" int pdbeda_ctx_create_on_stream(int device_id, void *hip_stream, pdbe
     if (hip_stream) {
         ctx->stream = (hipStream_t)hip_stream;
     } else {
+        // (plain priority, like the upload engine's copy streams: r05 tried the contexts' streams above the copy streams -- with
+        //  several PROCESSES on one GPU any mix of priorities took an entry from 1.4 to 9-15 ms)
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PDBEDA_ERR_DEVICE; }
         ctx->own_stream = true;
     }
@@ -686,8 +689,153 @@ static hipError_t event_wait(pdbeda_ctx *ctx, hipEvent_t ev) {
 // 0.9-1.1 ms with one reader, and four worker processes together reached 39 GB/s (`tools/exp/file_h2d.py`; a pageable copy
 // out of an mmap of the file runs at link speed only while its pages stay mapped -- a fresh mapping per file pays 0.6 ms of
 // page faults per 32 MB before the first byte moves).  byteswap: the file has the other endianness.
-static const size_t FILE_CHUNK = (size_t)4 << 20;
-static const int FILE_READERS = 2;
+static const size_t FILE_CHUNK_MAX = (size_t)4 << 20;
+static size_t file_chunk_bytes() {   // (PDBEDA_FILE_CHUNK_KB: experiments)
+    static const size_t v = [] { const char *e = getenv("PDBEDA_FILE_CHUNK_KB"); long kb = e ? atol(e) : 4096; return (size_t)std::min<long>(std::max<long>(kb, 64), 4096) << 10; }();
+    return v;
+}
+#define FILE_CHUNK (file_chunk_bytes())
+static unsigned reader_spins() { static const unsigned v = [] { const char *e = getenv("PDBEDA_READER_SPINS"); return e ? (unsigned)atoi(e) : 4u; }(); return v; }
+// ---- The upload engine: ONE per process and device ------------------------------------------------------------------------
+// A map read from a file goes to HBM in 4 MiB chunks: a reader thread pread()s a chunk out of the page cache into one of its
+// two pinned slots and queues the slot's PCIe copy on its own stream.  A single pread stream moves ~10 GB/s --
+// a kernel memcpy --, so ONE map needs five or six readers to fill a 57 GB/s link: rounds 3-4 gave every context two readers of
+// its own (18 GB/s for a lone load; the pools reached the link only with eight loads in flight, i.e. sixteen reader threads and
+// 128 MiB of pinned rings).  Now the readers belong to the process: the chunks of every load in flight go through one FIFO, a
+// lone load gets all readers, and the number of threads and pinned chunks does not grow with the number of contexts.
+static const int FILE_READERS_DEFAULT = 3;
+struct UploadLoad {
+    int fd = -1;
+    int64_t offset = 0;
+    char *dst = nullptr;
+    size_t need = 0;
+    int64_t n_chunks = 0;
+    std::vector<std::pair<size_t, size_t>> pieces;   // (position, length) of chunk k: small ones first -- the link starts while the big ones are read
+    double timeout_s = 0.0;
+    std::chrono::steady_clock::time_point deadline;
+    std::mutex mu;
+    std::condition_variable cv;
+    int64_t handled = 0;                          // chunks whose copy is queued, or that were given up
+    hipError_t e = hipSuccess;
+    const char *why = nullptr;
+    bool timed_out = false;
+    bool used[pdbeda_ctx::MAX_READERS] = {false, false, false, false, false, false, false, false};
+    bool failed() { return e != hipSuccess || why || timed_out; }   // (under mu)
+    // PDBEDA_UPLOAD_TRACE=1 (experiments): seconds spent in pread / in the runtime's calls, summed over the readers
+    double t_pread = 0.0, t_queue = 0.0, t_slot = 0.0;
+    int chunks_by[pdbeda_ctx::MAX_READERS] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+static bool upload_trace() { static const bool v = [] { const char *e = getenv("PDBEDA_UPLOAD_TRACE"); return e && e[0] && e[0] != '0'; }(); return v; }
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct UploadEngine {
+    int device = 0, n_readers = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::pair<UploadLoad *, int64_t>> chunks;
+    struct Reader {
+        hipStream_t stream = nullptr;
+        char *slot[2] = {nullptr, nullptr};
+        hipEvent_t done[2] = {nullptr, nullptr};
+        int64_t count = 0;
+        bool ok = false;
+    } readers[pdbeda_ctx::MAX_READERS];
+
+    void run(int r) {
+        Reader &me = readers[r];
+        (void)hipSetDevice(device);
+        for (;;) {
+            std::pair<UploadLoad *, int64_t> task;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !chunks.empty(); });
+                task = chunks.front();
+                chunks.pop_front();
+            }
+            UploadLoad *ld = task.first;
+            const int64_t c = task.second;
+            bool skip;
+            {
+                std::lock_guard<std::mutex> g(ld->mu);
+                skip = ld->failed();
+            }
+            hipError_t ce = hipSuccess;
+            const char *why = nullptr;
+            bool timed_out = false, queued = false;
+            double t_a = 0, t_b = 0, t_c = 0, t_d = 0;
+            if (!skip) {
+                const int slot = (int)(me.count & 1);
+                t_a = now_s();
+                if (me.count >= 2) {   // the chunk sent from this slot two rounds ago must have left it
+                    for (unsigned spins = 0;; ++spins) {
+                        const hipError_t q = hipEventQuery(me.done[slot]);
+                        if (q == hipSuccess) break;
+                        if (q != hipErrorNotReady) { ce = q; break; }
+                        if (spins >= reader_spins()) {   // (no long busy poll: six readers hammering hipEventQuery slowed every OTHER thread's runtime calls)
+                            if (ld->timeout_s > 0.0 && std::chrono::steady_clock::now() > ld->deadline) { timed_out = true; break; }   // (the entry's one deadline, as ctx_wait)
+                            std::this_thread::sleep_for(std::chrono::microseconds(30));
+                        }
+                    }
+                }
+                t_b = now_s();
+                if (ce == hipSuccess && !timed_out) {
+                    const size_t pos = ld->pieces[(size_t)c].first, len = ld->pieces[(size_t)c].second;
+                    for (size_t got = 0; got < len;) {
+                        const ssize_t n = pread(ld->fd, me.slot[slot] + got, len - got, (off_t)(ld->offset + (int64_t)pos + (int64_t)got));
+                        if (n < 0 && errno == EINTR) continue;
+                        if (n <= 0) { why = n < 0 ? strerror(errno) : "unexpected end of file"; break; }
+                        got += (size_t)n;
+                    }
+                    t_c = now_s();
+                    if (!why) {
+                        ce = hipMemcpyAsync(ld->dst + pos, me.slot[slot], len, hipMemcpyHostToDevice, me.stream);
+                        if (ce == hipSuccess) ce = hipEventRecord(me.done[slot], me.stream);
+                        if (ce == hipSuccess) { queued = true; ++me.count; }
+                    }
+                    t_d = now_s();
+                }
+            }
+            {
+                std::lock_guard<std::mutex> g(ld->mu);
+                if (ce != hipSuccess && ld->e == hipSuccess) ld->e = ce;
+                if (why && !ld->why) ld->why = why;
+                if (timed_out) ld->timed_out = true;
+                if (queued) ld->used[r] = true;
+                ld->t_slot += t_b - t_a; ld->t_pread += t_c - t_b; ld->t_queue += t_d - t_c; ld->chunks_by[r]++;
+                if (++ld->handled == ld->n_chunks) ld->cv.notify_all();   // (the load lives on its caller's stack: nothing of it is touched after this)
+            }
+        }
+    }
+};
+
+static std::mutex g_engine_mu;
+static std::map<int, UploadEngine *> g_engines;   // (never destroyed: the readers are parked on the queue when the process ends)
+
+static UploadEngine *upload_engine(int device) {
+    std::lock_guard<std::mutex> g(g_engine_mu);
+    auto it = g_engines.find(device);
+    if (it != g_engines.end()) return it->second;
+    UploadEngine *en = new UploadEngine();
+    en->device = device;
+    int want = FILE_READERS_DEFAULT;
+    if (const char *v = getenv("PDBEDA_FILE_READERS")) want = atoi(v);
+    want = std::max(1, std::min(want, (int)pdbeda_ctx::MAX_READERS));
+    for (int r = 0; r < want; ++r) {
+        UploadEngine::Reader &rd = en->readers[en->n_readers];
+        bool ok = hipStreamCreateWithFlags(&rd.stream, hipStreamNonBlocking) == hipSuccess;
+        for (int k = 0; k < 2 && ok; ++k)
+            ok = hipHostMalloc((void **)&rd.slot[k], FILE_CHUNK_MAX, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&rd.done[k], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); break; }   // (fewer readers than asked for: what was made so far serves)
+        rd.ok = true;
+        ++en->n_readers;
+    }
+    for (int r = 0; r < en->n_readers; ++r) {
+        try { std::thread(&UploadEngine::run, en, r).detach(); } catch (...) { en->n_readers = r; break; }
+    }
+    g_engines[device] = en;
+    return en;
+}
+
 static int upload_file_impl(pdbeda_ctx *ctx, const char *path, int64_t offset, int byteswap, const pdbeda_geometry *geom, pdbeda_map **out, double *mean, double *std) {
     if (!ctx || !path || !geom || !out || offset < 0) return PDBEDA_ERR_ARGUMENT;
     *out = nullptr;
@@ -702,14 +850,15 @@ static int upload_file_impl(pdbeda_ctx *ctx, const char *path, int64_t offset, i
         close(fd);
         return fail(ctx, PDBEDA_ERR_ARGUMENT, "%s holds fewer than %lld grid bytes after offset %lld", path, (long long)need, (long long)offset);
     }
-    for (int k = 0; k < pdbeda_ctx::RING; ++k) {
-        if (!ctx->ring[k] && hipHostMalloc((void **)&ctx->ring[k], FILE_CHUNK, hipHostMallocDefault) != hipSuccess) { ctx->ring[k] = nullptr; (void)hipGetLastError(); }
-        if (!ctx->ring_done[k] && hipEventCreateWithFlags(&ctx->ring_done[k], hipEventDisableTiming) != hipSuccess) { ctx->ring_done[k] = nullptr; (void)hipGetLastError(); }
-        if (!ctx->ring[k] || !ctx->ring_done[k]) { close(fd); return fail(ctx, PDBEDA_ERR_MEMORY, "no pinned chunk for the file upload"); }
-    }
-    if (!ctx->ring_stream && hipStreamCreateWithFlags(&ctx->ring_stream, hipStreamNonBlocking) != hipSuccess) { ctx->ring_stream = nullptr; (void)hipGetLastError(); }
-    if (!ctx->ring_joined && hipEventCreateWithFlags(&ctx->ring_joined, hipEventDisableTiming) != hipSuccess) { ctx->ring_joined = nullptr; (void)hipGetLastError(); }
-    if (!ctx->ring_stream || !ctx->ring_joined) { close(fd); return fail(ctx, PDBEDA_ERR_MEMORY, "no second stream for the file upload"); }
+    UploadEngine *engine = upload_engine(ctx->device);
+    if (engine->n_readers < 1) { close(fd); return fail(ctx, PDBEDA_ERR_MEMORY, "no reader (pinned chunks, copy stream, thread) for the file upload"); }
+    for (int r = 0; r < engine->n_readers; ++r)
+        if (!ctx->reader_ev[r] && hipEventCreateWithFlags(&ctx->reader_ev[r], hipEventDisableTiming) != hipSuccess) {
+            ctx->reader_ev[r] = nullptr;
+            (void)hipGetLastError();
+            close(fd);
+            return fail(ctx, PDBEDA_ERR_MEMORY, "no event for the file upload");
+        }
     pdbeda_map *m = new pdbeda_map();
     m->ctx = ctx;
     int rc = fill_geom(ctx, geom, &m->geom);
@@ -724,69 +873,89 @@ static int upload_file_impl(pdbeda_ctx *ctx, const char *path, int64_t offset, i
     hipError_t e = hipMemcpyAsync(m->geom_dev, &m->geom, sizeof(Geom), hipMemcpyHostToDevice, ctx->stream);
     // The arena may be a recycled one: the pool protects a recycled arena by STREAM ORDER on ctx->stream (maps and lists are
     // freed without a host sync while their kernels are still queued; the debug poison fill above is queued there too).  The
-    // helper's copies go through ring_stream, which knows nothing of that order -- so it waits, once, for everything queued
-    // on ctx->stream up to here before its first chunk may land.
-    if (e == hipSuccess) e = hipEventRecord(ctx->ring_joined, ctx->stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->ring_stream, ctx->ring_joined, 0);
+    // readers' copies go through their own streams, which know nothing of that order -- so the first chunk is handed out only
+    // when everything queued on ctx->stream up to here has run (normally: nothing is pending, the query says so at once).
+    if (e == hipSuccess) {
+        hipError_t q = hipStreamQuery(ctx->stream);
+        if (q == hipErrorNotReady) q = ctx_wait(ctx);     // (timed, under the watchdog)
+        if (q != hipSuccess) e = q;
+    }
     const char *why = nullptr;
-    {
-        // reader t takes chunks t, t + READERS, ... through its own ring slots (t, t + READERS): nothing is shared but the
-        // stream, and the order in which the chunks' copies are queued does not matter (disjoint destinations)
-        static_assert(pdbeda_ctx::RING == 2 * FILE_READERS, "two ring slots per reader");
-        const int64_t n_chunks = (int64_t)((need + FILE_CHUNK - 1) / FILE_CHUNK);
-        const double timeout_s = ctx->timeout_s;
-        const auto deadline = ctx->deadline;
-        struct ReaderResult { hipError_t e = hipSuccess; const char *why = nullptr; bool timed_out = false; };
-        auto reader = [&](int t, ReaderResult *res) {
-            if (t != 0 && hipSetDevice(ctx->device) != hipSuccess) { res->e = hipGetLastError(); return; }
-            const hipStream_t my_stream = t == 0 ? ctx->stream : ctx->ring_stream;
-            int64_t mine = 0;
-            for (int64_t c = t; c < n_chunks; c += FILE_READERS, ++mine) {
-                const int slot = t + FILE_READERS * (int)(mine & 1);
-                if (mine >= 2) {   // the chunk sent from this slot two rounds ago must have left it
-                    for (unsigned spins = 0;; ++spins) {
-                        const hipError_t q = hipEventQuery(ctx->ring_done[slot]);
-                        if (q == hipSuccess) break;
-                        if (q != hipErrorNotReady) { res->e = q; return; }
-                        if (spins > 256) {
-                            if (timeout_s > 0.0 && std::chrono::steady_clock::now() > deadline) { res->timed_out = true; return; }   // (the entry's one deadline, as ctx_wait)
-                            std::this_thread::sleep_for(std::chrono::microseconds(20));
-                        }
-                    }
-                }
-                const size_t pos = (size_t)c * FILE_CHUNK, len = std::min(FILE_CHUNK, need - pos);
-                for (size_t got = 0; got < len;) {
-                    const ssize_t r = pread(fd, ctx->ring[slot] + got, len - got, (off_t)(offset + (int64_t)pos + (int64_t)got));
-                    if (r < 0 && errno == EINTR) continue;
-                    if (r <= 0) { res->why = r < 0 ? strerror(errno) : "unexpected end of file"; return; }
-                    got += (size_t)r;
-                }
-                hipError_t ce = hipMemcpyAsync((char *)d + pos, ctx->ring[slot], len, hipMemcpyHostToDevice, my_stream);
-                if (ce == hipSuccess) ce = hipEventRecord(ctx->ring_done[slot], my_stream);
-                if (ce != hipSuccess) { res->e = ce; return; }
-            }
-        };
-        ReaderResult rr[FILE_READERS];
-        if (e == hipSuccess && !ctx->timed_out) {
-            std::thread helper;
-            bool helped = false;
-            if (n_chunks > 1) {
-                try { helper = std::thread(reader, 1, &rr[1]); helped = true; } catch (...) { helped = false; }   // (no thread to be had: one reader does both shares)
-            }
-            reader(0, &rr[0]);
-            if (helper.joinable()) helper.join();
-            if (!helped && n_chunks > 1 && rr[0].e == hipSuccess && !rr[0].why && !rr[0].timed_out) reader(1, &rr[1]);
-            // the context's stream waits for the helper's copies: everything behind this call is ordered after the whole map
-            if (hipEventRecord(ctx->ring_joined, ctx->ring_stream) != hipSuccess || hipStreamWaitEvent(ctx->stream, ctx->ring_joined, 0) != hipSuccess) e = hipGetLastError();
-            for (int t = 0; t < FILE_READERS; ++t) {
-                if (rr[t].e != hipSuccess && e == hipSuccess) e = rr[t].e;
-                if (rr[t].why && !why) why = rr[t].why;
-                if (rr[t].timed_out) {
-                    ctx->timed_out = true;
-                    ctx->err = "watchdog: the stream did not drain within the per-entry time-out; context abandoned";
-                    if (e == hipSuccess) e = hipErrorNotReady;
+    static const int upload_mode = [] { const char *v = getenv("PDBEDA_UPLOAD_MODE"); return v ? atoi(v) : 0; }();   // (experiments) 1: mmap + pageable copy, 2: in segments
+    if (e == hipSuccess && !ctx->timed_out && upload_mode >= 1) {
+        const long page = sysconf(_SC_PAGESIZE);
+        const int64_t lo = offset / page * page;
+        const size_t maplen = (size_t)(offset - lo) + need;
+        const double t_m0 = now_s();
+        const int n_seg = upload_mode >= 2 ? upload_mode : 1;
+        void *p = mmap(nullptr, maplen, PROT_READ, MAP_PRIVATE | (n_seg == 1 ? MAP_POPULATE : 0), fd, (off_t)lo);
+        if (p == MAP_FAILED) { why = strerror(errno); }
+        else {
+            const double t_m1 = now_s();
+            const char *src = (const char *)p + (offset - lo);
+            if (n_seg == 1) {
+                e = hipMemcpyAsync(d, src, need, hipMemcpyHostToDevice, ctx->stream);
+            } else {
+                // segment k + 1 is faulted in (by a helper) while segment k crosses the link
+                const size_t seg = ((need / n_seg) + page - 1) / page * page;
+                auto populate = [&](size_t a, size_t b) { if (b > a) (void)madvise((char *)p + (offset - lo) / page * page + a / page * page, b - a / page * page, 22 /* MADV_POPULATE_READ */); };
+                populate(0, std::min(seg, need));
+                for (size_t a = 0; a < need && e == hipSuccess; a += seg) {
+                    const size_t b = std::min(a + seg, need), b2 = std::min(b + seg, need);
+                    std::thread helper;
+                    if (b2 > b) helper = std::thread(populate, b, b2);
+                    e = hipMemcpyAsync((char *)d + a, src + a, b - a, hipMemcpyHostToDevice, ctx->stream);
+                    if (helper.joinable()) helper.join();
                 }
             }
+            const double t_m2 = now_s();
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            const double t_m3 = now_s();
+            munmap(p, maplen);
+            if (upload_trace()) fprintf(stderr, "upload mmap %.1f MB: map %.3f ms, copy call %.3f ms, sync %.3f ms, unmap %.3f ms\n", need / 1e6, 1e3 * (t_m1 - t_m0), 1e3 * (t_m2 - t_m1), 1e3 * (t_m3 - t_m2), 1e3 * (now_s() - t_m3));
+        }
+    } else if (e == hipSuccess && !ctx->timed_out) {
+        UploadLoad ld;
+        ld.fd = fd; ld.offset = offset; ld.dst = (char *)d; ld.need = need;
+        // chunk sizes ramp up: a pread of 4 MiB takes 0.4 ms before its copy can start -- with every reader on such a chunk the
+        // link idled for the first 0.4 ms of every map; the first round is 256 KiB each, the second 1 MiB, then full chunks
+        for (size_t pos = 0, k = 0; pos < need; ++k) {
+            const size_t round = k / (size_t)engine->n_readers;
+            const size_t len = std::min(need - pos, round == 0 ? std::min(FILE_CHUNK, (size_t)256 << 10) : (round == 1 ? std::min(FILE_CHUNK, (size_t)1 << 20) : FILE_CHUNK));
+            ld.pieces.emplace_back(pos, len);
+            pos += len;
+        }
+        ld.n_chunks = (int64_t)ld.pieces.size();
+        ld.timeout_s = ctx->timeout_s;
+        ld.deadline = ctx->deadline;
+        const double t_q = now_s();
+        {
+            std::lock_guard<std::mutex> g(engine->mu);
+            for (int64_t c = 0; c < ld.n_chunks; ++c) engine->chunks.emplace_back(&ld, c);
+        }
+        engine->cv.notify_all();
+        {
+            std::unique_lock<std::mutex> lk(ld.mu);
+            ld.cv.wait(lk, [&] { return ld.handled == ld.n_chunks; });   // (a reader gives a chunk up at the entry's deadline: this wait ends)
+        }
+        if (upload_trace())
+            fprintf(stderr, "upload %.1f MB: chunks handled after %.3f ms; readers' sums: slot wait %.3f, pread %.3f, queueing %.3f ms; chunks by reader %d %d %d %d %d %d %d %d\n",
+                    need / 1e6, 1e3 * (now_s() - t_q), 1e3 * ld.t_slot, 1e3 * ld.t_pread, 1e3 * ld.t_queue, ld.chunks_by[0], ld.chunks_by[1], ld.chunks_by[2],
+                    ld.chunks_by[3], ld.chunks_by[4], ld.chunks_by[5], ld.chunks_by[6], ld.chunks_by[7]);
+        // the context's stream waits for the readers' copies of THIS map: an event behind whatever each reader has queued so far
+        // (a little more than needed when it has gone on to another load's chunk -- never less)
+        for (int r = 0; r < engine->n_readers; ++r) {
+            if (!ld.used[r]) continue;
+            hipError_t je = hipEventRecord(ctx->reader_ev[r], engine->readers[r].stream);
+            if (je == hipSuccess) je = hipStreamWaitEvent(ctx->stream, ctx->reader_ev[r], 0);
+            if (je != hipSuccess && e == hipSuccess) e = je;
+        }
+        if (ld.e != hipSuccess && e == hipSuccess) e = ld.e;
+        why = ld.why;
+        if (ld.timed_out) {
+            ctx->timed_out = true;
+            ctx->err = "watchdog: the stream did not drain within the per-entry time-out; context abandoned";
+            if (e == hipSuccess) e = hipErrorNotReady;
         }
     }
     close(fd);
@@ -808,7 +977,9 @@ static int upload_file_impl(pdbeda_ctx *ctx, const char *path, int64_t offset, i
             e = hipErrorOutOfMemory;
         }
     }
-    const hipError_t e2 = ctx_sync(ctx);      // (the ring and &m->geom are free again)
+    const double t_s0 = now_s();
+    const hipError_t e2 = ctx_sync(ctx);      // (&m->geom is free again)
+    if (upload_trace()) fprintf(stderr, "upload: final wait %.3f ms\n", 1e3 * (now_s() - t_s0));
     if (have_scratch) arena_put(ctx, scratch);
     if (e == hipSuccess) e = e2;
     if (e != hipSuccess || why) {

@@ -24,6 +24,6 @@ try:
     for e in entries[:8]:
         multipleStructures.analyzeEntry(e, ctx, failures, True)
     pr.disable()
-    pstats.Stats(pr).sort_stats("tottime").print_stats(30)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(30); pstats.Stats(pr).sort_stats("cumtime").print_stats(45)
 finally:
     shutil.rmtree(tmp, ignore_errors=True)
