@@ -2387,7 +2387,7 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
         arena_put(ctx, aux);
         return bail(fail(ctx, PDBEDA_ERR_DEVICE, "aggregate cloud: %s", hipGetErrorString(e)), clouds, u);
     };
-    std::vector<char> block(upload_bytes, 0);      // (stays alive until group_bounds has waited for the stream)
+    std::vector<char> block(upload_bytes, 0);      // (staged: the copy below reads a pinned block or, too large for that, has finished reading when it returns)
     {
         auto put = [&](const void *dev, const void *src, size_t bytes) { if (bytes) memcpy(block.data() + ((const char *)dev - aux.base), src, bytes); };
         put(d_pool_cloud, pool_cloud.data(), 4 * (size_t)n_pool);
@@ -2397,12 +2397,45 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
         put(d_pa, pair_a.data(), 4 * (size_t)n_pairs);
         put(d_pb, pair_b.data(), 4 * (size_t)n_pairs);
     }
-    hipError_t e = hipMemcpyAsync(aux.base, block.data(), upload_bytes, hipMemcpyHostToDevice, st);
+    hipError_t e;
+    {
+        const H2DItem in[1] = {{aux.base, block.data(), upload_bytes}};
+        e = h2d_row(ctx, in, 1);
+    }
     if (e != hipSuccess) { arena_put(ctx, gs.in_arena); return fail_dev(e, nullptr); }
+    // The union job is sized by the HOST (round 5; a wait for the groups' bounds before): the voxels of a pooled cloud lie inside
+    // its atom's sphere box [C - R - 1, C + R], so the box around the boxes of a residue's pooled atoms -- around all of them for
+    // the domain group -- holds the group's voxels.  The device makes the volumes from the voxels' own bounds as before (never
+    // larger than these), and k_make_vols holds its totals against the host's.
+    int64_t union_totals[2] = {0, 0};
+    {
+        std::vector<int64_t> lo(3 * (size_t)n_groups, INT64_MAX), hi(3 * (size_t)n_groups, INT64_MIN);
+        for (int64_t p = 0; p < n_pool; ++p) {
+            const int64_t a = at->alias[pool_atom[(size_t)p]];          // (the clouds are those of the coordinate's last atom: its coordinate, its radius)
+            const double rad = (double)at->radius[a];
+            const double o[3] = {m->geom.origin[0] + rad, m->geom.origin[1] + rad, m->geom.origin[2] + rad};
+            int32_t C[3], R[3];
+            xyz2crs(m->geom, at->xyz + 3 * a, C);
+            xyz2crs(m->geom, o, R);
+            for (int g : {(int)pool_group[(size_t)p], n_rg})
+                for (int k = 0; k < 3; ++k) {
+                    lo[3 * (size_t)g + k] = std::min<int64_t>(lo[3 * (size_t)g + k], (int64_t)C[k] - R[k] - 1);
+                    hi[3 * (size_t)g + k] = std::max<int64_t>(hi[3 * (size_t)g + k], (int64_t)C[k] + R[k]);
+                }
+        }
+        for (int g = 0; g < n_groups; ++g) {
+            if (hi[3 * (size_t)g] < lo[3 * (size_t)g]) continue;
+            const int64_t dc = hi[3 * (size_t)g] - lo[3 * (size_t)g] + 1, dr = hi[3 * (size_t)g + 1] - lo[3 * (size_t)g + 1] + 1, ds = hi[3 * (size_t)g + 2] - lo[3 * (size_t)g + 2] + 1;
+            union_totals[0] += (dc + 63) / 64 * dr * ds;
+            union_totals[1] += dc * dr * ds;
+        }
+        if (ctx->debug_shrink_totals) { union_totals[0] /= 2; union_totals[1] /= 2; }
+    }
+    const bool host_sized = union_totals[0] < (1ll << 31) && union_totals[1] < (1ll << 40);   // (absurd boxes: let the waiting path size and report)
     { PROF(ctx, "k_pool_gather"); hipLaunchKernelGGL(k_pool_gather, dim3(grid_for(2 * V, 256)), dim3(256), 0, st, cow->crs_dev, cow->offsets_dev, d_pool_cloud, d_pool_voff,
                                                      d_pool_group, (int)n_pool, V, n_rg, gs.d_crs, gs.d_item_group); }
     if (n_pairs > 0) { PROF(ctx, "k_test_overlap"); hipLaunchKernelGGL(k_test_overlap, dim3((unsigned)n_pairs), dim3(256), 0, st, cow->crs_dev, d_set_off, d_pa, d_pb, d_touch); }
-    rc = group_bounds(m, &gs, 2 * V, n_groups, false);      // (synchronises: the host staging vectors above are free again)
+    rc = group_bounds(m, &gs, 2 * V, n_groups, false, host_sized ? union_totals : nullptr);      // (no wait when the host has sized the job)
     if (rc) { arena_put(ctx, gs.in_arena); arena_put(ctx, aux); return bail(rc, clouds, nullptr); }
     pdbeda_bloblist *uni = nullptr;
     rc = grouped_job(m, gs, 2 * V, n_groups, false, 0.0f, &uni);
