@@ -199,7 +199,7 @@ struct pdbeda_bloblist {
     float cut_pos = 0.0f, cut_neg = 0.0f;
     bool want_pos = false, want_neg = false;
     uint32_t flags = 0;
-    int tier = 0, reruns = 0;
+    int tier = 0, unit_form = 0, reruns = 0;
     size_t job_bytes = 0;              // bytes the job carved out of its arena (a recycled arena may be larger)
 };
 
@@ -1307,7 +1307,7 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
     job.label_of_comp = n_tiles ? cv.take<int32_t>(max_comps) : nullptr;
     job.word_comps = n_tiles ? cv.take<uint8_t>((size_t)n_tiles * 2 * 256 * 8) : nullptr;
     job.unit_done = n_tiles ? cv.take<uint32_t>((size_t)n_tiles) : nullptr;
-    job.unit_flag = n_tiles ? cv.take<uint32_t>(2) : nullptr;
+    job.unit_flag = n_tiles ? cv.take<uint32_t>(4) : nullptr;
     job.tile_mode = n_tiles ? cv.take<uint8_t>(n_tiles) : nullptr;
     job.tile_runs = n_tiles ? cv.take<uint32_t>(n_tiles) : nullptr;
     job.root_mask = n_tiles ? cv.take<uint64_t>((size_t)n_tiles * 4) : nullptr;
@@ -1383,6 +1383,10 @@ static void launch_tile_label(pdbeda_ctx *ctx, unsigned n_tiles, const Job &job,
         if (td.ctiles > 1) hipLaunchKernelGGL((k_face_merge<CW, FM_THREADS_WIDE>), dim3(td.ctiles, td.rtiles, td.stiles), dim3(FM_THREADS_WIDE), 0, ctx->stream, job, dens, geom_dev, td, pair_slots);
         else hipLaunchKernelGGL((k_face_merge<CW, FM_THREADS>), dim3(td.ctiles, td.rtiles, td.stiles), dim3(FM_THREADS), 0, ctx->stream, job, dens, geom_dev, td, pair_slots);
     }
+    if (job.unit_form) {   // the job is known to have unit tiles (its first run said so): their labelling, then their pairs
+        { PROF(ctx, "k_unit_label"); hipLaunchKernelGGL((k_unit_label<CW>), dim3(td.ctiles, td.rtiles, td.stiles), dim3(512), 0, ctx->stream, job, dens, geom_dev, td); }
+        { PROF(ctx, "k_unit_pairs"); hipLaunchKernelGGL((k_unit_pairs<CW>), dim3(td.ctiles, td.rtiles, td.stiles), dim3(512), 0, ctx->stream, job, td); }
+    }
 }
 
 // fused: the launch also ranks the roots and writes the blob table (k_emit_tiles is then not launched) -- see k_labels_tiles
@@ -1409,7 +1413,7 @@ struct WholeMapJob {
     bool labels = false;
     size_t bytes = 0;
 };
-static int whole_map_enqueue(pdbeda_map *m, float cut_pos, float cut_neg, bool want_pos, bool want_neg, uint32_t flags, int tier, WholeMapJob *out) {
+static int whole_map_enqueue(pdbeda_map *m, float cut_pos, float cut_neg, bool want_pos, bool want_neg, uint32_t flags, int tier, int unit_form, WholeMapJob *out) {
     pdbeda_ctx *ctx = m->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const Geom &g = m->geom;
@@ -1464,6 +1468,7 @@ static int whole_map_enqueue(pdbeda_map *m, float cut_pos, float cut_neg, bool w
     job_carve(job, arena.base, n_planes, total_words, total_keys, max_runs, max_blobs, lab_elems, &labels_dev, tiles_pp, max_comps);
     job.vol_sign[0] = td.sign[0];
     job.vol_sign[1] = td.sign[1];
+    job.unit_form = unit_form;
     // the job's number: unique in the process (contexts recycle each other's memory through the driver), started at a random value
     // (so is another process's); stale flags of an earlier job in recycled memory never match it.  Never 0 / the poison pattern.
     static std::atomic<uint32_t> g_epoch{[] {
@@ -1515,8 +1520,8 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
                            pdbeda_bloblist **out_pos, pdbeda_bloblist **out_neg) {
     pdbeda_ctx *ctx = m->ctx;
     WholeMapJob wj;
-    const int tier = ctx->debug_worst_case_arena ? 1 : 0;
-    int rc = whole_map_enqueue(m, cut_pos, cut_neg, want_pos, want_neg, flags, tier, &wj);
+    const int tier = ctx->debug_worst_case_arena ? 1 : 0, form = tier;   // (the debug hook: the second run's shape at once)
+    int rc = whole_map_enqueue(m, cut_pos, cut_neg, want_pos, want_neg, flags, tier, form, &wj);
     if (rc) return rc;
     const int n_planes = (want_pos ? 1 : 0) + (want_neg ? 1 : 0);
     pdbeda_bloblist *first = nullptr;
@@ -1532,7 +1537,7 @@ static int full_blobs_impl(pdbeda_map *m, float cut_pos, float cut_neg, bool wan
         else { bl->owns_arena = false; bl->sibling = first; first->sibling = bl; }
         bl->labels_dev = wj.labels_dev;
         bl->labels_done = wj.labels;
-        bl->cut_pos = cut_pos; bl->cut_neg = cut_neg; bl->want_pos = want_pos; bl->want_neg = want_neg; bl->flags = flags; bl->tier = tier;
+        bl->cut_pos = cut_pos; bl->cut_neg = cut_neg; bl->want_pos = want_pos; bl->want_neg = want_neg; bl->flags = flags; bl->tier = tier; bl->unit_form = form;
         bl->job_bytes = wj.bytes;
         if (bl->sign > 0) *out_pos = bl; else *out_neg = bl;
     }
@@ -1567,28 +1572,30 @@ static int list_resolve_counts(pdbeda_bloblist *bl) {
     Counters ctr;
     HIP_TRY(ctx, d2h(ctx, &ctr, bl->job.ctr, sizeof ctr));
     HIP_TRY(ctx, ctx_sync(ctx));
-    if (bl->whole_map && ctr.overflow != 0u) {
-        // the typical-size arena was too small for this map (see whole_map_enqueue): the job is run again, once, in a worst-case
-        // arena; both lists of a fused call move to the new job
+    while (bl->whole_map && ctr.overflow != 0u) {
+        // The job is run again, ONCE (both lists of a fused call move to the new job), when the typical-size arena was too small
+        // for this map (bits 0 / 1), or when the map has unit tiles and the job was enqueued without their two launches (bit 2,
+        // Job::unit_form).  The second run has both: the worst-case arena and the unit launches -- a first run without the unit
+        // launches does not know how many ids its unit tiles would have asked for.
         pdbeda_bloblist *ow = owner_of(bl);
-        if (!ow || ow->tier != 0) return fail(ctx, PDBEDA_ERR_STATE, "whole-map labelling overflowed its worst-case arena");
+        if (!ow) return fail(ctx, PDBEDA_ERR_STATE, "whole-map labelling: a list without its job");
+        const int tier = 1, form = 1;
+        if (tier == ow->tier && form == ow->unit_form) return fail(ctx, PDBEDA_ERR_STATE, "whole-map labelling overflowed its worst-case arena");
         if (ow->voxels_done || bl->voxels_done) return fail(ctx, PDBEDA_ERR_STATE, "whole-map labelling: overflow noticed after the voxel lists were made");
         WholeMapJob wj;
         arena_put(ctx, ow->arena);                         // (stream order: the first run's kernels are done -- ctx_sync above)
-        int rc = whole_map_enqueue(ow->map, ow->cut_pos, ow->cut_neg, ow->want_pos, ow->want_neg, ow->flags, 1, &wj);
+        int rc = whole_map_enqueue(ow->map, ow->cut_pos, ow->cut_neg, ow->want_pos, ow->want_neg, ow->flags, tier, form, &wj);
         if (rc) { ow->arena.base = nullptr; ow->arena.cap = 0; return rc; }
         ow->arena = wj.arena;
         pdbeda_bloblist *both[2] = {ow, ow->sibling};
         for (pdbeda_bloblist *l : both) {
             if (!l) continue;
             l->job = wj.job; l->td = wj.td; l->labels_dev = wj.labels_dev; l->labels_done = wj.labels;
-            l->tier = 1; l->reruns += 1; l->have_counts = false; l->job_bytes = wj.bytes;
+            l->tier = tier; l->unit_form = form; l->reruns += 1; l->have_counts = false; l->job_bytes = wj.bytes;
         }
         HIP_TRY(ctx, d2h(ctx, &ctr, bl->job.ctr, sizeof ctr));
         HIP_TRY(ctx, ctx_sync(ctx));
-        if (ctr.overflow != 0u) return fail(ctx, PDBEDA_ERR_STATE, "whole-map labelling overflowed its worst-case arena");
     }
-    if (bl->whole_map && ctr.unit_wait_failed) return fail(ctx, PDBEDA_ERR_DEVICE, "whole-map labelling: a tile waited in vain for the labels of a neighbour tile that overflowed LDS (k_face_merge)");
     if (!bl->whole_map && ctr.unit_wait_failed) return fail(ctx, PDBEDA_ERR_DEVICE, "sphere batch: the device's volumes outgrew what the host sized the job for");
     if (bl->vol_lo == 0 && bl->vol_hi == bl->job.n_vols) { bl->rank_lo = 0; bl->rank_hi = ctr.n_blobs; }
     else if (bl->whole_map && bl->job.n_vols == 2 && bl->vol_hi == bl->vol_lo + 1) {

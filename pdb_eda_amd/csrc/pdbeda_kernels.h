@@ -89,10 +89,11 @@ struct Counters {
     unsigned int n_comps;
     unsigned int n_blobs;
     unsigned int n_blobs_vol0;   // blobs whose first key lies in volume 0 (the split of a fused green / red job's table)
-    unsigned int unit_wait_failed;   // k_face_merge: a unit tile waited a second for a neighbour's labels (see there): the job's results are void
+    unsigned int unit_wait_failed;   // sphere batches: the device's volumes outgrew what the host sized the job for (k_make_vols)
     unsigned int unit_tiles[3];  // whole-map tiles that fell back to unit mode: run slots / edge buffer / component table full
     // whole-map jobs are carved for what maps typically need, not for the worst case (round 4): bit 0 = the unit tiles asked for
-    // more run / component ids than the job has, bit 1 = more blobs than table rows.  Every kernel stays inside the arena (the
+    // more run / component ids than the job has, bit 1 = more blobs than table rows, bit 2 = the job has unit tiles and was enqueued
+    // without their two launches (Job::unit_form).  Every kernel stays inside the arena (the
     // unit work is skipped, rows beyond the table are dropped); the host sees the flag at its first read of the counters and
     // runs the job again in a worst-case arena.
     unsigned int overflow;
@@ -123,8 +124,8 @@ struct Job {
     // per tile, sign and mask word: the tile-local components of the word's first 7 word-runs and of the run at its last bit,
     // a byte each -- k_face_merge unites across tile faces from the mask words and these records alone (one round trip)
     uint8_t *word_comps;               // [tile][2][256][8]
-    uint32_t *unit_done;               // [tile]: == epoch once the tile's workgroup of k_face_merge has labelled it (unit tiles) or has nothing to label
-    uint32_t *unit_flag;      // [0] == epoch iff some tile of THIS job fell back to unit mode (stale values of a recycled arena never match); [1] == epoch once k_tile_label's workgroup 0 has initialised the counters
+    uint32_t *unit_done;               // (unused since round 5: was a per-tile flag the k_face_merge workgroups polled)
+    uint32_t *unit_flag;      // [0] == epoch iff some tile of THIS job is a wide or a unit tile (stale values of a recycled arena never match); [1] == epoch once k_tile_label's workgroup 0 has initialised the counters; [2] == epoch iff some tile is a UNIT tile (modes 1 / 3: the two extra launches, Job::unit_form)
     uint32_t epoch;           // job number of the context (never 0)
     uint8_t *tile_mode;       // per tile: 0 = united in LDS; 1 / 3 = unit tile (too many runs / no ids for its components); 2 = wide tile (united in LDS, components above the tiles' id ranges)
     uint32_t *tile_runs;      // per tile: number of word-runs (ids tile * runs_per_tile ...)
@@ -178,6 +179,13 @@ struct Job {
     // counters itself it read the whole counter array -- 32 KiB at 256^3, but 256 KiB at 512^3, by each of 8 192 workgroups
     // (round 4: the fused label writer took 557 us at 512^3 for that reason, 3.3 x what eight 256^3 maps take).  nullptr otherwise.
     uint32_t *group_count;
+    // Tiles beyond every LDS capacity ("unit tiles": more than 4 096 word-runs -- checkerboards) are labelled and united by TWO
+    // launches of their own behind k_face_merge (k_unit_label, k_unit_pairs: the launch boundary is the only synchronisation).
+    // A job is first enqueued WITHOUT them (unit_form 0: four launches, no cost for the maps that have no such tile); if a tile
+    // turns out to be one, k_face_merge raises Counters::overflow bit 2, every later kernel leaves the unit work alone, and the
+    // host runs the job again in this form.  (Rounds 3-4: the tiles' k_face_merge workgroups did both phases themselves and
+    // polled each other's flags in between -- bounded, but a late dispatch on a shared GPU failed the job.)
+    int32_t unit_form;
 };
 
 struct InboxEntry {           // 88 bytes: what a (tile, root) pair folds into the root's record (no key: the root holds the first voxel)

@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
         // nothing significant, or too many runs for LDS: publish the masks; an overflowing tile is labelled run by run
         // (every run its own component) by its workgroup of k_face_merge
         if (my_valid) { lj.mask[my_word] = m; lj.run_base[my_word] = 0u; }
-        if (tid == 0) { lj.tile_mode[tile_id] = n_runs ? 1 : 0; lj.tile_runs[bid] = 0u; if (n_runs) *lj.unit_flag = lj.epoch; }
+        if (tid == 0) { lj.tile_mode[tile_id] = n_runs ? 1 : 0; lj.tile_runs[bid] = 0u; if (n_runs) { lj.unit_flag[0] = lj.epoch; lj.unit_flag[2] = lj.epoch; } }
         mark_comps_unused(lj, (uint32_t)bid * CCAP, 0u, tid, NT);
         return;
     }
@@ -599,7 +599,7 @@ __global__ void __launch_bounds__(512, 8) k_tile_label(Job job, const float *__r
         gb = s_gb[0];
         if (gb == 0xffffffffu) {   // block-uniform: a unit tile, labelled run by run by its workgroup of k_face_merge
             if (my_valid) lj.run_base[my_word] = 0u;
-            if (tid == 0) { lj.tile_mode[tile_id] = 3; lj.tile_runs[bid] = 0u; *lj.unit_flag = lj.epoch; }
+            if (tid == 0) { lj.tile_mode[tile_id] = 3; lj.tile_runs[bid] = 0u; lj.unit_flag[0] = lj.epoch; lj.unit_flag[2] = lj.epoch; }
             mark_comps_unused(lj, cb, 0u, tid, NT);
             return;
         }
@@ -706,9 +706,15 @@ struct NbWords {
     uint32_t base[13];
 };
 
-// unit_only: keep only the pairs with a unit tile on either side (the companion of k_face_merge).
+// Which of a word's pairs a caller wants (the tiles' modes: 0 united in LDS, 2 wide -- united in LDS, components by run id --,
+// 1 / 3 unit tiles, labelled by k_unit_label):
+//   PAIRS_ALL   every cross-tile pair (the generic path)
+//   PAIRS_WIDE  the pairs with a WIDE tile on either side and no unit tile on the other: everything they need was written by
+//               k_tile_label, so k_face_merge unites them itself
+//   PAIRS_UNIT  the pairs with a UNIT tile on either side: k_unit_pairs, behind k_unit_label
+enum { PAIRS_ALL = 0, PAIRS_WIDE = 1, PAIRS_UNIT = 2 };
 template <typename JobRef>
-__device__ inline bool load_cross_tile(const JobRef &job, const TileDims &td, int64_t w, uint64_t m, NbWords &nw, uint32_t &my_base, bool unit_only = false) {
+__device__ inline bool load_cross_tile(const JobRef &job, const TileDims &td, int64_t w, uint64_t m, NbWords &nw, uint32_t &my_base, int which = PAIRS_ALL) {
     const int plane = (job.n_vols > 1 && w >= job.vols[1].word_base) ? 1 : 0;
     const VolDesc vd = job.vols[plane];
     const int64_t rem = w - vd.word_base;
@@ -717,17 +723,23 @@ __device__ inline bool load_cross_tile(const JobRef &job, const TileDims &td, in
     const int rl = (int)(row % vd.dim[1]);
     const int sl = (int)(row / vd.dim[1]);
     const uint32_t my_mode = job.tile_mode[tile_index(td, 0, wq, rl, sl)];
-    const bool my_unit = my_mode != 0u;            // components by run id; its pairs belong to the unit path
-    const bool in_lds = my_mode == 0u || my_mode == 2u;   // ... but a WIDE tile (2) united its own pairs in LDS, like a normal one
+    const bool in_lds = my_mode == 0u || my_mode == 2u;   // a WIDE tile (2) united its own pairs in LDS, like a normal one
+    if (which == PAIRS_WIDE && (my_mode & 1u)) return false;   // (a unit tile's pairs: all of them the other pass's)
     // does any of the 13 earlier neighbours live in ANOTHER tile?
     const bool edge = ((rl & 7) == 0 && rl > 0) || ((sl & 7) == 0 && sl > 0) || ((rl & 7) == 7 && rl + 1 < vd.dim[1] && sl > 0) ||
                       (wq % td.cw == 0 && wq > 0) || (wq % td.cw == td.cw - 1 && wq + 1 < vd.row_words && (rl > 0 || sl > 0));
     if (!edge && in_lds) return false;
-    const bool all_nb = !unit_only || my_unit;   // otherwise a neighbour counts only if ITS tile is a unit tile
+    // does the pair with a neighbour in a tile of mode `nm` belong to this pass?
+    auto wanted = [&](uint32_t nm) {
+        if (which == PAIRS_ALL) return true;
+        if (which == PAIRS_UNIT) return ((my_mode | nm) & 1u) != 0u;
+        return (my_mode == 2u || nm == 2u) && (nm & 1u) == 0u;
+    };
+    const bool all_nb = which == PAIRS_ALL || (which == PAIRS_UNIT && (my_mode & 1u));   // otherwise a neighbour counts by ITS tile's mode
     bool want[13];
     int64_t at[13];
     want[0] = (m & 1ull) && wq > 0 && (!in_lds || (wq % td.cw == 0));
-    if (want[0] && !all_nb) want[0] = job.tile_mode[tile_index(td, 0, wq - 1, rl, sl)] != 0;
+    if (want[0] && !all_nb) want[0] = wanted(job.tile_mode[tile_index(td, 0, wq - 1, rl, sl)]);
     at[0] = w - 1;
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
@@ -745,7 +757,7 @@ __device__ inline bool load_cross_tile(const JobRef &job, const TileDims &td, in
             if (ok && in_lds && row_same_tile && (w2 / td.cw == wq / td.cw)) ok = false;  // united in LDS
             if (dw < 0 && !(m & 1ull)) ok = false;
             if (dw > 0 && !(m >> 63)) ok = false;
-            if (ok && !all_nb) ok = job.tile_mode[tile_index(td, 0, w2, r2, s2)] != 0;
+            if (ok && !all_nb) ok = wanted(job.tile_mode[tile_index(td, 0, w2, r2, s2)]);
             want[i] = ok;
             at[i] = rowbase + w2;
         }
@@ -816,8 +828,8 @@ __device__ inline void cross_tile_pairs(uint64_t m, uint32_t my_base, const NbWo
 // belong to the unit path (skipped here by the tile modes).  Grids wider than one tile add the c faces (waves 6 / 7): the
 // run at position 0 of a row against the runs that end the 9 rows around it in the tile to the left.
 //
-// Tiles that overflowed LDS in k_tile_label ("unit tiles") are handled at the end of the same workgroups: normally no tile did
-// (one flag, read with everything else) and the rare path costs neither a launch nor a workgroup of its own.
+// Tiles that overflowed LDS in k_tile_label ("unit tiles") are not this kernel's work (k_unit_label / k_unit_pairs, behind it,
+// for the jobs that have any): here their pairs are skipped, and a job enqueued without the two launches is flagged for a second run.
 constexpr int PAIR_SLOTS = 1024; // LDS hash set of a tile's distinct cross-face component pairs (a full set unites on the spot)
 constexpr int FM_THREADS = 384, FM_THREADS_WIDE = 512;  // 2 signs x 46 pairs of rows x 4 word slots = 368 lanes; grids wider than a tile: 128 more for the c faces
 constexpr int FACE_PAIRS = 46;
@@ -825,14 +837,14 @@ constexpr int FACE_PAIRS = 46;
 // One mask word of the unit-tile companion of k_face_merge: it owns EVERY pair that has a unit tile on either side
 // (all rows), and unites on the spot.
 template <typename JobRef>
-__device__ void unit_edges_word(const JobRef &job, const TileDims &td, const VolDesc &v0, int plane, int sl, int r, int wq) {
+__device__ void unit_edges_word(const JobRef &job, const TileDims &td, const VolDesc &v0, int plane, int sl, int r, int wq, int which) {
     const int rw = v0.row_words;
     const int64_t w = (int64_t)plane * rw * v0.dim[1] * v0.dim[2] + ((int64_t)sl * v0.dim[1] + r) * rw + wq;
     const uint64_t m = job.mask[w];
     if (m == 0ull) return;
     NbWords nw;
     uint32_t my_base;
-    if (!load_cross_tile(job, td, w, m, nw, my_base, true)) return;
+    if (!load_cross_tile(job, td, w, m, nw, my_base, which)) return;
     cross_tile_pairs(m, my_base, nw, [&](uint32_t a, uint32_t b) { kuf_unite(job.kpar, job.comp_of_run[a], job.comp_of_run[b]); });
 }
 
@@ -1046,52 +1058,50 @@ __global__ void __launch_bounds__(NTH, 8) k_face_merge(Job job_arg, const float 
     /*@F4*/
     /*@F5*/
     if (any_unit) {
-        // Some tile overflowed LDS in k_tile_label.  Its own workgroup labels it here, run by run (phase 1), and every pair with
-        // such a tile on either side is then united word by word (phase 2) by the workgroup of the tile that holds the LATER
-        // word of the pair: all of its words if the tile is a unit tile itself, else the words on its faces that look at one.
-        // Phase 2 reads what phase 1 of the neighbour tiles wrote: a flag per tile says that it has.  The earlier WORDS a word
-        // looks at lie in the 17 tiles around with ds <= 0 -- 13 earlier tiles and 4 later ones (a word on the tile's last
-        // row looks at row r + 1 of section s - 1, which is the next tile along r unless s starts the tile; its last word
-        // looks into the next tile along c).  Nobody waits before its own phase 1 is published, so a wait can only be for a
-        // workgroup that has not been dispatched yet, and that one is at most ctiles + 1 indices ahead: the launch moves as long
-        // as that many consecutive workgroups are resident -- no grid barrier, nothing that needs the whole grid at once
-        // (the 128 fallback workgroups this replaces had to be co-resident, all of them).
-        __syncthreads();   // (everybody is done with the pair tables: their LDS is the scratch below)
-        const bool mine_unit = (lj.tile_mode[tile] & 1) != 0;   // block-uniform: 1 / 3 (a wide tile, 2, was labelled by k_tile_label)
-        if (mine_unit) {
-            unit_label_tile<CW>(lj, dens, gp, td, w0, rt * TILE_R, st * TILE_S, reinterpret_cast<unsigned char *>(s_set));
-            __threadfence();   // publish run bases / records / run -> component ids to the other XCDs
-        }
-        __syncthreads();
-        if (tid == 0) {
-            __hip_atomic_store(&lj.unit_done[tile], lj.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            for (int k = 0; k < 18; ++k) {   // (dc, dr, ds) with ds = -1 or 0, but for the tile itself
-                const int dc = k % 3 - 1, dr = (k / 3) % 3 - 1, ds = k / 9 - 1;
-                if (dc == 0 && dr == 0 && ds == 0) continue;
-                const int c2 = ct + dc, r2 = rt + dr, s2 = st + ds;
-                if (c2 < 0 || c2 >= td.ctiles || r2 < 0 || r2 >= td.rtiles || s2 < 0) continue;
-                const int nb = (s2 * td.rtiles + r2) * td.ctiles + c2;
-                if (lj.tile_mode[nb] == 0) continue;
-                // (bounded: about a second.  A flag that never comes up -- it cannot, while workgroups are dispatched in order --
-                //  must not hang the GPU: the job is marked failed instead, and the host turns that into an error)
-                unsigned spins = 0;
-                while (__hip_atomic_load(&lj.unit_done[nb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != lj.epoch) {
-                    if (++spins > (1u << 21)) { __hip_atomic_store(&lj.ctr->unit_wait_failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                    __builtin_amdgcn_s_sleep(16);
-                }
-            }
-            __threadfence();
-        }
-        __syncthreads();
-        // (a unit tile that found no room for its ids raised the flag before its done flag: whoever waited for it sees it here)
-        const bool ids_ran_out = __hip_atomic_load(&lj.ctr->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        // Some tile left the fast path in k_tile_label.  A WIDE tile (more than CCAP components) is complete -- united in LDS, its
+        // components under global ids: the pairs it has across its faces are united here, word by word (by the workgroup of the
+        // tile that holds the later word).  A UNIT tile (more word-runs than LDS holds: checkerboards) is not labelled yet: that,
+        // and every pair with such a tile on either side, is the work of k_unit_label / k_unit_pairs, two launches behind this one
+        // that the host enqueues only for a job known to need them (Job::unit_form) -- a job enqueued without them says so here
+        // and is run again.  Nobody waits for another workgroup (rounds 3-4: both phases ran here, behind per-tile flags the
+        // workgroups polled).
         const VolDesc v0 = lj.vols[0];
         constexpr int NU = 64 * CW;
-        for (int k = tid; k < td.n_planes * NU && !ids_ran_out; k += NTH) {
+        for (int k = tid; k < td.n_planes * NU; k += NTH) {
             const int plane = k / NU, u = k % NU, wl = u % CW, rowl = u / CW;
             const int r = rt * TILE_R + (rowl & 7), s = st * TILE_S + (rowl >> 3), wq = w0 + wl;
-            if (r < ur && s < us && wq < row_words) unit_edges_word(lj, td, v0, plane, s, r, wq);
+            if (r < ur && s < us && wq < row_words) unit_edges_word(lj, td, v0, plane, s, r, wq, PAIRS_WIDE);
         }
+        if (lj.unit_form == 0 && tid == 0 && lj.unit_flag[2] == lj.epoch) atomicOr(&lj.ctr->overflow, 4u);
+    }
+}
+
+// The two launches of the unit path (Job::unit_form 1), one workgroup per tile each.
+// k_unit_label: a unit tile is labelled run by run (every run its own component: unit_label_tile).
+template <int CW>
+__global__ void __launch_bounds__(512) k_unit_label(Job job_arg, const float *__restrict__ dens, const Geom *__restrict__ gp, TileDims td) {
+    PDBEDA_LATE_JOB(lj);
+    __shared__ __attribute__((aligned(16))) unsigned char s_scratch[1024];
+    const int ct = (int)blockIdx.x, rt = (int)blockIdx.y, st = (int)blockIdx.z;
+    const int tile = (st * td.rtiles + rt) * td.ctiles + ct;
+    if ((lj.tile_mode[tile] & 1) == 0) return;   // block-uniform: 1 / 3 (a wide tile, 2, was labelled by k_tile_label)
+    unit_label_tile<CW>(lj, dens, gp, td, ct * CW, rt * TILE_R, st * TILE_S, s_scratch);
+}
+// k_unit_pairs: every pair with a unit tile on either side is united, word by word, by the workgroup of the tile that holds the
+// LATER word of the pair: all words of a unit tile, else the words on the tile's faces that look at one (unit_edges_word).
+template <int CW>
+__global__ void __launch_bounds__(512) k_unit_pairs(Job job_arg, TileDims td) {
+    PDBEDA_LATE_JOB(lj);
+    const int tid = threadIdx.x;
+    const int ct = (int)blockIdx.x, rt = (int)blockIdx.y, st = (int)blockIdx.z;
+    // (a unit tile that found no room for its ids raised the flag: the job's results are void, nothing is looked up)
+    if (__hip_atomic_load(&lj.ctr->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    const VolDesc v0 = lj.vols[0];
+    constexpr int NU = 64 * CW;
+    for (int k = tid; k < td.n_planes * NU; k += 512) {
+        const int plane = k / NU, u = k % NU, wl = u % CW, rowl = u / CW;
+        const int r = rt * TILE_R + (rowl & 7), s = st * TILE_S + (rowl >> 3), wq = ct * CW + wl;
+        if (r < td.ur && s < td.us && wq < td.row_words) unit_edges_word(lj, td, v0, plane, s, r, wq, PAIRS_UNIT);
     }
 }
 

@@ -208,15 +208,29 @@ BIG_CASES = {
     "c0_1stp_like": ((100, 108, 96), 200, 31, 0.45),     # BASELINE configs[0] stand-in: ~100^3, ~1 k atoms
     "c2_bench_entry": ((128, 128, 128), 400, 5, 0.5),    # bench.py's analysis_entry: 128^3, 2 000 atoms ("~2 A entry")
     "c3_multiple_entry": ((200, 200, 200), 100, 0, 0.5),  # one entry of configs[3]: 200^3, 500 atoms
+    "c5_hex_perm": ((128, 128, 128), 400, 11, 0.5),      # round 5: a NON-orthogonal cell at a BASELINE size (gamma = 120, Y/X/Z axis order, crsStart != 0)
+}
+# what a case's CCP4 header carries beyond (ncrs, spacing): a case without an entry here is an orthogonal cube whose cell is its grid
+BIG_CASE_SPECS = {
+    "c5_hex_perm": dict(interval=(144, 160, 136), crs_start=(-8, 12, 6), axis_order=(2, 1, 3), cell=(72.0, 80.0, 68.0), angles=(90.0, 90.0, 120.0)),
 }
 
 
-def cube_entry(ncrs, n_residues, seed, spacing=0.5):
-    """(spec, header, structure, params, 2Fo-Fc grid, Fo-Fc grid, rotation matrices) of one synthetic entry."""
+def cube_entry(ncrs, n_residues, seed, spacing=0.5, spec_kwargs=None):
+    """(spec, header, structure, params, 2Fo-Fc grid, Fo-Fc grid, rotation matrices) of one synthetic entry.
+    ``spec_kwargs``: the rest of the map's geometry (``BIG_CASE_SPECS``: cell, angles, interval, crs_start, axis_order)."""
     from . import ccp4
-    spec = MapSpec(ncrs=tuple(ncrs), spacing=spacing)
+    spec = MapSpec(ncrs=tuple(ncrs), spacing=spacing, **(spec_kwargs or {}))
     header = ccp4.DensityHeader.fromFileHeader(ccp4_header_bytes(spec))
-    lo, hi = np.array(header.crs2xyzCoord([6, 6, 6])), np.array(header.crs2xyzCoord([n - 7 for n in ncrs]))
+    if spec_kwargs:
+        nc, nr, ns = spec.ncrs
+        corners = np.array([header.crs2xyzCoord([c, r, s]) for c in (6, nc - 7) for r in (6, nr - 7) for s in (6, ns - 7)], dtype=np.float64)
+        lo, hi = corners.min(axis=0), corners.max(axis=0)
+        if not header.orthogonal:       # keep the chain inside the skewed cell: shrink the box around its centre
+            mid = (lo + hi) / 2
+            lo, hi = mid - (hi - lo) / 4, mid + (hi - lo) / 4
+    else:
+        lo, hi = np.array(header.crs2xyzCoord([6, 6, 6])), np.array(header.crs2xyzCoord([n - 7 for n in ncrs]))
     st = chain_structure(n_residues, seed, lo, hi, hetero_every=9, zero_occupancy_every=37)
     params = synthetic_params()
     dens = gaussian_sum_grid(header, st, params["full_atom_name_map_electrons"], sigma=0.55, noise=0.02, seed=seed)

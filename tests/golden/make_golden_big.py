@@ -25,7 +25,7 @@ from pdb_eda_amd import synthetic, structure  # noqa: E402
 
 def run_case(name, ccp4, da):
     ncrs, n_res, seed, spacing = synthetic.BIG_CASES[name]
-    spec, header, st, params, dens, diff, rot = synthetic.cube_entry(ncrs, n_res, seed, spacing)
+    spec, header, st, params, dens, diff, rot = synthetic.cube_entry(ncrs, n_res, seed, spacing, synthetic.BIG_CASE_SPECS.get(name))
     da.setGlobals(params)
     t0 = time.perf_counter()
     densityObj = ccp4.parse(io.BytesIO(synthetic.ccp4_bytes(spec, dens)), name)

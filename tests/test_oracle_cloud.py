@@ -55,11 +55,11 @@ def test_composite_equals_reference_small(name):
     _check(_analyse(header, z["dens"], st, params), z)
 
 
-@pytest.mark.parametrize("name", ["c0_1stp_like", "c3_multiple_entry", "c2_bench_entry"])
+@pytest.mark.parametrize("name", ["c0_1stp_like", "c3_multiple_entry", "c2_bench_entry", "c5_hex_perm"])
 def test_composite_equals_reference_at_baseline_sizes(name):
     from pdb_eda_amd import synthetic
     z = np.load(os.path.join(HERE, "golden", "analysis_big_%s.npz" % name), allow_pickle=False)
     ncrs, n_res, seed, spacing = synthetic.BIG_CASES[name]
-    spec, header, st, params, dens, diff, rot = synthetic.cube_entry(ncrs, n_res, seed, spacing)
+    spec, header, st, params, dens, diff, rot = synthetic.cube_entry(ncrs, n_res, seed, spacing, synthetic.BIG_CASE_SPECS.get(name))
     assert float(np.sum(dens, dtype=np.float64)) == float(z["dens_checksum"])
     _check(_analyse(header, dens, st, params), z)
