@@ -54,9 +54,10 @@ def test_stream_pool_matches_sequential(gpu_ctx):
 @pytest.mark.parametrize("shape,roughness", [((40, 48, 256), 0.5), ((24, 40, 600), 0.5),      # one tile column; three (the last one partial)
                                              ((40, 48, 256), 1.5)])                                # smooth: dense and wide tiles instead of unit tiles
 def test_unit_fallback_on_many_streams(shape, roughness):
-    """Dense maps (tiles overflow LDS -> their workgroups of k_face_merge label them run by run and wait for each other's
-    flags, later tiles along r and c included) labelled concurrently on six streams: every stream gets the oracle's answer
-    (counts, keys and the label volume) and nobody starves the others of workgroup slots."""
+    """Dense maps (tiles overflow LDS: "unit tiles", labelled and united by two launches of their own in a second run of the
+    job -- round 5; rounds 3-4 did both inside k_face_merge behind flags the workgroups polled, and a late dispatch on a busy
+    GPU failed the job) labelled concurrently on EIGHT streams: every stream gets the oracle's answer (counts, keys and the
+    label volume), every job ran twice and none failed."""
     import io
     from oracle import oracle as ora
     from pdb_eda_amd import ccp4, synthetic, multipleStructures
@@ -77,12 +78,13 @@ def test_unit_fallback_on_many_streams(shape, roughness):
             same = np.array_equal(st["n"], want["n"]) and np.array_equal(st["firstKey"], want["firstKey"]) and \
                 np.array_equal(green.labels(dm._map.unique_shape), want["labels"])
             c = green.counters()
-            out.append((same, c["unit_tiles_runs"] + c["unit_tiles_comps"] if roughness < 1.0 else c["run_ids"]))
+            out.append((same, c["unit_tiles_runs"] + c["unit_tiles_comps"] if roughness < 1.0 else c["run_ids"], c["reruns"]))
         return out
-    res = multipleStructures.StreamPool(device=0, n_streams=6).map(work, list(range(12)))
+    res = multipleStructures.StreamPool(device=0, n_streams=8).map(work, list(range(16)))
     assert all(r != 0 for r in res)
-    assert all(ok for r in res for ok, _ in r)
-    assert all(n_unit > 0 for r in res for _, n_unit in r)      # the fallback path really ran
+    assert all(ok for r in res for ok, _, _ in r)
+    assert all(n_unit > 0 for r in res for _, n_unit, _ in r)      # the fallback path really ran
+    assert all(reruns == (1 if roughness < 1.0 else 0) for r in res for _, _, reruns in r)   # ... as the second run of its job; dense / wide tiles need none
 
 
 def test_device_failure_stops_the_pool():
