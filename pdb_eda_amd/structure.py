@@ -15,6 +15,8 @@ preparation, not part of the accelerated path.
 import re
 
 import itertools
+import os
+import sys
 import numpy as np
 
 __all__ = ["Structure", "Model", "Chain", "Residue", "Atom", "PDBHeader", "PDBEntry", "read_pdb", "columns", "Columns"]
@@ -154,6 +156,17 @@ def _hostwalk():
     return _hostwalk_module[0]
 
 
+def _hostwalk_fell_back(where, exception):
+    """The C walk raised and the Python loops take over: silent by default (an object tree it does not read is an ordinary case),
+    but PDBEDA_DEBUG_HOSTWALK=1 says so on stderr -- a C module that fails on trees it SHOULD read must not hide behind its
+    fallback -- and PDBEDA_DEBUG_HOSTWALK=raise turns the fallback into the error."""
+    mode = os.environ.get("PDBEDA_DEBUG_HOSTWALK", "")
+    if mode == "raise":
+        raise exception
+    if mode not in ("", "0"):
+        print("pdb_eda_amd: _hostwalk.%s fell back to the Python loops: %s: %s" % (where, type(exception).__name__, exception), file=sys.stderr)
+
+
 class Columns(object):
     """A columnar snapshot of a structure: what the analysis reads from the object tree (see the module text), gathered in
     ONE walk so that the per-entry host work runs on arrays instead of on 10^3..10^4 Python objects.
@@ -179,9 +192,10 @@ class Columns(object):
                 try:
                     res_model, res_chain, res_number, res_name, het, children = walk.residue_columns(residues)
                     walked = walk.atom_columns(children)
-                except Exception:
+                except Exception as exception:
                     if native:
                         raise
+                    _hostwalk_fell_back("Columns", exception)
                     walked = None                      # an object tree the C walk does not read: the loops below do
         if walked is not None:
             atoms, name, occupancy, counts, occ, bfac, xyz, name_id, distinct = walked
