@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of library builds on the multiple-structure leg (same box, alternating): bash tools/exp/ab_pool.sh main abl/libBASE.so ...
+# A/B of library builds on the multiple-structure leg (same box, alternating): bash tools/exp/ab_pool.sh main ablx/libBASE.so ...
 for lib in "$@"; do
   if [ "$lib" = main ]; then unset PDBEDA_LIB; else export PDBEDA_LIB=$PWD/$lib; fi
   python3 bench.py --steps 5 --warmup 2 --windows 0 --streams 1 --no-cpu-baseline --no-analysis --no-sigma3 --sweep-entries 0 --workers 4 2>/dev/null | python3 -c "

@@ -1,7 +1,7 @@
 # Diagnostic build + run: s_memrealtime stamps at the /*@<letter><n>*/ marker comments of the kernel sources (an instrumented
 # COPY of csrc, never the product).  Threads 0 and 256 of every workgroup stamp (wave 0 and wave 4): slots n and 8 + n.
-#   python tools/exp/markstamps.py build L        -> abl/libMST_L.so   (markers /*@L0*/ ... of k_labels_tiles; R: k_resolve_tiles; F: k_face_merge)
-#   PDBEDA_LIB=$PWD/abl/libMST_L.so python tools/exp/markstamps.py run L [nsd]   (GPU box)
+#   python tools/exp/markstamps.py build L        -> ablx/libMST_L.so   (markers /*@L0*/ ... of k_labels_tiles; R: k_resolve_tiles; F: k_face_merge)
+#   PDBEDA_LIB=$PWD/ablx/libMST_L.so python tools/exp/markstamps.py run L [nsd]   (GPU box)
 import os, re, sys, subprocess, shutil
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 letter = sys.argv[2]
@@ -39,7 +39,7 @@ extern "C" int pdbeda_bloblist_stamps(pdbeda_bloblist *bl, unsigned long long *o
 '''
     for f, txt in (("pdbeda_hip.hip", h), ("pdbeda_device.h", open(os.path.join(dst, "pdbeda_device.h")).read())):
         open(os.path.join(dst, f), "w").write(txt.replace('#include "../../include/pdbeda.h"', '#include "%s/pdbeda.h"' % inc))
-    out = os.path.join(root, "abl", "libMST_%s.so" % letter)
+    out = os.path.join(root, "ablx", "libMST_%s.so" % letter)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off", "-std=c++17", "-Wno-unused-function",
                            "-o", out, os.path.join(dst, "pdbeda_hip.hip")])
     print("built", out, "with", cnt, "stamps")

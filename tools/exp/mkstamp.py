@@ -1,6 +1,6 @@
 # Diagnostic build (never shipped): a COPY of csrc with s_memrealtime stamps in k_tile_label -- after every barrier (thread 0) and,
 # per wave, at the end of the stream (A1), of the numbering (A2), of the unions (B) and of the folds (C2).
-#   python tools/exp/mkstamp.py  -> abl/libSTAMP.so ;  on the GPU box: PDBEDA_LIB=abl/libSTAMP.so python tools/exp/stamps.py
+#   python tools/exp/mkstamp.py  -> ablx/libSTAMP.so ;  on the GPU box: PDBEDA_LIB=ablx/libSTAMP.so python tools/exp/stamps.py
 #   python tools/exp/mkstamp.py [NAME [csrc-dir]]  (another source tree, e.g. last round's, for a side-by-side)
 import os, shutil, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -45,7 +45,7 @@ extern "C" int pdbeda_bloblist_stamps(pdbeda_bloblist *bl, unsigned long long *o
 '''
 for f, txt in (("pdbeda_hip.hip", h), ("pdbeda_device.h", open(os.path.join(dst, "pdbeda_device.h")).read())):
     open(os.path.join(dst, f), "w").write(txt.replace('#include "../../include/pdbeda.h"', '#include "%s/pdbeda.h"' % inc).replace('#include "/root/repo/include/pdbeda.h"', '#include "%s/pdbeda.h"' % inc))
-os.makedirs(os.path.join(root, "abl"), exist_ok=True)
+os.makedirs(os.path.join(root, "ablx"), exist_ok=True)
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off", "-std=c++17", "-Wno-unused-function",
-                       "-o", os.path.join(root, "abl", "lib%s.so" % name), os.path.join(dst, "pdbeda_hip.hip")])
-print("built abl/lib%s.so" % name)
+                       "-o", os.path.join(root, "ablx", "lib%s.so" % name), os.path.join(dst, "pdbeda_hip.hip")])
+print("built ablx/lib%s.so" % name)

@@ -14,7 +14,7 @@ else
   export TMPDIR=/tmp
   for v in PH1 PH2 PH3 PH4; do
     out=$root/gpurun_out/phase_$v; rm -rf "$out"; mkdir -p "$out"
-    ( cd /tmp && PDBEDA_LIB=$root/abl/lib$v.so rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES --output-format csv -d "$out" -o p -- python3 "$root/tools/exp/run_step_noaccess.py" > "$out/log.txt" 2>&1 ) || true
+    ( cd /tmp && PDBEDA_LIB=$root/ablx/lib$v.so rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES --output-format csv -d "$out" -o p -- python3 "$root/tools/exp/run_step_noaccess.py" > "$out/log.txt" 2>&1 ) || true
     python3 - "$out" $v <<'PY'
 import sys, glob, csv, collections
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)

@@ -1,5 +1,5 @@
 # Build a variant of the library from a patched COPY of csrc (experiments only; the product tree is not touched):
-#   python tools/exp/variant.py NAME 'old1=>new1' 'old2=>new2' ...      -> abl/libNAME.so
+#   python tools/exp/variant.py NAME 'old1=>new1' 'old2=>new2' ...      -> ablx/libNAME.so
 import os, shutil, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 name, edits = sys.argv[1], sys.argv[2:]
@@ -18,7 +18,7 @@ for e in edits:
     assert hit, "pattern not found: " + old
 for f, t in texts.items():
     open(os.path.join(dst, f), "w").write(t.replace('#include "../../include/pdbeda.h"', '#include "%s/pdbeda.h"' % inc))
-os.makedirs(os.path.join(root, "abl"), exist_ok=True)
+os.makedirs(os.path.join(root, "ablx"), exist_ok=True)
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off", "-std=c++17", "-Wno-unused-function",
-                       "-o", os.path.join(root, "abl", "lib%s.so" % name), os.path.join(dst, "pdbeda_hip.hip")])
-print("built abl/lib%s.so" % name)
+                       "-o", os.path.join(root, "ablx", "lib%s.so" % name), os.path.join(dst, "pdbeda_hip.hip")])
+print("built ablx/lib%s.so" % name)
