@@ -1292,12 +1292,15 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS, FUSED ? 8 : 1) k_lab
     const uint32_t rb = (uint32_t)bid * (uint32_t)(NU * 32), cb = (uint32_t)bid * CCAP;
     // every load of the prologue is issued before anything depends on one: the tile's first 2048 run -> component ids and its
     // label table do not wait for tile_mode / tile_runs (ids beyond the tile's run count hold stale bytes: stored, never used)
-    static_assert(NTL == 512 && LCAP == 4096, "four unconditional comp loads per thread cover the first 2048 runs");
-    uint32_t c_pre[4];
+    // (round 5: TWO unconditional loads per thread -- 1 024 runs; a tile at 1.5 sigma has ~790, at most ~990 -- where four, 2 048
+    //  runs, read 8 KiB a tile of which 3 were ever used; tiles with more runs fetch the rest once tile_runs is known)
+    static_assert(NTL == 512 && LCAP == 4096, "two unconditional comp loads per thread cover the first 1024 runs");
+    constexpr int CPRE = 2;
+    uint32_t c_pre[CPRE];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) c_pre[k] = lj.comp_of_run[rb + tid + NTL * k];
-    // (tile-local: a byte each -- packed at once, one register through the prologue instead of four)
-    const uint32_t c_pack = ((c_pre[0] - cb) & 0xffu) | (((c_pre[1] - cb) & 0xffu) << 8) | (((c_pre[2] - cb) & 0xffu) << 16) | ((c_pre[3] - cb) << 24);
+    for (int k = 0; k < CPRE; ++k) c_pre[k] = lj.comp_of_run[rb + tid + NTL * k];
+    // (tile-local: a byte each -- packed at once, one register through the prologue)
+    const uint32_t c_pack = ((c_pre[0] - cb) & 0xffu) | (((c_pre[1] - cb) & 0xffu) << 8);
     // non-fused: the root of a component carries its label (k_emit_tiles).  k_emit_tiles numbers the blobs of volume 1 by their
     // rank in the whole table: their labels are -1 - rank, and the blobs of volume 0 come off here (one scalar load beside the others)
     int32_t lab_pre = 0;
@@ -1446,10 +1449,10 @@ __global__ void __launch_bounds__(PDBEDA_LABELS_NT_THREADS, FUSED ? 8 : 1) k_lab
         //  ranks in its rows: it keeps the table, and does not read the bytes)
         if (!FUSED || fast) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) s_comp8[tid + NTL * k] = (uint8_t)(c_pack >> (8 * k));
+            for (int k = 0; k < CPRE; ++k) s_comp8[tid + NTL * k] = (uint8_t)(c_pack >> (8 * k));
         }
         if (fast)
-            for (uint32_t i = tid + 4 * NTL; i < n_runs; i += NTL) s_comp8[i] = (uint8_t)(lj.comp_of_run[rb + i] - cb);
+            for (uint32_t i = tid + CPRE * NTL; i < n_runs; i += NTL) s_comp8[i] = (uint8_t)(lj.comp_of_run[rb + i] - cb);
     }
     __syncthreads();
     /*@L4*/

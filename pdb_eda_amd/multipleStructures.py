@@ -242,7 +242,7 @@ def _worker_init(device, params, time_out, silent):
 
 
 def _worker_context(k=0):
-    ctxs = _worker_state.setdefault("ctxs", [None] * N_WORKER_CONTEXTS)
+    ctxs = _worker_state.setdefault("ctxs", [None] * (N_WORKER_CONTEXTS * max(1, WORKER_LANES)))
     if ctxs[k] is None:
         ctxs[k] = _native.Context(_worker_state["device"])
         if _worker_state["time_out"] > 0:
@@ -255,27 +255,60 @@ def _worker_entry(entry):
     return _worker_chunk([entry])[0]
 
 
-N_WORKER_CONTEXTS = 3    # contexts (= HIP streams, arena pools, pinned rings) a pool worker rotates its entries over
+N_WORKER_CONTEXTS = 3    # contexts (= HIP streams, arena pools) ONE lane of a pool worker rotates its entries over
+WORKER_LANES = int(os.environ.get("PDBEDA_WORKER_LANES", "1"))      # lanes of a pool worker: entries analysed at once (threads of the worker)
+WORKER_DEPTH = int(os.environ.get("PDBEDA_WORKER_DEPTH", "2"))      # entries a lane loads ahead of the one it analyses (<= N_WORKER_CONTEXTS - 1)
 
 
 def _worker_chunk(entries):
     """A few entries in a worker process, as a pipeline: while entry i is analysed (host-side table building: holds the GIL)
-    helper threads bring the maps of the NEXT TWO entries into HBM on the worker's other contexts (file reads and PCIe copies
-    happen inside the library, GIL released) -- a worker used to alternate between feeding the PCIe link and feeding the
-    interpreter, and four of them left the link idle 40 % of the time; with one entry ahead the link still idled between a
-    worker's uploads (header parse, mean / std, the first chunk's read: tools/prof_pipeline2.py), with two there is always a
-    copy queued.  Entry i lives on context i % 3 from its upload to its record.  With a time-out the pipeline is one entry
+    helper threads bring the maps of the next ``WORKER_DEPTH`` entries into HBM on the lane's other contexts (file reads and
+    PCIe copies happen inside the library, GIL released).  A worker may also run several such lanes (``WORKER_LANES`` threads
+    over interleaved shares of the chunk, each with its own contexts).  Round 5 measured the shapes against each other with
+    the process-wide upload engine underneath (tools/prof_pool.py pools, four workers, both maps): one lane two entries ahead
+    1.44 ms per entry, two lanes one ahead 1.48, two lanes two ahead 1.46, three lanes 1.47 -- and three workers 1.51, two
+    1.57: the pool sits on the link's rate for chunked copies plus ~0.17 ms of per-entry work the processes do not overlap,
+    whatever its shape; the default stays the simplest (one lane, two ahead).  With a time-out there is one lane, one entry
     deep (an entry's ONE deadline starts with its upload: it must not spend it queueing).  Returns [(record or 0, failure
     reason or None)]; a time-out abandons the context it happened on."""
+    time_out = _worker_state["time_out"]
+    lanes = 1 if time_out > 0 else max(1, min(WORKER_LANES, len(entries)))
+    if lanes == 1:
+        return _worker_lane(entries, 0)
+    out = [None] * len(entries)
+    errors = []
+
+    def run(k):
+        try:
+            for j, pair in enumerate(_worker_lane(entries[k::lanes], k * N_WORKER_CONTEXTS)):
+                out[k + j * lanes] = pair
+        except BaseException as exception:       # a device failure in one lane: the chunk fails with it (after the other lane has returned)
+            errors.append(exception)
+    threads = [threading.Thread(target=run, args=(k,), daemon=True) for k in range(1, lanes)]
+    for t in threads:
+        t.start()
+    run(0)
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return out
+
+
+def _worker_lane(entries, ctx_base):
+    """One lane of ``_worker_chunk``: its entries in order, on the contexts ``ctx_base`` .. ``ctx_base + N_WORKER_CONTEXTS - 1``."""
     silent = _worker_state["silent"]
 
     time_out = _worker_state["time_out"]
-    depth = 1 if time_out > 0 else N_WORKER_CONTEXTS - 1
+    depth = 1 if time_out > 0 else max(1, min(WORKER_DEPTH, N_WORKER_CONTEXTS - 1))
     started = {}
+
+    def context(i):
+        return _worker_context(ctx_base + i % N_WORKER_CONTEXTS)
 
     def load(i, box):
         try:
-            ctx = _worker_context(i % N_WORKER_CONTEXTS)
+            ctx = context(i)
             started[i] = time.monotonic()
             if time_out > 0:
                 ctx.set_timeout(time_out)            # the entry's ONE deadline starts with its upload
@@ -295,15 +328,15 @@ def _worker_chunk(entries):
         thread, box = pending.popleft()
         thread.join()
         if i + depth < len(entries):
-            pending.append(start(i + depth))         # (its context is free: entry i + depth - 3 has returned its record)
+            pending.append(start(i + depth))         # (its context is free: the entry that used it has returned its record)
         reasons = {}
         try:
-            record = analyzeEntry(entry, _worker_context(i % N_WORKER_CONTEXTS), reasons, silent, loaded=box[0])
+            record = analyzeEntry(entry, context(i), reasons, silent, loaded=box[0])
             if time_out > 0 and record and time.monotonic() - started.get(i, time.monotonic()) > time_out:
                 _drop(entry.pdbid, "Timeout", reasons, silent)     # (host phases cannot be interrupted: judged when the entry returns)
                 record = 0
         except _native.PdbedaTimeout:
-            _worker_state["ctxs"][i % N_WORKER_CONTEXTS] = None
+            _worker_state["ctxs"][ctx_base + i % N_WORKER_CONTEXTS] = None
             _drop(entry.pdbid, "Timeout", reasons, silent)
             record = 0
         except BaseException:
