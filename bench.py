@@ -138,7 +138,7 @@ def analysis_leg(ctx, case="c2_bench_entry", reps=5):
     assert rel < 1e-8 and an.numVoxelsAggregated == int(golden["num_voxels"]), "analysis leg differs from the reference: %r vs %r" % (an.densityElectronRatio, want)
     ref_s = json.loads(str(golden["reference_seconds"]))
     return {"sphere_region_sums": sphere, "workload": "synthetic ~2 A entry: %d^3 grid at 0.5 A, %d atoms (%d with clouds), 2Fo-Fc + Fo-Fc maps parsed from CCP4 bytes" %
-                        (edge, len(list(st.get_atoms())), len(an.atomCloudDescriptions)),
+                        (edge, len(list(st.get_atoms())), an.cloudCounts[0]),
             "ms": {k: round(1e3 * v, 2) for k, v in best.items()}, "ms_per_entry": 1e3 * total, "entries_per_min": 60.0 / total,
             "density_electron_ratio": an.densityElectronRatio,
             "reference": {"density_electron_ratio": want, "relative_difference": rel, "num_voxels_aggregated_equal": True,

@@ -2410,11 +2410,13 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
         e = h2d_row(ctx, in, 1);
     }
     if (e != hipSuccess) { arena_put(ctx, gs.in_arena); return fail_dev(e, nullptr); }
-    // The union job is sized by the HOST (round 5; a wait for the groups' bounds before): the voxels of a pooled cloud lie inside
-    // its atom's sphere box [C - R - 1, C + R], so the box around the boxes of a residue's pooled atoms -- around all of them for
-    // the domain group -- holds the group's voxels.  The device makes the volumes from the voxels' own bounds as before (never
-    // larger than these), and k_make_vols holds its totals against the host's.
+    // The union job's volumes are made by the HOST (round 5; three launches -- k_init_bounds, k_list_boxes, k_make_vols -- and a
+    // wait for their totals before): the voxels of a pooled cloud lie inside its atom's sphere box [C - R - 1, C + R], so the box
+    // around the boxes of a residue's pooled atoms -- around all of them for the domain group -- holds the group's voxels.  A
+    // volume a little larger than its voxels' own bounds changes nothing in the result: keys are lexicographic in (c, r, s)
+    // whatever the box, so the blobs come out in the same order with the same sums.
     int64_t union_totals[2] = {0, 0};
+    std::vector<VolDesc> union_vols((size_t)n_groups);
     {
         std::vector<int64_t> lo(3 * (size_t)n_groups, INT64_MAX), hi(3 * (size_t)n_groups, INT64_MIN);
         for (int64_t p = 0; p < n_pool; ++p) {
@@ -2431,18 +2433,40 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
                 }
         }
         for (int g = 0; g < n_groups; ++g) {
+            VolDesc &vd = union_vols[(size_t)g];
+            memset(&vd, 0, sizeof vd);
+            vd.group = g;
+            vd.word_base = union_totals[0];
+            vd.key_base = union_totals[1];
             if (hi[3 * (size_t)g] < lo[3 * (size_t)g]) continue;
-            const int64_t dc = hi[3 * (size_t)g] - lo[3 * (size_t)g] + 1, dr = hi[3 * (size_t)g + 1] - lo[3 * (size_t)g + 1] + 1, ds = hi[3 * (size_t)g + 2] - lo[3 * (size_t)g + 2] + 1;
-            union_totals[0] += (dc + 63) / 64 * dr * ds;
-            union_totals[1] += dc * dr * ds;
+            bool fits = true;
+            for (int k = 0; k < 3; ++k) {
+                const int64_t d = hi[3 * (size_t)g + k] - lo[3 * (size_t)g + k] + 1;
+                fits = fits && d < (1ll << 30) && lo[3 * (size_t)g + k] > INT32_MIN && hi[3 * (size_t)g + k] < INT32_MAX;
+                vd.org[k] = (int32_t)lo[3 * (size_t)g + k];
+                vd.dim[k] = (int32_t)d;
+            }
+            if (!fits) { union_totals[0] = INT64_MAX / 2; break; }
+            vd.row_words = (vd.dim[0] + 63) / 64;
+            union_totals[0] += (int64_t)vd.row_words * vd.dim[1] * vd.dim[2];
+            union_totals[1] += (int64_t)vd.dim[0] * vd.dim[1] * vd.dim[2];
         }
-        if (ctx->debug_shrink_totals) { union_totals[0] /= 2; union_totals[1] /= 2; }
     }
-    const bool host_sized = union_totals[0] < (1ll << 31) && union_totals[1] < (1ll << 40);   // (absurd boxes: let the waiting path size and report)
+    const bool host_sized = !ctx->debug_shrink_totals && union_totals[0] < (1ll << 31) && union_totals[1] < (1ll << 40);   // (absurd boxes, or the debug hook that wants the device's own sizing: the waiting path sizes and reports)
     { PROF(ctx, "k_pool_gather"); hipLaunchKernelGGL(k_pool_gather, dim3(grid_for(2 * V, 256)), dim3(256), 0, st, cow->crs_dev, cow->offsets_dev, d_pool_cloud, d_pool_voff,
                                                      d_pool_group, (int)n_pool, V, n_rg, gs.d_crs, gs.d_item_group); }
     if (n_pairs > 0) { PROF(ctx, "k_test_overlap"); hipLaunchKernelGGL(k_test_overlap, dim3((unsigned)n_pairs), dim3(256), 0, st, cow->crs_dev, d_set_off, d_pa, d_pb, d_touch); }
-    rc = group_bounds(m, &gs, 2 * V, n_groups, false, host_sized ? union_totals : nullptr);      // (no wait when the host has sized the job)
+    if (host_sized) {
+        const H2DItem in[1] = {{gs.d_vols, union_vols.data(), sizeof(VolDesc) * (size_t)n_groups}};
+        e = h2d_row(ctx, in, 1);
+        if (e != hipSuccess) { arena_put(ctx, gs.in_arena); return fail_dev(e, nullptr); }
+        gs.total_words = union_totals[0];
+        gs.total_keys = union_totals[1];
+        gs.host_totals = true;
+        rc = 0;
+    } else {
+        rc = group_bounds(m, &gs, 2 * V, n_groups, false);      // (synchronises)
+    }
     if (rc) { arena_put(ctx, gs.in_arena); arena_put(ctx, aux); return bail(rc, clouds, nullptr); }
     pdbeda_bloblist *uni = nullptr;
     rc = grouped_job(m, gs, 2 * V, n_groups, false, 0.0f, &uni);

@@ -341,6 +341,7 @@ class DensityAnalysis(object):
         self._totalAggregatedDensity = None
         self._atomTypeOverlapCompleteness = None
         self._atomTypeOverlapIncompleteness = None
+        self._cloudTables = None
         self._fc = None
 
     # ---- lazy properties (ref densityAnalysis.py:326-565) ------------------------------------
@@ -358,9 +359,31 @@ class DensityAnalysis(object):
     symmetryOnlyAtomCoords = _lazy('_symmetryOnlyAtomCoords', '_calculateSymmetryAtoms')
     asymmetryAtomCoords = _lazy('_asymmetryAtomCoords', '_calculateSymmetryAtoms')
     medians = _lazy('_medians', 'aggregateCloud')
-    atomCloudDescriptions = _lazy('_atomCloudDescriptions', 'aggregateCloud')
-    residueCloudDescriptions = _lazy('_residueCloudDescriptions', 'aggregateCloud')
-    domainCloudDescriptions = _lazy('_domainCloudDescriptions', 'aggregateCloud')
+
+    def _described(name, which):
+        """The description tables (ref densityAnalysis.py:682-731, 734-767) are MADE on first access: aggregateCloud keeps what they
+        are made from (numeric columns, row indices) -- `pdb_eda multiple` and the optimiser read the medians and the number of rows,
+        never the rows (a 2 000-atom entry spent 0.4 ms of its 1.6 on string columns and lists of Python rows nobody looked at)."""
+        def getter(self):
+            if getattr(self, name) is None:
+                if self._cloudTables is None:
+                    self.aggregateCloud()
+                if self._cloudTables is not None and getattr(self, name) is None:
+                    setattr(self, name, self._cloudTables[which]())
+            return getattr(self, name)
+        return property(getter)
+
+    atomCloudDescriptions = _described('_atomCloudDescriptions', 'atoms')
+    residueCloudDescriptions = _described('_residueCloudDescriptions', 'residues')
+    domainCloudDescriptions = _described('_domainCloudDescriptions', 'domains')
+    del _described
+
+    @property
+    def cloudCounts(self):
+        """(atoms, residue clouds, domain clouds) analysed = the lengths of the three description tables, without making them."""
+        if self._cloudTables is None:
+            self.aggregateCloud()
+        return self._cloudTables["counts"] if self._cloudTables is not None else None
     numVoxelsAggregated = _lazy('_numVoxelsAggregated', 'aggregateCloud')
     totalAggregatedElectrons = _lazy('_totalAggregatedElectrons', 'aggregateCloud')
     totalAggregatedDensity = _lazy('_totalAggregatedDensity', 'aggregateCloud')
@@ -519,31 +542,31 @@ class DensityAnalysis(object):
         cols = inp["cols"]
         plain = inp["plain_residues"].tolist()
 
-        def cloudRows(t):
+        def cloudRows(t, by_ratio=False):
             which = [plain[ri] for ri in t["residue"].tolist()]
-            return [[cols.res_chain[k], cols.res_number[k], cols.res_name[k], tot / el, nv, el, nv * unitVolume, cen]
+            rows = [[cols.res_chain[k], cols.res_number[k], cols.res_name[k], tot / el, nv, el, nv * unitVolume, cen]
                     for k, tot, nv, el, cen in zip(which, t["total"].tolist(), t["n"].tolist(), t["electrons"].tolist(), t["centroid"].tolist())]
-        residueList = cloudRows(res["res"])
-        domainList = cloudRows(res["dom"])
+            if by_ratio:
+                rows.sort(key=lambda x: x[3])
+            return rows
         numVoxels, totalElectrons, totalDensity = res["numVoxels"], res["totalElectrons"], res["totalDensity"]
         if totalElectrons < minTotalElectrons:
             return
         densityElectronRatio = totalDensity / totalElectrons
-        domainList.sort(key=lambda x: x[3])
 
         try:
-            atoms, medians = self._cloudStatistics(inp, res, densityElectronRatio, unitVolume, typeMap)
+            atoms, n_atoms, medians = self._cloudStatistics(inp, res, densityElectronRatio, unitVolume, typeMap)
         except Exception:
             return
+        self._cloudTables = {"atoms": atoms, "residues": lambda: cloudRows(res["res"]), "domains": lambda: cloudRows(res["dom"], True),
+                             "counts": (n_atoms, len(res["res"]["n"]), len(res["dom"]["n"]))}
+        self._atomCloudDescriptions = self._residueCloudDescriptions = self._domainCloudDescriptions = None
 
         self._densityElectronRatio = densityElectronRatio
         self._numVoxelsAggregated = numVoxels
         self._totalAggregatedElectrons = totalElectrons
         self._totalAggregatedDensity = totalDensity
         self._medians = medians
-        self._atomCloudDescriptions = atoms
-        self._residueCloudDescriptions = residueList
-        self._domainCloudDescriptions = domainList
         self._atomTypeOverlapCompleteness = completely
         self._atomTypeOverlapIncompleteness = incompletely
 
@@ -558,11 +581,6 @@ class DensityAnalysis(object):
             near = dist < np.nanmedian(dist) + np.nanstd(dist) * 2              # (the reference filters the finished table: same rows)
             idx, dist, total, count, centroid = idx[near], dist[near], total[near], count[near], centroid[near]
         n = len(idx)
-        table = np.zeros(n, dtype=np.dtype([
-            ('chain', 'U20'), ('residue_number', int), ('residue_name', 'U10'), ('atom_name', 'U10'), ('atom_type', 'U%d' % atomTypeLengthGlobal),
-            ('density_electron_ratio', float), ('num_voxels', int), ('electrons', int), ('bfactor', float), ('centroid_distance', float),
-            ('centroid_xyz', float, (3,)), ('adj_density_electron_ratio', float), ('domain_fraction', float), ('corrected_fraction', float),
-            ('corrected_density_electron_ratio', float), ('volume', float)]))
         cols, rows = inp["cols"], inp["rows"][idx]
         of_residue = cols.res_of_atom[rows]
         # atom types as numbers: inp["type_names"] is sorted, so the types present, in np.unique's order, are the ids present
@@ -571,17 +589,27 @@ class DensityAnalysis(object):
         atom_types = np.asarray(inp["type_names"])[present] if len(present) else np.zeros(0, dtype='U1')
         n_types = len(atom_types)
         group = np.searchsorted(present, type_id)
-        table['chain'] = np.asarray(cols.res_chain)[of_residue]
-        table['residue_number'] = np.asarray(cols.res_number)[of_residue]
-        table['residue_name'] = np.asarray(cols.res_name)[of_residue]
-        table['atom_name'] = np.asarray(cols.atom_names)[cols.name_of_atom[rows]] if n else ''
-        table['atom_type'] = atom_types[group] if n else ''
-        table['density_electron_ratio'] = total / inp["electrons"][idx] / inp["occupancy"][idx]
-        table['num_voxels'] = count
-        table['electrons'] = inp["electrons"][idx]
-        table['bfactor'] = cols.bfactor[rows]
-        table['centroid_distance'] = dist
-        table['centroid_xyz'] = centroid
+        # the numeric columns of the atom table (the reference's structured array, 734-741); the table itself -- with its string
+        # columns -- is made from them when somebody asks for it (``make_table`` below)
+        table = {'density_electron_ratio': total / inp["electrons"][idx] / inp["occupancy"][idx], 'num_voxels': np.asarray(count, dtype=np.int64),
+                 'bfactor': np.array(cols.bfactor[rows], dtype=np.float64), 'centroid_distance': np.asarray(dist, dtype=np.float64)}
+
+        def make_table():
+            out = np.zeros(n, dtype=np.dtype([
+                ('chain', 'U20'), ('residue_number', int), ('residue_name', 'U10'), ('atom_name', 'U10'), ('atom_type', 'U%d' % atomTypeLengthGlobal),
+                ('density_electron_ratio', float), ('num_voxels', int), ('electrons', int), ('bfactor', float), ('centroid_distance', float),
+                ('centroid_xyz', float, (3,)), ('adj_density_electron_ratio', float), ('domain_fraction', float), ('corrected_fraction', float),
+                ('corrected_density_electron_ratio', float), ('volume', float)]))
+            out['chain'] = np.asarray(cols.res_chain)[of_residue]
+            out['residue_number'] = np.asarray(cols.res_number)[of_residue]
+            out['residue_name'] = np.asarray(cols.res_name)[of_residue]
+            out['atom_name'] = np.asarray(cols.atom_names)[cols.name_of_atom[rows]] if n else ''
+            out['atom_type'] = atom_types[group] if n else ''
+            out['electrons'] = inp["electrons"][idx]
+            out['centroid_xyz'] = centroid
+            for field, values in table.items():
+                out[field] = values
+            return out
 
         # rows in type order, once: every median below sorts the values of one type at a time, in place
         by_type = np.argsort(group.astype(np.int16 if n_types < 32768 else np.int64), kind="stable")
@@ -634,7 +662,7 @@ class DensityAnalysis(object):
         m_corrected, m_corrected_ratio = typeMedians(table['corrected_fraction'], also=(lambda c: c * ratio + ratio,))
         medians['corrected_fraction'] = asDict(m_corrected)
         medians['corrected_density_electron_ratio'] = asDict(m_corrected_ratio)
-        return table, medians
+        return make_table, n, medians
 
     # ---- symmetry atoms (ref densityAnalysis.py:885-912 + cutils.pyx:73-103) -------------------
     def _calculateSymmetryAtoms(self):

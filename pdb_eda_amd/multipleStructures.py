@@ -110,8 +110,8 @@ def analyzeEntry(entry, ctx=None, failures=None, silent=False, loaded=None):
              'num_voxels_aggregated': analyzer.numVoxelsAggregated, 'total_aggregated_electrons': analyzer.totalAggregatedElectrons,
              'density_mean': densityObj.header.densityMean, 'diff_density_mean': diffDensityObj.header.densityMean,
              'resolution': pdbObj.header.resolution, 'space_group': pdbObj.header.spaceGroup,
-             'num_atoms_analyzed': len(analyzer.atomCloudDescriptions), 'num_residue_clouds_analyzed': len(analyzer.residueCloudDescriptions),
-             'num_domain_clouds_analyzed': len(analyzer.domainCloudDescriptions), 'atom_overlap_completeness': complete}
+             'num_atoms_analyzed': analyzer.cloudCounts[0], 'num_residue_clouds_analyzed': analyzer.cloudCounts[1],
+             'num_domain_clouds_analyzed': analyzer.cloudCounts[2], 'atom_overlap_completeness': complete}
     properties = dict(getattr(biopdbObj, "header", None) or {})          # the structure header items (ref 346)
     properties['residue_counts'] = dict(collections.Counter(residue.resname for residue in biopdbObj.get_residues()))
     properties['element_counts'] = dict(collections.Counter(atom.element for atom in biopdbObj.get_atoms()))
