@@ -689,9 +689,9 @@ static hipError_t event_wait(pdbeda_ctx *ctx, hipEvent_t ev) {
 // 0.9-1.1 ms with one reader, and four worker processes together reached 39 GB/s (`tools/exp/file_h2d.py`; a pageable copy
 // out of an mmap of the file runs at link speed only while its pages stay mapped -- a fresh mapping per file pays 0.6 ms of
 // page faults per 32 MB before the first byte moves).  byteswap: the file has the other endianness.
-static const size_t FILE_CHUNK_MAX = (size_t)4 << 20;
+static const size_t FILE_CHUNK_MAX = (size_t)16 << 20;   // a reader's pinned slot; chunks are 8 MiB by default (four workers, both maps: 4 MiB 1.44-1.45 ms per entry, 8 MiB 1.40-1.42, 16 MiB 1.39-1.40)
 static size_t file_chunk_bytes() {   // (PDBEDA_FILE_CHUNK_KB: experiments)
-    static const size_t v = [] { const char *e = getenv("PDBEDA_FILE_CHUNK_KB"); long kb = e ? atol(e) : 4096; return (size_t)std::min<long>(std::max<long>(kb, 64), 4096) << 10; }();
+    static const size_t v = [] { const char *e = getenv("PDBEDA_FILE_CHUNK_KB"); long kb = e ? atol(e) : 8192; return (size_t)std::min<long>(std::max<long>(kb, 64), 16384) << 10; }();
     return v;
 }
 #define FILE_CHUNK (file_chunk_bytes())
@@ -917,7 +917,7 @@ static int upload_file_impl(pdbeda_ctx *ctx, const char *path, int64_t offset, i
     } else if (e == hipSuccess && !ctx->timed_out) {
         UploadLoad ld;
         ld.fd = fd; ld.offset = offset; ld.dst = (char *)d; ld.need = need;
-        // chunk sizes ramp up: a pread of 4 MiB takes 0.4 ms before its copy can start -- with every reader on such a chunk the
+        // chunk sizes ramp up: a pread of a full chunk takes the better part of a millisecond before its copy can start -- with every reader on such a chunk the
         // link idled for the first 0.4 ms of every map; the first round is 256 KiB each, the second 1 MiB, then full chunks
         for (size_t pos = 0, k = 0; pos < need; ++k) {
             const size_t round = k / (size_t)engine->n_readers;
