@@ -689,7 +689,7 @@ static hipError_t event_wait(pdbeda_ctx *ctx, hipEvent_t ev) {
 // 0.9-1.1 ms with one reader, and four worker processes together reached 39 GB/s (`tools/exp/file_h2d.py`; a pageable copy
 // out of an mmap of the file runs at link speed only while its pages stay mapped -- a fresh mapping per file pays 0.6 ms of
 // page faults per 32 MB before the first byte moves).  byteswap: the file has the other endianness.
-static const size_t FILE_CHUNK_MAX = (size_t)16 << 20;   // a reader's pinned slot; chunks are 8 MiB by default (four workers, both maps: 4 MiB 1.44-1.45 ms per entry, 8 MiB 1.40-1.42, 16 MiB 1.39-1.40)
+static const size_t FILE_CHUNK_MAX = (size_t)16 << 20;   // the most a chunk may be; chunks (= a reader's pinned slots) are 8 MiB by default (four workers, both maps: 4 MiB 1.44-1.45 ms per entry, 8 MiB 1.40-1.42, 16 MiB 1.39-1.40)
 static size_t file_chunk_bytes() {   // (PDBEDA_FILE_CHUNK_KB: experiments)
     static const size_t v = [] { const char *e = getenv("PDBEDA_FILE_CHUNK_KB"); long kb = e ? atol(e) : 8192; return (size_t)std::min<long>(std::max<long>(kb, 64), 16384) << 10; }();
     return v;
@@ -824,7 +824,7 @@ static UploadEngine *upload_engine(int device) {
         UploadEngine::Reader &rd = en->readers[en->n_readers];
         bool ok = hipStreamCreateWithFlags(&rd.stream, hipStreamNonBlocking) == hipSuccess;
         for (int k = 0; k < 2 && ok; ++k)
-            ok = hipHostMalloc((void **)&rd.slot[k], FILE_CHUNK_MAX, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&rd.done[k], hipEventDisableTiming) == hipSuccess;
+            ok = hipHostMalloc((void **)&rd.slot[k], FILE_CHUNK, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&rd.done[k], hipEventDisableTiming) == hipSuccess;
         if (!ok) { (void)hipGetLastError(); break; }   // (fewer readers than asked for: what was made so far serves)
         rd.ok = true;
         ++en->n_readers;
