@@ -259,6 +259,27 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
         finally:
             lazy.close()
         lazy_done = lazy_passes * args.entries
+        # ONE load by itself (this process, the pools are closed): a 32 MB map file -> HBM through the upload engine, statistics included
+        load_single = None
+        try:
+            from pdb_eda_amd import _native as native, ccp4 as ccp4_mod
+            lone = native.Context(local_rank)
+            head = ccp4_mod.read(loaders[0].density_path, "lone", ctx=lone, lazy=True)
+            geom, off = head.header.geometry(), 1024 + head.header.symmetryBytes
+            times = []
+            for k in range(12):
+                path = loaders[k % len(loaders)].density_path
+                t1 = time.perf_counter()
+                one_map = native.DeviceMap.from_file(lone, path, off, False, geom)
+                times.append(time.perf_counter() - t1)
+                one_map.free()
+            n_bytes = 4 * args.entry_size ** 3
+            load_single = {"bytes": n_bytes, "median_ms": 1e3 * float(np.median(times[2:])), "GBs_median": n_bytes / float(np.median(times[2:])) / 1e9,
+                           "GBs_best": n_bytes / min(times[2:]) / 1e9,
+                           "note": "pdbeda_map_upload_file_stats of one map alone: open, chunked pread -> pinned -> HBM on three reader threads, mean / std, one wait"}
+            lone.close()
+        except Exception as error:
+            load_single = {"error": "%s: %s" % (type(error).__name__, error)}
         per_rank = [own_rate]
         total_done = n_done
         if dist is not None:
@@ -313,7 +334,7 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
                 "entries_per_min_per_rank": [round(v, 1) for v in per_rank],
                 "one_worker_ms_per_entry": 1e3 * single, "one_worker_entries_per_min": 60.0 / single,
                 "pool_vs_one_worker": (total_done / world / elapsed) * single, "generation_s": gen_s,
-                "roofline": pcie,
+                "roofline": pcie, "load_GBs_single": (load_single or {}).get("GBs_median"), "load_single": load_single,
                 "golden_records_checked": checked["records"] if golden is not None else None,
                 "lazy_diff_map": {"entries": lazy_done, "entries_ok": lazy_ok, "seconds": lazy_elapsed, "entries_per_min": 60.0 * lazy_done / lazy_elapsed,
                                   "note": "the same entry list with the product's default loader: the Fo-Fc file's header is read, its grid would follow on first use "

@@ -767,7 +767,7 @@ int ora_cloud_finish(ora_cloud_state *s, double centroid_cutoff, double min_clou
         a0 = a1;
     }
     /* domain clouds (692-712) and the totals (714-726) */
-    ora_cloud1 **dpool = (ora_cloud1 **)malloc(sizeof(ora_cloud1 *) * (size_t)(n_dom_pool > 0 ? n_dom_pool : 1));
+    ora_cloud1 **dpool = (ora_cloud1 **)calloc((size_t)(n_dom_pool > 0 ? n_dom_pool : 1), sizeof(ora_cloud1 *));
     int64_t *dcomp = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_dom_pool > 0 ? n_dom_pool : 1));
     if (!dpool || !dcomp) return -1;
     for (int64_t i = 0; i < n_dom_pool; ++i) dpool[i] = &dom_pool[i];

@@ -13,7 +13,7 @@ out=$root/gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o bench -- python3 "$root/bench.py" --steps 30 --warmup 5 --windows 0 --entries 0 --sweep-entries 0 --no-cpu-baseline --no-analysis --no-sigma3 --streams 1 > "$out/bench_under_rocprof.json" 2> "$out/trace.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o bench -- python3 "$root/bench.py" --steps 30 --warmup 5 --windows 0 --entries 0 --sweep-entries 0 --no-cpu-baseline --no-analysis --no-sigma3 --no-beyond-cache --streams 1 > "$out/bench_under_rocprof.json" 2> "$out/trace.err"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o p -- python3 "$root/tools/profile_step.py" > "$out/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o p -- python3 "$root/tools/profile_step.py" > "$out/pmc_write.log" 2>&1
 cd "$root"
