@@ -381,6 +381,8 @@ class ProcessPool(object):
         while it analyses the current one (``_worker_chunk``); every chunk starts with an upload nothing overlaps, so chunks of
         16 instead of 8 took the pool from 1.77 to 1.51 ms per entry (tools/prof_pipeline2.py)."""
         entries = list(entries)
+        if chunk is None and os.environ.get("PDBEDA_POOL_CHUNK"):
+            chunk = int(os.environ["PDBEDA_POOL_CHUNK"])      # (experiments)
         if chunk is None:
             rounds = max(1, -(-len(entries) // (16 * self.n_workers)))
             chunk = max(1, -(-len(entries) // (rounds * self.n_workers)))
