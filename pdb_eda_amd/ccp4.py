@@ -79,7 +79,26 @@ def parse(handle, pdbid, verbose=False, ctx=None):
     return DensityMatrix(header, header.origin, grid, pdbid, ctx=ctx)
 
 
+def _libm_fma():
+    """libm's fma (correctly rounded, IEEE 754): Python 3.10 has no math.fma."""
+    import ctypes
+    import ctypes.util
+    try:
+        fn = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6").fma
+        fn.restype, fn.argtypes = ctypes.c_double, [ctypes.c_double] * 3
+        return fn if fn(3.0, 5.0, 7.0) == 22.0 else None
+    except (OSError, AttributeError):
+        return None
+
+
+_fma_c = _libm_fma()
+
+
 def _fma(a, b, c):
+    """a * b + c with ONE rounding.  libm's when it loads (a header costs twelve of these: exact rational arithmetic took 0.1 ms of a
+    pool entry's 1.2 ms of Python), else by exact rational arithmetic -- the same value either way."""
+    if _fma_c is not None:
+        return _fma_c(float(a), float(b), float(c))
     from fractions import Fraction
     return float(Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c)))
 
