@@ -6,20 +6,21 @@
 //      ballots -> bit masks of both signs (fused green / red); the significant values are parked in the wave's
 //      own slice of LDS, compacted in lane order
 //   -- barrier 1 (the masks of all sections are in LDS) --
-//   A2 lane = (sign, row, word) of the section: the lane counts the word-runs of its mask word; ONE packed
-//      32-lane DPP scan numbers them (ids follow wave, sign, row, word: the runs of a row are consecutive), numbers
-//      the words of the section below as that wave does (so nobody waits for anybody's ids) and places the parked values
-//   B  26-connected components inside the tile, without a run list and without rounds: the touching pairs between
-//      my word and an earlier neighbour row are the set bits of two bit expressions (a pair is charged to the
-//      later of its two run starts, which makes it unique; pairs with the two diagonal rows of the section below
-//      are dropped where a voxel straight below already implies them).  The lanes of a wave LIST their pairs, then
-//      lane k unites pair k, k + 64, ... in a lock-free union-find in LDS (optimistic atomic min on the larger id;
-//      find splits the path it walks).  Waves do not wait for each other.
+//   A2 lane = (sign, row, word) of the section: the lane counts the word-runs of its ROW's mask word; ONE packed
+//      32-lane DPP scan numbers them (ids follow wave, sign, row, word) and places the parked values: these are the ids the
+//      later kernels look voxels up by, and what C2 hands out -- the unions do not run on them (round 5)
+//   B  26-connected components inside the tile on BLOCK NODES: the word-runs of the OR of the four row masks of a 2 x 2
+//      (row, section) group -- connected sets under 26-connectivity; 16 groups a tile instead of 64 rows, a third of the nodes,
+//      no pair inside a group.  Wave = (sign, one of the four earlier groups), lane = (group, word): the touching pairs are the
+//      set bits of one bit expression over the rows on the shared face (a pair is charged to the later of its two run starts,
+//      which makes it unique), either side's node is the last start <= the bit in its group's OR mask.  The lanes of a wave LIST
+//      their pairs, then lane k unites pair k, k + 64, ... in a lock-free union-find in LDS (optimistic atomic min on the larger
+//      id; find splits the path it walks).  Waves do not wait for each other: every wave of a sign numbers the nodes for itself.
 //   -- barrier 2 (all unions done) --
-//   C1 roots take component numbers; every lane describes the runs of its word in the idle upper halves of the
-//      parent table
+//   C1 roots (among the node ids) take component numbers; every lane describes the row-runs of its word in the idle upper
+//      halves of the parent table
 //   -- barrier 3 --
-//   C2 a THREAD PER RUN: fp64 (sum rho, sum rho * c) over the run's parked values in order, rounded once to the
+//   C2 a THREAD PER ROW-RUN: its node (the group's starts, kept in LDS), fp64 (sum rho, sum rho * c) over the run's parked values in order, rounded once to the
 //      job's quantum and folded into the component's accumulators with integer LDS atomics (FixSums: the result
 //      does not depend on the order); run -> component ids are published for the label writer, and per mask word
 //      the components of its first 7 runs and of the run at its last bit, a byte each, for the face merge
@@ -32,11 +33,13 @@
 // LDS pre-reduction per tile).  Tiles beyond the LDS tables (round 4): more than CCAP components -> a WIDE tile (tile_mode 2: its
 // components take ids above the tiles' own ranges, its sums are made CCAP components at a time); more than RCAP word-runs -> a
 // DENSE tile (the parked values' LDS becomes parent slots RCAP .. RCAP_DENSE - 1, the values are re-read from L2); both keep
-// their in-LDS unions.  Only a tile with more than RCAP_DENSE word-runs, or one that finds no ids, falls back to "unit mode"
-// (tile_mode 1 / 3: its workgroup of k_face_merge labels it run by run, every run its own component, and unites its pairs
-// globally): slower, same result.
+// their in-LDS unions.  Only a tile with more than RCAP_DENSE word-runs (both signs of a checkerboard), or one that finds no ids,
+// is a "unit tile" (tile_mode 1 / 3): labelled run by run, every run its own component, and united globally by two launches
+// of their own (k_unit_label, k_unit_pairs) in a SECOND run of the job -- the first run, enqueued without them, flags itself
+// (Counters::overflow bit 2; round 5: no workgroup waits for another any more).  Slower, same result.
 //
-// The step is FOUR launches (round 4; six in round 3): k_tile_label -> k_face_merge -> k_resolve_tiles -> k_labels_tiles<fused>.
+// The step is FOUR launches (round 4; six in round 3): k_tile_label -> k_face_merge -> k_resolve_tiles -> k_labels_tiles<fused>
+// (+ the two unit launches behind k_face_merge in the second run of a job that has unit tiles).
 // The cross-tile unions hang by FIRST KEY (kpar[]: first key << 32 | id, the later first voxel under the earlier one), so the
 // root of a blob holds the blob's first key the moment the unions are done: k_resolve_tiles paints the keys while it finds the
 // roots (no fold of keys, no painting kernel), and the label writer -- every component's packed parent carries its root's
