@@ -166,11 +166,12 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
         checked = {"records": 0}
 
         def check_golden(records):
-            # file -> pinned ring -> pool at 200^3: a wrong-but-non-zero record must not pass the bench
+            # file -> upload engine -> pool at 200^3: a wrong-but-non-zero record must not pass the bench
+            # (records of the entry list, possibly repeated: entry k of the list reads files k % distinct, and files 0 are the golden entry's)
             if golden is None:
                 return
             for i, r in enumerate(records):
-                if i % distinct != 0:
+                if (i % args.entries) % distinct != 0:
                     continue
                 assert r, "the golden entry failed in the pool"
                 got = r["stats"]["density_electron_ratio"]
@@ -181,18 +182,29 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
         pool.warm()
         pool.map(entries[:2 * args.workers])                          # untimed: first-use costs of every worker (imports, arenas)
         barrier()
-        # the timed region is the WHOLE entry list, repeated until it has run for at least --entry-seconds (a 0.2 s region says little)
-        elapsed, passes, ok = 0.0, 0, 0
-        while True:
+        # The timed region is ONE map over the entry list repeated `passes` times -- as many as a first, calibrating pass says it
+        # takes to run for --entry-seconds (a 0.2 s region says little).  (Rounds 3-4 timed the passes one by one, each ending in a
+        # barrier: a pass of 125 entries is eight tasks, every one with a pipeline to fill, and a drain at its end -- 4-6 % of the
+        # region was the leg's own stop-and-go, which a run over a real list does not have.)
+        def passes_for(pool_):
             t0 = time.perf_counter()
-            records = pool.map(entries)
+            first = pool_.map(entries)
             barrier()
-            elapsed += time.perf_counter() - t0
-            ok += sum(1 for r in records if r)
-            passes += 1
-            check_golden(records)
-            if not keep_going(elapsed < args.entry_seconds and passes < 64, dist, torch):   # (every rank runs the same passes)
-                break
+            dt = time.perf_counter() - t0
+            check_golden(first)
+            want = max(1, min(64, int(args.entry_seconds / max(dt, 1e-3)) + 1))
+            if dist is not None:     # (every rank maps the same number of entries)
+                t = torch.tensor([want], dtype=torch.int64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                want = int(t.item())
+            return want
+        passes = passes_for(pool)
+        t0 = time.perf_counter()
+        records = pool.map(entries * passes)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        ok = sum(1 for r in records if r)
+        check_golden(records)
         n_done = passes * args.entries
         own_rate = 60.0 * n_done / elapsed
         # ONE cold-cache data point: the pages of the bench's own files are dropped (fsync + POSIX_FADV_DONTNEED: an ordinary user may
@@ -245,17 +257,13 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
             lazy.warm()
             lazy.map(entries[:2 * args.workers])
             barrier()
-            lazy_elapsed, lazy_passes, lazy_ok = 0.0, 0, 0
-            while True:
-                t1 = time.perf_counter()
-                lazy_records = lazy.map(entries)
-                barrier()
-                lazy_elapsed += time.perf_counter() - t1
-                lazy_ok += sum(1 for r in lazy_records if r)
-                lazy_passes += 1
-                check_golden(lazy_records)
-                if not keep_going(lazy_elapsed < args.entry_seconds and lazy_passes < 64, dist, torch):
-                    break
+            lazy_passes = passes_for(lazy)
+            t1 = time.perf_counter()
+            lazy_records = lazy.map(entries * lazy_passes)
+            barrier()
+            lazy_elapsed = time.perf_counter() - t1
+            lazy_ok = sum(1 for r in lazy_records if r)
+            check_golden(lazy_records)
         finally:
             lazy.close()
         lazy_done = lazy_passes * args.entries
@@ -326,7 +334,7 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
                              "sample": "%d x %d^3 entries (%d atoms) per pass, repeated for %.0f s: read the 2Fo-Fc CCP4 file, numpy-tree mean / std, aggregateCloud "
                                        "(flattening + oracle composite + statistics tail), the entry's diffs -- multiprocessing.Pool(%d), one entry per task"
                                        % (len(tasks), args.entry_size, n_atoms, cpu_pool["seconds"], cores)})
-        return {"workload": "configs[3]: %d entries per rank and pass (%d distinct on disk = %.0f MB of CCP4 files per rank), each two CCP4 files of a %d^3 grid + a "
+        return {"workload": "configs[3]: %d entries per rank, the list mapped `passes` times over in ONE call (%d distinct on disk = %.0f MB of CCP4 files per rank), each two CCP4 files of a %d^3 grid + a "
                             "%d-atom model: read, parse, upload (BOTH maps: PDBEDA_EAGER_DIFF_MAP=1), aggregateCloud + the per-entry record of `pdb_eda multiple`"
                             % (args.entries, distinct, distinct * file_mb, args.entry_size, n_atoms),
                 "entries": total_done, "entries_ok": ok, "passes": passes, "workers_per_gpu": args.workers, "seconds": elapsed,
