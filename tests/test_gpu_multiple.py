@@ -306,6 +306,49 @@ def test_file_upload_into_a_recycled_arena(tmp_path, monkeypatch):
     ctx.close()
 
 
+@pytest.mark.timeout(240)
+def test_upload_engine_serves_many_loads_at_once(tmp_path):
+    """Round 5: file uploads go through ONE engine per process -- three reader threads take the chunks of every load in flight from
+    a FIFO, chunk sizes ramp up, a context's stream waits for an event behind each reader's copies.  Six threads (a context each)
+    upload files of very different sizes at once, over and over -- a few voxels (one short chunk), sizes that end in the middle of
+    the ramp, a big-endian file (swapped on the device), 27 MB (full chunks on every reader): every download must equal its file,
+    and the statistics that ride along must be numpy's."""
+    import threading
+    import numpy as np
+    from pdb_eda_amd import _native, ccp4, synthetic
+    shapes = [(3, 5, 7), (40, 33, 29), (64, 64, 64), (100, 90, 75), (128, 120, 110), (200, 176, 190)]
+    files = []
+    for k, shp in enumerate(shapes):
+        spec = synthetic.MapSpec(ncrs=shp[::-1], spacing=0.5)
+        grid = synthetic.smooth_noise(shp, seed=40 + k, sigma_voxels=1.2)
+        path = tmp_path / ("u%d.ccp4" % k)
+        path.write_bytes(synthetic.ccp4_bytes(spec, grid, big_endian=(k == 3)))
+        header = ccp4.DensityHeader.fromFileHeader(synthetic.ccp4_header_bytes(spec, big_endian=(k == 3)))
+        files.append((str(path), grid, header.geometry(), k == 3))
+    errors = []
+
+    def work(t):
+        try:
+            ctx = _native.Context(0)
+            for rep in range(6):
+                path, grid, geom, swapped = files[(t + rep) % len(files)]
+                got = _native.DeviceMap.from_file(ctx, path, 1024, swapped, geom)
+                mean, std = got.stats()
+                assert np.array_equal(got.download().reshape(grid.shape), grid), (t, rep)
+                assert mean == float(np.mean(grid, dtype=np.float64)) or abs(mean - float(np.mean(grid.astype(np.float64)))) < 1e-12
+                assert abs(std - float(np.std(grid.astype(np.float64)))) < 1e-9
+                got.free()
+            ctx.close()
+        except BaseException as exception:
+            errors.append((t, exception))
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+
+
 def test_file_upload_brings_the_statistics_along(gpu_ctx, tmp_path):
     """pdbeda_map_upload_file_stats: a map read from a file comes with its mean / std from the same wait (and the quantum of
     its blob sums): exactly the numbers pdbeda_map_stats gives on the same grid uploaded from memory (== np.mean / np.std)."""
