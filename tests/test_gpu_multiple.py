@@ -165,6 +165,56 @@ def test_watchdog_deadline_is_per_entry_not_per_wait():
         ctx.test_overlap(crs, off, [0], [1])
 
 
+@pytest.mark.timeout(120)
+def test_a_timed_out_upload_does_not_wedge_the_upload_engine(tmp_path):
+    """The readers of the upload engine belong to the process, not to a context: an upload whose entry runs out of time (its context is
+    abandoned) must leave them serving everybody else.  A context with a deadline that has all but passed uploads a 27 MB file --
+    PdbedaTimeout, or, if the box was quick, a map --, while and after which other contexts upload the same file and get its bytes."""
+    import threading
+    import numpy as np
+    from pdb_eda_amd import _native, ccp4, synthetic
+    spec = synthetic.MapSpec(ncrs=(200, 176, 190), spacing=0.45)
+    grid = synthetic.smooth_noise((190, 176, 200), seed=8, sigma_voxels=1.3)
+    path = tmp_path / "t.ccp4"
+    path.write_bytes(synthetic.ccp4_bytes(spec, grid))
+    geom = ccp4.DensityHeader.fromFileHeader(synthetic.ccp4_header_bytes(spec)).geometry()
+    good, errors = [], []
+
+    def ordinary(k):
+        try:
+            ctx = _native.Context(0)
+            for _ in range(4):
+                m = _native.DeviceMap.from_file(ctx, str(path), 1024, False, geom)
+                good.append(bool(np.array_equal(m.download().reshape(grid.shape), grid)))
+                m.free()
+            ctx.close()
+        except BaseException as exception:
+            errors.append(exception)
+    others = [threading.Thread(target=ordinary, args=(k,)) for k in range(2)]
+    for t in others:
+        t.start()
+    timed_out = 0
+    for _ in range(6):
+        ctx = _native.Context(0)
+        ctx.set_timeout(2e-4)                       # 0.2 ms: the file needs ~1 ms alone, more beside two other uploaders
+        try:
+            m = _native.DeviceMap.from_file(ctx, str(path), 1024, False, geom)
+            m.free()
+        except _native.PdbedaTimeout:
+            timed_out += 1
+        ctx.close()                                 # (an abandoned context: parked, reaped once the copies behind it have drained)
+    for t in others:
+        t.join()
+    assert not errors, errors
+    assert len(good) == 8 and all(good)
+    assert timed_out >= 1
+    ctx = _native.Context(0)                        # ... and afterwards
+    m = _native.DeviceMap.from_file(ctx, str(path), 1024, False, geom)
+    assert np.array_equal(m.download().reshape(grid.shape), grid)
+    m.free()
+    ctx.close()
+
+
 @pytest.mark.timeout(300)
 def test_process_pool_matches_sequential(tmp_path, gpu_ctx):
     """BASELINE configs[3] shape: entries read from CCP4 files by worker PROCESSES (spawn; one stream each) give the records of
