@@ -298,10 +298,188 @@ done:
     return out;
 }
 
+/* ---- the statistics tail of aggregateCloud (densityAnalysis.py:734-767 of the reference; densityAnalysis._cloudStatistics here) ----
+ * Per atom type: medians of nine columns of the atom table (np.nanmedian: NaNs last, the middle value or the mean of the middle
+ * two), the b-factor regression (scipy.stats.linregress: slope and two-sided p-value) and the corrected fractions.  The numpy form
+ * is ~60 small array calls (0.45 ms of a 2 000-atom entry's 1.3 ms); this is one pass per type over plain arrays.  Sums are taken
+ * in index order, as np.bincount takes them. */
+
+/* the regularised incomplete beta function I_x(a, b) by its continued fraction (Lentz), as in every numerical text */
+static double beta_cf(double a, double b, double x) {
+    const double tiny = 1e-300, eps = 1e-16;
+    const double qab = a + b, qap = a + 1.0, qam = a - 1.0;
+    double c = 1.0, d = 1.0 - qab * x / qap;
+    if (fabs(d) < tiny) d = tiny;
+    d = 1.0 / d;
+    double h = d;
+    for (int m = 1; m <= 500; ++m) {
+        const int m2 = 2 * m;
+        double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+        d = 1.0 + aa * d; if (fabs(d) < tiny) d = tiny;
+        c = 1.0 + aa / c; if (fabs(c) < tiny) c = tiny;
+        d = 1.0 / d; h *= d * c;
+        aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+        d = 1.0 + aa * d; if (fabs(d) < tiny) d = tiny;
+        c = 1.0 + aa / c; if (fabs(c) < tiny) c = tiny;
+        d = 1.0 / d;
+        const double del = d * c;
+        h *= del;
+        if (fabs(del - 1.0) < eps) break;
+    }
+    return h;
+}
+static double beta_inc(double a, double b, double x) {
+    if (!(x > 0.0)) return 0.0;
+    if (!(x < 1.0)) return 1.0;
+    const double bt = exp(lgamma(a + b) - lgamma(a) - lgamma(b) + a * log(x) + b * log(1.0 - x));
+    if (x < (a + 1.0) / (a + b + 2.0)) return bt * beta_cf(a, b, x) / a;
+    return 1.0 - bt * beta_cf(b, a, 1.0 - x) / b;
+}
+/* Student's t distribution function at t <= 0 with df degrees of freedom (scipy.special.stdtr) */
+static double stdtr_neg(double df, double t) {
+    if (t != t) return t;
+    if (t == 0.0) return 0.5;
+    if (isinf(t)) return 0.0;
+    return 0.5 * beta_inc(0.5 * df, 0.5, df / (df + t * t));
+}
+
+/* np.nanmedian of vals[0 .. m) (scratch: sorted in place; NaNs must have been left out): f applied to the one or two middle values */
+typedef double (*mono_fn)(double, const double *);
+static double f_id(double x, const double *p) { (void)p; return x; }
+static double f_times(double x, const double *p) { return x * p[0]; }
+static double f_fraction(double x, const double *p) { return (x - p[0]) / p[0]; }
+static double f_ratio(double x, const double *p) { return x * p[0] + p[0]; }
+/* the k-th smallest of a[0 .. m) (0-based), by selection: a is permuted so that a[k] holds it, smaller values before it, larger after */
+static void select_kth(double *a, int64_t m, int64_t k) {
+    int64_t lo = 0, hi = m - 1;
+    while (lo < hi) {
+        const double pivot = a[lo + (hi - lo) / 2];
+        int64_t i = lo, j = hi;
+        while (i <= j) {
+            while (a[i] < pivot) ++i;
+            while (a[j] > pivot) --j;
+            if (i <= j) { const double t = a[i]; a[i] = a[j]; a[j] = t; ++i; --j; }
+        }
+        if (k <= j) hi = j; else if (k >= i) lo = i; else return;
+    }
+}
+/* np.nanmedian's two middle order statistics of vals[0 .. m) (no NaNs among them; permuted in place) */
+static void middle_two(double *a, int64_t m, double *lo_v, double *hi_v) {
+    const int64_t k = (m - 1) / 2;
+    select_kth(a, m, k);
+    *lo_v = a[k];
+    if (m / 2 == k) { *hi_v = a[k]; return; }
+    double mn = a[k + 1];                       /* the next order statistic: the smallest of what lies behind position k */
+    for (int64_t i = k + 2; i < m; ++i) if (a[i] < mn) mn = a[i];
+    *hi_v = mn;
+}
+
+static PyObject *cloud_stats(PyObject *self, PyObject *args) {
+    (void)self;
+    PyObject *o[6];
+    int n_types = 0;
+    double ratio = 0.0, unit_volume = 0.0;
+    if (!PyArg_ParseTuple(args, "OiOOOOOdd", &o[0], &n_types, &o[1], &o[2], &o[3], &o[4], &o[5], &ratio, &unit_volume)) return NULL;
+    Py_buffer v[6];
+    const Py_ssize_t sizes[6] = {8, 8, 8, 8, 8, 8};
+    const char *names[6] = {"group", "density_electron_ratio", "num_voxels", "bfactor", "centroid_distance", "table_slopes"};
+    int got = 0;
+    for (; got < 6; ++got)
+        if (view_of(o[got], &v[got], sizes[got], names[got]) < 0) { for (int k = 0; k < got; ++k) PyBuffer_Release(&v[k]); return NULL; }
+    PyObject *out = NULL;
+    const int64_t n = v[0].len / 8;
+    const int64_t *group = (const int64_t *)v[0].buf, *nvox = (const int64_t *)v[2].buf;
+    const double *der = (const double *)v[1].buf, *bfac_in = (const double *)v[3].buf, *dist = (const double *)v[4].buf, *table_slopes = (const double *)v[5].buf;
+    const int nt = n_types > 0 ? n_types : 0;
+    double *row = NULL, *typ = NULL, *scratch = NULL, *logb = NULL;
+    int64_t *start = NULL, *order = NULL;
+    if (v[1].len / 8 != n || v[2].len / 8 != n || v[3].len / 8 != n || v[4].len / 8 != n || v[5].len / 8 != nt) { PyErr_SetString(PyExc_ValueError, "cloud_stats: array lengths do not agree"); goto done; }
+    for (int64_t i = 0; i < n; ++i) if (group[i] < 0 || group[i] >= nt) { PyErr_SetString(PyExc_ValueError, "cloud_stats: type out of range"); goto done; }
+    /* rows: adj, bfactor (filled), domain_fraction, corrected_fraction, corrected_ratio, volume; types: ten medians / slopes */
+    row = (double *)malloc((size_t)(6 * n + 1) * 8); typ = (double *)malloc((size_t)(10 * nt + 1) * 8); scratch = (double *)malloc((size_t)(n + 1) * 8); logb = (double *)malloc((size_t)(n + 1) * 8);
+    start = (int64_t *)malloc((size_t)(nt + 2) * 8); order = (int64_t *)malloc((size_t)(n + 1) * 8);
+    if (!row || !typ || !scratch || !logb || !start || !order) { PyErr_NoMemory(); goto done; }
+    {
+        double *adj = row, *bfac = row + n, *fraction = row + 2 * n, *corrected = row + 3 * n, *corrected_ratio = row + 4 * n, *volume = row + 5 * n;
+        double *m_vox = typ, *m_volume = typ + nt, *m_der = typ + 2 * nt, *m_dist = typ + 3 * nt, *m_adj = typ + 4 * nt, *m_b = typ + 5 * nt,
+               *m_fraction = typ + 6 * nt, *slopes = typ + 7 * nt, *m_corrected = typ + 8 * nt, *m_corrected_ratio = typ + 9 * nt;
+        /* rows in type order (stable) */
+        for (int t = 0; t <= nt; ++t) start[t] = 0;
+        for (int64_t i = 0; i < n; ++i) start[group[i] + 1]++;
+        for (int t = 0; t < nt; ++t) start[t + 1] += start[t];
+        {
+            int64_t *fill = (int64_t *)scratch;      /* (n + 1 doubles hold nt <= n + 1 cursors only if nt <= n + 1: checked) */
+            if (nt > n + 1) { PyErr_SetString(PyExc_ValueError, "cloud_stats: more types than rows"); goto done; }
+            for (int t = 0; t < nt; ++t) fill[t] = start[t];
+            for (int64_t i = 0; i < n; ++i) order[fill[group[i]]++] = i;
+        }
+        /* the median of a column per type, and -- dst2 -- of a weakly monotone function f2 of it (the same order statistics) */
+#define MEDIAN_OF(expr, keep, dst, f2, par2, dst2) \
+        for (int t = 0; t < nt; ++t) { int64_t m = 0; for (int64_t k = start[t]; k < start[t + 1]; ++k) { const int64_t i = order[k]; const double x = (expr); if ((keep) && x == x) scratch[m++] = x; } \
+                                       double lo_v = NAN, hi_v = NAN; if (m > 0) middle_two(scratch, m, &lo_v, &hi_v); \
+                                       (dst)[t] = m > 0 ? (lo_v + hi_v) / 2.0 : NAN; \
+                                       if (dst2) ((double *)(dst2))[t] = m > 0 ? (f2(lo_v, par2) + f2(hi_v, par2)) / 2.0 : NAN; }
+        MEDIAN_OF((double)nvox[i], 1, m_vox, f_times, &unit_volume, m_volume)
+        for (int64_t i = 0; i < n; ++i) {
+            adj[i] = der[i] / (double)nvox[i] * m_vox[group[i]];
+            volume[i] = (double)nvox[i] * unit_volume;
+            bfac[i] = bfac_in[i];
+        }
+        MEDIAN_OF(der[i], 1, m_der, f_id, NULL, (double *)NULL)
+        MEDIAN_OF(dist[i], 1, m_dist, f_id, NULL, (double *)NULL)
+        MEDIAN_OF(adj[i], 1, m_adj, f_fraction, &ratio, m_fraction)
+        MEDIAN_OF(bfac[i], bfac[i] > 0.0, m_b, f_id, NULL, (double *)NULL)
+        for (int64_t i = 0; i < n; ++i) if (bfac[i] <= 0.0) bfac[i] = m_b[group[i]];
+        for (int64_t i = 0; i < n; ++i) { fraction[i] = (adj[i] - ratio) / ratio; logb[i] = log(bfac[i]); }
+        /* slope of the b-factor dependence per type: scipy.stats.linregress(log b, fraction) where there is something to fit */
+        for (int t = 0; t < nt; ++t) {
+            const int64_t lo = start[t], hi = start[t + 1];
+            const double cnt = (double)(hi - lo), safe_n = cnt > 1.0 ? cnt : 1.0;
+            double sx = 0.0, sy = 0.0, b_lo = NAN, b_hi = NAN;
+            int64_t n_nan = 0;
+            for (int64_t k = lo; k < hi; ++k) {
+                const int64_t i = order[k];
+                sx += logb[i]; sy += fraction[i];
+                if (bfac[i] != bfac[i]) ++n_nan;
+                else { if (!(b_lo <= bfac[i])) b_lo = bfac[i]; if (!(b_hi >= bfac[i])) b_hi = bfac[i]; }
+            }
+            const double xm = sx / safe_n, ym = sy / safe_n;
+            double ssxm = 0.0, ssym = 0.0, ssxym = 0.0;
+            for (int64_t k = lo; k < hi; ++k) {
+                const int64_t i = order[k];
+                const double dx = logb[i] - xm, dy = fraction[i] - ym;
+                ssxm += dx * dx; ssym += dy * dy; ssxym += dx * dy;
+            }
+            ssxm /= safe_n; ssym /= safe_n; ssxym /= safe_n;
+            const int one_value = (n_nan == hi - lo) || (n_nan == 0 && b_lo == b_hi);
+            const int fitted = (hi - lo > 2) && !one_value;
+            double r = (ssxm == 0.0 || ssym == 0.0) ? 0.0 : ssxym / sqrt(ssxm * ssym);
+            if (r > 1.0) r = 1.0; else if (r < -1.0) r = -1.0;   /* (a NaN stays a NaN, as np.clip leaves it) */
+            const double slope = ssxym / ssxm, df = cnt - 2.0;
+            const double tt = r * sqrt(df / ((1.0 - r + 1.0e-20) * (1.0 + r + 1.0e-20)));
+            const double pv = 2.0 * stdtr_neg(df > 1.0 ? df : 1.0, -fabs(tt));
+            slopes[t] = (fitted && !(pv > 0.05)) ? slope : table_slopes[t];
+        }
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t g = group[i];
+            corrected[i] = fraction[i] - (logb[i] - log(m_b[g])) * slopes[g];
+            corrected_ratio[i] = corrected[i] * ratio + ratio;
+        }
+        MEDIAN_OF(corrected[i], 1, m_corrected, f_ratio, &ratio, m_corrected_ratio)
+#undef MEDIAN_OF
+    }
+    out = Py_BuildValue("(NN)", bytes_of(row, (size_t)(6 * n) * 8), bytes_of(typ, (size_t)(10 * nt) * 8));
+done:
+    free(row); free(typ); free(scratch); free(logb); free(start); free(order);
+    for (int k = 0; k < 6; ++k) PyBuffer_Release(&v[k]);
+    return out;
+}
+
 static PyMethodDef methods[] = {
     {"residue_columns", residue_columns, METH_O, "residue_columns(residues) -> (model ids, chain ids, numbers, names, hetero flags, child lists)"},
     {"atom_columns", atom_columns, METH_O, "atom_columns(child lists) -> the per-atom columns of structure.Columns"},
     {"cloud_inputs", cloud_inputs, METH_VARARGS, "cloud_inputs(res_of_atom, pair_of_atom, res_plain, known, occupancy, coord32, nb_off, nb) -> the index arrays of pdbeda_cloud_atoms"},
+    {"cloud_stats", cloud_stats, METH_VARARGS, "cloud_stats(group, n_types, density_electron_ratio, num_voxels, bfactor, centroid_distance, table_slopes, ratio, unit_volume) -> (six row columns, ten per-type columns) of aggregateCloud's statistics tail"},
     {NULL, NULL, 0, NULL}};
 
 static struct PyModuleDef module = {PyModuleDef_HEAD_INIT, "_hostwalk", "one-pass walk of a structure's object tree", -1, methods, NULL, NULL, NULL, NULL};

@@ -571,7 +571,7 @@ class DensityAnalysis(object):
         self._atomTypeOverlapIncompleteness = incompletely
 
     @staticmethod
-    def _cloudStatistics(inp, res, ratio, unitVolume, typeMap):
+    def _cloudStatistics(inp, res, ratio, unitVolume, typeMap, native=None):
         """The host-side statistics over the atom table (what densityAnalysis.py:734-767 computes), on whole columns: the
         per-atom-type medians come from ONE sort per column instead of a masked nanmedian per (column, type)."""
         idx = res["atom"]
@@ -611,6 +611,26 @@ class DensityAnalysis(object):
                 out[field] = values
             return out
 
+        asDict = lambda per_type: dict(zip(atom_types.tolist(), per_type))     # noqa: E731
+        walk = _structure._hostwalk() if native is not False else None
+        if walk is None and native:
+            raise ImportError("pdb_eda_amd/_hostwalk.so is not built (python __graft_entry__.py)")
+        if walk is not None and hasattr(walk, "cloud_stats") and n:
+            # the medians, the b-factor regressions and the corrected columns in one pass in C (round 5: ~60 small numpy calls were
+            # 0.45 ms of a 2 000-atom entry's 1.3 ms); the numpy form below stays as its fallback and its check (tests/test_structure.py)
+            table_slopes = np.array([slopesGlobal[t] for t in atom_types.tolist()], dtype=np.float64)
+            rows_b, types_b = walk.cloud_stats(np.ascontiguousarray(group, dtype=np.int64), n_types, np.ascontiguousarray(table['density_electron_ratio'], dtype=np.float64),
+                                               table['num_voxels'], table['bfactor'], table['centroid_distance'], table_slopes, float(ratio), float(unitVolume))
+            r6 = np.frombuffer(rows_b, dtype=np.float64).reshape(6, n)
+            t10 = np.frombuffer(types_b, dtype=np.float64).reshape(10, n_types)
+            for k, field in enumerate(('adj_density_electron_ratio', 'bfactor', 'domain_fraction', 'corrected_fraction', 'corrected_density_electron_ratio', 'volume')):
+                table[field] = r6[k]
+            per_type = dict(zip(('num_voxels', 'volume', 'density_electron_ratio', 'centroid_distance', 'adj_density_electron_ratio', 'bfactor',
+                                 'domain_fraction', 'slopes', 'corrected_fraction', 'corrected_density_electron_ratio'), t10))
+            medians = {field: asDict(per_type[field]) for field in ('num_voxels', 'density_electron_ratio', 'centroid_distance', 'adj_density_electron_ratio', 'volume',
+                                                                    'bfactor', 'slopes', 'domain_fraction', 'corrected_fraction', 'corrected_density_electron_ratio')}
+            return make_table, n, medians
+
         # rows in type order, once: every median below sorts the values of one type at a time, in place
         by_type = np.argsort(group.astype(np.int16 if n_types < 32768 else np.int64), kind="stable")
         start = np.searchsorted(group[by_type], np.arange(n_types + 1))
@@ -632,8 +652,6 @@ class DensityAnalysis(object):
             out = [np.where(count > 0, (f(middle[0]) + f(middle[1])) / 2.0, np.nan) for f in (lambda x: x,) + tuple(also)]
             return out[0] if not also else out
 
-        def asDict(per_type):
-            return dict(zip(atom_types.tolist(), per_type))
         medians = {}
         m_vox, m_volume = typeMedians(table['num_voxels'], also=(lambda nv: nv * unitVolume,))
         medians['num_voxels'] = asDict(m_vox)

@@ -253,3 +253,57 @@ def test_device_blobs_sequence_semantics_without_a_device():
     assert both[1:3] == [a[1], a[2]] and a == list(a) and list(b) == b and a != b
     assert (a + [1])[-1] == 1 and ([0] + b)[0] == 0
     assert ccp4.DeviceBlobs([]) == [] and not ccp4.DeviceBlobs([]) and ccp4.DeviceBlobs([]).columns()["n"].size == 0
+
+
+def test_cloud_statistics_in_c_equal_the_numpy_form():
+    """The statistics tail of aggregateCloud (per-type medians, b-factor regressions, corrected fractions) runs in C
+    (_hostwalk.cloud_stats, round 5); the numpy form it replaces stays as the fallback and is the check here: random tables with
+    types of one row, b-factors that are all zero in a type (no fit, NaN medians), a single distinct b-factor, missing b-factors
+    among valid ones, NaN distances.  Medians are the same order statistics: equal; the regressions sum in the same order: 1e-12."""
+    import types
+    import numpy as np
+    import __graft_entry__
+    __graft_entry__.build()
+    from pdb_eda_amd import densityAnalysis as da, synthetic
+    params = synthetic.synthetic_params()
+    da.setGlobals(params)
+    type_names = sorted(params["radii"])
+    rng = np.random.default_rng(12)
+    for trial in range(30):
+        n = int(rng.integers(1, 600))
+        n_pairs = int(rng.integers(1, 40))
+        pair_type_id = rng.integers(0, len(type_names), n_pairs)
+        pair = rng.integers(0, n_pairs, n)
+        b = np.round(rng.uniform(5.0, 60.0, n), 2)
+        tid = pair_type_id[pair]
+        if trial % 3 == 0:
+            b[tid == tid[0]] = 0.0                      # a type without a positive b-factor
+        if trial % 4 == 0:
+            b[tid == tid[-1]] = 17.5                    # one distinct value: no fit
+        if trial % 5 == 0:
+            b[rng.integers(0, n, max(1, n // 10))] = 0.0   # missing b-factors among valid ones: filled with the type's median
+        dist = rng.uniform(0.0, 0.6, n)
+        if trial % 7 == 0:
+            dist[rng.integers(0, n, 1)] = np.nan
+        cols = types.SimpleNamespace(res_of_atom=np.zeros(n, dtype=np.int64), bfactor=b, res_chain=["A"], res_number=[1], res_name=["ALA"],
+                                     atom_names=["CA"], name_of_atom=np.zeros(n, dtype=np.int64))
+        inp = {"cols": cols, "rows": np.arange(n), "pair_type_id": pair_type_id, "pair": pair, "type_names": type_names,
+               "electrons": rng.integers(1, 9, n).astype(np.float64), "occupancy": rng.choice([1.0, 0.5], n)}
+        res = {"atom": np.arange(n), "atom_distance": dist, "atom_total": rng.uniform(0.5, 20.0, n), "atom_n": rng.integers(1, 60, n),
+               "atom_centroid": rng.uniform(0, 30, (n, 3))}
+        with np.errstate(all="ignore"):
+            make_c, n_c, med_c = da.DensityAnalysis._cloudStatistics(inp, res, 0.67, 0.125, None, native=True)
+            make_p, n_p, med_p = da.DensityAnalysis._cloudStatistics(inp, res, 0.67, 0.125, None, native=False)
+            tab_c, tab_p = make_c(), make_p()
+        assert n_c == n_p and list(med_c) == list(med_p)
+        for field in med_p:
+            assert list(med_c[field]) == list(med_p[field])
+            for t in med_p[field]:
+                a, w = float(med_c[field][t]), float(med_p[field][t])
+                assert (np.isnan(a) and np.isnan(w)) or a == pytest.approx(w, rel=1e-12, abs=1e-15), (trial, field, t, a, w)
+        for field in tab_p.dtype.names:
+            if tab_p.dtype[field].kind == "f":
+                assert np.allclose(tab_c[field], tab_p[field], rtol=1e-12, atol=1e-15, equal_nan=True), (trial, field)
+            else:
+                assert np.array_equal(tab_c[field], tab_p[field]), (trial, field)
+

@@ -14,7 +14,7 @@ cp pdb_eda_amd/_hostwalk.so /tmp/_hostwalk.plain.so
 cp oracle/libpdbeda_oracle.so /tmp/libpdbeda_oracle.plain.so
 restore() { cp /tmp/_hostwalk.plain.so pdb_eda_amd/_hostwalk.so; cp /tmp/libpdbeda_oracle.plain.so oracle/libpdbeda_oracle.so; }
 trap restore EXIT
-gcc $SAN -shared -fPIC -Wall -I"$inc" -o pdb_eda_amd/_hostwalk.so pdb_eda_amd/csrc/hostwalk.c
+gcc $SAN -ffp-contract=off -shared -fPIC -Wall -I"$inc" -o pdb_eda_amd/_hostwalk.so pdb_eda_amd/csrc/hostwalk.c -lm
 gcc $SAN -shared -fPIC -ffp-contract=off -fno-fast-math -Wall -Wextra -o oracle/libpdbeda_oracle.so oracle/pdbeda_oracle.c -lm
 # (Python itself is not instrumented: leaks of the interpreter are not ours to report; PDBEDA_DEBUG_HOSTWALK=raise: a C walk that
 #  fails must fail the test instead of hiding behind its Python fallback)
