@@ -22,6 +22,7 @@ import time
 import numpy as np
 
 from . import _native, ccp4, densityAnalysis
+from . import structure as _structure
 
 statsHeaders = ['density_electron_ratio', 'voxel_volume', 'f000', 'num_voxels_aggregated', 'total_aggregated_electrons', 'density_mean',
                 'diff_density_mean', 'resolution', 'space_group', 'num_atoms_analyzed', 'num_residue_clouds_analyzed',
@@ -113,8 +114,9 @@ def analyzeEntry(entry, ctx=None, failures=None, silent=False, loaded=None):
              'num_atoms_analyzed': analyzer.cloudCounts[0], 'num_residue_clouds_analyzed': analyzer.cloudCounts[1],
              'num_domain_clouds_analyzed': analyzer.cloudCounts[2], 'atom_overlap_completeness': complete}
     properties = dict(getattr(biopdbObj, "header", None) or {})          # the structure header items (ref 346)
-    properties['residue_counts'] = dict(collections.Counter(residue.resname for residue in biopdbObj.get_residues()))
-    properties['element_counts'] = dict(collections.Counter(atom.element for atom in biopdbObj.get_atoms()))
+    cols = _structure.columns(biopdbObj)          # (the snapshot the analysis made: its lists, not a second walk of the object tree)
+    properties['residue_counts'] = dict(collections.Counter(cols.res_name))
+    properties['element_counts'] = dict(collections.Counter([atom.element for atom in cols.atoms]))
     slopes = {t: float(v) for t, v in analyzer.medians['slopes'].items() if not np.isnan(v)}
     return {"pdbid": entry.pdbid, "diffs": {k: float(v) for k, v in diffs.items()}, "stats": stats, "slopes": slopes,
             "atomtype_overlap_completeness": dict(analyzer.atomTypeOverlapCompleteness),
