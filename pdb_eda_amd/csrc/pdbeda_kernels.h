@@ -1701,87 +1701,77 @@ __global__ void __launch_bounds__(256) k_np_chunk_sums(const float *__restrict__
 
 __global__ void __launch_bounds__(256) k_np_final(const float *__restrict__ x, int64_t n, int64_t n_full, int mode, const double *__restrict__ mean_p,
                                                   const double *__restrict__ chunk_sums, int take_sqrt, double *__restrict__ out) {
-    __shared__ int s_off[160], s_len[160], s_nleaf;
-    __shared__ double s_leaf[160];
+    // The tail's recursion tree as a heap in LDS (node i -> 2i, 2i + 1): a right child is at most l / 2 + 7.5 long, so from 8 191 elements
+    // the lengths are <= 4 103, 2 059, 1 037, 526, 270, 142, 78: every node of level 7 (ids 128..255) is a leaf.  Built level by level, leaves
+    // summed by eight lanes each, combined level by level (left + right): round 5 -- one thread walking explicit stacks (private arrays =
+    // scratch memory, then LDS) was 60 of this kernel's 80 us behind a 200^3 upload.
+    __shared__ int s_off[256], s_len[256];
+    __shared__ double s_val[256];
     __shared__ double s_buf[1024];
+    __shared__ float s_tail[NP_CHUNK];
     const int tid = threadIdx.x;
     const double shift = mode == 1 ? mean_p[0] : 0.0;
     const int rem = (int)(n - n_full * NP_CHUNK);
-    const float *xr = x + n_full * NP_CHUNK;
-    // ---- the tail chunk: leaves of the recursion in order (explicit stack), their sums in parallel ----
-    if (tid == 0) {
-        int nl = 0;
-        if (rem > 0) {
-            int so[16], sl[16], sp = 0;
-            so[0] = 0; sl[0] = rem;
-            while (sp >= 0) {
-                const int o = so[sp], l = sl[sp];
-                --sp;
-                if (l <= 128) { s_off[nl] = o; s_len[nl] = l; ++nl; continue; }
-                int n2 = l / 2;
-                n2 -= n2 % 8;
-                ++sp; so[sp] = o + n2; sl[sp] = l - n2;   // right: popped second
-                ++sp; so[sp] = o; sl[sp] = n2;            // left: popped first
-            }
-        }
-        s_nleaf = nl;
-    }
+    const float *xg = x + n_full * NP_CHUNK;
+    for (int i = tid; i < rem; i += 256) s_tail[i] = xg[i];
+    s_len[tid] = tid == 1 ? rem : 0;
+    s_off[tid] = 0;
     __syncthreads();
-    const int nleaf = s_nleaf;
-    for (int task = tid; task < nleaf * 8; task += 256) {   // (leaf, accumulator j): the 8 lanes of a leaf are neighbours
-        const int leaf = task >> 3, j = task & 7, o = s_off[leaf], l = s_len[leaf];
+    for (int d = 0; d < 7; ++d) {
+        const int i = (1 << d) + tid;
+        if (tid < (1 << d) && s_len[i] > 128) {
+            const int l = s_len[i], o = s_off[i];
+            int n2 = l / 2;
+            n2 -= n2 % 8;
+            s_off[2 * i] = o; s_len[2 * i] = n2;
+            s_off[2 * i + 1] = o + n2; s_len[2 * i + 1] = l - n2;
+        }
+        __syncthreads();
+    }
+    for (int task = tid; task < 256 * 8; task += 256) {   // (node, accumulator j): the 8 lanes of a leaf are neighbours
+        const int node = task >> 3, j = task & 7, o = s_off[node], l = s_len[node];
+        const bool leaf = l > 0 && l <= 128;               // (uniform over the 8 lanes of a node)
         double r = 0.0;
-        if (l >= 8) {
-            r = np_elem(xr[o + j], mode, shift);
-            for (int i = 8; i < l - (l % 8); i += 8) r += np_elem(xr[o + i + j], mode, shift);
+        if (leaf && l >= 8) {
+            r = np_elem(s_tail[o + j], mode, shift);
+            for (int i = 8; i < l - (l % 8); i += 8) r += np_elem(s_tail[o + i + j], mode, shift);
         }
         r += __shfl_xor(r, 1);
         r += __shfl_xor(r, 2);
         r += __shfl_xor(r, 4);
-        if (j == 0) {
+        if (leaf && j == 0) {
             double res = l >= 8 ? r : 0.0;
-            for (int i = l >= 8 ? l - (l % 8) : 0; i < l; ++i) res += np_elem(xr[o + i], mode, shift);
-            s_leaf[leaf] = res;
+            for (int i = l >= 8 ? l - (l % 8) : 0; i < l; ++i) res += np_elem(s_tail[o + i], mode, shift);
+            s_val[node] = res;
         }
     }
     __syncthreads();
+    for (int d = 6; d >= 0; --d) {
+        const int i = (1 << d) + tid;
+        if (tid < (1 << d) && s_len[i] > 128) s_val[i] = s_val[2 * i] + s_val[2 * i + 1];
+        __syncthreads();
+    }
     double total = 0.0;
-    // ---- chunk sums in order (staged through LDS, added by ONE thread) ----
+    // ---- chunk sums in order (staged through LDS, added by ONE thread: the order IS the result) ----
     for (int64_t base = 0; base < n_full; base += 1024) {
         for (int k = tid; k < 1024; k += 256) s_buf[k] = base + k < n_full ? chunk_sums[base + k] : 0.0;
         __syncthreads();
         if (tid == 0) {
             const int cnt = n_full - base < 1024 ? (int)(n_full - base) : 1024;
-            for (int k = 0; k < cnt; ++k) total += s_buf[k];
+            int k = 0;
+            for (; k + 8 <= cnt; k += 8) {    // eight loads in flight, then the chain of adds
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = s_buf[k + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) total += v[q];
+            }
+            for (; k < cnt; ++k) total += s_buf[k];
         }
         __syncthreads();
     }
     if (tid == 0) {
-        if (nleaf > 0) {   // combine the tail's leaves along the recursion tree (post-order, explicit stack)
-            int len[16], stage[16], sp = 0, next = 0;
-            double left[16], ret = 0.0;
-            len[0] = rem; stage[0] = 0;
-            while (sp >= 0) {
-                if (stage[sp] == 0) {
-                    if (len[sp] <= 128) { ret = s_leaf[next++]; --sp; continue; }
-                    int n2 = len[sp] / 2;
-                    n2 -= n2 % 8;
-                    stage[sp] = 1;
-                    ++sp; len[sp] = n2; stage[sp] = 0;
-                } else if (stage[sp] == 1) {
-                    int n2 = len[sp] / 2;
-                    n2 -= n2 % 8;
-                    left[sp] = ret;
-                    stage[sp] = 2;
-                    const int rl = len[sp] - n2;
-                    ++sp; len[sp] = rl; stage[sp] = 0;
-                } else {
-                    ret = left[sp] + ret;
-                    --sp;
-                }
-            }
-            total += ret;
-        }
+        if (rem > 0) total += s_val[1];
         const double v = total / (double)n;
         out[0] = take_sqrt ? __dsqrt_rn(v) : v;
     }
