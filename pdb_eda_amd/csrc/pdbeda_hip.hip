@@ -695,6 +695,18 @@ static size_t file_chunk_bytes() {   // (PDBEDA_FILE_CHUNK_KB: experiments)
     return v;
 }
 #define FILE_CHUNK (file_chunk_bytes())
+// A load that finds the engine idle is cut into smaller chunks: with nobody else's copies to fill the link, the pread of a full chunk (0.2-0.4 ms at
+// the 20-40 GB/s of one thread) is time the link idles at the start of the map; with other loads in flight the larger chunk's fewer copies win
+// (one engine serves the copies one after another, 6 us apart).  PDBEDA_FILE_CHUNK_ALONE_KB (experiments; 0 = the full chunk always): one 32 MB map alone
+// 0.85 ms with 8 MiB chunks, 0.77 with 4 or 2, 1.0 with 1; a pool of four worker processes (each engine mostly sees one load) is the same within its noise.
+static size_t file_chunk_alone_bytes() {
+    static const size_t v = [] {
+        const char *e = getenv("PDBEDA_FILE_CHUNK_ALONE_KB");
+        const long kb = e ? atol(e) : 4096;
+        return kb <= 0 ? file_chunk_bytes() : std::min(file_chunk_bytes(), std::max<size_t>((size_t)kb << 10, (size_t)64 << 10));
+    }();
+    return v;
+}
 static unsigned reader_spins() { static const unsigned v = [] { const char *e = getenv("PDBEDA_READER_SPINS"); return e ? (unsigned)atoi(e) : 4u; }(); return v; }
 // ---- The upload engine: ONE per process and device ------------------------------------------------------------------------
 // A map read from a file goes to HBM in 4 MiB chunks: a reader thread pread()s a chunk out of the page cache into one of its
@@ -730,6 +742,7 @@ static double now_s() { return std::chrono::duration<double>(std::chrono::steady
 
 struct UploadEngine {
     int device = 0, n_readers = 0;
+    std::atomic<int> active{0};   // loads between their submission and their last chunk
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::pair<UploadLoad *, int64_t>> chunks;
@@ -881,47 +894,15 @@ static int upload_file_impl(pdbeda_ctx *ctx, const char *path, int64_t offset, i
         if (q != hipSuccess) e = q;
     }
     const char *why = nullptr;
-    static const int upload_mode = [] { const char *v = getenv("PDBEDA_UPLOAD_MODE"); return v ? atoi(v) : 0; }();   // (experiments) 1: mmap + pageable copy, 2: in segments
-    if (e == hipSuccess && !ctx->timed_out && upload_mode >= 1) {
-        const long page = sysconf(_SC_PAGESIZE);
-        const int64_t lo = offset / page * page;
-        const size_t maplen = (size_t)(offset - lo) + need;
-        const double t_m0 = now_s();
-        const int n_seg = upload_mode >= 2 ? upload_mode : 1;
-        void *p = mmap(nullptr, maplen, PROT_READ, MAP_PRIVATE | (n_seg == 1 ? MAP_POPULATE : 0), fd, (off_t)lo);
-        if (p == MAP_FAILED) { why = strerror(errno); }
-        else {
-            const double t_m1 = now_s();
-            const char *src = (const char *)p + (offset - lo);
-            if (n_seg == 1) {
-                e = hipMemcpyAsync(d, src, need, hipMemcpyHostToDevice, ctx->stream);
-            } else {
-                // segment k + 1 is faulted in (by a helper) while segment k crosses the link
-                const size_t seg = ((need / n_seg) + page - 1) / page * page;
-                auto populate = [&](size_t a, size_t b) { if (b > a) (void)madvise((char *)p + (offset - lo) / page * page + a / page * page, b - a / page * page, 22 /* MADV_POPULATE_READ */); };
-                populate(0, std::min(seg, need));
-                for (size_t a = 0; a < need && e == hipSuccess; a += seg) {
-                    const size_t b = std::min(a + seg, need), b2 = std::min(b + seg, need);
-                    std::thread helper;
-                    if (b2 > b) helper = std::thread(populate, b, b2);
-                    e = hipMemcpyAsync((char *)d + a, src + a, b - a, hipMemcpyHostToDevice, ctx->stream);
-                    if (helper.joinable()) helper.join();
-                }
-            }
-            const double t_m2 = now_s();
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            const double t_m3 = now_s();
-            munmap(p, maplen);
-            if (upload_trace()) fprintf(stderr, "upload mmap %.1f MB: map %.3f ms, copy call %.3f ms, sync %.3f ms, unmap %.3f ms\n", need / 1e6, 1e3 * (t_m1 - t_m0), 1e3 * (t_m2 - t_m1), 1e3 * (t_m3 - t_m2), 1e3 * (now_s() - t_m3));
-        }
-    } else if (e == hipSuccess && !ctx->timed_out) {
+    if (e == hipSuccess && !ctx->timed_out) {
         UploadLoad ld;
         ld.fd = fd; ld.offset = offset; ld.dst = (char *)d; ld.need = need;
         // chunk sizes ramp up: a pread of a full chunk takes the better part of a millisecond before its copy can start -- with every reader on such a chunk the
         // link idled for the first 0.4 ms of every map; the first round is 256 KiB each, the second 1 MiB, then full chunks
+        const size_t full = engine->active.fetch_add(1) == 0 ? file_chunk_alone_bytes() : FILE_CHUNK;
         for (size_t pos = 0, k = 0; pos < need; ++k) {
             const size_t round = k / (size_t)engine->n_readers;
-            const size_t len = std::min(need - pos, round == 0 ? std::min(FILE_CHUNK, (size_t)256 << 10) : (round == 1 ? std::min(FILE_CHUNK, (size_t)1 << 20) : FILE_CHUNK));
+            const size_t len = std::min(need - pos, round == 0 ? std::min(full, (size_t)256 << 10) : (round == 1 ? std::min(full, (size_t)1 << 20) : full));
             ld.pieces.emplace_back(pos, len);
             pos += len;
         }
@@ -938,6 +919,7 @@ static int upload_file_impl(pdbeda_ctx *ctx, const char *path, int64_t offset, i
             std::unique_lock<std::mutex> lk(ld.mu);
             ld.cv.wait(lk, [&] { return ld.handled == ld.n_chunks; });   // (a reader gives a chunk up at the entry's deadline: this wait ends)
         }
+        engine->active.fetch_sub(1);
         if (upload_trace())
             fprintf(stderr, "upload %.1f MB: chunks handled after %.3f ms; readers' sums: slot wait %.3f, pread %.3f, queueing %.3f ms; chunks by reader %d %d %d %d %d %d %d %d\n",
                     need / 1e6, 1e3 * (now_s() - t_q), 1e3 * ld.t_slot, 1e3 * ld.t_pread, 1e3 * ld.t_queue, ld.chunks_by[0], ld.chunks_by[1], ld.chunks_by[2],
