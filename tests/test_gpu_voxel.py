@@ -348,6 +348,21 @@ def test_random_maps_vs_oracle(gpu_ctx, shape, seed, nsd):
         assert np.array_equal(lab[crs[:, 2], crs[:, 1], crs[:, 0]], np.repeat(np.arange(len(st["n"])), st["n"]))
 
 
+@pytest.mark.parametrize("n_rows", [1, 2, 3, 5, 9, 16, 17, 18, 32, 33, 127, 128, 129, 511, 576, 577, 1023, 1024, 1025, 1031, 2047, 2049, 3100])
+def test_mean_std_are_numpys_to_the_bit_on_every_tail_shape(gpu_ctx, n_rows):
+    """np.mean / np.std of the voxels (ccp4.py:343-363) depend on numpy's summation TREE: 8192-element calls added in order, each a pairwise
+    sum over 128-element leaves with eight accumulators, the array's tail by the general recursion n2 = (n / 2) & ~7.  k_np_final builds the
+    tail's tree as a heap in LDS (round 5): grids of 1 x n_rows x 8 (+ 3) voxels walk the tail through leaves shorter than 8, one leaf, a
+    first split, lengths that are no multiple of 8, tails just below and above a full call, and several calls + a tail.  Equality, not closeness."""
+    rng = np.random.default_rng(1000 + n_rows)
+    for nc in (8, 11):
+        g = (rng.standard_normal((1, n_rows, nc)) * 3.0 + 0.7).astype(np.float32)
+        dm = _dm(g, gpu_ctx)
+        flat = g.reshape(-1).astype(np.float64)
+        assert dm.meanDensity == float(np.mean(flat)), (n_rows, nc, g.size)
+        assert dm.stdDensity == float(np.std(flat)), (n_rows, nc, g.size)
+
+
 def test_recycled_arenas_and_edge_overflow(monkeypatch):
     """Every device arena poisoned with 0xFF when handed out (a kernel that trusts recycled memory to be zero
     shows up at once) and a cross-tile pair buffer far too small (shards overflow: their tail is united on the
