@@ -245,6 +245,18 @@ static hipError_t ctx_wait(pdbeda_ctx *ctx) {
     }
 }
 
+// The small staged copies of a call (inputs through the pinned block, results into it) are KERNELS that read / write the pinned block over the
+// link, not hipMemcpyAsync (round 5).  A copy of a few hundred bytes is a packet on the SDMA engine, where it waits behind every 4-8 MiB chunk the
+// upload engine has queued (up to 0.46 ms), and each hop between the compute queue and the copy engine is a semaphore: the analysis of a resident
+// entry 0.48 -> 0.44 ms alone, 0.68-0.80 -> 0.60 beside two uploading threads; four workers 41.6 k -> 44.5 k entries/min.  PDBEDA_COPY_KERNELS=0: the
+// runtime's copies (A/B).
+static bool copy_kernels() { static const bool v = [] { const char *e = getenv("PDBEDA_COPY_KERNELS"); return !(e && e[0] == '0'); }(); return v; }
+static hipError_t copy_by_kernel(pdbeda_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    hipLaunchKernelGGL(k_copy_bytes, dim3((unsigned)std::min<size_t>((bytes >> 12) + 1, 64)), dim3(256), 0, ctx->stream, (const unsigned char *)src, (unsigned char *)dst,
+                       (unsigned long long)bytes);
+    return hipGetLastError();
+}
+
 static hipError_t ctx_sync(pdbeda_ctx *ctx) {
     const hipError_t e = ctx_wait(ctx);
     if (e == hipSuccess)
@@ -261,7 +273,8 @@ static hipError_t d2h(pdbeda_ctx *ctx, void *dst, const void *src, size_t bytes)
     if (bytes == 0) return hipSuccess;
     const size_t need = (bytes + 63) & ~(size_t)63;
     if (ctx->pinned && ctx->pinned_used + need <= ctx->pinned_cap) {
-        const hipError_t e = hipMemcpyAsync(ctx->pinned + ctx->pinned_used, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+        const hipError_t e = copy_kernels() ? copy_by_kernel(ctx, ctx->pinned + ctx->pinned_used, src, bytes)
+                                            : hipMemcpyAsync(ctx->pinned + ctx->pinned_used, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) { ctx->pending.push_back({dst, ctx->pinned_used, bytes}); ctx->pinned_used += need; }
         return e;
     }
@@ -367,7 +380,7 @@ static hipError_t h2d_row(pdbeda_ctx *ctx, const H2DItem *items, int n) {
         char *stage = ctx->pinned + ctx->pinned_used;
         for (int k = 0; k < n; ++k)
             if (items[k].bytes) memcpy(stage + ((char *)items[k].dst - lo), items[k].src, items[k].bytes);
-        const hipError_t e = hipMemcpyAsync(lo, stage, span, hipMemcpyHostToDevice, ctx->stream);
+        const hipError_t e = copy_kernels() ? copy_by_kernel(ctx, lo, stage, span) : hipMemcpyAsync(lo, stage, span, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) ctx->pinned_used += need;
         return e;
     }
@@ -377,6 +390,11 @@ static hipError_t h2d_row(pdbeda_ctx *ctx, const H2DItem *items, int n) {
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+static hipError_t h2d_one(pdbeda_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    const H2DItem in[1] = {{dst, src, bytes}};
+    return h2d_row(ctx, in, 1);
 }
 
 // Several results of one call, complete after the next ctx_sync(): packed on the device (k_pack) and brought over in ONE copy
@@ -406,10 +424,10 @@ static hipError_t d2h_many(pdbeda_ctx *ctx, const D2HItem *items, int n_items) {
             off += (it.bytes + 63) & ~(size_t)63;
             words = std::max<size_t>(words, it.bytes / 4);
         }
-        char *block = ctx->dev_stage + ctx->dev_stage_used;
+        char *block = copy_kernels() ? ctx->pinned + ctx->pinned_used : ctx->dev_stage + ctx->dev_stage_used;   // (packed straight into the pinned block)
         hipLaunchKernelGGL(k_pack, dim3(grid_for((int64_t)words, 256, 256)), dim3(256), 0, ctx->stream, a, reinterpret_cast<uint32_t *>(block));
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + ctx->pinned_used, block, total, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && !copy_kernels()) e = hipMemcpyAsync(ctx->pinned + ctx->pinned_used, block, total, hipMemcpyDeviceToHost, ctx->stream);
         if (e != hipSuccess) { for (int j = 0; j < n; ++j) ctx->pending.pop_back(); return e; }
         ctx->dev_stage_used += total;
         ctx->pinned_used += total;
@@ -612,7 +630,7 @@ static int map_create(pdbeda_ctx *ctx, const float *host, const float *dev, cons
     if (rc) { delete m; return rc; }
     Carver cv(m->arena.base);
     m->geom_dev = cv.take<Geom>(1);
-    hipError_t e = hipMemcpyAsync(m->geom_dev, &m->geom, sizeof(Geom), hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = h2d_one(ctx, m->geom_dev, &m->geom, sizeof(Geom));
     if (host) {
         float *d = cv.take<float>((size_t)m->n_vox);
         m->dens = d;
@@ -883,7 +901,7 @@ static int upload_file_impl(pdbeda_ctx *ctx, const char *path, int64_t offset, i
     float *d = cv.take<float>((size_t)n_vox);
     m->dens = d;
     m->own_dens = true;
-    hipError_t e = hipMemcpyAsync(m->geom_dev, &m->geom, sizeof(Geom), hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = h2d_one(ctx, m->geom_dev, &m->geom, sizeof(Geom));
     // The arena may be a recycled one: the pool protects a recycled arena by STREAM ORDER on ctx->stream (maps and lists are
     // freed without a host sync while their kernels are still queued; the debug poison fill above is queued there too).  The
     // readers' copies go through their own streams, which know nothing of that order -- so the first chunk is handed out only
@@ -1004,7 +1022,7 @@ extern "C" int pdbeda_map_combine(pdbeda_map *a, pdbeda_map *b, double alpha, pd
     Carver cv(m->arena.base);
     m->geom_dev = cv.take<Geom>(1);
     float *d = cv.take<float>((size_t)m->n_vox);
-    hipError_t e = hipMemcpyAsync(m->geom_dev, &m->geom, sizeof(Geom), hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = h2d_one(ctx, m->geom_dev, &m->geom, sizeof(Geom));
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_map_combine, dim3(grid_for(m->n_vox / 4 + 1, 256, 4096)), dim3(256), 0, ctx->stream, a->dens, b->dens, alpha, m->n_vox, d);
         e = hipGetLastError();
@@ -1130,7 +1148,8 @@ static int stats_enqueue(pdbeda_map *m, double *chunk_sums, double host[2], doub
     if (rc_range) return rc_range;
     // one copy of the six doubles into the staging block, delivered to the caller's two arrays at the next ctx_sync
     if (ctx->pinned && ctx->pinned_used + 64 <= ctx->pinned_cap) {
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + ctx->pinned_used, res, 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, copy_kernels() ? copy_by_kernel(ctx, ctx->pinned + ctx->pinned_used, res, 6 * sizeof(double))
+                                    : hipMemcpyAsync(ctx->pinned + ctx->pinned_used, res, 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         ctx->pending.push_back({host, ctx->pinned_used, 2 * sizeof(double)});
         ctx->pending.push_back({range, ctx->pinned_used + 4 * sizeof(double), 2 * sizeof(double)});
         ctx->pinned_used += 64;
@@ -1198,7 +1217,7 @@ extern "C" int pdbeda_point_density(pdbeda_map *m, const int32_t *crs, int64_t n
         Carver cv(base);
         int32_t *d_crs = cv.take<int32_t>(3 * n);
         double *d_out = cv.take<double>(n);
-        HIP_TRY(ctx, hipMemcpyAsync(d_crs, crs, 12 * n, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, h2d_one(ctx, d_crs, crs, (size_t)(12 * n)));
         hipLaunchKernelGGL(k_point_density, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->geom_dev, m->dens, d_crs, n, d_out, (uint8_t *)nullptr);
         HIP_TRY(ctx, d2h(ctx, out, d_out, 8 * n));
         return 0;
@@ -1214,7 +1233,7 @@ extern "C" int pdbeda_valid_crs(pdbeda_map *m, const int32_t *crs, int64_t n, ui
         Carver cv(base);
         int32_t *d_crs = cv.take<int32_t>(3 * n);
         uint8_t *d_out = cv.take<uint8_t>(n);
-        HIP_TRY(ctx, hipMemcpyAsync(d_crs, crs, 12 * n, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, h2d_one(ctx, d_crs, crs, (size_t)(12 * n)));
         hipLaunchKernelGGL(k_point_density, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->geom_dev, m->dens, d_crs, n, (double *)nullptr, d_out);
         HIP_TRY(ctx, d2h(ctx, out, d_out, n));
         return 0;
@@ -1230,7 +1249,7 @@ extern "C" int pdbeda_crs2xyz(pdbeda_map *m, const int32_t *crs, int64_t n, doub
         Carver cv(base);
         int32_t *d_crs = cv.take<int32_t>(3 * n);
         double *d_xyz = cv.take<double>(3 * n);
-        HIP_TRY(ctx, hipMemcpyAsync(d_crs, crs, 12 * n, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, h2d_one(ctx, d_crs, crs, (size_t)(12 * n)));
         hipLaunchKernelGGL(k_crs2xyz, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->geom_dev, d_crs, n, d_xyz);
         HIP_TRY(ctx, d2h(ctx, xyz, d_xyz, 24 * n));
         return 0;
@@ -1246,7 +1265,7 @@ extern "C" int pdbeda_xyz2crs(pdbeda_map *m, const double *xyz, int64_t n, int32
         Carver cv(base);
         double *d_xyz = cv.take<double>(3 * n);
         int32_t *d_crs = cv.take<int32_t>(3 * n);
-        HIP_TRY(ctx, hipMemcpyAsync(d_xyz, xyz, 24 * n, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, h2d_one(ctx, d_xyz, xyz, (size_t)(24 * n)));
         hipLaunchKernelGGL(k_xyz2crs, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->geom_dev, d_xyz, n, d_crs);
         HIP_TRY(ctx, d2h(ctx, crs, d_crs, 12 * n));
         return 0;
@@ -1919,7 +1938,7 @@ static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, con
             memcpy(stage + ((char *)gs->d_xyz - gs->in_arena.base), xyz, 24 * (size_t)n_items);
             memcpy(stage + ((char *)gs->d_radii - gs->in_arena.base), radii, 4 * (size_t)n_items);
             memcpy(stage + ((char *)gs->d_item_group - gs->in_arena.base), item_group.data(), 4 * (size_t)n_items);
-            HIP_TRY(ctx, hipMemcpyAsync(gs->in_arena.base, stage, block, hipMemcpyHostToDevice, st));
+            HIP_TRY(ctx, copy_kernels() ? copy_by_kernel(ctx, gs->in_arena.base, stage, block) : hipMemcpyAsync(gs->in_arena.base, stage, block, hipMemcpyHostToDevice, st));
             ctx->pinned_used += need;
             return group_bounds(m, gs, n_items, n_groups, true, totals);
         }
@@ -1929,8 +1948,8 @@ static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, con
             const H2DItem in[3] = {{gs->d_xyz, xyz, (size_t)(24 * n_items)}, {gs->d_radii, radii, (size_t)(4 * n_items)}, {gs->d_item_group, item_group.data(), (size_t)(4 * n_items)}};
             HIP_TRY(ctx, h2d_row(ctx, in, 3));       // (a row at the head of the scratch arena: one copy)
         } else {
-            HIP_TRY(ctx, hipMemcpyAsync(gs->d_crs, crs, 12 * n_items, hipMemcpyHostToDevice, st));
-            HIP_TRY(ctx, hipMemcpyAsync(gs->d_item_group, item_group.data(), 4 * n_items, hipMemcpyHostToDevice, st));
+            HIP_TRY(ctx, h2d_one(ctx, gs->d_crs, crs, (size_t)(12 * n_items)));
+            HIP_TRY(ctx, h2d_one(ctx, gs->d_item_group, item_group.data(), (size_t)(4 * n_items)));
         }
     }
     return group_bounds(m, gs, n_items, n_groups, xyz != nullptr);   // (synchronises: item_group may go)
@@ -1952,7 +1971,7 @@ static int grouped_job(pdbeda_map *m, GroupSetup &gs, int64_t n_items, int64_t n
     job_carve(job, arena.base, (int)n_groups, gs.total_words, gs.total_keys, max_runs, max_runs, 0, nullptr);
     hipStream_t st = ctx->stream;
     hipError_t e = hipSuccess;
-    if (n_groups > 0) e = hipMemcpyAsync(job.vols, gs.d_vols, sizeof(VolDesc) * n_groups, hipMemcpyDeviceToDevice, st);
+    if (n_groups > 0) e = copy_kernels() ? copy_by_kernel(ctx, job.vols, gs.d_vols, sizeof(VolDesc) * (size_t)n_groups) : hipMemcpyAsync(job.vols, gs.d_vols, sizeof(VolDesc) * n_groups, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess)   // counters + masks + first-key bitmap + both levels of rank counters (adjacent in the arena: job_carve): one fill
         e = hipMemsetAsync(job.ctr, 0, (size_t)((char *)(job.mid_count + (job.key_words + KEY_FINE - 1) / KEY_FINE * (KEY_FINE / 16)) - (char *)job.ctr), st);
     if (e == hipSuccess && n_items > 0) {
@@ -2072,10 +2091,11 @@ extern "C" int pdbeda_test_overlap(pdbeda_ctx *ctx, const int32_t *crs, const in
         int32_t *d_b = cv.take<int32_t>(n_pairs);
         unsigned int *d_out = cv.take<unsigned int>(n_pairs);
         hipStream_t st = ctx->stream;
-        if (nv > 0) HIP_TRY(ctx, hipMemcpyAsync(d_crs, crs, 12 * nv, hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(d_off, set_offsets, 8 * (n_sets + 1), hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(d_a, a_idx, 4 * n_pairs, hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(d_b, b_idx, 4 * n_pairs, hipMemcpyHostToDevice, st));
+        if (nv > 0) HIP_TRY(ctx, h2d_one(ctx, d_crs, crs, (size_t)(12 * nv)));
+        {
+            const H2DItem in[3] = {{d_off, set_offsets, (size_t)(8 * (n_sets + 1))}, {d_a, a_idx, (size_t)(4 * n_pairs)}, {d_b, b_idx, (size_t)(4 * n_pairs)}};
+            HIP_TRY(ctx, h2d_row(ctx, in, 3));      // (consecutive takes: one copy)
+        }
         HIP_TRY(ctx, hipMemsetAsync(d_out, 0, 4 * n_pairs, st));
         hipLaunchKernelGGL(k_test_overlap, dim3((unsigned)n_pairs), dim3(256), 0, st, d_crs, d_off, d_a, d_b, d_out);
         HIP_TRY(ctx, d2h(ctx, h_out.data(), d_out, 4 * n_pairs));
@@ -2123,7 +2143,7 @@ extern "C" int pdbeda_symmetry_atoms(pdbeda_ctx *ctx, const double *xyz, int64_t
         const int64_t n = (int64_t)picked.size();
         if (n == 0 || n > cap || !out_xyz) return 0;
         h_xyz.resize(3 * (size_t)n);
-        HIP_TRY(ctx, hipMemcpyAsync(d_picked, picked.data(), 8 * n, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, h2d_one(ctx, d_picked, picked.data(), (size_t)(8 * n)));
         { PROF(ctx, "k_symmetry_pick"); hipLaunchKernelGGL(k_symmetry_pick, dim3(grid_for(n, 256)), dim3(256), 0, st, d_xyz, n_atoms, d_rot, (int)n_ops, d_ortho, d_lo, d_hi, d_picked, n, d_out); }
         HIP_TRY(ctx, d2h(ctx, h_xyz.data(), d_out, 24 * n));
         return 0;

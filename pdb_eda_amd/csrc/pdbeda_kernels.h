@@ -1137,6 +1137,21 @@ __global__ void __launch_bounds__(256) k_voxel_lists(Job job, const int64_t *__r
 // device -> host copy is a launch of the runtime's own on the stream (~5 us + the gap), and an accessor that returns seven columns
 // of a blob table paid seven of them (round 4: 52 of an analysis entry's 114 launches were such copies).  Sizes and offsets are
 // multiples of 4 bytes.
+// k_copy_bytes: a small copy done by a kernel -- between device scratch and the context's PINNED staging block, which the device reads and
+// writes over the link directly.  (A hipMemcpyAsync of a few hundred bytes is a packet on the SDMA engine: it waits behind every 4-8 MiB
+// chunk the upload engine has queued there, and each hop between the compute queue and the copy engine is a semaphore.)
+__global__ void __launch_bounds__(256) k_copy_bytes(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst, unsigned long long bytes) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x, t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0) {
+        const unsigned long long n16 = bytes >> 4;
+        const uint4 *s16 = reinterpret_cast<const uint4 *>(src);
+        uint4 *d16 = reinterpret_cast<uint4 *>(dst);
+        for (unsigned long long i = t; i < n16; i += stride) d16[i] = s16[i];
+        for (unsigned long long i = (n16 << 4) + t; i < bytes; i += stride) dst[i] = src[i];
+    } else {
+        for (unsigned long long i = t; i < bytes; i += stride) dst[i] = src[i];
+    }
+}
 struct PackSeg { const uint32_t *src; unsigned long long words, dst_word; };
 struct PackArgs { PackSeg seg[8]; int n; };
 __global__ void __launch_bounds__(256) k_pack(PackArgs a, uint32_t *__restrict__ dst) {
