@@ -47,6 +47,14 @@ def traced_chunk(entries):
     return os.getpid(), t_chunk, time.monotonic(), stamps, out
 
 
+def cpu_stat():
+    """The cgroup's CPU accounting (a GPU box gives 16 CPUs' worth of time per 100 ms period, whatever the affinity mask says)."""
+    try:
+        return {k: int(v) for k, v in (line.split() for line in open("/sys/fs/cgroup/cpu.stat")) if k in ("usage_usec", "nr_periods", "nr_throttled", "throttled_usec")}
+    except OSError:
+        return {}
+
+
 if __name__ == "__main__":
     import numpy as np
     from pdb_eda_amd import synthetic, multipleStructures, densityAnalysis, _native
@@ -67,9 +75,11 @@ if __name__ == "__main__":
             chunk = int(os.environ.get("PIPE_CHUNK", "8"))
             chunks = [entries[k:k + chunk] for k in range(0, len(entries), chunk)]
             pool.run(traced_chunk, chunks[:workers])
+            cpu0 = cpu_stat()
             t0 = time.monotonic()
             res = pool.run(traced_chunk, chunks)
             wall = time.monotonic() - t0
+            cpu1 = cpu_stat()
         finally:
             pool.close()
         dur = {"load": [], "wait": [], "analyse": []}
@@ -85,6 +95,10 @@ if __name__ == "__main__":
             v = 1e3 * np.array(dur[kind])
             print("  %-8s mean %.2f  median %.2f  p90 %.2f ms" % (kind, v.mean(), np.median(v), np.percentile(v, 90)))
         print("  first load of a chunk (nothing overlaps it): mean %.2f ms" % (1e3 * np.mean(first_load)))
+        if cpu0 and cpu1:
+            d = {k: cpu1[k] - cpu0[k] for k in cpu0}
+            print("  cgroup: %.1f CPUs busy on average; %d of %d periods throttled, %.2f s of thread time throttled" %
+                  (1e-6 * d["usage_usec"] / wall, d["nr_throttled"], d["nr_periods"], 1e-6 * d["throttled_usec"]))
         busy = sum(c1 - c0 for _, c0, c1, _, _ in res)
         print("  sum of chunk times / (workers * wall) = %.2f (1.0 = every worker always inside a chunk)" % (busy / (workers * wall)))
     finally:
