@@ -267,25 +267,21 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
         finally:
             lazy.close()
         lazy_done = lazy_passes * args.entries
-        # ONE load by itself (this process, the pools are closed): a 32 MB map file -> HBM through the upload engine, statistics included
+        # ONE load by itself: a 32 MB map file -> HBM through the upload engine, statistics included -- in a lone pool worker (a fresh process;
+        # this one holds a dozen streams by now, and streams that exist slow a process's copy streams)
         load_single = None
         try:
-            from pdb_eda_amd import _native as native, ccp4 as ccp4_mod
-            lone = native.Context(local_rank)
-            head = ccp4_mod.read(loaders[0].density_path, "lone", ctx=lone, lazy=True)
-            geom, off = head.header.geometry(), 1024 + head.header.symmetryBytes
-            times = []
-            for k in range(12):
-                path = loaders[k % len(loaders)].density_path
-                t1 = time.perf_counter()
-                one_map = native.DeviceMap.from_file(lone, path, off, False, geom)
-                times.append(time.perf_counter() - t1)
-                one_map.free()
+            lone = multipleStructures.ProcessPool(local_rank, 1, params=synthetic.synthetic_params(), silent=True)
+            try:
+                lone.warm()
+                times = lone.run(synthetic.time_single_loads, [([l.density_path for l in loaders[:4]], 48)])[0][8:]
+            finally:
+                lone.close()
             n_bytes = 4 * args.entry_size ** 3
-            load_single = {"bytes": n_bytes, "median_ms": 1e3 * float(np.median(times[2:])), "GBs_median": n_bytes / float(np.median(times[2:])) / 1e9,
-                           "GBs_best": n_bytes / min(times[2:]) / 1e9,
-                           "note": "pdbeda_map_upload_file_stats of one map alone: open, chunked pread -> pinned -> HBM on three reader threads, mean / std, one wait"}
-            lone.close()
+            load_single = {"bytes": n_bytes, "loads": len(times), "median_ms": 1e3 * float(np.median(times)), "GBs_median": n_bytes / float(np.median(times)) / 1e9,
+                           "GBs_best": n_bytes / min(times) / 1e9,
+                           "note": "pdbeda_map_upload_file_stats of one map alone in a lone pool worker: open, chunked pread -> pinned -> HBM on three reader threads, "
+                                   "mean / std, one wait"}
         except Exception as error:
             load_single = {"error": "%s: %s" % (type(error).__name__, error)}
         per_rank = [own_rate]

@@ -630,15 +630,18 @@ static int map_create(pdbeda_ctx *ctx, const float *host, const float *dev, cons
     if (rc) { delete m; return rc; }
     Carver cv(m->arena.base);
     m->geom_dev = cv.take<Geom>(1);
-    hipError_t e = h2d_one(ctx, m->geom_dev, &m->geom, sizeof(Geom));
+    hipError_t e = hipSuccess;
     if (host) {
         float *d = cv.take<float>((size_t)m->n_vox);
         m->dens = d;
         m->own_dens = true;
-        if (e == hipSuccess) e = hipMemcpyAsync(d, host, sizeof(float) * (size_t)m->n_vox, hipMemcpyHostToDevice, ctx->stream);
+        // (measured, round 5: the same grid through the upload engine -- readers memcpy chunks into their pinned slots -- takes twice as long as the runtime's
+        //  own copy from pageable memory, which pins the caller's pages and lets the engine read them in place: 0.6 against 0.3 ms for 8 MB)
+        e = hipMemcpyAsync(d, host, sizeof(float) * (size_t)m->n_vox, hipMemcpyHostToDevice, ctx->stream);
     } else {
         m->dens = dev;
     }
+    if (e == hipSuccess) e = h2d_one(ctx, m->geom_dev, &m->geom, sizeof(Geom));
     // (an uploaded map with its statistics from the same wait: see upload_file_impl)
     const bool with_stats = (mean || std) && host && e == hipSuccess;
     double st_host[2] = {0.0, 0.0}, range[2] = {0.0, 0.0};
@@ -735,8 +738,9 @@ static unsigned reader_spins() { static const unsigned v = [] { const char *e = 
 // lone load gets all readers, and the number of threads and pinned chunks does not grow with the number of contexts.
 static const int FILE_READERS_DEFAULT = 3;
 struct UploadLoad {
-    int fd = -1;
+    int fd = -1;                                   // the source: a file (pread at offset + position) ...
     int64_t offset = 0;
+    const char *src = nullptr;                     // ... or the caller's memory (fd < 0)
     char *dst = nullptr;
     size_t need = 0;
     int64_t n_chunks = 0;
@@ -811,7 +815,8 @@ struct UploadEngine {
                 t_b = now_s();
                 if (ce == hipSuccess && !timed_out) {
                     const size_t pos = ld->pieces[(size_t)c].first, len = ld->pieces[(size_t)c].second;
-                    for (size_t got = 0; got < len;) {
+                    if (ld->fd < 0) memcpy(me.slot[slot], ld->src + pos, len);
+                    for (size_t got = 0; ld->fd >= 0 && got < len;) {
                         const ssize_t n = pread(ld->fd, me.slot[slot] + got, len - got, (off_t)(ld->offset + (int64_t)pos + (int64_t)got));
                         if (n < 0 && errno == EINTR) continue;
                         if (n <= 0) { why = n < 0 ? strerror(errno) : "unexpected end of file"; break; }
@@ -867,41 +872,20 @@ static UploadEngine *upload_engine(int device) {
     return en;
 }
 
-static int upload_file_impl(pdbeda_ctx *ctx, const char *path, int64_t offset, int byteswap, const pdbeda_geometry *geom, pdbeda_map **out, double *mean, double *std) {
-    if (!ctx || !path || !geom || !out || offset < 0) return PDBEDA_ERR_ARGUMENT;
-    *out = nullptr;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const int64_t n_vox = (int64_t)geom->ncrs[0] * geom->ncrs[1] * geom->ncrs[2];
-    if (n_vox <= 0 || n_vox >= (1ll << 32)) return fail(ctx, PDBEDA_ERR_ARGUMENT, "grid size out of range");
-    const size_t need = sizeof(float) * (size_t)n_vox;
-    const int fd = open(path, O_RDONLY | O_CLOEXEC);
-    if (fd < 0) return fail(ctx, PDBEDA_ERR_ARGUMENT, "cannot open %s: %s", path, strerror(errno));
-    struct stat sb;
-    if (fstat(fd, &sb) != 0 || (int64_t)sb.st_size < offset + (int64_t)need) {
-        close(fd);
-        return fail(ctx, PDBEDA_ERR_ARGUMENT, "%s holds fewer than %lld grid bytes after offset %lld", path, (long long)need, (long long)offset);
-    }
-    UploadEngine *engine = upload_engine(ctx->device);
-    if (engine->n_readers < 1) { close(fd); return fail(ctx, PDBEDA_ERR_MEMORY, "no reader (pinned chunks, copy stream, thread) for the file upload"); }
+static bool ensure_reader_events(pdbeda_ctx *ctx, UploadEngine *engine) {
     for (int r = 0; r < engine->n_readers; ++r)
         if (!ctx->reader_ev[r] && hipEventCreateWithFlags(&ctx->reader_ev[r], hipEventDisableTiming) != hipSuccess) {
             ctx->reader_ev[r] = nullptr;
             (void)hipGetLastError();
-            close(fd);
-            return fail(ctx, PDBEDA_ERR_MEMORY, "no event for the file upload");
+            return false;
         }
-    pdbeda_map *m = new pdbeda_map();
-    m->ctx = ctx;
-    int rc = fill_geom(ctx, geom, &m->geom);
-    if (rc == 0) rc = arena_get(ctx, align_up(sizeof(Geom)) + align_up(need), &m->arena);
-    if (rc) { close(fd); delete m; return rc; }
-    m->n_vox = n_vox;
-    Carver cv(m->arena.base);
-    m->geom_dev = cv.take<Geom>(1);
-    float *d = cv.take<float>((size_t)n_vox);
-    m->dens = d;
-    m->own_dens = true;
-    hipError_t e = h2d_one(ctx, m->geom_dev, &m->geom, sizeof(Geom));
+    return true;
+}
+
+// One map's bytes -- from a file (fd >= 0: pread at offset + position) or from the caller's memory (src) -- into HBM at dst through the process's
+// upload engine; on return every chunk is queued on a reader's stream (or given up) and ctx->stream waits for them.  *why: a file-level reason.
+static hipError_t engine_copy(pdbeda_ctx *ctx, UploadEngine *engine, int fd, int64_t offset, const char *src, char *dst, size_t need, const char **why) {
+    hipError_t e = hipSuccess;
     // The arena may be a recycled one: the pool protects a recycled arena by STREAM ORDER on ctx->stream (maps and lists are
     // freed without a host sync while their kernels are still queued; the debug poison fill above is queued there too).  The
     // readers' copies go through their own streams, which know nothing of that order -- so the first chunk is handed out only
@@ -911,10 +895,9 @@ static int upload_file_impl(pdbeda_ctx *ctx, const char *path, int64_t offset, i
         if (q == hipErrorNotReady) q = ctx_wait(ctx);     // (timed, under the watchdog)
         if (q != hipSuccess) e = q;
     }
-    const char *why = nullptr;
     if (e == hipSuccess && !ctx->timed_out) {
         UploadLoad ld;
-        ld.fd = fd; ld.offset = offset; ld.dst = (char *)d; ld.need = need;
+        ld.fd = fd; ld.offset = offset; ld.src = src; ld.dst = dst; ld.need = need;
         // chunk sizes ramp up: a pread of a full chunk takes the better part of a millisecond before its copy can start -- with every reader on such a chunk the
         // link idled for the first 0.4 ms of every map; the first round is 256 KiB each, the second 1 MiB, then full chunks
         const size_t full = engine->active.fetch_add(1) == 0 ? file_chunk_alone_bytes() : FILE_CHUNK;
@@ -951,13 +934,47 @@ static int upload_file_impl(pdbeda_ctx *ctx, const char *path, int64_t offset, i
             if (je != hipSuccess && e == hipSuccess) e = je;
         }
         if (ld.e != hipSuccess && e == hipSuccess) e = ld.e;
-        why = ld.why;
+        *why = ld.why;
         if (ld.timed_out) {
             ctx->timed_out = true;
             ctx->err = "watchdog: the stream did not drain within the per-entry time-out; context abandoned";
             if (e == hipSuccess) e = hipErrorNotReady;
         }
     }
+    return e;
+}
+
+static int upload_file_impl(pdbeda_ctx *ctx, const char *path, int64_t offset, int byteswap, const pdbeda_geometry *geom, pdbeda_map **out, double *mean, double *std) {
+    if (!ctx || !path || !geom || !out || offset < 0) return PDBEDA_ERR_ARGUMENT;
+    *out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t n_vox = (int64_t)geom->ncrs[0] * geom->ncrs[1] * geom->ncrs[2];
+    if (n_vox <= 0 || n_vox >= (1ll << 32)) return fail(ctx, PDBEDA_ERR_ARGUMENT, "grid size out of range");
+    const size_t need = sizeof(float) * (size_t)n_vox;
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return fail(ctx, PDBEDA_ERR_ARGUMENT, "cannot open %s: %s", path, strerror(errno));
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || (int64_t)sb.st_size < offset + (int64_t)need) {
+        close(fd);
+        return fail(ctx, PDBEDA_ERR_ARGUMENT, "%s holds fewer than %lld grid bytes after offset %lld", path, (long long)need, (long long)offset);
+    }
+    UploadEngine *engine = upload_engine(ctx->device);
+    if (engine->n_readers < 1) { close(fd); return fail(ctx, PDBEDA_ERR_MEMORY, "no reader (pinned chunks, copy stream, thread) for the file upload"); }
+    if (!ensure_reader_events(ctx, engine)) { close(fd); return fail(ctx, PDBEDA_ERR_MEMORY, "no event for the file upload"); }
+    pdbeda_map *m = new pdbeda_map();
+    m->ctx = ctx;
+    int rc = fill_geom(ctx, geom, &m->geom);
+    if (rc == 0) rc = arena_get(ctx, align_up(sizeof(Geom)) + align_up(need), &m->arena);
+    if (rc) { close(fd); delete m; return rc; }
+    m->n_vox = n_vox;
+    Carver cv(m->arena.base);
+    m->geom_dev = cv.take<Geom>(1);
+    float *d = cv.take<float>((size_t)n_vox);
+    m->dens = d;
+    m->own_dens = true;
+    const char *why = nullptr;
+    hipError_t e = engine_copy(ctx, engine, fd, offset, nullptr, (char *)d, need, &why);   // (first: the stream is idle, its query says so at once)
+    if (e == hipSuccess) e = h2d_one(ctx, m->geom_dev, &m->geom, sizeof(Geom));
     close(fd);
     if (e == hipSuccess && !why && byteswap) {
         hipLaunchKernelGGL(k_byteswap32, dim3(grid_for(n_vox, 256, 8192)), dim3(256), 0, ctx->stream, (uint32_t *)d, n_vox);

@@ -298,3 +298,26 @@ class SyntheticEntryFiles(object):
         st, pdb = self.structure()
         st.__dict__.pop("_pdbeda_columns", None)        # (a real entry arrives with a fresh structure: no snapshot carried over)
         return dens, diff, st, pdb
+
+
+def time_single_loads(task):
+    """bench.py's ``load_single``: ``task`` = (paths, repetitions) -> seconds of every ``DeviceMap.from_file`` of ONE map at a time on a
+    context of its own (run in a pool worker: a fresh process with nothing else on the card -- the bench's own process holds a dozen
+    streams by then, which slows every copy stream of the process)."""
+    import time
+    from . import _native, ccp4, multipleStructures
+    paths, repetitions = task
+    ctx = _native.Context(multipleStructures._worker_state.get("device", 0))
+    try:
+        head = ccp4.read(paths[0], "lone", ctx=ctx, lazy=True)
+        geom, off = head.header.geometry(), 1024 + head.header.symmetryBytes
+        times = []
+        for k in range(repetitions):
+            t1 = time.perf_counter()
+            one_map = _native.DeviceMap.from_file(ctx, paths[k % len(paths)], off, False, geom)
+            times.append(time.perf_counter() - t1)
+            one_map.free()
+        return times
+    finally:
+        ctx.close()
+
