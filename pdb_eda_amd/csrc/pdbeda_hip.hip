@@ -1867,11 +1867,11 @@ static int group_alloc(pdbeda_ctx *ctx, int64_t n_items, int64_t n_groups, Group
     gs->d_radii = cv.take<float>(ni);
     gs->d_item_group = cv.take<int32_t>(ni);
     gs->d_boxes = cv.take<AtomBox>(ni);
+    gs->d_vols = cv.take<VolDesc>(ng);       // (boxes, volumes and counters follow the inputs: a per-atom sphere batch whose bounds the host makes sends all six in one row)
+    gs->d_ctr = cv.take<Counters>(1);
     gs->d_crs = cv.take<int32_t>(3 * ni);
     gs->g_lo = cv.take<int32_t>(3 * ng);
     gs->g_hi = cv.take<int32_t>(3 * ng);
-    gs->d_vols = cv.take<VolDesc>(ng);
-    gs->d_ctr = cv.take<Counters>(1);
     return 0;
 }
 
@@ -1945,6 +1945,66 @@ static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, con
             totals[0] += last_words;
             totals[1] += last_keys;
             if (totals[0] >= (1ll << 40) || totals[1] >= (1ll << 46)) per_atom = false;   // (absurd: let the waiting path report it)
+        }
+        // Round 5: the host makes the boxes and the volume descriptors too (xyz2crs is one function for host and device: the same IEEE operations in
+        // the same order) -- k_init_bounds, k_atom_boxes and k_make_vols were three launches in front of every per-atom batch (the clouds of
+        // aggregateCloud, the region tables), and a launch costs several times its 5 us when other processes' uploads hold the link.
+        // PDBEDA_HOST_BOXES=0: the device makes them (A/B, and what the test of the two paths' equality runs against).
+        static const bool host_boxes = [] { const char *e = getenv("PDBEDA_HOST_BOXES"); return !(e && e[0] == '0'); }();
+        const size_t row = (size_t)((char *)(gs->d_ctr + 1) - gs->in_arena.base), row_need = (row + 63) & ~(size_t)63;
+        if (per_atom && host_boxes && !ctx->debug_shrink_totals && (char *)gs->d_xyz == gs->in_arena.base && ctx->pinned && row <= ((size_t)1 << 20) &&
+            ctx->pinned_used + row_need <= ctx->pinned_cap) {
+            char *stage = ctx->pinned + ctx->pinned_used;
+            memcpy(stage + ((char *)gs->d_xyz - gs->in_arena.base), xyz, 24 * (size_t)n_items);
+            memcpy(stage + ((char *)gs->d_radii - gs->in_arena.base), radii, 4 * (size_t)n_items);
+            memcpy(stage + ((char *)gs->d_item_group - gs->in_arena.base), item_group.data(), 4 * (size_t)n_items);
+            AtomBox *boxes = reinterpret_cast<AtomBox *>(stage + ((char *)gs->d_boxes - gs->in_arena.base));
+            VolDesc *vols = reinterpret_cast<VolDesc *>(stage + ((char *)gs->d_vols - gs->in_arena.base));
+            Counters *ctr0 = reinterpret_cast<Counters *>(stage + ((char *)gs->d_ctr - gs->in_arena.base));
+            int64_t words = 0, keys = 0;
+            float cached_rad = NAN;
+            int32_t R[3] = {0, 0, 0};
+            for (int64_t a = 0; a < n_items; ++a) {
+                if (!(radii[a] == cached_rad)) {
+                    const double rad = (double)radii[a];
+                    const double o[3] = {m->geom.origin[0] + rad, m->geom.origin[1] + rad, m->geom.origin[2] + rad};
+                    xyz2crs(m->geom, o, R);
+                    cached_rad = radii[a];
+                }
+                int32_t C[3];
+                xyz2crs(m->geom, xyz + 3 * a, C);
+                AtomBox bx;
+                bool empty = false;
+                for (int k = 0; k < 3; ++k) {      // (int32 arithmetic as in k_atom_boxes)
+                    bx.lo[k] = C[k] - R[k] - 1;
+                    bx.hi[k] = C[k] + R[k];
+                    empty = empty || bx.hi[k] < bx.lo[k];
+                }
+                if (empty) { for (int k = 0; k < 3; ++k) { bx.lo[k] = 0; bx.hi[k] = -1; } }
+                boxes[a] = bx;
+                VolDesc vd;
+                memset(&vd, 0, sizeof vd);
+                for (int k = 0; k < 3 && !empty; ++k) { vd.org[k] = bx.lo[k]; vd.dim[k] = bx.hi[k] - bx.lo[k] + 1; }
+                vd.row_words = (vd.dim[0] + 63) / 64;
+                vd.group = (int32_t)a;
+                vd.word_base = words;
+                vd.key_base = keys;
+                vols[a] = vd;
+                words += (int64_t)vd.row_words * vd.dim[1] * vd.dim[2];
+                keys += (int64_t)vd.dim[0] * vd.dim[1] * vd.dim[2];
+            }
+            if (words == totals[0] && keys == totals[1]) {      // (they are: both follow from the radii; a mismatch takes the device's path below)
+                memset(ctr0, 0, sizeof *ctr0);
+                ctr0->total_words = words;
+                ctr0->total_keys = keys;
+                HIP_TRY(ctx, copy_kernels() ? copy_by_kernel(ctx, gs->in_arena.base, stage, row) : hipMemcpyAsync(gs->in_arena.base, stage, row, hipMemcpyHostToDevice, st));
+                ctx->pinned_used += row_need;
+                gs->total_words = words;
+                gs->total_keys = keys;
+                gs->host_totals = true;
+                if (gs->total_words >= (1ll << 31) * 2) return fail(ctx, PDBEDA_ERR_ARGUMENT, "sphere batch too large (%lld mask words)", (long long)gs->total_words);
+                return 0;
+            }
         }
         if (ctx->debug_shrink_totals) { totals[0] /= 2; totals[1] /= 2; }
         // (coordinates, radii and groups sit in a row at the head of the scratch arena: one staged block, one copy)

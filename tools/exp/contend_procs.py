@@ -37,9 +37,23 @@ def work(args):
         t.start()
     barrier.wait()
     ts, t_end, m0, t0 = [], time.perf_counter() + seconds, sum(moved), time.perf_counter()
+    prim = os.environ.get("CONTEND_PRIMITIVE", "")
+    dmap = loaded[0]._map if prim else None        # the resident 2Fo-Fc map
+    pts = np.random.default_rng(k).integers(10, 190, size=(100, 3)).astype(np.int32)
+    big = np.random.default_rng(k).integers(10, 190, size=(20000, 3)).astype(np.int32)
+    pure = n_up > 0 and os.environ.get("CONTEND_PURE_UPLOADER", "") == "1"      # a process that uploads does nothing else
     while time.perf_counter() < t_end:
         t1 = time.perf_counter()
-        multipleStructures.analyzeEntry(entry, ctx, {}, True, loaded=loaded)
+        if pure:
+            time.sleep(0.05)
+        elif prim == "sum":            # two kernels, a result copied out, one wait: nothing read from the host
+            dmap.sum_of_abs(0.5)
+        elif prim == "points":       # 1.2 KB staged in, one kernel, 800 B out, one wait
+            dmap.point_density(pts)
+        elif prim == "points_big":   # 240 KB staged in, one kernel, 160 KB out, one wait
+            dmap.point_density(big)
+        else:
+            multipleStructures.analyzeEntry(entry, ctx, {}, True, loaded=loaded)
         ts.append(time.perf_counter() - t1)
     gbs = (sum(moved) - m0) / (time.perf_counter() - t0) / 1e9
     stop.set()
