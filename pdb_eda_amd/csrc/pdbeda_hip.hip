@@ -1732,8 +1732,7 @@ static int list_materialise_voxels(pdbeda_bloblist *bl) {
     ow->cursor_dev = cv.take<unsigned int>(std::max<int64_t>(nb, 1));
     ow->crs_dev = cv.take<int32_t>(3 * std::max<int64_t>(max_vox, 1));
     hipStream_t st = ctx->stream;
-    HIP_TRY(ctx, hipMemsetAsync(ow->cursor_dev, 0, 4 * std::max<int64_t>(nb, 1), st));
-    hipLaunchKernelGGL(k_blob_offsets, dim3(1), dim3(1024), 0, st, job, ow->offsets_dev);
+    hipLaunchKernelGGL(k_blob_offsets, dim3(1), dim3(1024), 0, st, job, ow->offsets_dev, ow->cursor_dev);
     if (job.total_words > 0)
         hipLaunchKernelGGL(k_voxel_lists, dim3(grid_for(job.total_words * 64, 256, 8192)), dim3(256), 0, st, job, ow->offsets_dev,
                            ow->cursor_dev, ow->crs_dev);
@@ -2048,9 +2047,15 @@ static int grouped_job(pdbeda_map *m, GroupSetup &gs, int64_t n_items, int64_t n
     job_carve(job, arena.base, (int)n_groups, gs.total_words, gs.total_keys, max_runs, max_runs, 0, nullptr);
     hipStream_t st = ctx->stream;
     hipError_t e = hipSuccess;
-    if (n_groups > 0) e = copy_kernels() ? copy_by_kernel(ctx, job.vols, gs.d_vols, sizeof(VolDesc) * (size_t)n_groups) : hipMemcpyAsync(job.vols, gs.d_vols, sizeof(VolDesc) * n_groups, hipMemcpyDeviceToDevice, st);
-    if (e == hipSuccess)   // counters + masks + first-key bitmap + both levels of rank counters (adjacent in the arena: job_carve): one fill
-        e = hipMemsetAsync(job.ctr, 0, (size_t)((char *)(job.mid_count + (job.key_words + KEY_FINE - 1) / KEY_FINE * (KEY_FINE / 16)) - (char *)job.ctr), st);
+    {   // volume descriptors into the job + zeroes over counters, masks, first-key bitmap and both levels of rank counters (adjacent in the arena: job_carve): one launch
+        static_assert(sizeof(VolDesc) % 16 == 0, "VolDesc is copied in 16-byte units");
+        const size_t zero_bytes = ((size_t)((char *)(job.mid_count + (job.key_words + KEY_FINE - 1) / KEY_FINE * (KEY_FINE / 16)) - (char *)job.ctr) + 15) & ~(size_t)15;   // (into the carve's own padding)
+        const size_t vol16 = sizeof(VolDesc) * (size_t)n_groups / 16;
+        hipLaunchKernelGGL(k_job_init, dim3((unsigned)std::min<size_t>((std::max(zero_bytes / 16, vol16) + 255) / 256, 2048)), dim3(256), 0, st,
+                           reinterpret_cast<const uint4 *>(gs.d_vols), reinterpret_cast<uint4 *>(job.vols), (unsigned long long)vol16,
+                           reinterpret_cast<uint4 *>(job.ctr), (unsigned long long)(zero_bytes / 16));
+        e = hipGetLastError();
+    }
     if (e == hipSuccess && n_items > 0) {
         if (spheres)
             { PROF(ctx, "k_sphere_paint"); hipLaunchKernelGGL(k_sphere_paint, dim3((unsigned)n_items), dim3(256), 0, st, m->geom_dev, m->dens, gs.d_xyz, gs.d_radii,
@@ -2455,13 +2460,14 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
     rc = group_alloc(ctx, 2 * V, n_groups, &gs);
     if (rc) return bail(rc, clouds, nullptr);
     Arena aux;
-    rc = arena_get(ctx, 2 * align_up(4 * n_pool) + align_up(8 * (n_pool + 1)) + align_up(8 * n_pool) + align_up(8 * (n + 1)) + 3 * align_up(4 * std::max<int64_t>(n_pairs, 1)), &aux);
+    rc = arena_get(ctx, align_up(sizeof(VolDesc) * (size_t)n_groups) + 2 * align_up(4 * n_pool) + align_up(8 * (n_pool + 1)) + align_up(8 * n_pool) + align_up(8 * (n + 1)) + 3 * align_up(4 * std::max<int64_t>(n_pairs, 1)), &aux);
     if (rc) { arena_put(ctx, gs.in_arena); return bail(rc, clouds, nullptr); }
     // what the device needs of the host's decisions, in ONE copy: pooled clouds, their groups, voxel offsets, the atoms' voxel
     // slices, the bonded pairs and the pairs' (zeroed) touch flags sit in a row in the scratch arena and in one host block
     // (six copies and a fill were seven launches on the stream, 6-8 us apart each: round 4, tools/exp/trace_cloud.sh)
     Carver cv(aux.base);
     const int64_t np1 = std::max<int64_t>(n_pairs, 1);
+    VolDesc *d_union_vols = cv.take<VolDesc>(n_groups);      // (the union job's volume descriptors ride in the same block: round 5)
     int32_t *d_pool_cloud = cv.take<int32_t>(n_pool), *d_pool_group = cv.take<int32_t>(n_pool);
     int64_t *d_pool_voff = cv.take<int64_t>(n_pool + 1);
     int64_t *d_set_off = cv.take<int64_t>(n + 1);
@@ -2473,22 +2479,6 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
         arena_put(ctx, aux);
         return bail(fail(ctx, PDBEDA_ERR_DEVICE, "aggregate cloud: %s", hipGetErrorString(e)), clouds, u);
     };
-    std::vector<char> block(upload_bytes, 0);      // (staged: the copy below reads a pinned block or, too large for that, has finished reading when it returns)
-    {
-        auto put = [&](const void *dev, const void *src, size_t bytes) { if (bytes) memcpy(block.data() + ((const char *)dev - aux.base), src, bytes); };
-        put(d_pool_cloud, pool_cloud.data(), 4 * (size_t)n_pool);
-        put(d_pool_group, pool_group.data(), 4 * (size_t)n_pool);
-        put(d_pool_voff, pool_voff.data(), 8 * (size_t)(n_pool + 1));
-        put(d_set_off, set_off.data(), 8 * (size_t)(n + 1));
-        put(d_pa, pair_a.data(), 4 * (size_t)n_pairs);
-        put(d_pb, pair_b.data(), 4 * (size_t)n_pairs);
-    }
-    hipError_t e;
-    {
-        const H2DItem in[1] = {{aux.base, block.data(), upload_bytes}};
-        e = h2d_row(ctx, in, 1);
-    }
-    if (e != hipSuccess) { arena_put(ctx, gs.in_arena); return fail_dev(e, nullptr); }
     // The union job's volumes are made by the HOST (round 5; three launches -- k_init_bounds, k_list_boxes, k_make_vols -- and a
     // wait for their totals before): the voxels of a pooled cloud lie inside its atom's sphere box [C - R - 1, C + R], so the box
     // around the boxes of a residue's pooled atoms -- around all of them for the domain group -- holds the group's voxels.  A
@@ -2532,13 +2522,28 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
         }
     }
     const bool host_sized = !ctx->debug_shrink_totals && union_totals[0] < (1ll << 31) && union_totals[1] < (1ll << 40);   // (absurd boxes, or the debug hook that wants the device's own sizing: the waiting path sizes and reports)
+    hipError_t e;
+    std::vector<char> block(upload_bytes, 0);      // (staged: the copy below reads a pinned block or, too large for that, has finished reading when it returns)
+    {
+        auto put = [&](const void *dev, const void *src, size_t bytes) { if (bytes) memcpy(block.data() + ((const char *)dev - aux.base), src, bytes); };
+        put(d_pool_cloud, pool_cloud.data(), 4 * (size_t)n_pool);
+        put(d_pool_group, pool_group.data(), 4 * (size_t)n_pool);
+        put(d_pool_voff, pool_voff.data(), 8 * (size_t)(n_pool + 1));
+        put(d_set_off, set_off.data(), 8 * (size_t)(n + 1));
+        put(d_pa, pair_a.data(), 4 * (size_t)n_pairs);
+        put(d_pb, pair_b.data(), 4 * (size_t)n_pairs);
+        if (host_sized) put(d_union_vols, union_vols.data(), sizeof(VolDesc) * (size_t)n_groups);
+    }
+    {
+        const H2DItem in[1] = {{aux.base, block.data(), upload_bytes}};
+        e = h2d_row(ctx, in, 1);
+    }
+    if (e != hipSuccess) { arena_put(ctx, gs.in_arena); return fail_dev(e, nullptr); }
     { PROF(ctx, "k_pool_gather"); hipLaunchKernelGGL(k_pool_gather, dim3(grid_for(2 * V, 256)), dim3(256), 0, st, cow->crs_dev, cow->offsets_dev, d_pool_cloud, d_pool_voff,
                                                      d_pool_group, (int)n_pool, V, n_rg, gs.d_crs, gs.d_item_group); }
     if (n_pairs > 0) { PROF(ctx, "k_test_overlap"); hipLaunchKernelGGL(k_test_overlap, dim3((unsigned)n_pairs), dim3(256), 0, st, cow->crs_dev, d_set_off, d_pa, d_pb, d_touch); }
     if (host_sized) {
-        const H2DItem in[1] = {{gs.d_vols, union_vols.data(), sizeof(VolDesc) * (size_t)n_groups}};
-        e = h2d_row(ctx, in, 1);
-        if (e != hipSuccess) { arena_put(ctx, gs.in_arena); return fail_dev(e, nullptr); }
+        gs.d_vols = d_union_vols;          // (in the aux block, which outlives the job's enqueue)
         gs.total_words = union_totals[0];
         gs.total_keys = union_totals[1];
         gs.host_totals = true;
@@ -2556,8 +2561,10 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
     if (e != hipSuccess) return fail_dev(e, uni);
     std::vector<int32_t> comp(2 * (size_t)n_pool);
     std::vector<unsigned int> touch((size_t)n_pairs);
-    e = d2h(ctx, comp.data(), d_comp, 8 * n_pool);
-    if (e == hipSuccess && n_pairs > 0) e = d2h(ctx, touch.data(), d_touch, 4 * n_pairs);
+    // (the pairs' touch flags and the pooled clouds' components are neighbours in the aux arena: one copy brings both)
+    const size_t tail_bytes = (size_t)((char *)(d_comp + 2 * n_pool) - (char *)d_touch);
+    std::vector<char> tail(tail_bytes);
+    e = d2h(ctx, tail.data(), d_touch, tail_bytes);
     if (e != hipSuccess) return fail_dev(e, uni);
     std::vector<int64_t> u_n;
     std::vector<double> u_tot, u_cen;
@@ -2565,6 +2572,8 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
     rc = list_stats_one_trip(uni, 2 * n_pool + 64, u_n, u_tot, u_cen, u_grp);   // (synchronises: comp / touch have landed too; a union component holds at least one pooled cloud)
     arena_put(ctx, aux);
     if (rc) return bail(rc, clouds, uni);
+    if (n_pairs > 0) memcpy(touch.data(), tail.data(), 4 * (size_t)n_pairs);
+    memcpy(comp.data(), tail.data() + ((char *)d_comp - (char *)d_touch), 8 * (size_t)n_pool);
     const int64_t nu = (int64_t)u_n.size();
     pdbeda_bloblist_free(uni);
     pdbeda_bloblist_free(clouds);

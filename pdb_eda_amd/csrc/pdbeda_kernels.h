@@ -1069,7 +1069,7 @@ __global__ void __launch_bounds__(256) k_emit_tiles(Job job, const Geom *__restr
 
 // Voxel lists grouped by blob: offsets = exclusive scan of b_n (single block), then each
 // voxel takes a slot in its blob with an atomic cursor (order inside a blob is a set).
-__global__ void __launch_bounds__(1024) k_blob_offsets(Job job, int64_t *__restrict__ offsets) {
+__global__ void __launch_bounds__(1024) k_blob_offsets(Job job, int64_t *__restrict__ offsets, unsigned int *__restrict__ cursor) {   // (cursor: zeroed here -- a fill of its own was a launch)
     __shared__ long long s_w[16];
     __shared__ long long s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1089,7 +1089,7 @@ __global__ void __launch_bounds__(1024) k_blob_offsets(Job job, int64_t *__restr
         __syncthreads();
         long long pre = s_carry;
         for (int k = 0; k < wv; ++k) pre += s_w[k];
-        if (i < nb) offsets[i] = pre + x - v;
+        if (i < nb) { offsets[i] = pre + x - v; cursor[i] = 0u; }
         __syncthreads();
         if (tid == 1023) s_carry = pre + x;
         __syncthreads();
@@ -1151,6 +1151,15 @@ __global__ void __launch_bounds__(256) k_copy_bytes(const unsigned char *__restr
     } else {
         for (unsigned long long i = t; i < bytes; i += stride) dst[i] = src[i];
     }
+}
+// k_job_init: what stands in front of a grouped job's first kernel, in one launch -- the volume descriptors into the job's arena and zeroes over its
+// counters, masks, first-key bitmap and rank counters (a copy and a fill before).  Both regions start 16-byte aligned; lengths in 16-byte units.
+__global__ void __launch_bounds__(256) k_job_init(const uint4 *__restrict__ vol_src, uint4 *__restrict__ vol_dst, unsigned long long vol16,
+                                                  uint4 *__restrict__ zero, unsigned long long zero16) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x, t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (unsigned long long i = t; i < vol16; i += stride) vol_dst[i] = vol_src[i];
+    const uint4 z = {0u, 0u, 0u, 0u};
+    for (unsigned long long i = t; i < zero16; i += stride) zero[i] = z;
 }
 struct PackSeg { const uint32_t *src; unsigned long long words, dst_word; };
 struct PackArgs { PackSeg seg[8]; int n; };

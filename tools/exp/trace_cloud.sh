@@ -10,10 +10,11 @@ import csv, glob
 f = glob.glob("gpurun_out/trace_cloud/**/t_kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0] for r in rows]
-# the last aggregateCloud starts at the last k_atom_boxes that follows a k_range_final / upload
-last = max(i for i, n in enumerate(names) if n == "k_list_boxes")
-start = max(i for i in range(last) if names[i] == "k_atom_boxes" and (i == 0 or names[i - 1] != "k_make_vols")) if False else last - 40
+# the last aggregateCloud ends with the last k_pool_component; its first launch is the copy kernel in front of the last but one k_sphere_paint
+last = max(i for i, n in enumerate(names) if n == "k_pool_component")
+paints = [i for i in range(last) if names[i] == "k_sphere_paint"]
+start = (paints[-1] - 1) if paints else last - 30
 t0 = int(rows[max(start, 0)]["Start_Timestamp"])
-for r, n in list(zip(rows, names))[max(start, 0):last + 25]:
+for r, n in list(zip(rows, names))[max(start, 0):last + 3]:
     print("%9.1f us  %-20s %7.1f us  grid %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3, n, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Grid_Size_X", r.get("Grid_Size", "?"))))
 PY
