@@ -475,11 +475,127 @@ done:
     return out;
 }
 
+
+/* table_rows(columns) -> list of row lists: what list(map(list, zip(*columns))) makes, in one pass and without the column lists of numbers.
+ * A column is a list / tuple (items taken as they are), a C-contiguous numpy array -- 1-D float64 / int64 / int32 / bool: Python floats, ints, bools
+ * (what .tolist() would hold); 2-D float64 (n x k): a list of k floats per row -- or a pair (list / tuple, index array of int64): the picked items.
+ * The result tables of densityAnalysis (region discrepancies, blob statistics: densityAnalysis.py:914-1035) are 2 000 rows x 16 columns; zip + list took
+ * 0.25-0.5 ms a table, the columns' .tolist() another 0.1-0.2. */
+#define ROWS_MAX_COLS 32
+typedef struct { int kind; PyObject *fast; PyObject **items; Py_buffer view; int has_view; Py_buffer idx; int has_idx; Py_ssize_t n, k; } RowCol;   /* kind 0 objects, 1 f64, 2 i64, 3 i32, 4 bool, 5 f64 n x k */
+
+static void rowcols_release(RowCol *c, int n) {
+    for (int j = 0; j < n; ++j) {
+        Py_XDECREF(c[j].fast);
+        if (c[j].has_view) PyBuffer_Release(&c[j].view);
+        if (c[j].has_idx) PyBuffer_Release(&c[j].idx);
+    }
+}
+
+static PyObject *table_rows(PyObject *self, PyObject *arg) {
+    PyObject *cols = PySequence_Fast(arg, "table_rows: a sequence of columns");
+    if (!cols) return NULL;
+    const Py_ssize_t nc = PySequence_Fast_GET_SIZE(cols);
+    if (nc < 1 || nc > ROWS_MAX_COLS) { Py_DECREF(cols); PyErr_SetString(PyExc_ValueError, "table_rows: 1 .. 32 columns"); return NULL; }
+    RowCol c[ROWS_MAX_COLS];
+    memset(c, 0, sizeof c);
+    int made = 0;
+    PyObject *out = NULL;
+    Py_ssize_t n = -1;
+    for (Py_ssize_t j = 0; j < nc; ++j, ++made) {
+        PyObject *o = PySequence_Fast_GET_ITEM(cols, j);
+        RowCol *rc = &c[j];
+        PyObject *src = o;
+        if (PyTuple_Check(o) && PyTuple_GET_SIZE(o) == 2 && PyObject_CheckBuffer(PyTuple_GET_ITEM(o, 1)) && (PyList_Check(PyTuple_GET_ITEM(o, 0)) || PyTuple_Check(PyTuple_GET_ITEM(o, 0)))) {
+            if (PyObject_GetBuffer(PyTuple_GET_ITEM(o, 1), &rc->idx, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) < 0) goto fail;
+            rc->has_idx = 1;
+            if (rc->idx.ndim != 1 || rc->idx.itemsize != 8 || !rc->idx.format || (rc->idx.format[0] != 'l' && rc->idx.format[0] != 'q')) { PyErr_SetString(PyExc_TypeError, "table_rows: an index is a 1-D int64 array"); goto fail; }
+            src = PyTuple_GET_ITEM(o, 0);
+        }
+        if (PyList_Check(src) || PyTuple_Check(src)) {
+            rc->fast = PySequence_Fast(src, "table_rows: column");
+            if (!rc->fast) goto fail;
+            rc->items = PySequence_Fast_ITEMS(rc->fast);
+            rc->kind = 0;
+            rc->n = rc->has_idx ? rc->idx.shape[0] : PySequence_Fast_GET_SIZE(rc->fast);
+            if (rc->has_idx) {
+                const long long *ix = (const long long *)rc->idx.buf;
+                const Py_ssize_t len = PySequence_Fast_GET_SIZE(rc->fast);
+                for (Py_ssize_t i = 0; i < rc->n; ++i) if (ix[i] < 0 || ix[i] >= len) { PyErr_SetString(PyExc_IndexError, "table_rows: index out of range"); goto fail; }
+            }
+        } else if (PyObject_CheckBuffer(src)) {
+            if (PyObject_GetBuffer(src, &rc->view, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) < 0) goto fail;
+            rc->has_view = 1;
+            const char f = rc->view.format ? rc->view.format[0] : 'B';
+            if (rc->view.ndim == 1 && f == 'd') rc->kind = 1;
+            else if (rc->view.ndim == 1 && (f == 'l' || f == 'q') && rc->view.itemsize == 8) rc->kind = 2;
+            else if (rc->view.ndim == 1 && f == 'i' && rc->view.itemsize == 4) rc->kind = 3;
+            else if (rc->view.ndim == 1 && f == '?') rc->kind = 4;
+            else if (rc->view.ndim == 2 && f == 'd') { rc->kind = 5; rc->k = rc->view.shape[1]; }
+            else { PyErr_SetString(PyExc_TypeError, "table_rows: arrays are 1-D float64 / int64 / int32 / bool or 2-D float64"); goto fail; }
+            rc->n = rc->view.shape[0];
+        } else {
+            PyErr_SetString(PyExc_TypeError, "table_rows: a column is a list, a tuple, an array or (list, index array)");
+            goto fail;
+        }
+        if (n < 0) n = rc->n;
+        else if (rc->n != n) { PyErr_SetString(PyExc_ValueError, "table_rows: columns of different lengths"); goto fail; }
+    }
+    out = PyList_New(n);
+    if (!out) goto fail;
+    /* thousands of fresh lists would run the cycle collector several times over rows that hold scalars and strings only (2 000 x 16: 0.48 ms with,
+     * 0.24 without); it is switched back to what it was before the rows are handed out */
+    const int gc_was_on = PyGC_Disable();
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject *row = PyList_New(nc);
+        if (!row) { if (gc_was_on) PyGC_Enable(); goto fail_out; }
+        PyList_SET_ITEM(out, i, row);
+        for (Py_ssize_t j = 0; j < nc; ++j) {
+            const RowCol *rc = &c[j];
+            PyObject *v = NULL;
+            switch (rc->kind) {
+            case 0: v = rc->items[rc->has_idx ? ((const long long *)rc->idx.buf)[i] : i]; Py_INCREF(v); break;
+            case 1: v = PyFloat_FromDouble(((const double *)rc->view.buf)[i]); break;
+            case 2: v = PyLong_FromLongLong(((const long long *)rc->view.buf)[i]); break;
+            case 3: v = PyLong_FromLong(((const int *)rc->view.buf)[i]); break;
+            case 4: v = PyBool_FromLong(((const unsigned char *)rc->view.buf)[i]); break;
+            default: {
+                v = PyList_New(rc->k);
+                if (v) {
+                    const double *p = (const double *)rc->view.buf + i * rc->k;
+                    for (Py_ssize_t q = 0; q < rc->k; ++q) {
+                        PyObject *f = PyFloat_FromDouble(p[q]);
+                        if (!f) { Py_CLEAR(v); break; }
+                        PyList_SET_ITEM(v, q, f);
+                    }
+                }
+            }
+            }
+            if (!v) { if (gc_was_on) PyGC_Enable(); goto fail_out; }
+            PyList_SET_ITEM(row, j, v);
+        }
+    }
+    if (gc_was_on) PyGC_Enable();
+    rowcols_release(c, made);
+    Py_DECREF(cols);
+    return out;
+fail_out:
+    Py_DECREF(out);
+    rowcols_release(c, made);
+    Py_DECREF(cols);
+    return NULL;
+fail:
+    rowcols_release(c, made + 1 <= ROWS_MAX_COLS ? made + 1 : made);
+    Py_DECREF(cols);
+    return NULL;
+}
+
 static PyMethodDef methods[] = {
     {"residue_columns", residue_columns, METH_O, "residue_columns(residues) -> (model ids, chain ids, numbers, names, hetero flags, child lists)"},
     {"atom_columns", atom_columns, METH_O, "atom_columns(child lists) -> the per-atom columns of structure.Columns"},
     {"cloud_inputs", cloud_inputs, METH_VARARGS, "cloud_inputs(res_of_atom, pair_of_atom, res_plain, known, occupancy, coord32, nb_off, nb) -> the index arrays of pdbeda_cloud_atoms"},
     {"cloud_stats", cloud_stats, METH_VARARGS, "cloud_stats(group, n_types, density_electron_ratio, num_voxels, bfactor, centroid_distance, table_slopes, ratio, unit_volume) -> (six row columns, ten per-type columns) of aggregateCloud's statistics tail"},
+    {"table_rows", table_rows, METH_O, "table_rows(columns) -> list of row lists (columns: lists, numpy arrays, or (list, int64 index array))"},
     {NULL, NULL, 0, NULL}};
 
 static struct PyModuleDef module = {PyModuleDef_HEAD_INIT, "_hostwalk", "one-pass walk of a structure's object tree", -1, methods, NULL, NULL, NULL, NULL};

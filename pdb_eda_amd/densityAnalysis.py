@@ -720,10 +720,10 @@ class DensityAnalysis(object):
             raise ValueError("XB must be a 2-dimensional array.")
         listed = blobList.columns() if isinstance(blobList, ccp4.DeviceBlobs) else None
         if listed is not None:                   # straight from the device list's columns: no blob object is made for the table
-            centroid_xyz = listed["centroid"]
-            centroid = centroid_xyz.tolist()
+            centroid_xyz = np.ascontiguousarray(listed["centroid"], dtype=np.float64)
+            centroid = centroid_xyz                                  # (n x 3: _rows makes a list of three floats per row)
             total = listed["totalDensity"]
-            num_voxels, volume = listed["n"].tolist(), listed["volume"].tolist()
+            num_voxels, volume = np.asarray(listed["n"], dtype=np.int64), np.asarray(listed["volume"], dtype=np.float64)
         else:
             centroid = [blob.centroid for blob in blobList]
             centroid_xyz = np.array(centroid, dtype=np.float64)
@@ -732,11 +732,11 @@ class DensityAnalysis(object):
         idx, dist = self.densityObj._ctx.nearest_atom(centroid_xyz, np.asarray(symmetryAtomCoords, dtype=np.float64))
         rows, symmetry, coords = symmetryAtoms.columns(idx)
         cols = _structure.columns(self.biopdbObj)
-        rows = rows.tolist()
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
         chain, number, resname = (cols.atom_lists(which) for which in ("chain", "number", "resname"))
         sign = np.where(total >= 0, '+', '-').tolist()
-        return self._rows(list(dist), sign, np.abs(total / ratio).tolist(), num_voxels, volume,
-                          [chain[r] for r in rows], [number[r] for r in rows], [resname[r] for r in rows], [cols.name[r] for r in rows],
+        return self._rows(list(dist), sign, np.abs(total / ratio), num_voxels, volume,
+                          (chain, rows), (number, rows), (resname, rows), (cols.name if isinstance(cols.name, (list, tuple)) else list(cols.name), rows),       # (picked by _rows)
                           symmetry, coords, centroid)
 
     # ---- Fo / Fc maps, RSCC / RSR (ref densityAnalysis.py:426-446, 783-882) -------------------
@@ -881,7 +881,7 @@ class DensityAnalysis(object):
         ratio = self._needRatio()
         dm = self.densityObj
         pos, neg, cnt, valid = dm._map.region_sums(xyz, rad, off, dm.meanDensity + numSD * dm.stdDensity)
-        return [pos.tolist(), (pos / ratio).tolist()], valid
+        return [pos, pos / ratio], valid
 
     def _discrepancyColumns(self, xyz, rad, off, numSD):
         """The ten columns of regionDiscrepancyHeader for every group, computed on whole columns (densityAnalysis.py:1200-1211)."""
@@ -893,11 +893,25 @@ class DensityAnalysis(object):
         absd = np.abs(pos) + np.abs(neg)
         expected = avg * cnt
         net = pos + neg
-        return [c.tolist() for c in (absd, absd / ratio, expected, expected / ratio, net, net / ratio, pos, pos / ratio, neg, neg / ratio)], valid
+        return [absd, absd / ratio, expected, expected / ratio, net, net / ratio, pos, pos / ratio, neg, neg / ratio], valid      # (whole columns: _rows makes the Python numbers)
 
     @staticmethod
     def _rows(*columns):
-        return list(map(list, zip(*columns)))
+        """The table rows (lists) of whole columns: lists, numpy arrays (their ``.tolist()`` values), or (list, int64 index array) picks.
+        One pass in C (``_hostwalk.table_rows``) when the helper is built; ``list(map(list, zip(...)))`` over plain lists otherwise."""
+        walk = _structure._hostwalk()
+        if walk is not None and hasattr(walk, "table_rows") and 1 <= len(columns) <= 32:
+            prepared = [np.ascontiguousarray(c) if isinstance(c, np.ndarray) else c for c in columns]
+            if all(not isinstance(c, np.ndarray) or ((c.ndim == 1 and c.dtype in (np.float64, np.int64, np.int32, np.bool_)) or (c.ndim == 2 and c.dtype == np.float64))
+                   for c in prepared):
+                return walk.table_rows(prepared)
+        plain = []
+        for c in columns:
+            if isinstance(c, tuple) and len(c) == 2 and isinstance(c[1], np.ndarray):
+                plain.append([c[0][r] for r in c[1].tolist()])
+            else:
+                plain.append(c.tolist() if isinstance(c, np.ndarray) else c)
+        return list(map(list, zip(*plain)))
 
     def _atomPick(self, type):
         """Rows of the structure columns of the atoms named ``type`` (all when empty) and their leading table columns (model,
@@ -951,14 +965,14 @@ class DensityAnalysis(object):
         """ref densityAnalysis.py:1037-1068."""
         rad = list(radius) if isinstance(radius, (list, tuple, np.ndarray)) else [radius] * len(xyzCoordList)
         columns, valid = self._densityColumns(*self._flatten([list(xyzCoordList)], [rad]), numSD)
-        row = [column[0] for column in columns]
+        row = [column.tolist()[0] for column in columns]
         return (row, bool(valid[0])) if testValidCrs else row
 
     def calculateRegionDiscrepancy(self, xyzCoordList, radius, numSD=3.0, testValidCrs=False):
         """ref densityAnalysis.py:1160-1211."""
         rad = list(radius) if isinstance(radius, (list, tuple, np.ndarray)) else [radius] * len(xyzCoordList)
         columns, valid = self._discrepancyColumns(*self._flatten([list(xyzCoordList)], [rad]), numSD)
-        row = [column[0] for column in columns]
+        row = [column.tolist()[0] for column in columns]
         return (row, bool(valid[0])) if testValidCrs else row
 
     def calculateAtomRegionDensity(self, radius, numSD=1.5, type="", useOptimizedRadii=False):
@@ -971,7 +985,7 @@ class DensityAnalysis(object):
         """ref densityAnalysis.py:975-999."""
         cols, atom_rows, lead, xyz = self._symmetryPick(type)
         columns, valid = self._densityColumns(xyz, self._pairRadius(cols, radius, useOptimizedRadii)[atom_rows], np.arange(len(atom_rows) + 1, dtype=np.int64), numSD)
-        return self._rows(*lead, valid.astype(bool).tolist(), *columns)
+        return self._rows(*lead, valid.astype(bool), *columns)
 
     def calculateResidueRegionDensity(self, radius, numSD=1.5, type="", atomMask=None, useOptimizedRadii=False):
         """ref densityAnalysis.py:1001-1035 (residues left without atoms by the mask are skipped)."""
@@ -990,7 +1004,7 @@ class DensityAnalysis(object):
         """ref densityAnalysis.py:1106-1128."""
         cols, atom_rows, lead, xyz = self._symmetryPick(type)
         columns, valid = self._discrepancyColumns(xyz, np.full(len(atom_rows), radius, dtype=np.float32), np.arange(len(atom_rows) + 1, dtype=np.int64), numSD)
-        return self._rows(*lead, valid.astype(bool).tolist(), *columns)
+        return self._rows(*lead, valid.astype(bool), *columns)
 
     def calculateResidueRegionDiscrepancies(self, radius, numSD=3.0, type="", atomMask=None):
         """ref densityAnalysis.py:1130-1158 (with a mask, only atoms the mask names; residues it empties stay in the table)."""

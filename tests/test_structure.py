@@ -307,3 +307,37 @@ def test_cloud_statistics_in_c_equal_the_numpy_form():
             else:
                 assert np.array_equal(tab_c[field], tab_p[field]), (trial, field)
 
+
+def test_table_rows_in_c_equal_the_zip_form():
+    """densityAnalysis._rows: the result tables' rows made in one C pass (_hostwalk.table_rows) from whole columns -- lists, numpy arrays,
+    (list, index) picks -- are what list(map(list, zip(...))) makes of the columns' .tolist(): the same values AND the same Python types."""
+    from pdb_eda_amd import densityAnalysis, structure
+    walk = structure._hostwalk()
+    assert walk is not None and hasattr(walk, "table_rows")
+    rng = np.random.default_rng(5)
+    n = 257
+    f = rng.standard_normal(n)
+    i64 = rng.integers(-5, 5000, n)
+    i32 = i64.astype(np.int32)
+    flag = rng.random(n) < 0.3
+    xyz = rng.standard_normal((n, 3))
+    names = ["A%d" % k for k in range(40)]
+    pick = rng.integers(0, 40, n).astype(np.int64)
+    tuples = [(k, k + 1) for k in range(n)]
+    scalars = list(np.float64(f))                   # (numpy scalars in a list stay what they are)
+    got = densityAnalysis.DensityAnalysis._rows(f, i64, i32, flag, xyz, (names, pick), tuples, scalars, xyz[:, ::2])     # (the last: not contiguous)
+    want = list(map(list, zip(f.tolist(), i64.tolist(), i32.tolist(), flag.tolist(), xyz.tolist(), [names[r] for r in pick.tolist()], tuples, scalars, xyz[:, ::2].tolist())))
+    assert got == want
+    for a, b in zip(got[3], want[3]):
+        assert type(a) is type(b)
+    assert all(type(row[0]) is float and type(row[1]) is int and type(row[3]) is bool and type(row[4]) is list for row in got)
+    assert densityAnalysis.DensityAnalysis._rows(np.zeros(0), []) == []
+    with pytest.raises(ValueError):
+        walk.table_rows([f, i64[:-1]])
+    with pytest.raises(IndexError):
+        walk.table_rows([(names, np.array([40], dtype=np.int64))])
+    with pytest.raises(TypeError):
+        walk.table_rows([f.astype(np.float32)])
+    # columns the helper does not take (float32) go the plain way inside _rows
+    assert densityAnalysis.DensityAnalysis._rows(f.astype(np.float32), i64) == list(map(list, zip(f.astype(np.float32).tolist(), i64.tolist())))
+
