@@ -252,7 +252,12 @@ class _SymAtomList(object):
             r, atom_rows = r[keep], atom_rows[keep]
         symmetry = [tuple(t) for t in self._sym[r].tolist()]
         atoms = self._cols.atoms
-        coords = [atoms[a].coord if same else xyz for a, same, xyz in zip(atom_rows.tolist(), self._ident[r].tolist(), self._xyz[r])]
+        coords = [atoms[a].coord for a in atom_rows.tolist()]            # (most listed atoms are the structure's own: their coordinate objects as they are)
+        moved = np.nonzero(~self._ident[r])[0]
+        if len(moved):
+            xyz = self._xyz[r[moved]]
+            for k, row in zip(moved.tolist(), xyz):                          # (a row view per symmetry copy only: iterating every row was 0.2 ms of a 1 400-blob table)
+                coords[k] = row
         return atom_rows, symmetry, coords
 
     def _make(self, r):
