@@ -1679,18 +1679,20 @@ extern "C" int pdbeda_bloblist_stats(pdbeda_bloblist *bl, int64_t *n, double *to
 // Rows beyond the blob count are stale arena bytes, copied and dropped.  Falls back to the two-step path when the guess was
 // too small (or the list is not a whole batch job).
 static int list_stats_one_trip(pdbeda_bloblist *bl, int64_t guess, std::vector<int64_t> &n, std::vector<double> &tot, std::vector<double> &cen,
-                               std::vector<int32_t> &grp) {
+                               std::vector<int32_t> &grp, const D2HItem *extra = nullptr) {      // (extra: one more result of the caller's, in the same pack and wait)
     pdbeda_ctx *ctx = bl->ctx;
     const Job &job = bl->job;
     guess = std::min<int64_t>(guess, (int64_t)job.blob_cap);
     const bool whole_job = !bl->whole_map && bl->vol_lo == 0 && bl->vol_hi == job.n_vols;
-    if (!bl->have_counts && whole_job && guess > 0 && 44 * guess + 4096 < (int64_t)ctx->pinned_cap - (int64_t)ctx->pinned_used) {
+    const int64_t extra_bytes = extra ? (int64_t)extra->bytes + 64 : 0;
+    if (!bl->have_counts && whole_job && guess > 0 && 44 * guess + 4096 + extra_bytes < (int64_t)ctx->pinned_cap - (int64_t)ctx->pinned_used) {
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         n.resize((size_t)guess); tot.resize((size_t)guess); cen.resize(3 * (size_t)guess); grp.resize((size_t)guess);
         Counters ctr;
-        const D2HItem parts[5] = {{&ctr, job.ctr, sizeof ctr}, {n.data(), job.b_n, (size_t)(8 * guess)}, {tot.data(), job.b_total, (size_t)(8 * guess)},
-                                  {cen.data(), job.b_centroid, (size_t)(24 * guess)}, {grp.data(), job.b_group, (size_t)(4 * guess)}};
-        HIP_TRY(ctx, d2h_many(ctx, parts, 5));
+        const D2HItem parts[6] = {{&ctr, job.ctr, sizeof ctr}, {n.data(), job.b_n, (size_t)(8 * guess)}, {tot.data(), job.b_total, (size_t)(8 * guess)},
+                                  {cen.data(), job.b_centroid, (size_t)(24 * guess)}, {grp.data(), job.b_group, (size_t)(4 * guess)},
+                                  extra ? *extra : D2HItem{nullptr, nullptr, 0}};
+        HIP_TRY(ctx, d2h_many(ctx, parts, 6));
         HIP_TRY(ctx, ctx_sync(ctx));
         if (ctr.unit_wait_failed) return fail(ctx, PDBEDA_ERR_DEVICE, "sphere batch: the device's volumes outgrew what the host sized the job for");
         bl->rank_lo = 0; bl->rank_hi = ctr.n_blobs; bl->job_blobs = ctr.n_blobs; bl->have_counts = true;
@@ -1700,6 +1702,7 @@ static int list_stats_one_trip(pdbeda_bloblist *bl, int64_t guess, std::vector<i
             return PDBEDA_OK;
         }
     }
+    if (extra && extra->dst && extra->bytes) HIP_TRY(ctx, d2h(ctx, extra->dst, extra->src, extra->bytes));      // (delivered by the waits below)
     const int64_t nb = pdbeda_bloblist_count(bl);
     if (nb < 0) return (int)nb;
     n.resize((size_t)nb); tot.resize((size_t)nb); cen.resize(3 * (size_t)nb); grp.resize((size_t)nb);
@@ -2032,7 +2035,7 @@ static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, con
 }
 
 // Paint the group volumes and enqueue the labelling engine on them; the input scratch is recycled in stream order.
-static int grouped_job(pdbeda_map *m, GroupSetup &gs, int64_t n_items, int64_t n_groups, bool spheres, float cutoff, pdbeda_bloblist **out) {
+static int grouped_job(pdbeda_map *m, GroupSetup &gs, int64_t n_items, int64_t n_groups, bool spheres, float cutoff, pdbeda_bloblist **out, const PoolPaint *pool = nullptr) {
     pdbeda_ctx *ctx = m->ctx;
     const int64_t max_runs = gs.total_keys / 2 + gs.total_words + 1;
     int rc_fix = map_fix_mul(m);
@@ -2060,6 +2063,8 @@ static int grouped_job(pdbeda_map *m, GroupSetup &gs, int64_t n_items, int64_t n
         if (spheres)
             { PROF(ctx, "k_sphere_paint"); hipLaunchKernelGGL(k_sphere_paint, dim3((unsigned)n_items), dim3(256), 0, st, m->geom_dev, m->dens, gs.d_xyz, gs.d_radii,
                                gs.d_item_group, gs.d_boxes, job.vols, job.mask, cutoff, gs.d_ctr, job.ctr); }
+        else if (pool)      // (aggregateCloud's union job: the pooled voxels painted straight from the clouds' lists, the bonded pairs tested by the same launch)
+            { PROF(ctx, "k_pool_paint"); hipLaunchKernelGGL(k_pool_paint, dim3(pool->paint_blocks + (unsigned)pool->n_pairs), dim3(256), 0, st, *pool, job.vols, job.mask); }
         else
             { PROF(ctx, "k_list_paint"); hipLaunchKernelGGL(k_list_paint, dim3(grid_for(n_items, 256)), dim3(256), 0, st, gs.d_crs, gs.d_item_group, n_items, job.vols, job.mask); }
         e = hipGetLastError();
@@ -2539,9 +2544,19 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
         e = h2d_row(ctx, in, 1);
     }
     if (e != hipSuccess) { arena_put(ctx, gs.in_arena); return fail_dev(e, nullptr); }
-    { PROF(ctx, "k_pool_gather"); hipLaunchKernelGGL(k_pool_gather, dim3(grid_for(2 * V, 256)), dim3(256), 0, st, cow->crs_dev, cow->offsets_dev, d_pool_cloud, d_pool_voff,
-                                                     d_pool_group, (int)n_pool, V, n_rg, gs.d_crs, gs.d_item_group); }
-    if (n_pairs > 0) { PROF(ctx, "k_test_overlap"); hipLaunchKernelGGL(k_test_overlap, dim3((unsigned)n_pairs), dim3(256), 0, st, cow->crs_dev, d_set_off, d_pa, d_pb, d_touch); }
+    PoolPaint paint;
+    memset(&paint, 0, sizeof paint);
+    paint.src_crs = cow->crs_dev; paint.src_off = cow->offsets_dev;
+    paint.pool_cloud = d_pool_cloud; paint.pool_voff = d_pool_voff; paint.pool_group = d_pool_group;
+    paint.n_pool = (int)n_pool; paint.domain_group = n_rg; paint.V = V;
+    paint.set_off = d_set_off; paint.pair_a = d_pa; paint.pair_b = d_pb; paint.touch = d_touch; paint.n_pairs = (int)n_pairs;
+    paint.paint_blocks = grid_for(2 * V, 256, 1ll << 30);
+    const bool fused_paint = host_sized && 2 * V <= (1ll << 30) * 256 && n_pairs < (1ll << 30);      // (the device-sized path needs the gathered list for its boxes)
+    if (!fused_paint) {
+        { PROF(ctx, "k_pool_gather"); hipLaunchKernelGGL(k_pool_gather, dim3(grid_for(2 * V, 256)), dim3(256), 0, st, cow->crs_dev, cow->offsets_dev, d_pool_cloud, d_pool_voff,
+                                                         d_pool_group, (int)n_pool, V, n_rg, gs.d_crs, gs.d_item_group); }
+        if (n_pairs > 0) { PROF(ctx, "k_test_overlap"); hipLaunchKernelGGL(k_test_overlap, dim3((unsigned)n_pairs), dim3(256), 0, st, cow->crs_dev, d_set_off, d_pa, d_pb, d_touch); }
+    }
     if (host_sized) {
         gs.d_vols = d_union_vols;          // (in the aux block, which outlives the job's enqueue)
         gs.total_words = union_totals[0];
@@ -2553,7 +2568,7 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
     }
     if (rc) { arena_put(ctx, gs.in_arena); arena_put(ctx, aux); return bail(rc, clouds, nullptr); }
     pdbeda_bloblist *uni = nullptr;
-    rc = grouped_job(m, gs, 2 * V, n_groups, false, 0.0f, &uni);
+    rc = grouped_job(m, gs, 2 * V, n_groups, false, 0.0f, &uni, fused_paint ? &paint : nullptr);
     if (rc) { arena_put(ctx, aux); return bail(rc, clouds, nullptr); }
     { PROF(ctx, "k_pool_component"); hipLaunchKernelGGL(k_pool_component, dim3(grid_for(2 * n_pool, 256)), dim3(256), 0, st, uni->job, cow->crs_dev, cow->offsets_dev, d_pool_cloud,
                                                         d_pool_group, (int)n_pool, n_rg, d_comp); }
@@ -2563,13 +2578,12 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
     std::vector<unsigned int> touch((size_t)n_pairs);
     // (the pairs' touch flags and the pooled clouds' components are neighbours in the aux arena: one copy brings both)
     const size_t tail_bytes = (size_t)((char *)(d_comp + 2 * n_pool) - (char *)d_touch);
-    std::vector<char> tail(tail_bytes);
-    e = d2h(ctx, tail.data(), d_touch, tail_bytes);
-    if (e != hipSuccess) return fail_dev(e, uni);
+    std::vector<char> tail((tail_bytes + 3) & ~(size_t)3);
+    const D2HItem tail_item = {tail.data(), d_touch, tail.size()};      // (whole words: the pack kernel copies words; the carve's padding covers the round-up)
     std::vector<int64_t> u_n;
     std::vector<double> u_tot, u_cen;
     std::vector<int32_t> u_grp;
-    rc = list_stats_one_trip(uni, 2 * n_pool + 64, u_n, u_tot, u_cen, u_grp);   // (synchronises: comp / touch have landed too; a union component holds at least one pooled cloud)
+    rc = list_stats_one_trip(uni, 2 * n_pool + 64, u_n, u_tot, u_cen, u_grp, &tail_item);   // (synchronises: comp / touch land with the statistics; a union component holds at least one pooled cloud)
     arena_put(ctx, aux);
     if (rc) return bail(rc, clouds, uni);
     if (n_pairs > 0) memcpy(touch.data(), tail.data(), 4 * (size_t)n_pairs);

@@ -1832,10 +1832,15 @@ __global__ void k_xyz2crs(const Geom *__restrict__ gp, const double *__restrict_
 }
 
 // utils.testOverlap batched (cutils.pyx:8-25): block per pair, threads over |A| x |B|.
+__device__ __forceinline__ void test_overlap_pair(int p, const int32_t *__restrict__ crs, const int64_t *__restrict__ set_off,
+                                                  const int32_t *__restrict__ a_idx, const int32_t *__restrict__ b_idx, unsigned int *__restrict__ out);
 __global__ void __launch_bounds__(256) k_test_overlap(const int32_t *__restrict__ crs, const int64_t *__restrict__ set_off,
                                                       const int32_t *__restrict__ a_idx, const int32_t *__restrict__ b_idx,
                                                       unsigned int *__restrict__ out) {
-    const int p = blockIdx.x;
+    test_overlap_pair((int)blockIdx.x, crs, set_off, a_idx, b_idx, out);
+}
+__device__ __forceinline__ void test_overlap_pair(int p, const int32_t *__restrict__ crs, const int64_t *__restrict__ set_off,
+                                                  const int32_t *__restrict__ a_idx, const int32_t *__restrict__ b_idx, unsigned int *__restrict__ out) {
     const int64_t a0 = set_off[a_idx[p]], a1 = set_off[a_idx[p] + 1];
     const int64_t b0 = set_off[b_idx[p]], b1 = set_off[b_idx[p] + 1];
     const int64_t na = a1 - a0, nb = b1 - b0;
@@ -1847,6 +1852,38 @@ __global__ void __launch_bounds__(256) k_test_overlap(const int32_t *__restrict_
         hit = d0 >= -1 && d0 <= 1 && d1 >= -1 && d1 <= 1 && d2 >= -1 && d2 <= 1;
     }
     if (hit) atomicOr(&out[p], 1u);
+}
+
+// The union job of aggregateCloud in ONE launch in front of its labelling kernels (round 5; three before: k_pool_gather, k_test_overlap, k_list_paint):
+// blocks below paint_blocks take a pooled voxel each per thread -- item i < V goes to the residue group of its cloud's atom, item V + i to the domain
+// group -- and set its bit in the group's volume straight from the clouds' voxel lists (no gathered copy of the coordinates); the blocks above test one
+// bonded pair each (utils.testOverlap).  Behind k_job_init: the volume descriptors and the zeroed masks are the job's.
+struct PoolPaint {
+    const int32_t *src_crs; const int64_t *src_off;                                  // the clouds' voxel lists
+    const int32_t *pool_cloud; const int64_t *pool_voff; const int32_t *pool_group;  // pooled clouds, their voxel offsets and residue groups
+    int n_pool; int domain_group; long long V;
+    const int64_t *set_off; const int32_t *pair_a, *pair_b; unsigned int *touch; int n_pairs;
+    unsigned int paint_blocks;
+};
+__global__ void __launch_bounds__(256) k_pool_paint(PoolPaint a, const VolDesc *__restrict__ vols, uint64_t *__restrict__ mask) {
+    if (blockIdx.x >= a.paint_blocks) {      // block-uniform
+        test_overlap_pair((int)(blockIdx.x - a.paint_blocks), a.src_crs, a.set_off, a.pair_a, a.pair_b, a.touch);
+        return;
+    }
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * a.V) return;
+    const bool dom = i >= a.V;
+    const long long j = dom ? i - a.V : i;
+    int lo = 0, hi = a.n_pool - 1;   // the pooled cloud that holds voxel j: pool_voff[p] <= j < pool_voff[p + 1]
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.pool_voff[mid] <= j) lo = mid; else hi = mid - 1;
+    }
+    const long long src = a.src_off[a.pool_cloud[lo]] + (j - a.pool_voff[lo]);
+    const VolDesc vd = vols[dom ? a.domain_group : a.pool_group[lo]];
+    const int lc = a.src_crs[3 * src] - vd.org[0], lr = a.src_crs[3 * src + 1] - vd.org[1], ls = a.src_crs[3 * src + 2] - vd.org[2];
+    const int64_t w = vd.word_base + ((int64_t)ls * vd.dim[1] + lr) * vd.row_words + (lc >> 6);
+    atomicOr((unsigned long long *)&mask[w], 1ull << (lc & 63));
 }
 
 // utils.createSymmetryAtoms (cutils.pyx:73-103): candidate t = ((cell * n_ops) + op) * n_atoms + atom in the reference's
