@@ -146,11 +146,29 @@ def analysis_leg(ctx, case="c2_bench_entry", reps=5):
             "note": "single host thread + one stream; checked here against the reference's result on the same entry (Cython path, one core, build container)"}
 
 
+def link_rate(torch):
+    """Pinned host -> HBM copy of 64 MiB, the best of six batches of five copies: GB/s."""
+    pin = torch.empty(16 << 20, dtype=torch.float32).pin_memory()
+    dev = torch.empty(16 << 20, dtype=torch.float32, device="cuda")
+    dev.copy_(pin, non_blocking=True)
+    torch.cuda.synchronize()
+    best = 0.0
+    for _ in range(6):      # (the best of six batches: the pools' worker processes may still be winding down beside the first ones)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            dev.copy_(pin, non_blocking=True)
+        torch.cuda.synchronize()
+        best = max(best, 5 * pin.numel() * 4 / (time.perf_counter() - t1) / 1e9)
+    del pin, dev
+    return best
+
+
 def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
     import shutil
     import tempfile
     from pdb_eda_amd import synthetic, multipleStructures, densityAnalysis
     densityAnalysis.setGlobals(synthetic.synthetic_params())
+    link_before = link_rate(torch)
     tmp = tempfile.mkdtemp(prefix="pdbeda_bench_%d_" % rank)
     try:
         t0 = time.perf_counter()
@@ -299,19 +317,9 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
         n_atoms = len(list(loaders[0].structure()[0].get_atoms()))
         file_mb = 2 * 4 * args.entry_size ** 3 / 1e6
         # the leg's roofline is the host link: an entry's map bytes must cross it, whatever else happens.  The link's rate is
-        # measured HERE (a pinned 64 MiB buffer, the best of six batches of five copies), so the fraction compares like with like.
-        pin = torch.empty(16 << 20, dtype=torch.float32).pin_memory()
-        dev = torch.empty(16 << 20, dtype=torch.float32, device="cuda")
-        dev.copy_(pin, non_blocking=True)
-        torch.cuda.synchronize()
-        h2d_gbs = 0.0
-        for _ in range(6):      # (the best of six batches: the pools' worker processes may still be winding down beside the first ones)
-            t1 = time.perf_counter()
-            for _ in range(5):
-                dev.copy_(pin, non_blocking=True)
-            torch.cuda.synchronize()
-            h2d_gbs = max(h2d_gbs, 5 * pin.numel() * 4 / (time.perf_counter() - t1) / 1e9)
-        del pin, dev
+        # measured in this run (link_rate: a pinned 64 MiB buffer, the best of six batches of five copies), so the fraction compares like with like.
+        h2d_gbs = max(link_before, link_rate(torch))      # (measured before the pools started and after they closed: the better of the two -- one run of
+                                                          #  round 5 measured 49 GB/s behind the pools where every other run measures 57)
         per_gpu_rate = total_done / world / elapsed                     # entries / s / GPU
         lazy_rate = lazy_done / world / lazy_elapsed
         pcie = {"bound": "pcie", "unit": "GB/s", "peak": h2d_gbs, "peak_source": "pinned host -> HBM copy of 64 MiB measured in this run (PCIe Gen5 x16: 63 GB/s spec)",
