@@ -1844,7 +1844,18 @@ struct GroupSetup {
     Counters *d_ctr = nullptr;
     int64_t total_words = 0, total_keys = 0;
     bool host_totals = false;   // the totals are the host's (per-atom spheres): nobody waited for the device's -- k_make_vols checks them
+    // staged inputs whose copy into the device scratch has not been launched yet: grouped_job's k_job_init does it (one launch less), flush_pending for everybody else
+    const char *pend_src = nullptr;
+    char *pend_dst = nullptr;
+    size_t pend_bytes = 0;
 };
+
+static hipError_t flush_pending(pdbeda_ctx *ctx, GroupSetup *gs) {
+    if (!gs->pend_bytes) return hipSuccess;
+    const hipError_t e = copy_by_kernel(ctx, gs->pend_dst, gs->pend_src, gs->pend_bytes);
+    gs->pend_bytes = 0;
+    return e;
+}
 
 static int expand_groups(const int64_t *group_offsets, int64_t n_groups, int64_t n_items, std::vector<int32_t> &item_group) {
     item_group.assign((size_t)n_items, 0);
@@ -1999,7 +2010,8 @@ static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, con
                 memset(ctr0, 0, sizeof *ctr0);
                 ctr0->total_words = words;
                 ctr0->total_keys = keys;
-                HIP_TRY(ctx, copy_kernels() ? copy_by_kernel(ctx, gs->in_arena.base, stage, row) : hipMemcpyAsync(gs->in_arena.base, stage, row, hipMemcpyHostToDevice, st));
+                if (copy_kernels()) { gs->pend_src = stage; gs->pend_dst = gs->in_arena.base; gs->pend_bytes = (row + 15) & ~(size_t)15; }   // (copied by the job's first launch; whole 16-byte units: the stage and the carve are padded)
+                else HIP_TRY(ctx, hipMemcpyAsync(gs->in_arena.base, stage, row, hipMemcpyHostToDevice, st));
                 ctx->pinned_used += row_need;
                 gs->total_words = words;
                 gs->total_keys = keys;
@@ -2038,6 +2050,12 @@ static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, con
 static int grouped_job(pdbeda_map *m, GroupSetup &gs, int64_t n_items, int64_t n_groups, bool spheres, float cutoff, pdbeda_bloblist **out, const PoolPaint *pool = nullptr) {
     pdbeda_ctx *ctx = m->ctx;
     const int64_t max_runs = gs.total_keys / 2 + gs.total_words + 1;
+    if (gs.pend_bytes && m->fix_mul == 0.0 && !m->fix_refused) {
+        // map_fix_mul is about to WAIT (a map whose range is not known yet), and a wait hands the pinned block out afresh: inputs staged there must be on
+        // their way before it, not left to k_job_init behind it
+        const hipError_t ep = flush_pending(ctx, &gs);
+        if (ep != hipSuccess) { arena_put(ctx, gs.in_arena); return fail(ctx, PDBEDA_ERR_DEVICE, "grouped blobs: %s", hipGetErrorString(ep)); }
+    }
     int rc_fix = map_fix_mul(m);
     if (rc_fix) { arena_put(ctx, gs.in_arena); return rc_fix; }
     Job job;
@@ -2053,11 +2071,16 @@ static int grouped_job(pdbeda_map *m, GroupSetup &gs, int64_t n_items, int64_t n
     {   // volume descriptors into the job + zeroes over counters, masks, first-key bitmap and both levels of rank counters (adjacent in the arena: job_carve): one launch
         static_assert(sizeof(VolDesc) % 16 == 0, "VolDesc is copied in 16-byte units");
         const size_t zero_bytes = ((size_t)((char *)(job.mid_count + (job.key_words + KEY_FINE - 1) / KEY_FINE * (KEY_FINE / 16)) - (char *)job.ctr) + 15) & ~(size_t)15;   // (into the carve's own padding)
-        const size_t vol16 = sizeof(VolDesc) * (size_t)n_groups / 16;
-        hipLaunchKernelGGL(k_job_init, dim3((unsigned)std::min<size_t>((std::max(zero_bytes / 16, vol16) + 255) / 256, 2048)), dim3(256), 0, st,
-                           reinterpret_cast<const uint4 *>(gs.d_vols), reinterpret_cast<uint4 *>(job.vols), (unsigned long long)vol16,
+        const size_t vol16 = sizeof(VolDesc) * (size_t)n_groups / 16, in16 = gs.pend_bytes / 16;
+        // (volume descriptors that are part of the inputs still to be copied come straight from the staged block)
+        const char *vol_src = reinterpret_cast<const char *>(gs.d_vols);
+        if (gs.pend_bytes && vol_src >= gs.pend_dst && vol_src < gs.pend_dst + gs.pend_bytes) vol_src = gs.pend_src + (vol_src - gs.pend_dst);
+        hipLaunchKernelGGL(k_job_init, dim3((unsigned)std::min<size_t>((std::max(std::max(zero_bytes / 16, vol16), in16) + 255) / 256, 2048)), dim3(256), 0, st,
+                           reinterpret_cast<const uint4 *>(gs.pend_src), reinterpret_cast<uint4 *>(gs.pend_dst), (unsigned long long)in16,
+                           reinterpret_cast<const uint4 *>(vol_src), reinterpret_cast<uint4 *>(job.vols), (unsigned long long)vol16,
                            reinterpret_cast<uint4 *>(job.ctr), (unsigned long long)(zero_bytes / 16));
         e = hipGetLastError();
+        gs.pend_bytes = 0;
     }
     if (e == hipSuccess && n_items > 0) {
         if (spheres)
@@ -2129,7 +2152,15 @@ extern "C" int pdbeda_region_sums(pdbeda_map *m, const double *xyz, const float 
     unsigned long long *d_cnt = cv.take<unsigned long long>(n_groups);
     unsigned int *d_inv = cv.take<unsigned int>(n_groups);
     hipStream_t st = ctx->stream;
-    hipError_t e = hipMemsetAsync(a.base, 0, cv.off, st);
+    hipError_t e;
+    {   // the staged inputs into the scratch (when group_setup left their copy to us) and zeroes over masks and sums: one launch
+        const size_t in16 = gs.pend_bytes / 16, zero16 = cv.off / 16;
+        hipLaunchKernelGGL(k_job_init, dim3((unsigned)std::min<size_t>((std::max(zero16, in16) + 255) / 256, 2048)), dim3(256), 0, st,
+                           reinterpret_cast<const uint4 *>(gs.pend_src), reinterpret_cast<uint4 *>(gs.pend_dst), (unsigned long long)in16,
+                           (const uint4 *)nullptr, (uint4 *)nullptr, 0ull, reinterpret_cast<uint4 *>(a.base), (unsigned long long)zero16);
+        e = hipGetLastError();
+        gs.pend_bytes = 0;
+    }
     if (e == hipSuccess && n_atoms > 0) {
         { PROF(ctx, "k_sphere_paint"); hipLaunchKernelGGL(k_sphere_paint, dim3((unsigned)n_atoms), dim3(256), 0, st, m->geom_dev, m->dens, gs.d_xyz, gs.d_radii,
                            gs.d_item_group, gs.d_boxes, gs.d_vols, mask, 0.0f, gs.d_ctr, (Counters *)nullptr); }
@@ -2540,8 +2571,17 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
         if (host_sized) put(d_union_vols, union_vols.data(), sizeof(VolDesc) * (size_t)n_groups);
     }
     {
-        const H2DItem in[1] = {{aux.base, block.data(), upload_bytes}};
-        e = h2d_row(ctx, in, 1);
+        const size_t span16 = (upload_bytes + 15) & ~(size_t)15, need = (span16 + 63) & ~(size_t)63;      // (upload_bytes is a carve boundary: a multiple of 256)
+        if (copy_kernels() && ctx->pinned && span16 <= ((size_t)1 << 20) && ctx->pinned_used + need <= ctx->pinned_cap) {
+            char *stage = ctx->pinned + ctx->pinned_used;      // staged now, copied by the union job's first launch (k_job_init)
+            memcpy(stage, block.data(), upload_bytes);
+            ctx->pinned_used += need;
+            gs.pend_src = stage; gs.pend_dst = aux.base; gs.pend_bytes = span16;
+            e = hipSuccess;
+        } else {
+            const H2DItem in[1] = {{aux.base, block.data(), upload_bytes}};
+            e = h2d_row(ctx, in, 1);
+        }
     }
     if (e != hipSuccess) { arena_put(ctx, gs.in_arena); return fail_dev(e, nullptr); }
     PoolPaint paint;
@@ -2553,6 +2593,8 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
     paint.paint_blocks = grid_for(2 * V, 256, 1ll << 30);
     const bool fused_paint = host_sized && 2 * V <= (1ll << 30) * 256 && n_pairs < (1ll << 30);      // (the device-sized path needs the gathered list for its boxes)
     if (!fused_paint) {
+        e = flush_pending(ctx, &gs);      // (these two read the aux block)
+        if (e != hipSuccess) { arena_put(ctx, gs.in_arena); return fail_dev(e, nullptr); }
         { PROF(ctx, "k_pool_gather"); hipLaunchKernelGGL(k_pool_gather, dim3(grid_for(2 * V, 256)), dim3(256), 0, st, cow->crs_dev, cow->offsets_dev, d_pool_cloud, d_pool_voff,
                                                          d_pool_group, (int)n_pool, V, n_rg, gs.d_crs, gs.d_item_group); }
         if (n_pairs > 0) { PROF(ctx, "k_test_overlap"); hipLaunchKernelGGL(k_test_overlap, dim3((unsigned)n_pairs), dim3(256), 0, st, cow->crs_dev, d_set_off, d_pa, d_pb, d_touch); }

@@ -1154,9 +1154,12 @@ __global__ void __launch_bounds__(256) k_copy_bytes(const unsigned char *__restr
 }
 // k_job_init: what stands in front of a grouped job's first kernel, in one launch -- the volume descriptors into the job's arena and zeroes over its
 // counters, masks, first-key bitmap and rank counters (a copy and a fill before).  Both regions start 16-byte aligned; lengths in 16-byte units.
-__global__ void __launch_bounds__(256) k_job_init(const uint4 *__restrict__ vol_src, uint4 *__restrict__ vol_dst, unsigned long long vol16,
+// in_*: the batch's staged inputs (pinned block -> device scratch) when their copy was left to this launch (group_setup's per-atom path, aggregateCloud's aux block).
+__global__ void __launch_bounds__(256) k_job_init(const uint4 *__restrict__ in_src, uint4 *__restrict__ in_dst, unsigned long long in16,
+                                                  const uint4 *__restrict__ vol_src, uint4 *__restrict__ vol_dst, unsigned long long vol16,
                                                   uint4 *__restrict__ zero, unsigned long long zero16) {
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x, t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (unsigned long long i = t; i < in16; i += stride) in_dst[i] = in_src[i];
     for (unsigned long long i = t; i < vol16; i += stride) vol_dst[i] = vol_src[i];
     const uint4 z = {0u, 0u, 0u, 0u};
     for (unsigned long long i = t; i < zero16; i += stride) zero[i] = z;
