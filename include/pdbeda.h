@@ -107,8 +107,9 @@ int pdbeda_map_from_device(pdbeda_ctx *ctx, const float *density_dev, const pdbe
  * DensityMatrix owns its array (ccp4.py:322-341).  A map that holds a NaN or an infinity is refused by the labelling calls. */
 int pdbeda_map_invalidate(pdbeda_map *map);
 /* The grid of a CCP4 FILE straight into HBM (ccp4.read -> parse, ccp4.py:58-127): n = ncrs[0]*ncrs[1]*ncrs[2] float32 values
- * starting at byte `offset` (1024 + the symmetry records) of `path`, read through a ring of pinned chunks (two pread() readers,
- * their PCIe copies queued on two streams; the context's stream is ordered behind both); byteswap != 0 when the file has the other endianness (swapped on the device).  No host copy
+ * starting at byte `offset` (1024 + the symmetry records) of `path`, read through the process's upload engine (three pread() readers with
+ * pinned chunks of their own, their PCIe copies queued on three streams; the context's stream is ordered behind them); byteswap != 0 when the
+ * file has the other endianness (swapped on the device).  No host copy
  * of the map exists afterwards (pdbeda_map_download fetches one on demand). */
 int pdbeda_map_upload_file(pdbeda_ctx *ctx, const char *path, int64_t offset, int byteswap, const pdbeda_geometry *geom, pdbeda_map **out);
 /* The same with the map's mean and standard deviation (pdbeda_map_stats: DensityMatrix.meanDensity / stdDensity, ccp4.py:343-361)

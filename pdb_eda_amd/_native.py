@@ -388,8 +388,8 @@ class DeviceMap(object):
 
     @classmethod
     def from_file(cls, ctx, path, offset, byteswap, geometry):
-        """The float32 grid stored at byte ``offset`` of ``path`` straight into HBM (pinned ring, two readers: file read and PCIe
-        copy overlap; no host copy of the map is kept)."""
+        """The float32 grid stored at byte ``offset`` of ``path`` straight into HBM through the process's upload engine (three reader
+        threads with pinned chunks and copy streams of their own: file reads and PCIe copies overlap; no host copy of the map is kept)."""
         self = cls.__new__(cls)
         self._ctx, self._geom, self._keep = ctx, geometry, None
         h = C.c_void_p()

@@ -25,7 +25,7 @@ __all__ = ["read", "parse", "read_grid", "DensityHeader", "DensityMatrix", "Dens
 def read(ccp4Filename, pdbid=None, verbose=False, ctx=None, lazy=False):
     """``ccp4.read`` (ref ccp4.py:58-74); ``ctx``: the context (= stream) the map becomes resident on.
 
-    An uncompressed mode-2 file goes from the page cache to HBM through the library's pinned ring
+    An uncompressed mode-2 file goes from the page cache to HBM through the library's upload engine
     (``pdbeda_map_upload_file``): only the header is parsed here, and ``DensityMatrix.density`` is fetched back on demand.
     ``lazy``: the header is read and the file's size checked now, the grid goes to HBM when something first asks for it
     (``DensityMatrix.resident`` tells) -- the Fo-Fc map of an entry whose analysis never looks at difference density (every
