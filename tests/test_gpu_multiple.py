@@ -1,10 +1,14 @@
 """Multiple-structure mode on one GPU: entries dealt to a pool of HIP streams (one context per
 worker thread) give the same records as sequential processing, failed entries are dropped without
 poisoning the pool, and the record matches the reference-derived goldens."""
+import os
+
 import numpy as np
 import pytest
 
 from conftest import load_analysis_case
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -415,3 +419,45 @@ def test_file_upload_brings_the_statistics_along(gpu_ctx, tmp_path):
     assert from_file.meanDensity == float(np.mean(g, dtype=np.float64)) and from_file.stdDensity == float(np.std(g.astype(np.float64)))
     a, b = from_file.createFullBlobList(from_file.meanDensity + 1.5 * from_file.stdDensity), from_memory.createFullBlobList(from_memory.meanDensity + 1.5 * from_memory.stdDensity)
     assert len(a) == len(b) and [x.totalDensity for x in a] == [y.totalDensity for y in b]      # (the same quantum: bit-equal sums)
+
+
+AB_WORKER = r'''
+import io, json, os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from pdb_eda_amd import _native, ccp4, synthetic, densityAnalysis, structure
+ctx = _native.Context(0)
+spec, header, st, params, dens, diff, rot = synthetic.cube_entry((64, 60, 56), 60, 21, 0.55)
+densityAnalysis.setGlobals(params)
+d0 = ccp4.parse(io.BytesIO(synthetic.ccp4_bytes(spec, dens)), "ab", ctx=ctx)
+d1 = ccp4.parse(io.BytesIO(synthetic.ccp4_bytes(spec, diff)), "ab", ctx=ctx)
+densityAnalysis._attachCutoffs(d0, d1)
+pdb = structure.PDBEntry(structure.PDBHeader(pdbid="ab", resolution=2.0, spaceGroup="P_1", rotationMats=rot))
+an = densityAnalysis.DensityAnalysis("ab", d0, d1, st, pdb)
+an.aggregateCloud()
+out = {"ratio": an.densityElectronRatio, "voxels": an.numVoxelsAggregated, "density": an.totalAggregatedDensity,
+       "medians": {k: {t: float(v) for t, v in d.items()} for k, d in an.medians.items()},
+       "residues": [[r[1], r[3], r[4], r[5], r[6]] + list(r[7]) for r in an.residueCloudDescriptions],
+       "atoms": an.calculateAtomRegionDiscrepancies(3.5, 3.0), "blobs": [list(map(repr, row)) for row in an.calculateAtomSpecificBlobStatistics(an.greenBlobList)]}
+json.dump(out, open(%(out)r, "w"), default=lambda o: o.tolist() if hasattr(o, "tolist") else repr(o))
+'''
+
+
+@pytest.mark.timeout(300)
+def test_the_ab_switches_change_no_result(tmp_path):
+    """PDBEDA_COPY_KERNELS=0 (the runtime's copies instead of kernels over the pinned block) and PDBEDA_HOST_BOXES=0 (the device's three kernels
+    instead of host-made boxes and volumes) are the A/B switches of round 5: the same analysis in a fresh process under each setting gives
+    the same numbers to the last bit (aggregateCloud's tables and medians, a region table, a blob table)."""
+    import json
+    import subprocess
+    import sys
+    outs = []
+    for k, env_extra in enumerate(({}, {"PDBEDA_COPY_KERNELS": "0"}, {"PDBEDA_HOST_BOXES": "0"})):
+        out, script = tmp_path / ("out%d.json" % k), tmp_path / ("worker%d.py" % k)
+        script.write_text(AB_WORKER % {"root": ROOT, "out": str(out)})
+        proc = subprocess.run([sys.executable, str(script)], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=280)
+        assert proc.returncode == 0, proc.stderr[-3000:]
+        outs.append(json.loads(out.read_text()))
+    assert outs[0]["voxels"] > 0 and len(outs[0]["atoms"]) > 100 and len(outs[0]["blobs"]) > 5
+    assert outs[1] == outs[0] and outs[2] == outs[0]
+
