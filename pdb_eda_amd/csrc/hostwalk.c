@@ -545,7 +545,12 @@ static PyObject *table_rows(PyObject *self, PyObject *arg) {
     if (!out) goto fail;
     /* thousands of fresh lists would run the cycle collector several times over rows that hold scalars and strings only (2 000 x 16: 0.48 ms with,
      * 0.24 without); it is switched back to what it was before the rows are handed out */
+#if PY_VERSION_HEX >= 0x030A0000
     const int gc_was_on = PyGC_Disable();
+#else
+    const int gc_was_on = 0;      /* (no C switch for the collector before 3.10: it runs as it likes) */
+#define PyGC_Enable() 0
+#endif
     for (Py_ssize_t i = 0; i < n; ++i) {
         PyObject *row = PyList_New(nc);
         if (!row) { if (gc_was_on) PyGC_Enable(); goto fail_out; }
