@@ -58,11 +58,14 @@ def parse_args():
 
 
 def csrc_sha16():
-    """Hash of the kernel sources: ties a committed counter profile to the code it was collected on."""
+    """Hash of the kernel sources (the library's .hip / .h files; not the CPython helper hostwalk.c, which no kernel sees): ties a
+    committed counter profile to the code it was collected on."""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "pdb_eda_amd", "csrc")
     for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".h")):
+            continue
         with open(os.path.join(csrc, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
