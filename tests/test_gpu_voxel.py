@@ -5,6 +5,7 @@ Bars (BASELINE.json north_star): voxel membership, counts, blob order bit exact;
 sums within 1e-5 relative -- the assertions below hold the tighter REL = 1e-9.
 """
 import io
+import os
 
 import numpy as np
 import pytest
@@ -710,3 +711,59 @@ def test_map_beyond_the_one_trip_rank_table(gpu_ctx, shape):
     g2, r2 = dm._map.full_blobs_pm(cut, -cut)           # no labels: k_emit_tiles ranks through the same totals
     assert np.array_equal(g2.stats()["firstKey"], green.stats()["firstKey"]) and np.array_equal(r2.stats()["n"], red.stats()["n"])
     green.free(); red.free(); g2.free(); r2.free()
+
+
+BORROWED_WORKER = r'''
+import io, sys
+import numpy as np
+import torch                                    # (first: torch brings its own HIP runtime, which wants to be the one that finds the GPU)
+torch.zeros(1, device="cuda")
+sys.path.insert(0, %(root)r)
+from pdb_eda_amd import _native, ccp4, synthetic
+ctx = _native.Context(0)
+g = synthetic.smooth_noise((40, 44, 72), 31, 1.5)
+spec = synthetic.MapSpec(ncrs=(72, 44, 40))
+dm = lambda grid: ccp4.parse(io.BytesIO(synthetic.ccp4_bytes(spec, grid)), "b", ctx=ctx)
+uploaded = dm(g)
+geom = uploaded.header.geometry()
+rng = np.random.default_rng(3)
+xyz = np.asarray([uploaded.header.crs2xyzCoord([int(c), int(r), int(s)]) for c, r, s in zip(rng.integers(4, 68, 60), rng.integers(4, 40, 60), rng.integers(4, 36, 60))], dtype=np.float64)
+radii = np.full(60, 1.4, dtype=np.float32)
+off = np.arange(61, dtype=np.int64)
+cut = float(uploaded.meanDensity + 1.0 * uploaded.stdDensity)
+def spheres(m, c):
+    st = m.sphere_blobs(xyz, radii, off, c).stats()
+    return st["n"].tolist(), st["totalDensity"].tolist(), st["group"].tolist()
+want = spheres(uploaded._map, cut)
+t = torch.from_numpy(g).to("cuda")
+torch.cuda.synchronize()
+borrowed = _native.DeviceMap(ctx, t, geom, device_ptr=t.data_ptr())
+assert spheres(borrowed, cut) == want, "first call of a borrowed map"
+assert borrowed.stats() == (uploaded.meanDensity, uploaded.stdDensity)
+for x, y in zip(borrowed.full_blobs_pm(cut, -cut, labels=True), uploaded._map.full_blobs_pm(cut, -cut, labels=True)):
+    sx, sy = x.stats(), y.stats()
+    assert np.array_equal(sx["n"], sy["n"]) and np.array_equal(sx["totalDensity"], sy["totalDensity"])
+    assert np.array_equal(x.labels(borrowed.unique_shape), y.labels(uploaded._map.unique_shape))
+t.mul_(20.0)                                    # rewritten in place: the cached quantum of the blob sums would be too fine for it
+torch.cuda.synchronize()
+borrowed.invalidate()
+scaled = dm((g * np.float32(20.0)).astype(np.float32))
+cut20 = float(scaled.meanDensity + 1.0 * scaled.stdDensity)
+assert spheres(borrowed, cut20) == spheres(scaled._map, cut20), "after invalidate"
+borrowed.free()
+print("borrowed ok")
+'''
+
+
+@pytest.mark.timeout(300)
+def test_borrowed_device_buffer(tmp_path):
+    """pdbeda_map_from_device (the caller's own HBM buffer: how bench.py hands its torch tensor over) and pdbeda_map_invalidate: a borrowed
+    map gives what an uploaded one gives -- also when its FIRST call is a per-atom sphere batch (nothing is known about the map yet: the
+    quantum of the blob sums is computed behind a wait of its own, while the batch's inputs sit staged in the pinned block) -- and a map
+    rewritten in place gives the new contents' results after invalidate().  In a child process: torch must initialise the GPU first."""
+    import subprocess
+    import sys
+    script = tmp_path / "borrowed.py"
+    script.write_text(BORROWED_WORKER % {"root": os.path.dirname(os.path.dirname(os.path.abspath(__file__)))})
+    proc = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=280)
+    assert proc.returncode == 0 and "borrowed ok" in proc.stdout, proc.stderr[-3000:]
