@@ -705,14 +705,15 @@ static hipError_t event_wait(pdbeda_ctx *ctx, hipEvent_t ev) {
 }
 
 // The grid of a CCP4 file straight into HBM: pread() fills pinned chunks while earlier ones are on their way over PCIe, and
-// no host copy of the map is ever made (ccp4.py:77-127 unpacks it into a Python tuple).  TWO readers (the caller and a helper
-// thread, two chunks each): one thread copies out of the page cache at 29-36 GB/s, the link takes 54 -- a 32 MB map arrived in
-// 0.9-1.1 ms with one reader, and four worker processes together reached 39 GB/s (`tools/exp/file_h2d.py`; a pageable copy
-// out of an mmap of the file runs at link speed only while its pages stay mapped -- a fresh mapping per file pays 0.6 ms of
-// page faults per 32 MB before the first byte moves).  byteswap: the file has the other endianness.
-static const size_t FILE_CHUNK_MAX = (size_t)16 << 20;   // the most a chunk may be; chunks (= a reader's pinned slots) are 8 MiB by default (four workers, both maps: 4 MiB 1.44-1.45 ms per entry, 8 MiB 1.40-1.42, 16 MiB 1.39-1.40)
+// no host copy of the map is ever made (ccp4.py:77-127 unpacks it into a Python tuple).  The readers are the PROCESS's (UploadEngine, below:
+// three threads, two pinned chunks and a copy stream each); rounds 3-4 gave every context a ring and two readers of its own.  A thread copies
+// out of the page cache at 20-40 GB/s (by host), one copy engine moves 54 GB/s: one 32 MB map alone arrives in 0.76-0.85 ms, four loads in
+// flight move 50-53 GB/s (`tools/exp/single_load.py`, `trace_load.sh`; a pageable copy out of an mmap of the file runs at link speed only
+// while its pages stay mapped -- a fresh mapping per file pays 0.6 ms of page faults per 32 MB before the first byte moves).
+// byteswap: the file has the other endianness.
+static const long FILE_CHUNK_MAX_KB = 16384;   // the most a chunk may be; chunks (= a reader's pinned slots) are 8 MiB by default (four workers, both maps: 4 MiB 1.44-1.45 ms per entry, 8 MiB 1.40-1.42, 16 MiB 1.39-1.40)
 static size_t file_chunk_bytes() {   // (PDBEDA_FILE_CHUNK_KB: experiments)
-    static const size_t v = [] { const char *e = getenv("PDBEDA_FILE_CHUNK_KB"); long kb = e ? atol(e) : 8192; return (size_t)std::min<long>(std::max<long>(kb, 64), 16384) << 10; }();
+    static const size_t v = [] { const char *e = getenv("PDBEDA_FILE_CHUNK_KB"); long kb = e ? atol(e) : 8192; return (size_t)std::min<long>(std::max<long>(kb, 64), FILE_CHUNK_MAX_KB) << 10; }();
     return v;
 }
 #define FILE_CHUNK (file_chunk_bytes())

@@ -1680,8 +1680,8 @@ __global__ void __launch_bounds__(256) k_reduce_final(const double *__restrict__
 //   n2 = (n/2) & ~7.  np.std: m = sum/n; x = a - m; x = x*x; sqrt(sum(x)/n)  (_methods._var).
 // k_np_chunk_sums: one workgroup per 8192-element chunk: coalesced 16-B loads -> LDS (leaf stride 136 floats: the
 // 8 x 4 (lane j, leaf) reads of a 32-lane group hit 32 different banks), thread (leaf, j) adds its 16 values in order,
-// wave butterflies build the tree.  k_np_final: the tail chunk + the in-order accumulation of the chunk sums (one thread:
-// the order IS the result), then the division / square root.
+// wave butterflies build the tree.  k_np_final: the tail chunk (its recursion tree as a heap in LDS, built and combined level by level
+// by the workgroup) + the in-order accumulation of the chunk sums (one thread: the order IS the result), then the division / square root.
 // mode 0: x   mode 1: (x - mean)^2
 // ------------------------------------------------------------------------------------
 constexpr int NP_CHUNK = 8192, NP_LSTRIDE = 136;
