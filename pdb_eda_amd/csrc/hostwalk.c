@@ -84,10 +84,11 @@ static PyObject *atom_columns(PyObject *self, PyObject *arg) {
         n += PyList_GET_SIZE(cl);
     }
     PyObject *atoms = PyList_New(n), *name = PyList_New(n), *occ_raw = PyList_New(n), *distinct = PyList_New(0), *ids = PyDict_New();
+    PyObject *coord_objs = PyList_New(n);      /* the atoms' own coordinate objects (what the symmetry-atom tables list), kept while they are in hand */
     PyObject *counts = PyByteArray_FromStringAndSize(NULL, 8 * n_res), *occ = PyByteArray_FromStringAndSize(NULL, 8 * n),
              *bfac = PyByteArray_FromStringAndSize(NULL, 8 * n), *coord = PyByteArray_FromStringAndSize(NULL, 12 * n),
              *name_id = PyByteArray_FromStringAndSize(NULL, 8 * n);
-    if (!atoms || !name || !occ_raw || !distinct || !ids || !counts || !occ || !bfac || !coord || !name_id) goto fail;
+    if (!atoms || !name || !occ_raw || !distinct || !ids || !counts || !occ || !bfac || !coord || !name_id || !coord_objs) goto fail;
     {
         int64_t *p_counts = (int64_t *)PyByteArray_AS_STRING(counts), *p_id = (int64_t *)PyByteArray_AS_STRING(name_id);
         double *p_occ = (double *)PyByteArray_AS_STRING(occ), *p_b = (double *)PyByteArray_AS_STRING(bfac);
@@ -126,8 +127,9 @@ static PyObject *atom_columns(PyObject *self, PyObject *arg) {
                 if (bad < 0) goto fail;
                 PyObject *xyz = PyObject_GetAttr(atom, s_coord);
                 if (!xyz) goto fail;
+                PyList_SET_ITEM(coord_objs, k, xyz);      /* (the list owns the reference from here) */
                 Py_buffer view;
-                if (PyObject_GetBuffer(xyz, &view, PyBUF_STRIDES | PyBUF_FORMAT) < 0) { Py_DECREF(xyz); goto fail; }
+                if (PyObject_GetBuffer(xyz, &view, PyBUF_STRIDES | PyBUF_FORMAT) < 0) goto fail;
                 int ok = view.ndim == 1 && view.shape[0] == 3 && view.format != NULL;
                 if (ok) {
                     const char *base = (const char *)view.buf;
@@ -143,22 +145,21 @@ static PyObject *atom_columns(PyObject *self, PyObject *arg) {
                     }
                 }
                 PyBuffer_Release(&view);
-                Py_DECREF(xyz);
                 if (!ok) { PyErr_SetString(PyExc_TypeError, "atom.coord is not three float32 / float64 values"); goto fail; }
             }
         }
         if (k != n) { PyErr_SetString(PyExc_RuntimeError, "the structure changed during the walk"); goto fail; }
     }
     {
-        PyObject *out = PyTuple_Pack(9, atoms, name, occ_raw, counts, occ, bfac, coord, name_id, distinct);
+        PyObject *out = PyTuple_Pack(10, atoms, name, occ_raw, counts, occ, bfac, coord, name_id, distinct, coord_objs);
         Py_DECREF(atoms); Py_DECREF(name); Py_DECREF(occ_raw); Py_DECREF(counts); Py_DECREF(occ); Py_DECREF(bfac); Py_DECREF(coord);
-        Py_DECREF(name_id); Py_DECREF(distinct); Py_DECREF(ids);
+        Py_DECREF(name_id); Py_DECREF(distinct); Py_DECREF(ids); Py_DECREF(coord_objs);
         return out;
     }
 fail:
     /* (lists that are only partly filled hold NULLs: the list deallocator copes with them) */
     Py_XDECREF(atoms); Py_XDECREF(name); Py_XDECREF(occ_raw); Py_XDECREF(counts); Py_XDECREF(occ); Py_XDECREF(bfac); Py_XDECREF(coord);
-    Py_XDECREF(name_id); Py_XDECREF(distinct); Py_XDECREF(ids);
+    Py_XDECREF(name_id); Py_XDECREF(distinct); Py_XDECREF(ids); Py_XDECREF(coord_objs);
     return NULL;
 }
 
@@ -478,7 +479,7 @@ done:
 
 /* table_rows(columns) -> list of row lists: what list(map(list, zip(*columns))) makes, in one pass and without the column lists of numbers.
  * A column is a list / tuple (items taken as they are), a C-contiguous numpy array -- 1-D float64 / int64 / int32 / bool: Python floats, ints, bools
- * (what .tolist() would hold); 2-D float64 (n x k): a list of k floats per row -- or a pair (list / tuple, index array of int64): the picked items.
+ * (what .tolist() would hold); 2-D float64 (n x k): a list of k floats per row; 2-D int64 (n x k): a TUPLE of k ints per row -- or a pair (list / tuple, index array of int64): the picked items.
  * The result tables of densityAnalysis (region discrepancies, blob statistics: densityAnalysis.py:914-1035) are 2 000 rows x 16 columns; zip + list took
  * 0.25-0.5 ms a table, the columns' .tolist() another 0.1-0.2. */
 #define ROWS_MAX_COLS 32
@@ -532,7 +533,8 @@ static PyObject *table_rows(PyObject *self, PyObject *arg) {
             else if (rc->view.ndim == 1 && f == 'i' && rc->view.itemsize == 4) rc->kind = 3;
             else if (rc->view.ndim == 1 && f == '?') rc->kind = 4;
             else if (rc->view.ndim == 2 && f == 'd') { rc->kind = 5; rc->k = rc->view.shape[1]; }
-            else { PyErr_SetString(PyExc_TypeError, "table_rows: arrays are 1-D float64 / int64 / int32 / bool or 2-D float64"); goto fail; }
+            else if (rc->view.ndim == 2 && (f == 'l' || f == 'q') && rc->view.itemsize == 8) { rc->kind = 6; rc->k = rc->view.shape[1]; }
+            else { PyErr_SetString(PyExc_TypeError, "table_rows: arrays are 1-D float64 / int64 / int32 / bool or 2-D float64 / int64"); goto fail; }
             rc->n = rc->view.shape[0];
         } else {
             PyErr_SetString(PyExc_TypeError, "table_rows: a column is a list, a tuple, an array or (list, index array)");
@@ -564,6 +566,18 @@ static PyObject *table_rows(PyObject *self, PyObject *arg) {
             case 2: v = PyLong_FromLongLong(((const long long *)rc->view.buf)[i]); break;
             case 3: v = PyLong_FromLong(((const int *)rc->view.buf)[i]); break;
             case 4: v = PyBool_FromLong(((const unsigned char *)rc->view.buf)[i]); break;
+            case 6: {      /* a TUPLE of ints per row (symmetry operators: (i, j, k, op)) */
+                v = PyTuple_New(rc->k);
+                if (v) {
+                    const long long *p = (const long long *)rc->view.buf + i * rc->k;
+                    for (Py_ssize_t q = 0; q < rc->k; ++q) {
+                        PyObject *f = PyLong_FromLongLong(p[q]);
+                        if (!f) { Py_CLEAR(v); break; }
+                        PyTuple_SET_ITEM(v, q, f);
+                    }
+                }
+                break;
+            }
             default: {
                 v = PyList_New(rc->k);
                 if (v) {

@@ -16,6 +16,7 @@ import collections
 import gzip
 import json
 import math
+import operator
 import os
 
 import numpy as np
@@ -243,16 +244,18 @@ class _SymAtomList(object):
         return len(self._rows)
 
     def columns(self, items=None, type=""):
-        """(rows of the structure columns, symmetry tuples, coordinates as the SymAtom objects would hold them) of the listed
+        """(rows of the structure columns, symmetry operators as an n x 4 int64 array -- a tuple per row once ``_rows`` has made the table --,
+        coordinates as the SymAtom objects would hold them) of the listed
         items (all by default), optionally only those whose atom name is ``type``."""
         r = self._rows if items is None else self._rows[np.asarray(items, dtype=np.int64)]
         atom_rows = self._idx[r]
         if type:
             keep = np.asarray(self._cols.name)[atom_rows] == type if len(r) else np.zeros(0, dtype=bool)
             r, atom_rows = r[keep], atom_rows[keep]
-        symmetry = [tuple(t) for t in self._sym[r].tolist()]
-        atoms = self._cols.atoms
-        coords = [atoms[a].coord for a in atom_rows.tolist()]            # (most listed atoms are the structure's own: their coordinate objects as they are)
+        symmetry = np.ascontiguousarray(self._sym[r], dtype=np.int64)      # (n x 4 ints: _rows makes the tuples)
+        own = self._cols.atom_lists("coord")                               # (most listed atoms are the structure's own: their coordinate objects as they are)
+        picked = atom_rows.tolist()
+        coords = list(operator.itemgetter(*picked)(own)) if len(picked) > 1 else [own[a] for a in picked]
         moved = np.nonzero(~self._ident[r])[0]
         if len(moved):
             xyz = self._xyz[r[moved]]
@@ -358,11 +361,11 @@ class DensityAnalysis(object):
         return property(getter)
 
     symmetryAtoms = _lazy('_symmetryAtoms', '_calculateSymmetryAtoms')
-    symmetryOnlyAtoms = _lazy('_symmetryOnlyAtoms', '_calculateSymmetryAtoms')
-    asymmetryAtoms = _lazy('_asymmetryAtoms', '_calculateSymmetryAtoms')
+    symmetryOnlyAtoms = _lazy('_symmetryOnlyAtoms', '_splitSymmetryAtoms')
+    asymmetryAtoms = _lazy('_asymmetryAtoms', '_splitSymmetryAtoms')
     symmetryAtomCoords = _lazy('_symmetryAtomCoords', '_calculateSymmetryAtoms')
-    symmetryOnlyAtomCoords = _lazy('_symmetryOnlyAtomCoords', '_calculateSymmetryAtoms')
-    asymmetryAtomCoords = _lazy('_asymmetryAtomCoords', '_calculateSymmetryAtoms')
+    symmetryOnlyAtomCoords = _lazy('_symmetryOnlyAtomCoords', '_splitSymmetryAtoms')
+    asymmetryAtomCoords = _lazy('_asymmetryAtomCoords', '_splitSymmetryAtoms')
     medians = _lazy('_medians', 'aggregateCloud')
 
     def _described(name, which):
@@ -705,6 +708,13 @@ class DensityAnalysis(object):
         allAtoms = _SymAtomList(cols, idx, sym, xyz, ident)
         self._symmetryAtoms = allAtoms
         self._symmetryAtomCoords = allCoords
+        self._symmetryOnlyAtoms = self._asymmetryAtoms = self._symmetryOnlyAtomCoords = self._asymmetryAtomCoords = None
+
+    def _splitSymmetryAtoms(self):
+        """The symmetry-only / asymmetric-unit halves of the list (ref densityAnalysis.py:905-912), made when somebody asks for them: the blob
+        statistics read the whole list only."""
+        allAtoms, allCoords = self.symmetryAtoms, self.symmetryAtomCoords
+        ident = allAtoms._ident
         self._symmetryOnlyAtoms = allAtoms.subset(np.nonzero(~ident)[0])
         self._symmetryOnlyAtomCoords = allCoords[~ident]
         self._asymmetryAtoms = allAtoms.subset(np.nonzero(ident)[0])
@@ -902,18 +912,21 @@ class DensityAnalysis(object):
 
     @staticmethod
     def _rows(*columns):
-        """The table rows (lists) of whole columns: lists, numpy arrays (their ``.tolist()`` values), or (list, int64 index array) picks.
+        """The table rows (lists) of whole columns: lists, numpy arrays (their ``.tolist()`` values; a 2-D array of ints gives a TUPLE per row), or
+        (list, int64 index array) picks.
         One pass in C (``_hostwalk.table_rows``) when the helper is built; ``list(map(list, zip(...)))`` over plain lists otherwise."""
         walk = _structure._hostwalk()
         if walk is not None and hasattr(walk, "table_rows") and 1 <= len(columns) <= 32:
             prepared = [np.ascontiguousarray(c) if isinstance(c, np.ndarray) else c for c in columns]
-            if all(not isinstance(c, np.ndarray) or ((c.ndim == 1 and c.dtype in (np.float64, np.int64, np.int32, np.bool_)) or (c.ndim == 2 and c.dtype == np.float64))
+            if all(not isinstance(c, np.ndarray) or ((c.ndim == 1 and c.dtype in (np.float64, np.int64, np.int32, np.bool_)) or (c.ndim == 2 and c.dtype in (np.float64, np.int64)))
                    for c in prepared):
                 return walk.table_rows(prepared)
         plain = []
         for c in columns:
             if isinstance(c, tuple) and len(c) == 2 and isinstance(c[1], np.ndarray):
                 plain.append([c[0][r] for r in c[1].tolist()])
+            elif isinstance(c, np.ndarray) and c.ndim == 2 and c.dtype.kind in "iu":
+                plain.append(list(map(tuple, c.tolist())))                     # (rows of ints are tuples: the symmetry operators)
             else:
                 plain.append(c.tolist() if isinstance(c, np.ndarray) else c)
         return list(map(list, zip(*plain)))

@@ -198,7 +198,9 @@ class Columns(object):
                     _hostwalk_fell_back("Columns", exception)
                     walked = None                      # an object tree the C walk does not read: the loops below do
         if walked is not None:
-            atoms, name, occupancy, counts, occ, bfac, xyz, name_id, distinct = walked
+            atoms, name, occupancy, counts, occ, bfac, xyz, name_id, distinct = walked[:9]
+            if len(walked) > 9:
+                self.__dict__.setdefault("_atom_lists", {})["coord"] = walked[9]      # (the atoms' coordinate objects, for the symmetry-atom tables)
             n = len(atoms)
             res_het = np.frombuffer(het, dtype=np.uint8).astype(bool)
             counts = np.frombuffer(counts, dtype=np.int64)
@@ -256,8 +258,11 @@ class Columns(object):
         self.pair_names = pair_names
 
     def atom_lists(self, which):
-        """Per-atom Python lists of residue-level columns ('model', 'chain', 'number', 'resname'), made on first use."""
+        """Per-atom Python lists of residue-level columns ('model', 'chain', 'number', 'resname') -- and 'coord': the atoms' own
+        coordinate objects --, made on first use."""
         cache = self.__dict__.setdefault("_atom_lists", {})
+        if which == "coord" and which not in cache:
+            cache[which] = [atom.coord for atom in self.atoms]
         if which not in cache:
             source = {"model": self.res_model, "chain": self.res_chain, "number": self.res_number, "resname": self.res_name}[which]
             column = np.fromiter(source, dtype=object, count=len(source))      # (the very objects, repeated by numpy)

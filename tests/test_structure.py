@@ -325,12 +325,14 @@ def test_table_rows_in_c_equal_the_zip_form():
     pick = rng.integers(0, 40, n).astype(np.int64)
     tuples = [(k, k + 1) for k in range(n)]
     scalars = list(np.float64(f))                   # (numpy scalars in a list stay what they are)
-    got = densityAnalysis.DensityAnalysis._rows(f, i64, i32, flag, xyz, (names, pick), tuples, scalars, xyz[:, ::2])     # (the last: not contiguous)
-    want = list(map(list, zip(f.tolist(), i64.tolist(), i32.tolist(), flag.tolist(), xyz.tolist(), [names[r] for r in pick.tolist()], tuples, scalars, xyz[:, ::2].tolist())))
+    ops = rng.integers(-1, 3, (n, 4))
+    got = densityAnalysis.DensityAnalysis._rows(f, i64, i32, flag, xyz, (names, pick), tuples, scalars, xyz[:, ::2], ops)     # (xyz[:, ::2]: not contiguous)
+    want = list(map(list, zip(f.tolist(), i64.tolist(), i32.tolist(), flag.tolist(), xyz.tolist(), [names[r] for r in pick.tolist()], tuples, scalars, xyz[:, ::2].tolist(),
+                              [tuple(t) for t in ops.tolist()])))
     assert got == want
     for a, b in zip(got[3], want[3]):
         assert type(a) is type(b)
-    assert all(type(row[0]) is float and type(row[1]) is int and type(row[3]) is bool and type(row[4]) is list for row in got)
+    assert all(type(row[0]) is float and type(row[1]) is int and type(row[3]) is bool and type(row[4]) is list and type(row[9]) is tuple for row in got)
     assert densityAnalysis.DensityAnalysis._rows(np.zeros(0), []) == []
     with pytest.raises(ValueError):
         walk.table_rows([f, i64[:-1]])
@@ -339,5 +341,17 @@ def test_table_rows_in_c_equal_the_zip_form():
     with pytest.raises(TypeError):
         walk.table_rows([f.astype(np.float32)])
     # columns the helper does not take (float32) go the plain way inside _rows
-    assert densityAnalysis.DensityAnalysis._rows(f.astype(np.float32), i64) == list(map(list, zip(f.astype(np.float32).tolist(), i64.tolist())))
+    assert densityAnalysis.DensityAnalysis._rows(f.astype(np.float32), i64, ops) == list(map(list, zip(f.astype(np.float32).tolist(), i64.tolist(), [tuple(t) for t in ops.tolist()])))
+
+
+def test_columns_keep_the_atoms_own_coordinate_objects():
+    """structure.Columns.atom_lists('coord'): the very objects atom.coord returns (the symmetry-atom tables list them, as the reference's SymAtom
+    holds them), from the C walk and from the plain one."""
+    from pdb_eda_amd import structure, synthetic
+    spec, header, st, params, dens, diff, rot = synthetic.cube_entry((40, 40, 40), 12, 3, 0.6)
+    for native in (None, False):
+        cols = structure.Columns(st, native=native) if "native" in structure.Columns.__init__.__code__.co_varnames else structure.Columns(st)
+        own = cols.atom_lists("coord")
+        assert len(own) == len(cols.atoms) > 20
+        assert all(a is atom.coord for a, atom in zip(own, cols.atoms))
 
