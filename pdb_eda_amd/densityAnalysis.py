@@ -586,7 +586,11 @@ class DensityAnalysis(object):
         dist = res["atom_distance"]
         total, count, centroid = res["atom_total"], res["atom_n"], res["atom_centroid"]
         if not np.isnan(dist).all():
-            near = dist < np.nanmedian(dist) + np.nanstd(dist) * 2              # (the reference filters the finished table: same rows)
+            walk0 = _structure._hostwalk() if native is not False else None
+            if walk0 is not None and hasattr(walk0, "nan_cutoff"):                # (numpy's own nanmedian + nanstd * 2, to the bit, without their 0.08 ms of Python)
+                near = dist < walk0.nan_cutoff(np.ascontiguousarray(dist, dtype=np.float64), 2.0)
+            else:
+                near = dist < np.nanmedian(dist) + np.nanstd(dist) * 2          # (the reference filters the finished table: same rows)
             idx, dist, total, count, centroid = idx[near], dist[near], total[near], count[near], centroid[near]
         n = len(idx)
         cols, rows = inp["cols"], inp["rows"][idx]

@@ -355,3 +355,24 @@ def test_columns_keep_the_atoms_own_coordinate_objects():
         assert len(own) == len(cols.atoms) > 20
         assert all(a is atom.coord for a, atom in zip(own, cols.atoms))
 
+
+def test_nan_cutoff_is_numpys_to_the_bit():
+    """_hostwalk.nan_cutoff(values, k) == np.nanmedian(values) + np.nanstd(values) * k exactly (the row filter of aggregateCloud's atom table,
+    densityAnalysis.py:731): lengths around numpy's pairwise blocks (8, 128, 8192), with and without NaNs, all NaN."""
+    import warnings
+    from pdb_eda_amd import structure
+    walk = structure._hostwalk()
+    assert walk is not None and hasattr(walk, "nan_cutoff")
+    rng = np.random.default_rng(7)
+    for n in (1, 2, 3, 7, 8, 9, 16, 17, 127, 128, 129, 136, 255, 256, 257, 1000, 2001, 8191, 8192, 8193, 9001, 20000):
+        for nan_share in (0.0, 0.05, 0.6):
+            for scale, shift in ((1.0, 0.0), (1e-3, 5.0)):
+                x = rng.random(n) * scale + shift
+                x[rng.random(n) < nan_share] = np.nan
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    want = np.nanmedian(x) + np.nanstd(x) * 2.5
+                got = walk.nan_cutoff(x, 2.5)
+                assert got == want or (np.isnan(got) and np.isnan(want)), (n, nan_share, scale)
+    assert np.isnan(walk.nan_cutoff(np.full(5, np.nan), 2.0)) and np.isnan(walk.nan_cutoff(np.zeros(0), 2.0))
+
