@@ -201,6 +201,12 @@ struct pdbeda_bloblist {
     uint32_t flags = 0;
     int tier = 0, unit_form = 0, reruns = 0;
     size_t job_bytes = 0;              // bytes the job carved out of its arena (a recycled arena may be larger)
+    // whole-map jobs, on the list that owns the arena: the first rows of the job's blob table, fetched WITH the counters (round 5: the count and the table of
+    // each of the two lists of a fused call were four waits; now one serves both)
+    int64_t spec_rows = 0;
+    std::vector<int64_t> spec_n, spec_key;
+    std::vector<double> spec_total, spec_centroid, spec_center, spec_volume;
+    std::vector<int32_t> spec_group;
 };
 
 static const int N_PARTIAL = 2048;
@@ -1582,6 +1588,7 @@ extern "C" int pdbeda_full_blobs_pm(pdbeda_map *m, float cutoff_pos, float cutof
 
 // ---- accessors ------------------------------------------------------------------------
 static pdbeda_bloblist *owner_of(pdbeda_bloblist *bl) { return bl->owns_arena ? bl : bl->sibling; }
+static const int64_t SPEC_ROWS = 2048;      // rows of a whole-map job's blob table fetched with its counters (84 B each: 172 KB; the analysis entry's 128^3 map has ~1 400 blobs)
 static int list_resolve_counts(pdbeda_bloblist *bl) {
     if (bl->have_counts) return 0;
     pdbeda_ctx *ctx = bl->ctx;
@@ -1589,8 +1596,33 @@ static int list_resolve_counts(pdbeda_bloblist *bl) {
     // rank range of this list inside the job's blob table: a list is the whole job, or one plane of a fused whole-map job
     // (k_emit published the split)
     Counters ctr;
-    HIP_TRY(ctx, d2h(ctx, &ctr, bl->job.ctr, sizeof ctr));
-    HIP_TRY(ctx, ctx_sync(ctx));
+    // a whole-map job: the first rows of its blob table ride along with the counters, kept on the list that owns the job for both lists of a fused call
+    // (rows beyond the blob count are stale bytes: never served)
+    auto fetch = [&]() -> int {
+        pdbeda_bloblist *ow = bl->whole_map ? owner_of(bl) : nullptr;
+        const int64_t g = ow ? std::min<int64_t>((int64_t)bl->job.blob_cap, SPEC_ROWS) : 0;
+        if (g > 0) {
+            const Job &job = bl->job;
+            ow->spec_rows = 0;
+            ow->spec_n.resize((size_t)g); ow->spec_key.resize((size_t)g); ow->spec_total.resize((size_t)g); ow->spec_centroid.resize(3 * (size_t)g);
+            ow->spec_center.resize(3 * (size_t)g); ow->spec_volume.resize((size_t)g); ow->spec_group.resize((size_t)g);
+            const D2HItem parts[8] = {{&ctr, job.ctr, sizeof ctr}, {ow->spec_n.data(), job.b_n, (size_t)(8 * g)}, {ow->spec_total.data(), job.b_total, (size_t)(8 * g)},
+                                      {ow->spec_centroid.data(), job.b_centroid, (size_t)(24 * g)}, {ow->spec_center.data(), job.b_center, (size_t)(24 * g)},
+                                      {ow->spec_volume.data(), job.b_volume, (size_t)(8 * g)}, {ow->spec_key.data(), job.b_key, (size_t)(8 * g)},
+                                      {ow->spec_group.data(), job.b_group, (size_t)(4 * g)}};
+            HIP_TRY(ctx, d2h_many(ctx, parts, 8));
+            HIP_TRY(ctx, ctx_sync(ctx));
+            ow->spec_rows = g;
+            return 0;
+        }
+        HIP_TRY(ctx, d2h(ctx, &ctr, bl->job.ctr, sizeof ctr));
+        HIP_TRY(ctx, ctx_sync(ctx));
+        return 0;
+    };
+    {
+        const int rc_fetch = fetch();
+        if (rc_fetch) return rc_fetch;
+    }
     while (bl->whole_map && ctr.overflow != 0u) {
         // The job is run again, ONCE (both lists of a fused call move to the new job), when the typical-size arena was too small
         // for this map (bits 0 / 1), or when the map has unit tiles and the job was enqueued without their two launches (bit 2,
@@ -1610,10 +1642,10 @@ static int list_resolve_counts(pdbeda_bloblist *bl) {
         for (pdbeda_bloblist *l : both) {
             if (!l) continue;
             l->job = wj.job; l->td = wj.td; l->labels_dev = wj.labels_dev; l->labels_done = wj.labels;
-            l->tier = tier; l->unit_form = form; l->reruns += 1; l->have_counts = false; l->job_bytes = wj.bytes;
+            l->tier = tier; l->unit_form = form; l->reruns += 1; l->have_counts = false; l->job_bytes = wj.bytes; l->spec_rows = 0;
         }
-        HIP_TRY(ctx, d2h(ctx, &ctr, bl->job.ctr, sizeof ctr));
-        HIP_TRY(ctx, ctx_sync(ctx));
+        const int rc_fetch = fetch();
+        if (rc_fetch) return rc_fetch;
     }
     if (!bl->whole_map && ctr.unit_wait_failed) return fail(ctx, PDBEDA_ERR_DEVICE, "sphere batch: the device's volumes outgrew what the host sized the job for");
     if (bl->vol_lo == 0 && bl->vol_hi == bl->job.n_vols) { bl->rank_lo = 0; bl->rank_hi = ctr.n_blobs; }
@@ -1623,6 +1655,18 @@ static int list_resolve_counts(pdbeda_bloblist *bl) {
     } else return fail(ctx, PDBEDA_ERR_STATE, "blob list covers an unexpected volume range");
     bl->job_blobs = ctr.n_blobs;
     bl->have_counts = true;
+    // the other list of a fused call reads the same counters: its range is known now too
+    if (bl->whole_map && bl->job.n_vols == 2) {
+        pdbeda_bloblist *ow = owner_of(bl);
+        pdbeda_bloblist *both[2] = {ow, ow ? ow->sibling : nullptr};
+        for (pdbeda_bloblist *l : both) {
+            if (!l || l == bl || l->freed || l->have_counts || l->job.ctr != bl->job.ctr || l->vol_hi != l->vol_lo + 1) continue;
+            l->rank_lo = l->vol_lo == 0 ? 0 : ctr.n_blobs_vol0;
+            l->rank_hi = l->vol_lo == 0 ? ctr.n_blobs_vol0 : ctr.n_blobs;
+            l->job_blobs = ctr.n_blobs;
+            l->have_counts = true;
+        }
+    }
     return 0;
 }
 
@@ -1666,6 +1710,19 @@ extern "C" int pdbeda_bloblist_stats(pdbeda_bloblist *bl, int64_t *n, double *to
     const Job &job = bl->job;
     const int64_t lo = bl->rank_lo, cnt = bl->rank_hi - bl->rank_lo;
     if (cnt == 0) return PDBEDA_OK;
+    if (bl->whole_map) {      // the rows that came with the counters
+        const pdbeda_bloblist *ow = owner_of(bl);
+        if (ow && ow->spec_rows >= lo + cnt && ow->job.ctr == job.ctr) {
+            if (n) memcpy(n, ow->spec_n.data() + lo, (size_t)(8 * cnt));
+            if (total_density) memcpy(total_density, ow->spec_total.data() + lo, (size_t)(8 * cnt));
+            if (centroid) memcpy(centroid, ow->spec_centroid.data() + 3 * lo, (size_t)(24 * cnt));
+            if (coord_center) memcpy(coord_center, ow->spec_center.data() + 3 * lo, (size_t)(24 * cnt));
+            if (volume) memcpy(volume, ow->spec_volume.data() + lo, (size_t)(8 * cnt));
+            if (first_key) memcpy(first_key, ow->spec_key.data() + lo, (size_t)(8 * cnt));
+            if (group) memcpy(group, ow->spec_group.data() + lo, (size_t)(4 * cnt));
+            return PDBEDA_OK;
+        }
+    }
     const D2HItem columns[7] = {{n, job.b_n + lo, (size_t)(8 * cnt)}, {total_density, job.b_total + lo, (size_t)(8 * cnt)},
                                 {centroid, job.b_centroid + 3 * lo, (size_t)(24 * cnt)}, {coord_center, job.b_center + 3 * lo, (size_t)(24 * cnt)},
                                 {volume, job.b_volume + lo, (size_t)(8 * cnt)}, {first_key, job.b_key + lo, (size_t)(8 * cnt)},
