@@ -397,6 +397,33 @@ def test_recycled_arenas_and_edge_overflow(monkeypatch):
         got.free()
 
 
+def test_sparse_maps_write_every_label_line(monkeypatch):
+    """Label volumes of SPARSE maps (pdb_eda's own 2.5 - 4 sigma: most 128-byte lines of the volume hold no label) on 0xFF-poisoned
+    arenas: a line that no kernel wrote shows at once.  Widths that are whole lines, whole 4-voxel groups only, and neither, partial
+    tiles on every axis, a map without a significant voxel, both launch forms (fused, one sign).  (Written for round 6's experiment
+    that zeroed the empty lines of sparse tiles in k_tile_label -- measured, slower, not merged: DESIGN section 4 -- and kept: the
+    sparse regime had no poisoned-arena case.)"""
+    from oracle import oracle as ora
+    from pdb_eda_amd import _native, synthetic
+    monkeypatch.setenv("PDBEDA_DEBUG_POISON", "1")
+    ctx = _native.Context(0)
+    cases = [((40, 48, 256), 21, 3.0), ((17, 23, 200), 22, 2.5), ((9, 30, 36), 23, 2.0), ((33, 20, 100), 24, 3.0), ((12, 9, 130), 25, 2.5),
+             ((24, 17, 600), 26, 3.0), ((24, 17, 516), 27, 3.5), ((10, 10, 67), 28, 2.5), ((70, 64, 128), 29, 4.0), ((16, 16, 256), 30, 50.0)]
+    for shape, seed, nsd in cases:
+        g = synthetic.smooth_noise(shape, seed, 1.5)
+        dm = _dm(g, ctx)
+        o = ora.Oracle(dm.header, g)
+        cut = dm.meanDensity + nsd * dm.stdDensity
+        for rep in range(2):   # (the second pass runs in the arena the first one gave back, poisoned again)
+            lists = dm._map.full_blobs_pm(cut, -cut, labels=True) if rep == 0 else (dm._map.full_blobs(cut, labels=True), dm._map.full_blobs(-cut, labels=True))
+            for bl, c in zip(lists, (cut, -cut)):
+                want = o.full_blobs(c, labels=True)
+                assert np.array_equal(bl.stats()["n"], want["n"]), (shape, nsd)
+                assert np.array_equal(bl.labels(dm._map.unique_shape), want["labels"]), (shape, nsd, rep)
+            for bl in lists:
+                bl.free()
+
+
 @pytest.mark.parametrize("nsd", [1.5, 0.5, 3.0])
 def test_protein_like_map_vs_oracle(gpu_ctx, nsd):
     """A chain of Gaussian atoms: ONE blob spans the map at 1.5 sigma (hot roots in the global union-find and in the

@@ -20,7 +20,7 @@ if sys.argv[1] == "build":
     assert cnt > 0, "no markers"
     open(os.path.join(dst, "pdbeda_tile.h"), "w").write(t)
     k = open(os.path.join(dst, "pdbeda_kernels.h")).read()
-    k = k.replace("    uint32_t *group_count;\n};", "    uint32_t *group_count;\n    unsigned long long *stamps;\n};", 1)
+    k = k.replace("    int32_t unit_form;\n};", "    int32_t unit_form;\n    unsigned long long *stamps;\n};", 1)
     assert "stamps" in k
     open(os.path.join(dst, "pdbeda_kernels.h"), "w").write(k)
     h = open(os.path.join(dst, "pdbeda_hip.hip")).read()

@@ -11,7 +11,8 @@ header = ccp4.DensityHeader.fromFileHeader(synthetic.ccp4_header_bytes(spec))
 ctx = _native.Context(0)
 dmap = _native.DeviceMap(ctx, grid, header.geometry())
 mean, std = dmap.stats()
-cut = mean + 1.5 * std
+nsd = float(sys.argv[1]) if len(sys.argv) > 1 else 1.5      # (python tools/profile_step.py 3.0: pdb_eda's own cutoff)
+cut = mean + nsd * std
 for _ in range(3):
     k = dmap.full_blobs_pm(cut, -cut, labels=True)
 ctx.synchronize()
@@ -20,4 +21,4 @@ for _ in range(10):
     k = dmap.full_blobs_pm(cut, -cut, labels=True)
 prof = ctx.profile_end()
 print(k[0].counters())
-print(os.environ.get("PDBEDA_LIB", "main").split("/")[-1], {a: round(ms / c * 1e3, 1) for a, (c, ms) in sorted(prof.items())})
+print(os.environ.get("PDBEDA_LIB", "main").split("/")[-1], "prezero=%s" % os.environ.get("PDBEDA_PREZERO", "1"), nsd, {a: round(ms / c * 1e3, 1) for a, (c, ms) in sorted(prof.items())})
