@@ -43,12 +43,14 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the bounded CPU-baseline sample")
     ap.add_argument("--windows", type=int, default=5, help="extra timed windows of --steps steps each (dispersion of ms_per_step)")
     ap.add_argument("--entries", type=int, default=125, help="multiple-structure leg (BASELINE configs[3]): entries per rank (1000 / 8 GPUs); 0 = skip")
-    ap.add_argument("--entry-files", type=int, default=16, help="multiple-structure leg: distinct entries on disk per rank (the entry list cycles through them)")
+    ap.add_argument("--entry-files", type=int, default=125, help="multiple-structure leg: distinct FILES on disk per rank (configs[3]: every entry of the list its own two files -- 125 x 64 MB = 8 GB, "
+                                                                 "beyond any last-level cache; the page cache does not deduplicate copies)")
+    ap.add_argument("--entry-generated", type=int, default=16, help="multiple-structure leg: distinct entries GENERATED per rank (0.3 s each); the other file names are byte copies of these, dealt round-robin")
     ap.add_argument("--entry-seconds", type=float, default=2.0, help="multiple-structure leg: repeat the entry list until the timed region is at least this long")
     ap.add_argument("--workers", type=int, default=4, help="multiple-structure leg: worker processes (= streams) per GPU")
     ap.add_argument("--entry-size", type=int, default=200, help="multiple-structure leg: grid edge of an entry (configs[3]: 200)")
     ap.add_argument("--entry-residues", type=int, default=100, help="multiple-structure leg: poly-ALA residues per entry (~500 atoms)")
-    ap.add_argument("--sweep-entries", type=int, default=32, help="optimise-mode leg (BASELINE configs[4]): resident entries per rank; 0 = skip")
+    ap.add_argument("--sweep-entries", type=int, default=63, help="optimise-mode leg (BASELINE configs[4]: a 500-entry list = 63 per rank at 8 GPUs): resident entries per rank; 0 = skip")
     ap.add_argument("--sweep-iterations", type=int, default=3, help="optimise-mode leg: parameter tables evaluated (one changed radius each)")
     ap.add_argument("--sweep-seconds", type=float, default=1.0, help="optimise-mode leg: repeat the sweep over the tables until the timed region is at least this long")
     ap.add_argument("--no-beyond-cache", action="store_true", help="skip the informational leg on a working set larger than the Infinity Cache")
@@ -175,13 +177,32 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
     tmp = tempfile.mkdtemp(prefix="pdbeda_bench_%d_" % rank)
     try:
         t0 = time.perf_counter()
-        distinct = max(1, args.entry_files)   # distinct synthetic entries on disk (each = 2 x 32 MB of CCP4 files at 200^3; generating one costs ~0.3 s)
+        # files on disk: `distinct` names (BASELINE configs[3]: every entry of a rank's list its own two CCP4 files), of which `generated` are
+        # distinct synthetic entries (0.3 s each) and the others byte copies of those under their own names -- own inodes, own pages in the
+        # page cache: a pass over the list reads 125 x 64 MB = 8 GB, beyond any last-level cache (16 files = 1 GB were re-read 13 x)
+        distinct = max(1, min(args.entry_files, args.entries))
+        generated = max(1, min(args.entry_generated, distinct))
         # entry 0 of every rank is the configs[3] entry the REFERENCE was run on (synthetic.BIG_CASES["c3_multiple_entry"]: 200^3, 100
         # residues, seed 0): its records are checked against the reference's numbers after every pool has returned
         golden_case = synthetic.BIG_CASES["c3_multiple_entry"]
         golden_ok = (args.entry_size, args.entry_residues) == (golden_case[0][0], golden_case[1])
         loaders = [synthetic.write_entry_files(tmp, "e%d" % k, args.entry_size, args.entry_residues, (golden_case[2] if k == 0 else 1000 * rank + k), as_paths=True)
-                   for k in range(distinct)]
+                   for k in range(generated)]
+        copy_error = None
+        for k in range(generated, distinct):       # name k = a copy of generated entry k % generated (same model, same record)
+            src = loaders[k % generated]
+            try:
+                paths = [os.path.join(tmp, "e%d%s.ccp4" % (k, suffix)) for suffix in ("", "_diff")]
+                for a, b in zip((src.density_path, src.diff_path), paths):
+                    shutil.copyfile(a, b)
+                loaders.append(synthetic.SyntheticEntryFiles(paths[0], paths[1], src.n_residues, src.seed, src.edge, src.spacing, True))
+            except OSError as error:               # (a small /tmp: the leg runs on the names it has, and says so)
+                copy_error = "%s: %s" % (type(error).__name__, error)
+                for path in paths:
+                    if os.path.exists(path):
+                        os.unlink(path)
+                break
+        distinct = len(loaders)
         gen_s = time.perf_counter() - t0
         golden = np.load(os.path.join(ROOT, "tests", "golden", "analysis_big_c3_multiple_entry.npz"), allow_pickle=False) if golden_ok else None
         checked = {"records": 0}
@@ -192,7 +213,7 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
             if golden is None:
                 return
             for i, r in enumerate(records):
-                if (i % args.entries) % distinct != 0:
+                if ((i % args.entries) % distinct) % generated != 0:      # (names 0, generated, 2 * generated, ... hold the golden entry's bytes)
                     continue
                 assert r, "the golden entry failed in the pool"
                 got = r["stats"]["density_electron_ratio"]
@@ -245,7 +266,7 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
             drop_error = "%s: %s" % (type(error).__name__, error)
         barrier()
         t0 = time.perf_counter()
-        cold_records = pool.map(entries[:distinct])
+        cold_records = pool.map(entries[:distinct])      # (every file of the rank once: 8 GB at the default sizes)
         barrier()
         cold_s = time.perf_counter() - t0
         check_golden(cold_records)
@@ -341,9 +362,11 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
                              "sample": "%d x %d^3 entries (%d atoms) per pass, repeated for %.0f s: read the 2Fo-Fc CCP4 file, numpy-tree mean / std, aggregateCloud "
                                        "(flattening + oracle composite + statistics tail), the entry's diffs -- multiprocessing.Pool(%d), one entry per task"
                                        % (len(tasks), args.entry_size, n_atoms, cpu_pool["seconds"], cores)})
-        return {"workload": "configs[3]: %d entries per rank, the list mapped `passes` times over in ONE call (%d distinct on disk = %.0f MB of CCP4 files per rank), each two CCP4 files of a %d^3 grid + a "
+        return {"workload": "configs[3]: %d entries per rank, the list mapped `passes` times over in ONE call (%d distinct files-pairs on disk = %.0f MB of CCP4 files per rank; %d generated entries, "
+                            "the other names byte copies of them), each two CCP4 files of a %d^3 grid + a "
                             "%d-atom model: read, parse, upload (BOTH maps: PDBEDA_EAGER_DIFF_MAP=1), aggregateCloud + the per-entry record of `pdb_eda multiple`"
-                            % (args.entries, distinct, distinct * file_mb, args.entry_size, n_atoms),
+                            % (args.entries, distinct, distinct * file_mb, generated, args.entry_size, n_atoms),
+                "distinct_files": distinct, "generated_entries": generated, "file_copy_error": copy_error,
                 "entries": total_done, "entries_ok": ok, "passes": passes, "workers_per_gpu": args.workers, "seconds": elapsed,
                 "entries_per_min": 60.0 * total_done / elapsed, "entries_per_min_per_gpu": 60.0 * total_done / world / elapsed,
                 "entries_per_min_per_rank": [round(v, 1) for v in per_rank],
@@ -890,6 +913,9 @@ def main():
                      "frac_on_event_time": dom_bytes / (per_kernel[dominant]["event_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                      "rocprofv3_avg_us": rocprof_avg_us,
                      "d2d_copy_ceiling_GBs": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs,
+                     # (the dispersion of the host-timed step rides in this object too: the driver's record keeps `roofline` whole)
+                     "ms_per_step_windows": {"n": len(windows), "steps_each": args.steps, "min": min(windows) if windows else None,
+                                             "median": float(np.median(windows)) if windows else None, "max": max(windows) if windows else None},
                      "timing": "HIP events on the launch stream (separate %d-step pass), minus the per-launch event gap calibrated in this run: "
                                "%.2f us = (sum of event times %.1f us - host-timed step %.1f us) / %.0f launches" % (args.steps, gap_us, step_events_us, step_wall_us, n_launch),
                      "pass_8B_per_voxel": {"bytes": 8 * n_vox, "kernel_sum_us": 1e6 * step_kernel_s,

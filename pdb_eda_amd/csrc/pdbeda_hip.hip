@@ -26,6 +26,7 @@
 
 #include "pdbeda_kernels.h"
 #include "pdbeda_tile.h"
+#include "pdbeda_upload.h"
 
 using namespace pdbeda;
 
@@ -409,14 +410,15 @@ struct D2HItem { void *dst; const void *src; size_t bytes; };
 static hipError_t d2h_many(pdbeda_ctx *ctx, const D2HItem *items, int n_items) {
     int live[8], n = 0;
     size_t total = 0;
-    bool packable = ctx->dev_stage != nullptr && ctx->pinned != nullptr;
+    bool packable = (ctx->dev_stage != nullptr || copy_kernels()) && ctx->pinned != nullptr;
     for (int k = 0; k < n_items; ++k) {
         if (!items[k].dst || items[k].bytes == 0) continue;
         if (n == 8 || (items[k].bytes & 3u) || ((uintptr_t)items[k].src & 3u)) { packable = false; break; }
         live[n++] = k;
         total += (items[k].bytes + 63) & ~(size_t)63;
     }
-    if (packable && n >= 2 && ctx->dev_stage_used + total <= ctx->dev_stage_cap && ctx->pinned_used + total <= ctx->pinned_cap) {
+    const bool via_dev_stage = !copy_kernels();      // (with copy kernels k_pack writes straight into the pinned block: nothing is staged on the device)
+    if (packable && n >= 2 && (!via_dev_stage || ctx->dev_stage_used + total <= ctx->dev_stage_cap) && ctx->pinned_used + total <= ctx->pinned_cap) {
         PackArgs a;
         memset(&a, 0, sizeof a);
         a.n = n;
@@ -435,7 +437,7 @@ static hipError_t d2h_many(pdbeda_ctx *ctx, const D2HItem *items, int n_items) {
         hipError_t e = hipGetLastError();
         if (e == hipSuccess && !copy_kernels()) e = hipMemcpyAsync(ctx->pinned + ctx->pinned_used, block, total, hipMemcpyDeviceToHost, ctx->stream);
         if (e != hipSuccess) { for (int j = 0; j < n; ++j) ctx->pending.pop_back(); return e; }
-        ctx->dev_stage_used += total;
+        if (via_dev_stage) ctx->dev_stage_used += total;
         ctx->pinned_used += total;
         return hipSuccess;
     }
@@ -502,7 +504,10 @@ extern "C" int pdbeda_ctx_create_on_stream(int device_id, void *hip_stream, pdbe
         delete ctx;
         return PDBEDA_ERR_MEMORY;
     }
-    if (hipHostMalloc((void **)&ctx->pinned, 4 << 20, hipHostMallocDefault) == hipSuccess) ctx->pinned_cap = 4 << 20;   // (without it results are copied directly)
+    // (coherent + mapped, explicitly: with PDBEDA_COPY_KERNELS the staged results are WRITTEN BY KERNELS into this block and read by the host after the
+    //  stream wait -- or after a hipStreamQuery poll under the watchdog --, which is only right for coherent host memory)
+    if (hipHostMalloc((void **)&ctx->pinned, 4 << 20, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess) ctx->pinned_cap = 4 << 20;   // (without it results are copied directly)
+    else (void)hipGetLastError();
     if (ctx->pinned_cap && hipMalloc((void **)&ctx->dev_stage, 2 << 20) == hipSuccess) ctx->dev_stage_cap = 2 << 20; else { ctx->dev_stage = nullptr; (void)hipGetLastError(); }
     if (const char *v = getenv("PDBEDA_DEBUG_POISON")) ctx->debug_poison = v[0] && v[0] != '0';
     if (const char *v = getenv("PDBEDA_DEBUG_SHRINK_TOTALS")) ctx->debug_shrink_totals = v[0] && v[0] != '0';
@@ -711,144 +716,30 @@ static hipError_t event_wait(pdbeda_ctx *ctx, hipEvent_t ev) {
 }
 
 // The grid of a CCP4 file straight into HBM: pread() fills pinned chunks while earlier ones are on their way over PCIe, and
-// no host copy of the map is ever made (ccp4.py:77-127 unpacks it into a Python tuple).  The readers are the PROCESS's (UploadEngine, below:
-// three threads, two pinned chunks and a copy stream each); rounds 3-4 gave every context a ring and two readers of its own.  A thread copies
-// out of the page cache at 20-40 GB/s (by host), one copy engine moves 54 GB/s: one 32 MB map alone arrives in 0.76-0.85 ms, four loads in
-// flight move 50-53 GB/s (`tools/exp/single_load.py`, `trace_load.sh`; a pageable copy out of an mmap of the file runs at link speed only
-// while its pages stay mapped -- a fresh mapping per file pays 0.6 ms of page faults per 32 MB before the first byte moves).
+// no host copy of the map is ever made (ccp4.py:77-127 unpacks it into a Python tuple).  The readers are the PROCESS's (UploadEngine,
+// pdbeda_upload.h: three threads, two pinned chunks and a copy stream each); rounds 3-4 gave every context a ring and two readers of its own.
+// A thread copies out of the page cache at 20-40 GB/s (by host), one copy engine moves 54 GB/s: one 32 MB map alone arrives in 0.76-0.85 ms,
+// four loads in flight move 50-53 GB/s (`tools/exp/single_load.py`, `trace_load.sh`; a pageable copy out of an mmap of the file runs at link
+// speed only while its pages stay mapped -- a fresh mapping per file pays 0.6 ms of page faults per 32 MB before the first byte moves).
 // byteswap: the file has the other endianness.
-static const long FILE_CHUNK_MAX_KB = 16384;   // the most a chunk may be; chunks (= a reader's pinned slots) are 8 MiB by default (four workers, both maps: 4 MiB 1.44-1.45 ms per entry, 8 MiB 1.40-1.42, 16 MiB 1.39-1.40)
-static size_t file_chunk_bytes() {   // (PDBEDA_FILE_CHUNK_KB: experiments)
-    static const size_t v = [] { const char *e = getenv("PDBEDA_FILE_CHUNK_KB"); long kb = e ? atol(e) : 8192; return (size_t)std::min<long>(std::max<long>(kb, 64), FILE_CHUNK_MAX_KB) << 10; }();
-    return v;
-}
-#define FILE_CHUNK (file_chunk_bytes())
-// A load that finds the engine idle is cut into smaller chunks: with nobody else's copies to fill the link, the pread of a full chunk (0.2-0.4 ms at
-// the 20-40 GB/s of one thread) is time the link idles at the start of the map; with other loads in flight the larger chunk's fewer copies win
-// (one engine serves the copies one after another, 6 us apart).  PDBEDA_FILE_CHUNK_ALONE_KB (experiments; 0 = the full chunk always): one 32 MB map alone
-// 0.85 ms with 8 MiB chunks, 0.77 with 4 or 2, 1.0 with 1; a pool of four worker processes (each engine mostly sees one load) is the same within its noise.
-static size_t file_chunk_alone_bytes() {
-    static const size_t v = [] {
-        const char *e = getenv("PDBEDA_FILE_CHUNK_ALONE_KB");
-        const long kb = e ? atol(e) : 4096;
-        return kb <= 0 ? file_chunk_bytes() : std::min(file_chunk_bytes(), std::max<size_t>((size_t)kb << 10, (size_t)64 << 10));
-    }();
-    return v;
-}
-static unsigned reader_spins() { static const unsigned v = [] { const char *e = getenv("PDBEDA_READER_SPINS"); return e ? (unsigned)atoi(e) : 4u; }(); return v; }
-// ---- The upload engine: ONE per process and device ------------------------------------------------------------------------
-// A map read from a file goes to HBM in 4 MiB chunks: a reader thread pread()s a chunk out of the page cache into one of its
-// two pinned slots and queues the slot's PCIe copy on its own stream.  A single pread stream moves ~10 GB/s --
-// a kernel memcpy --, so ONE map needs five or six readers to fill a 57 GB/s link: rounds 3-4 gave every context two readers of
-// its own (18 GB/s for a lone load; the pools reached the link only with eight loads in flight, i.e. sixteen reader threads and
-// 128 MiB of pinned rings).  Now the readers belong to the process: the chunks of every load in flight go through one FIFO, a
-// lone load gets all readers, and the number of threads and pinned chunks does not grow with the number of contexts.
-static const int FILE_READERS_DEFAULT = 3;
-struct UploadLoad {
-    int fd = -1;                                   // the source: a file (pread at offset + position) ...
-    int64_t offset = 0;
-    const char *src = nullptr;                     // ... or the caller's memory (fd < 0)
-    char *dst = nullptr;
-    size_t need = 0;
-    int64_t n_chunks = 0;
-    std::vector<std::pair<size_t, size_t>> pieces;   // (position, length) of chunk k: small ones first -- the link starts while the big ones are read
-    double timeout_s = 0.0;
-    std::chrono::steady_clock::time_point deadline;
-    std::mutex mu;
-    std::condition_variable cv;
-    int64_t handled = 0;                          // chunks whose copy is queued, or that were given up
-    hipError_t e = hipSuccess;
-    const char *why = nullptr;
-    bool timed_out = false;
-    bool used[pdbeda_ctx::MAX_READERS] = {false, false, false, false, false, false, false, false};
-    bool failed() { return e != hipSuccess || why || timed_out; }   // (under mu)
-    // PDBEDA_UPLOAD_TRACE=1 (experiments): seconds spent in pread / in the runtime's calls, summed over the readers
-    double t_pread = 0.0, t_queue = 0.0, t_slot = 0.0;
-    int chunks_by[pdbeda_ctx::MAX_READERS] = {0, 0, 0, 0, 0, 0, 0, 0};
-};
-static bool upload_trace() { static const bool v = [] { const char *e = getenv("PDBEDA_UPLOAD_TRACE"); return e && e[0] && e[0] != '0'; }(); return v; }
-static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-
-struct UploadEngine {
-    int device = 0, n_readers = 0;
-    std::atomic<int> active{0};   // loads between their submission and their last chunk
-    std::mutex mu;
-    std::condition_variable cv;
-    std::deque<std::pair<UploadLoad *, int64_t>> chunks;
-    struct Reader {
-        hipStream_t stream = nullptr;
-        char *slot[2] = {nullptr, nullptr};
-        hipEvent_t done[2] = {nullptr, nullptr};
-        int64_t count = 0;
-        bool ok = false;
-    } readers[pdbeda_ctx::MAX_READERS];
-
-    void run(int r) {
-        Reader &me = readers[r];
-        (void)hipSetDevice(device);
-        for (;;) {
-            std::pair<UploadLoad *, int64_t> task;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return !chunks.empty(); });
-                task = chunks.front();
-                chunks.pop_front();
-            }
-            UploadLoad *ld = task.first;
-            const int64_t c = task.second;
-            bool skip;
-            {
-                std::lock_guard<std::mutex> g(ld->mu);
-                skip = ld->failed();
-            }
-            hipError_t ce = hipSuccess;
-            const char *why = nullptr;
-            bool timed_out = false, queued = false;
-            double t_a = 0, t_b = 0, t_c = 0, t_d = 0;
-            if (!skip) {
-                const int slot = (int)(me.count & 1);
-                t_a = now_s();
-                if (me.count >= 2) {   // the chunk sent from this slot two rounds ago must have left it
-                    for (unsigned spins = 0;; ++spins) {
-                        const hipError_t q = hipEventQuery(me.done[slot]);
-                        if (q == hipSuccess) break;
-                        if (q != hipErrorNotReady) { ce = q; break; }
-                        if (spins >= reader_spins()) {   // (no long busy poll: six readers hammering hipEventQuery slowed every OTHER thread's runtime calls)
-                            if (ld->timeout_s > 0.0 && std::chrono::steady_clock::now() > ld->deadline) { timed_out = true; break; }   // (the entry's one deadline, as ctx_wait)
-                            std::this_thread::sleep_for(std::chrono::microseconds(30));
-                        }
-                    }
-                }
-                t_b = now_s();
-                if (ce == hipSuccess && !timed_out) {
-                    const size_t pos = ld->pieces[(size_t)c].first, len = ld->pieces[(size_t)c].second;
-                    if (ld->fd < 0) memcpy(me.slot[slot], ld->src + pos, len);
-                    for (size_t got = 0; ld->fd >= 0 && got < len;) {
-                        const ssize_t n = pread(ld->fd, me.slot[slot] + got, len - got, (off_t)(ld->offset + (int64_t)pos + (int64_t)got));
-                        if (n < 0 && errno == EINTR) continue;
-                        if (n <= 0) { why = n < 0 ? strerror(errno) : "unexpected end of file"; break; }
-                        got += (size_t)n;
-                    }
-                    t_c = now_s();
-                    if (!why) {
-                        ce = hipMemcpyAsync(ld->dst + pos, me.slot[slot], len, hipMemcpyHostToDevice, me.stream);
-                        if (ce == hipSuccess) ce = hipEventRecord(me.done[slot], me.stream);
-                        if (ce == hipSuccess) { queued = true; ++me.count; }
-                    }
-                    t_d = now_s();
-                }
-            }
-            {
-                std::lock_guard<std::mutex> g(ld->mu);
-                if (ce != hipSuccess && ld->e == hipSuccess) ld->e = ce;
-                if (why && !ld->why) ld->why = why;
-                if (timed_out) ld->timed_out = true;
-                if (queued) ld->used[r] = true;
-                ld->t_slot += t_b - t_a; ld->t_pread += t_c - t_b; ld->t_queue += t_d - t_c; ld->chunks_by[r]++;
-                if (++ld->handled == ld->n_chunks) ld->cv.notify_all();   // (the load lives on its caller's stack: nothing of it is touched after this)
-            }
-        }
-    }
+//
+// Round 6: the engine itself lives in pdbeda_upload.h and reaches the runtime through a table of function pointers -- the HIP calls below
+// here, a host stand-in in tests/upload_harness.cpp, where the engine runs under ThreadSanitizer and AddressSanitizer (tools/sanitize_cpu.sh).
+using pdbeda_upload::UploadEngine;
+using pdbeda_upload::UploadLoad;
+using pdbeda_upload::now_s;
+using pdbeda_upload::upload_trace;
+static_assert(pdbeda_ctx::MAX_READERS == pdbeda_upload::MAX_READERS, "a context keeps one event per reader");
+static int up_code(hipError_t e) { return e == hipSuccess ? pdbeda_upload::UP_OK : (e == hipErrorNotReady ? pdbeda_upload::UP_NOT_READY : (int)e); }
+static hipError_t up_error(int code) { return code == pdbeda_upload::UP_OK ? hipSuccess : (code < 0 ? hipErrorUnknown : (hipError_t)code); }
+static const pdbeda_upload::Backend g_hip_backend = {
+    [](int device) { return up_code(hipSetDevice(device)); },
+    [](pdbeda_upload::Stream *out) { hipStream_t s = nullptr; const hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking); if (e != hipSuccess) (void)hipGetLastError(); *out = (void *)s; return up_code(e); },
+    [](void **out, size_t bytes) { const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault); if (e != hipSuccess) (void)hipGetLastError(); return up_code(e); },
+    [](pdbeda_upload::Event *out) { hipEvent_t ev = nullptr; const hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming); if (e != hipSuccess) (void)hipGetLastError(); *out = (void *)ev; return up_code(e); },
+    [](pdbeda_upload::Event ev) { return up_code(hipEventQuery((hipEvent_t)ev)); },
+    [](void *dst, const void *src, size_t bytes, pdbeda_upload::Stream s) { return up_code(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)s)); },
+    [](pdbeda_upload::Event ev, pdbeda_upload::Stream s) { return up_code(hipEventRecord((hipEvent_t)ev, (hipStream_t)s)); },
 };
 
 static std::mutex g_engine_mu;
@@ -858,23 +749,7 @@ static UploadEngine *upload_engine(int device) {
     std::lock_guard<std::mutex> g(g_engine_mu);
     auto it = g_engines.find(device);
     if (it != g_engines.end()) return it->second;
-    UploadEngine *en = new UploadEngine();
-    en->device = device;
-    int want = FILE_READERS_DEFAULT;
-    if (const char *v = getenv("PDBEDA_FILE_READERS")) want = atoi(v);
-    want = std::max(1, std::min(want, (int)pdbeda_ctx::MAX_READERS));
-    for (int r = 0; r < want; ++r) {
-        UploadEngine::Reader &rd = en->readers[en->n_readers];
-        bool ok = hipStreamCreateWithFlags(&rd.stream, hipStreamNonBlocking) == hipSuccess;
-        for (int k = 0; k < 2 && ok; ++k)
-            ok = hipHostMalloc((void **)&rd.slot[k], FILE_CHUNK, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&rd.done[k], hipEventDisableTiming) == hipSuccess;
-        if (!ok) { (void)hipGetLastError(); break; }   // (fewer readers than asked for: what was made so far serves)
-        rd.ok = true;
-        ++en->n_readers;
-    }
-    for (int r = 0; r < en->n_readers; ++r) {
-        try { std::thread(&UploadEngine::run, en, r).detach(); } catch (...) { en->n_readers = r; break; }
-    }
+    UploadEngine *en = UploadEngine::create(&g_hip_backend, device);
     g_engines[device] = en;
     return en;
 }
@@ -905,42 +780,19 @@ static hipError_t engine_copy(pdbeda_ctx *ctx, UploadEngine *engine, int fd, int
     if (e == hipSuccess && !ctx->timed_out) {
         UploadLoad ld;
         ld.fd = fd; ld.offset = offset; ld.src = src; ld.dst = dst; ld.need = need;
-        // chunk sizes ramp up: a pread of a full chunk takes the better part of a millisecond before its copy can start -- with every reader on such a chunk the
-        // link idled for the first 0.4 ms of every map; the first round is 256 KiB each, the second 1 MiB, then full chunks
-        const size_t full = engine->active.fetch_add(1) == 0 ? file_chunk_alone_bytes() : FILE_CHUNK;
-        for (size_t pos = 0, k = 0; pos < need; ++k) {
-            const size_t round = k / (size_t)engine->n_readers;
-            const size_t len = std::min(need - pos, round == 0 ? std::min(full, (size_t)256 << 10) : (round == 1 ? std::min(full, (size_t)1 << 20) : full));
-            ld.pieces.emplace_back(pos, len);
-            pos += len;
-        }
-        ld.n_chunks = (int64_t)ld.pieces.size();
         ld.timeout_s = ctx->timeout_s;
         ld.deadline = ctx->deadline;
-        const double t_q = now_s();
-        {
-            std::lock_guard<std::mutex> g(engine->mu);
-            for (int64_t c = 0; c < ld.n_chunks; ++c) engine->chunks.emplace_back(&ld, c);
-        }
-        engine->cv.notify_all();
-        {
-            std::unique_lock<std::mutex> lk(ld.mu);
-            ld.cv.wait(lk, [&] { return ld.handled == ld.n_chunks; });   // (a reader gives a chunk up at the entry's deadline: this wait ends)
-        }
-        engine->active.fetch_sub(1);
-        if (upload_trace())
-            fprintf(stderr, "upload %.1f MB: chunks handled after %.3f ms; readers' sums: slot wait %.3f, pread %.3f, queueing %.3f ms; chunks by reader %d %d %d %d %d %d %d %d\n",
-                    need / 1e6, 1e3 * (now_s() - t_q), 1e3 * ld.t_slot, 1e3 * ld.t_pread, 1e3 * ld.t_queue, ld.chunks_by[0], ld.chunks_by[1], ld.chunks_by[2],
-                    ld.chunks_by[3], ld.chunks_by[4], ld.chunks_by[5], ld.chunks_by[6], ld.chunks_by[7]);
+        engine->submit(ld);      // (chunked, queued on the readers' streams or given up: pdbeda_upload.h)
         // the context's stream waits for the readers' copies of THIS map: an event behind whatever each reader has queued so far
         // (a little more than needed when it has gone on to another load's chunk -- never less)
         for (int r = 0; r < engine->n_readers; ++r) {
             if (!ld.used[r]) continue;
-            hipError_t je = hipEventRecord(ctx->reader_ev[r], engine->readers[r].stream);
+            hipError_t je = hipEventRecord(ctx->reader_ev[r], (hipStream_t)ld.stream_used[r]);      // (the stream this load's chunks went to: the reader may have taken a new one since)
             if (je == hipSuccess) je = hipStreamWaitEvent(ctx->stream, ctx->reader_ev[r], 0);
             if (je != hipSuccess && e == hipSuccess) e = je;
         }
-        if (ld.e != hipSuccess && e == hipSuccess) e = ld.e;
+        if (ld.e != pdbeda_upload::UP_OK && e == hipSuccess) e = up_error(ld.e);
+        if (ld.stalled && e == hipSuccess) { e = hipErrorNotReady; if (!ld.why) ld.why = "a copy stream of the upload engine stalled behind another copy and was given up; the map is incomplete"; }
         *why = ld.why;
         if (ld.timed_out) {
             ctx->timed_out = true;
@@ -1759,6 +1611,7 @@ static int list_stats_one_trip(pdbeda_bloblist *bl, int64_t guess, std::vector<i
             n.resize(nb); tot.resize(nb); cen.resize(3 * nb); grp.resize(nb);
             return PDBEDA_OK;
         }
+        extra = nullptr;      // (the guess was too small for the table; the caller's extra result has arrived with this first wait all the same)
     }
     if (extra && extra->dst && extra->bytes) HIP_TRY(ctx, d2h(ctx, extra->dst, extra->src, extra->bytes));      // (delivered by the waits below)
     const int64_t nb = pdbeda_bloblist_count(bl);
@@ -2145,7 +1998,7 @@ static int grouped_job(pdbeda_map *m, GroupSetup &gs, int64_t n_items, int64_t n
             { PROF(ctx, "k_sphere_paint"); hipLaunchKernelGGL(k_sphere_paint, dim3((unsigned)n_items), dim3(256), 0, st, m->geom_dev, m->dens, gs.d_xyz, gs.d_radii,
                                gs.d_item_group, gs.d_boxes, job.vols, job.mask, cutoff, gs.d_ctr, job.ctr); }
         else if (pool)      // (aggregateCloud's union job: the pooled voxels painted straight from the clouds' lists, the bonded pairs tested by the same launch)
-            { PROF(ctx, "k_pool_paint"); hipLaunchKernelGGL(k_pool_paint, dim3(pool->paint_blocks + (unsigned)pool->n_pairs), dim3(256), 0, st, *pool, job.vols, job.mask); }
+            { PoolPaint pp = *pool; pp.ctr = job.ctr; PROF(ctx, "k_pool_paint"); hipLaunchKernelGGL(k_pool_paint, dim3(pp.paint_blocks + (unsigned)pp.n_pairs), dim3(256), 0, st, pp, job.vols, job.mask); }
         else
             { PROF(ctx, "k_list_paint"); hipLaunchKernelGGL(k_list_paint, dim3(grid_for(n_items, 256)), dim3(256), 0, st, gs.d_crs, gs.d_item_group, n_items, job.vols, job.mask); }
         e = hipGetLastError();

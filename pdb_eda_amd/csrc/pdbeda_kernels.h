@@ -1867,6 +1867,7 @@ struct PoolPaint {
     int n_pool; int domain_group; long long V;
     const int64_t *set_off; const int32_t *pair_a, *pair_b; unsigned int *touch; int n_pairs;
     unsigned int paint_blocks;
+    Counters *ctr;      // the union job's: a voxel outside its group's host-made volume raises unit_wait_failed (the host turns that into an error)
 };
 __global__ void __launch_bounds__(256) k_pool_paint(PoolPaint a, const VolDesc *__restrict__ vols, uint64_t *__restrict__ mask) {
     if (blockIdx.x >= a.paint_blocks) {      // block-uniform
@@ -1885,6 +1886,13 @@ __global__ void __launch_bounds__(256) k_pool_paint(PoolPaint a, const VolDesc *
     const long long src = a.src_off[a.pool_cloud[lo]] + (j - a.pool_voff[lo]);
     const VolDesc vd = vols[dom ? a.domain_group : a.pool_group[lo]];
     const int lc = a.src_crs[3 * src] - vd.org[0], lr = a.src_crs[3 * src + 1] - vd.org[1], ls = a.src_crs[3 * src + 2] - vd.org[2];
+    // The volumes are the HOST's (the box around the sphere boxes of a group's pooled atoms, pdbeda_aggregate_cloud); the voxels come from
+    // the clouds the device painted inside those sphere boxes.  Same xyz2crs, same radius, same alias rule -- should the two ever drift
+    // apart, nothing is written outside the arena: the job is flagged and the call fails
+    if ((unsigned)lc >= (unsigned)vd.dim[0] || (unsigned)lr >= (unsigned)vd.dim[1] || (unsigned)ls >= (unsigned)vd.dim[2]) {
+        a.ctr->unit_wait_failed = 1u;
+        return;
+    }
     const int64_t w = vd.word_base + ((int64_t)ls * vd.dim[1] + lr) * vd.row_words + (lc >> 6);
     atomicOr((unsigned long long *)&mask[w], 1ull << (lc & 63));
 }

@@ -143,6 +143,53 @@ def test_watchdog_abandons_a_context():
     assert lib.pdbeda_reap_abandoned() == 0
 
 
+def _sorted_lists(crs, off):
+    """Voxel lists with every blob's rows sorted (the order inside a blob is the order its runs took their places in: not fixed)."""
+    crs = np.asarray(crs).copy()
+    for a, b in zip(off[:-1], off[1:]):
+        rows = crs[a:b]
+        crs[a:b] = rows[np.lexsort((rows[:, 2], rows[:, 1], rows[:, 0]))]
+    return crs, np.asarray(off)
+
+
+@pytest.mark.timeout(120)
+def test_staged_results_under_the_watchdog_equal_those_without(gpu_ctx):
+    """with PDBEDA_COPY_KERNELS (the default) every staged result -- packed tables, counters, regional sums -- is written by a
+    KERNEL into the context's pinned block, and under the watchdog the host reads it after a hipStreamQuery POLL instead of a stream
+    synchronize.  The same calls on a context with an armed (generous) time-out and on one without: identical results, bit for bit."""
+    from pdb_eda_amd import _native, ccp4, synthetic
+    g = synthetic.smooth_noise((40, 48, 96), 17, 1.5)
+    spec = synthetic.MapSpec(ncrs=(96, 48, 40), spacing=0.5)
+    header = ccp4.DensityHeader.fromFileHeader(synthetic.ccp4_header_bytes(spec))
+    xyz = np.array([[6.0, 7.0, 8.0], [12.5, 9.25, 6.0], [20.0, 11.0, 9.5], [30.0, 12.0, 10.0]])
+    rad = np.array([1.5, 2.0, 1.2, 2.4])
+    out = []
+    for timed in (False, True):
+        ctx = _native.Context(0)
+        if timed:
+            ctx.set_timeout(60.0)
+        m = _native.DeviceMap(ctx, g, header.geometry())
+        mean, std = m.stats()
+        cut = mean + 1.5 * std
+        green, red = m.full_blobs_pm(cut, -cut, labels=True)
+        sp = m.sphere_blobs(xyz, rad, np.arange(5), cut)
+        sums = m.region_sums(xyz, rad, np.arange(5), cut) if hasattr(m, "region_sums") else None
+        rec = {"mean": mean, "std": std, "green": green.stats(), "red": red.stats(), "labels": green.labels(m.unique_shape), "sphere": sp.stats(), "vox": _sorted_lists(*sp.voxels()), "sums": sums}
+        out.append(rec)
+        ctx.close()
+
+    def same(a, b):
+        if isinstance(a, dict):
+            return set(a) == set(b) and all(same(a[k], b[k]) for k in a)
+        if isinstance(a, (tuple, list)):
+            return len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+        if a is None:
+            return b is None
+        return np.array_equal(np.asarray(a), np.asarray(b))
+    for key in out[0]:
+        assert same(out[0][key], out[1][key]), key
+
+
 @pytest.mark.timeout(120)
 def test_watchdog_deadline_is_per_entry_not_per_wait():
     """One deadline for ALL waits of an entry (the reference's SIGALRM is around the whole of analyzePDBID): many short waits

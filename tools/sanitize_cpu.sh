@@ -21,3 +21,13 @@ gcc $SAN -shared -fPIC -ffp-contract=off -fno-fast-math -Wall -Wextra -o oracle/
 export LD_PRELOAD="$asan" ASAN_OPTIONS=detect_leaks=0:abort_on_error=1:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
 export PDBEDA_DEBUG_HOSTWALK=${PDBEDA_DEBUG_HOSTWALK:-1}
 python3 -m pytest tests -q -m "not gpu" -p no:cacheprovider "$@"
+unset LD_PRELOAD
+# Round 6: the upload engine of libpdbeda_hip.so (pdb_eda_amd/csrc/pdbeda_upload.h: reader threads, FIFO, slot recycling, deadlines,
+# stalled-stream replacement) on the host stand-in of tests/upload_harness.cpp, under ThreadSanitizer and again under ASan + UBSan
+for san in "thread" "address,undefined -fno-sanitize-recover=undefined"; do
+  g++ -std=c++17 -O1 -g -pthread -fno-omit-frame-pointer -fsanitize=$san -Ipdb_eda_amd/csrc tests/upload_harness.cpp -o /tmp/upload_harness_san
+  for scenario in many deadline stall; do
+    echo "upload engine, -fsanitize=${san%% *}, $scenario:"
+    TSAN_OPTIONS=halt_on_error=1:second_deadlock_stack=1 ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 /tmp/upload_harness_san $scenario
+  done
+done
