@@ -1221,11 +1221,11 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
 }
 
 // Enqueue the labelling engine on a job whose masks are already painted.
-static int engine_enqueue(pdbeda_ctx *ctx, pdbeda_map *m, Job &job, int64_t max_runs) {
+static int engine_enqueue(pdbeda_ctx *ctx, pdbeda_map *m, Job &job, int64_t max_runs, bool labelled = false) {   // labelled: k_atom_engine has done everything up to the painted keys
     hipStream_t st = ctx->stream;
     // per-run kernels are grid-stride over the ACTUAL run count (read on the device)
     const unsigned run_grid = grid_for(max_runs, 256, 2048);
-    if (job.total_words > 0) {
+    if (job.total_words > 0 && !labelled) {
         {   // few words in large volumes: a quarter of the words a block, four times the blocks (the loop over a wave's words is
             // serial; the rows of many small volumes -- atom spheres -- are mostly narrow: a thread each, 256 to the block)
             PROF(ctx, "k_run_index");
@@ -1755,6 +1755,7 @@ struct GroupSetup {
     Counters *d_ctr = nullptr;
     int64_t total_words = 0, total_keys = 0;
     bool host_totals = false;   // the totals are the host's (per-atom spheres): nobody waited for the device's -- k_make_vols checks them
+    bool atom_engine = false;   // per-atom spheres whose boxes the host made, every box one mask word a row and at most ATOM_WORDS rows: ONE launch labels the batch (k_atom_engine)
     // staged inputs whose copy into the device scratch has not been launched yet: grouped_job's k_job_init does it (one launch less), flush_pending for everybody else
     const char *pend_src = nullptr;
     char *pend_dst = nullptr;
@@ -1888,6 +1889,7 @@ static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, con
             int64_t words = 0, keys = 0;
             float cached_rad = NAN;
             int32_t R[3] = {0, 0, 0};
+            bool small_boxes = true;
             for (int64_t a = 0; a < n_items; ++a) {
                 if (!(radii[a] == cached_rad)) {
                     const double rad = (double)radii[a];
@@ -1914,6 +1916,7 @@ static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, con
                 vd.word_base = words;
                 vd.key_base = keys;
                 vols[a] = vd;
+                small_boxes = small_boxes && vd.row_words <= 1 && (int64_t)vd.dim[1] * vd.dim[2] <= ATOM_WORDS;
                 words += (int64_t)vd.row_words * vd.dim[1] * vd.dim[2];
                 keys += (int64_t)vd.dim[0] * vd.dim[1] * vd.dim[2];
             }
@@ -1927,6 +1930,8 @@ static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, con
                 gs->total_words = words;
                 gs->total_keys = keys;
                 gs->host_totals = true;
+                static const bool atom_engine_on = [] { const char *e = getenv("PDBEDA_ATOM_ENGINE"); return !(e && e[0] == '0'); }();   // (A/B switch)
+                gs->atom_engine = small_boxes && atom_engine_on && n_items < (1ll << 31);
                 if (gs->total_words >= (1ll << 31) * 2) return fail(ctx, PDBEDA_ERR_ARGUMENT, "sphere batch too large (%lld mask words)", (long long)gs->total_words);
                 return 0;
             }
@@ -1993,7 +1998,12 @@ static int grouped_job(pdbeda_map *m, GroupSetup &gs, int64_t n_items, int64_t n
         e = hipGetLastError();
         gs.pend_bytes = 0;
     }
-    if (e == hipSuccess && n_items > 0) {
+    const bool fused_atoms = spheres && gs.atom_engine && n_items > 0 && n_items == n_groups;
+    if (e == hipSuccess && fused_atoms) {   // a per-atom batch of small boxes: paint, run index, unions, resolve and key painting in one launch
+        PROF(ctx, "k_atom_engine");
+        hipLaunchKernelGGL(k_atom_engine, dim3((unsigned)n_items), dim3(256), 0, st, job, m->geom_dev, m->dens, gs.d_xyz, gs.d_radii, gs.d_boxes, cutoff);
+        e = hipGetLastError();
+    } else if (e == hipSuccess && n_items > 0) {
         if (spheres)
             { PROF(ctx, "k_sphere_paint"); hipLaunchKernelGGL(k_sphere_paint, dim3((unsigned)n_items), dim3(256), 0, st, m->geom_dev, m->dens, gs.d_xyz, gs.d_radii,
                                gs.d_item_group, gs.d_boxes, job.vols, job.mask, cutoff, gs.d_ctr, job.ctr); }
@@ -2003,7 +2013,7 @@ static int grouped_job(pdbeda_map *m, GroupSetup &gs, int64_t n_items, int64_t n
             { PROF(ctx, "k_list_paint"); hipLaunchKernelGGL(k_list_paint, dim3(grid_for(n_items, 256)), dim3(256), 0, st, gs.d_crs, gs.d_item_group, n_items, job.vols, job.mask); }
         e = hipGetLastError();
     }
-    if (e == hipSuccess) rc = engine_enqueue(ctx, m, job, max_runs);
+    if (e == hipSuccess) rc = engine_enqueue(ctx, m, job, max_runs, fused_atoms);
     // (the inputs are consumed by the paint kernel: whoever gets their arena next is enqueued behind it on this stream)
     arena_put(ctx, gs.in_arena);
     if (e != hipSuccess || rc) {

@@ -614,57 +614,59 @@ __device__ inline uint32_t n_components(const JobRef &job) { return job.comps_ar
 // so the lanes of a wave mostly belong to a handful of components: the lanes that share a root are summed in the wave
 // first and ONE lane sends the nine atomics (a 200-run atom cloud used to send 200 x 9 to the same cache line, where they
 // serialise).
+// (one wave's share: component i of the lane, or none -- every lane of the wave must call)
+__device__ inline void resolve_wave(const Job &job, uint32_t i, bool valid, int lane) {
+    int root = -1;
+    if (valid) {
+        root = uf_find(job.parent, (int)i);
+        if (root == (int)i) root = -1; else job.parent[i] = root;
+    }
+    uint32_t n = 0;
+    FixSums sum = fix_zero();
+    unsigned long long c = 0, r = 0, sv = 0, key = ~0ull;
+    if (root >= 0) {
+        n = job.r_n[i]; sum = fix_load(job, i);
+        c = (unsigned long long)job.r_c[i]; r = (unsigned long long)job.r_r[i]; sv = (unsigned long long)job.r_s[i]; key = job.r_key[i];
+    }
+    unsigned long long todo = __ballot(root >= 0);
+    while (todo) {
+        const int first = ctz64(todo);
+        const int r0 = __shfl(root, first);
+        const bool mine = root == r0;
+        const unsigned long long group = __ballot(mine);
+        todo &= ~group;
+        uint32_t gn = mine ? n : 0u;
+        FixSums g_sum = mine ? sum : fix_zero();
+        unsigned long long g_c = mine ? c : 0ull, g_r = mine ? r : 0ull, g_s = mine ? sv : 0ull, g_key = mine ? key : ~0ull;
+        if (group & (group - 1)) {           // more than one lane: butterfly over the wave (lanes outside the group carry the neutral element)
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                gn += __shfl_xor(gn, d);
+                g_sum.rho += __shfl_xor(g_sum.rho, d);
+                g_sum.c_lo += __shfl_xor(g_sum.c_lo, d); g_sum.c_hi += __shfl_xor(g_sum.c_hi, d);
+                g_sum.r_lo += __shfl_xor(g_sum.r_lo, d); g_sum.r_hi += __shfl_xor(g_sum.r_hi, d);
+                g_sum.s_lo += __shfl_xor(g_sum.s_lo, d); g_sum.s_hi += __shfl_xor(g_sum.s_hi, d);
+                g_c += __shfl_xor(g_c, d); g_r += __shfl_xor(g_r, d); g_s += __shfl_xor(g_s, d);
+                const unsigned long long k2 = __shfl_xor(g_key, d);
+                g_key = k2 < g_key ? k2 : g_key;
+            }
+        }
+        if (lane == first) {
+            atomicAdd(&job.r_n[r0], gn);
+            fix_fold(job, (uint32_t)r0, g_sum);
+            atomicAdd((unsigned long long *)&job.r_c[r0], g_c);
+            atomicAdd((unsigned long long *)&job.r_r[r0], g_r);
+            atomicAdd((unsigned long long *)&job.r_s[r0], g_s);
+            atomicMin(&job.r_key[r0], g_key);
+        }
+    }
+}
 __global__ void __launch_bounds__(256) k_resolve(Job job) {
     const uint32_t n_runs = n_components(job);
     const int lane = lane_id();
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_runs; i0 += stride) {      // (wave-uniform trip count)
-        const uint32_t i = i0 + (uint32_t)lane;
-        int root = -1;
-        if (i < n_runs) {
-            root = uf_find(job.parent, (int)i);
-            if (root == (int)i) root = -1; else job.parent[i] = root;
-        }
-        uint32_t n = 0;
-        FixSums sum = fix_zero();
-        unsigned long long c = 0, r = 0, sv = 0, key = ~0ull;
-        if (root >= 0) {
-            n = job.r_n[i]; sum = fix_load(job, i);
-            c = (unsigned long long)job.r_c[i]; r = (unsigned long long)job.r_r[i]; sv = (unsigned long long)job.r_s[i]; key = job.r_key[i];
-        }
-        unsigned long long todo = __ballot(root >= 0);
-        while (todo) {
-            const int first = ctz64(todo);
-            const int r0 = __shfl(root, first);
-            const bool mine = root == r0;
-            const unsigned long long group = __ballot(mine);
-            todo &= ~group;
-            uint32_t gn = mine ? n : 0u;
-            FixSums g_sum = mine ? sum : fix_zero();
-            unsigned long long g_c = mine ? c : 0ull, g_r = mine ? r : 0ull, g_s = mine ? sv : 0ull, g_key = mine ? key : ~0ull;
-            if (group & (group - 1)) {           // more than one lane: butterfly over the wave (lanes outside the group carry the neutral element)
-#pragma unroll
-                for (int d = 32; d > 0; d >>= 1) {
-                    gn += __shfl_xor(gn, d);
-                    g_sum.rho += __shfl_xor(g_sum.rho, d);
-                    g_sum.c_lo += __shfl_xor(g_sum.c_lo, d); g_sum.c_hi += __shfl_xor(g_sum.c_hi, d);
-                    g_sum.r_lo += __shfl_xor(g_sum.r_lo, d); g_sum.r_hi += __shfl_xor(g_sum.r_hi, d);
-                    g_sum.s_lo += __shfl_xor(g_sum.s_lo, d); g_sum.s_hi += __shfl_xor(g_sum.s_hi, d);
-                    g_c += __shfl_xor(g_c, d); g_r += __shfl_xor(g_r, d); g_s += __shfl_xor(g_s, d);
-                    const unsigned long long k2 = __shfl_xor(g_key, d);
-                    g_key = k2 < g_key ? k2 : g_key;
-                }
-            }
-            if (lane == first) {
-                atomicAdd(&job.r_n[r0], gn);
-                fix_fold(job, (uint32_t)r0, g_sum);
-                atomicAdd((unsigned long long *)&job.r_c[r0], g_c);
-                atomicAdd((unsigned long long *)&job.r_r[r0], g_r);
-                atomicAdd((unsigned long long *)&job.r_s[r0], g_s);
-                atomicMin(&job.r_key[r0], g_key);
-            }
-        }
-    }
+    for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_runs; i0 += stride)      // (wave-uniform trip count)
+        resolve_wave(job, i0 + (uint32_t)lane, i0 + (uint32_t)lane < n_runs, lane);
 }
 
 // A root paints its first key: the bit, the byte counter of the bit's 256-key cell, the 16-bit counter of its 2048-key bucket.
@@ -1406,6 +1408,328 @@ __global__ void __launch_bounds__(256) k_sphere_paint(const Geom *__restrict__ g
             }
         }
         if (bits) atomicOr((unsigned long long *)&mask[row_word + cur], bits);
+    }
+}
+
+// Lock-free union in an LDS parent table (parent[x] <= x, roots point at themselves): find both roots, hang the larger
+// under the smaller with an atomic min; if the larger was no root any more, carry on with its new parent.
+// (find splits the path it walks: every node on it is re-pointed at its grandparent with a plain store.  A store that
+//  overwrites a concurrent hook of a NON-root loses nothing: whoever hooks a non-root goes on to unite its old parent.)
+__device__ __forceinline__ uint32_t lds_find(uint32_t *parent, uint32_t x) {
+    uint32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (p != x) {
+        const uint32_t gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        x = p;
+        p = gp;
+    }
+    return x;
+}
+__device__ __forceinline__ void lds_unite(uint32_t *parent, uint32_t a, uint32_t b) {
+    while (true) {
+        a = lds_find(parent, a);
+        b = lds_find(parent, b);
+        if (a == b) return;
+        const uint32_t hi = a > b ? a : b, lo = a > b ? b : a;
+        const uint32_t old = atomicMin(&parent[hi], lo);
+        if (old == hi) return;
+        a = old;
+        b = lo;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Round 6: the whole labelling of a PER-ATOM sphere batch (the clouds of aggregateCloud, findAberrantBlobs on single atoms) in ONE
+// launch -- k_sphere_paint, k_run_index, k_union, k_resolve and k_paint_keys were five, 5 us of device work each and a host
+// launch apart.  An atom's volume is its own sphere box, nothing of the labelling crosses volumes, and a box is a few hundred
+// mask words of one word a row: a workgroup per atom does the five phases on its volume with workgroup barriers where the
+// generic kernels have launch boundaries.  The arithmetic is the generic kernels' own, statement by statement (the voxel test
+// of k_sphere_paint, narrow_run_records, the neighbour rows of k_union, resolve_wave, paint_key): the results are the same
+// integers.  Host side: group_setup knows the boxes (it made them) and takes this path when every box has one word a row and
+// at most ATOM_WORDS rows; anything else goes through the five kernels as before.
+//   * the masks live in LDS (and are written out for the accessors: voxel lists, pool look-ups);
+//   * run ids: one atomicAdd on the job's counter per volume -- the runs of a volume are consecutive ids;
+//   * a volume of at most ATOM_RUNS runs and ATOM_COMPS blobs (every atom cloud) never touches the global tables before its results
+//     are final: the unions run on an LDS parent table, the runs' integer sums are folded into LDS accumulators per blob, and what
+//     is written out is what k_resolve leaves -- a record per root, every run's root in parent[] -- plus the painted first keys.
+//     (The first form of this kernel ran the five phases on the global tables with barriers in between: 140 us for 2 000 atoms where
+//     the five kernels take 73 -- a chain of ~25 dependent memory round trips per workgroup, four waves each.)
+//   * a larger volume runs those phases on the job's global tables as the generic kernels do.  A find may read a stale parent from
+//     this CU's L1 (atomics execute in L2): harmless during the unions (uf_unite2 ends on the value its atomic min returns), but
+//     resolve and the painting of the keys need what the atomics left -- an agent-scope acquire (L1 invalidate) follows the barrier
+//     in front of either phase, which is what the launch boundaries did.
+// ------------------------------------------------------------------------------------
+constexpr int ATOM_WORDS = 512;    // rows of a box the fused kernel holds in LDS (a 3.5 A sphere at 0.5 A spacing: 16 x 16 = 256; at 0.35 A: 22 x 22)
+constexpr int ATOM_RUNS = 1024;    // runs of a volume whose unions run in LDS ...
+constexpr int ATOM_COMPS = 64;     // ... and blobs of a volume whose sums are folded in LDS (an atom has one to three clouds); beyond either: the global tables
+                                   // (16.5 KB of LDS a workgroup: eight workgroups a CU, 2 048 atoms in one round)
+// What a run [ra, rb] of the row (rl, sl) of volume vd contributes: the integers narrow_run_records / word_run_records_of store
+// (sums rounded once to the job's quantum), computed with the same statements.  v: the row's densities by voxel (rows of at most
+// NARROW_ROW voxels), or nullptr: fetched here.
+struct RunRecord { uint32_t n; FixSums fs; long long c, r, s; unsigned long long key; };
+__device__ __forceinline__ RunRecord atom_run_record(const Job &job, const Geom &g, const float *__restrict__ dens, const VolDesc &vd, int rl, int sl,
+                                                     int ra, int rb, const float *v) {
+    const int rawc0 = vd.org[0], rawr = vd.org[1] + rl, raws = vd.org[2] + sl, len = rb - ra + 1;
+    double s_rho = 0.0, s_rl = 0.0;
+    if (v) {
+#pragma unroll
+        for (int k = 0; k < NARROW_ROW; ++k)
+            if (k >= ra && k <= rb) { s_rho += (double)v[k]; s_rl += (double)v[k] * (double)k; }
+    } else {
+        for (int k = ra; k <= rb; ++k) { const double x = (double)fetch_wrapped(g, dens, rawc0 + k, rawr, raws); s_rho += x; s_rl += x * (double)k; }
+    }
+    RunRecord rec;
+    rec.n = (uint32_t)len;
+    rec.fs = fix_sums(fix_of(s_rho, job.fix_mul), fix_of(s_rl, job.fix_mul), 0, 0, rawc0, rawr, raws);
+    const long long first = (long long)rawc0 + ra;
+    rec.c = (long long)len * first + (long long)len * (len - 1) / 2;
+    rec.r = (long long)len * rawr;
+    rec.s = (long long)len * raws;
+    rec.key = (unsigned long long)(vd.key_base + ((int64_t)ra * vd.dim[1] + rl) * vd.dim[2] + sl);
+    return rec;
+}
+__device__ __forceinline__ void atom_store_record(const Job &job, uint32_t idx, const RunRecord &rec) {
+    job.parent[idx] = (int32_t)idx;
+    job.r_n[idx] = rec.n;
+    fix_store(job, idx, rec.fs);
+    job.r_c[idx] = rec.c; job.r_r[idx] = rec.r; job.r_s[idx] = rec.s;
+    job.r_key[idx] = rec.key;
+}
+
+__global__ void __launch_bounds__(256) k_atom_engine(Job job, const Geom *__restrict__ gp, const float *__restrict__ dens,
+                                                     const double *__restrict__ xyz, const float *__restrict__ radii,
+                                                     const AtomBox *__restrict__ boxes, float cutoff) {
+    __shared__ unsigned long long s_m[ATOM_WORDS];
+    __shared__ uint32_t s_rb[ATOM_WORDS];     // first run of the row, counted from the volume's first run
+    __shared__ uint32_t s_par[ATOM_RUNS];     // LDS path: parent of run k of the volume; after the numbering of the roots: component of the run
+    __shared__ unsigned long long s_acc[10][ATOM_COMPS], s_key[ATOM_COMPS];   // LDS path: the seven FixSums fields, sum c / r / s; first key
+    __shared__ uint32_t s_accn[ATOM_COMPS], s_root[ATOM_COMPS];
+    __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_carry, s_base, s_ncomp;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t a = blockIdx.x;
+    const AtomBox bx = boxes[a];
+    const int dc = bx.hi[0] - bx.lo[0] + 1, dr = bx.hi[1] - bx.lo[1] + 1, dsz = bx.hi[2] - bx.lo[2] + 1;
+    if (dc <= 0 || dr <= 0 || dsz <= 0) return;   // (block-uniform: an empty box has no words)
+    const Geom &g = *gp;
+    const VolDesc vd = job.vols[a];                // (a group per atom: the volume IS the box)
+    const int W = dr * dsz;                        // one word a row (the host checked: dc <= 64, W <= ATOM_WORDS)
+    for (int w = tid; w < W; w += 256) s_m[w] = 0ull;
+    if (tid == 0) { s_carry = 0u; s_ncomp = 0u; }
+    __syncthreads();
+    {   // ---- paint (k_sphere_paint): a thread per 16-voxel piece of a box row ----
+        const double px = xyz[3 * a], py = xyz[3 * a + 1], pz = xyz[3 * a + 2];
+        const double rad = (double)radii[a], cut = (double)cutoff;
+        const unsigned pieces = ((unsigned)dc + 15u) / 16u, n_items = pieces * (unsigned)W;
+        for (unsigned it = tid; it < n_items; it += 256u) {
+            const unsigned row = it / pieces, piece = it - row * pieces, sl = row / (unsigned)dr;
+            const int r = bx.lo[1] + (int)(row - sl * (unsigned)dr), s = bx.lo[2] + (int)sl;
+            const int c0 = bx.lo[0] + 16 * (int)piece;
+            const int cnt = dc - 16 * (int)piece < 16 ? dc - 16 * (int)piece : 16;
+            float dv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) dv[u] = u < cnt ? fetch_wrapped(g, dens, c0 + u, r, s) : 0.0f;
+            unsigned long long bits = 0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                if (u < cnt) {
+                    const double d = (double)dv[u];
+                    if ((0.0 < cut && cut < d) || (d < cut && cut < 0.0) || cut == 0.0) {
+                        double q[3];
+                        crs2xyz(g, c0 + u, r, s, q);
+                        const double dx = q[0] - px, dy = q[1] - py, dz = q[2] - pz;
+                        const double dist = __dsqrt_rn((dx * dx + dy * dy) + dz * dz);
+                        if (dist <= rad) bits |= 1ull << (16 * (int)piece + u);
+                    }
+                }
+            }
+            if (bits) atomicOr(&s_m[row], bits);
+        }
+    }
+    __syncthreads();
+    // ---- run index (k_run_index): runs per row, a scan over the volume's rows, ONE id range for the volume ----
+    for (int w0 = 0; w0 < W; w0 += 256) {   // (block-uniform trip count)
+        const int w = w0 + tid;
+        const uint32_t cnt = w < W ? (uint32_t)popc64(run_starts(s_m[w])) : 0u;
+        uint32_t x = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) s_wsum[wv] = x;
+        __syncthreads();
+        uint32_t pre = s_carry;
+        for (int k = 0; k < wv; ++k) pre += s_wsum[k];
+        if (w < W) s_rb[w] = pre + x - cnt;
+        __syncthreads();
+        if (tid == 255) s_carry = pre + x;
+    }
+    __syncthreads();
+    const uint32_t T = s_carry;   // runs of the volume (block-uniform)
+    // (the id range: one returning atomic per volume, in flight while the unions run in LDS)
+    if (tid == 0) s_base = T ? atomicAdd(&job.ctr->n_runs, T) : 0u;
+    if (T <= (uint32_t)ATOM_RUNS) {
+        // ---- LDS path: unions on an LDS parent table ----
+        for (uint32_t i = tid; i < T; i += 256u) s_par[i] = i;
+        __syncthreads();
+        for (int t = tid; t < 4 * W; t += 256) {   // (k_union: a thread per (row, earlier neighbour row))
+            const int w = t >> 2, nb = t & 3;
+            const unsigned long long m = s_m[w];
+            if (m == 0ull) continue;
+            const int sl = w / dr, rl = w - sl * dr;
+            const int r2 = rl + (nb == 3 ? 1 : (nb == 2 ? 0 : -1)), s2 = sl + (nb == 0 ? 0 : -1);
+            if (r2 < 0 || r2 >= dr || s2 < 0) continue;
+            const int w2 = s2 * dr + r2;
+            const unsigned long long nm = s_m[w2];
+            if (nm == 0ull) continue;
+            uint64_t todo = run_starts(m);
+            uint32_t k = 0;
+            while (todo) {
+                const int ra = ctz64(todo);
+                todo &= todo - 1;
+                const int rb = run_end_of(m, ra);
+                const uint32_t me = s_rb[w] + k;
+                ++k;
+                int lo = ra - 1, hi = rb + 1;
+                if (lo < 0) lo = 0;
+                if (hi > 63) hi = 63;
+                uint64_t hit = nm & (bits_below(hi + 1) & ~bits_below(lo));
+                while (hit) {
+                    const int p = ctz64(hit);
+                    int st;
+                    const uint32_t other = run_of_bit(nm, s_rb[w2], p, &st);
+                    lds_unite(s_par, me, other);
+                    hit &= ~bits_below(run_end_of(nm, st) + 1);
+                }
+            }
+        }
+        __syncthreads();
+        // the roots take component numbers (the smallest run id of a blob is its root: parents point downwards)
+        for (uint32_t i = tid; i < T; i += 256u)
+            if (s_par[i] == i) { const uint32_t c = atomicAdd(&s_ncomp, 1u); if (c < (uint32_t)ATOM_COMPS) s_root[c] = i; }
+        for (int c = tid; c < ATOM_COMPS; c += 256) {
+#pragma unroll
+            for (int f = 0; f < 10; ++f) s_acc[f][c] = 0ull;
+            s_accn[c] = 0u; s_key[c] = ~0ull;
+        }
+        __syncthreads();
+    }
+    __syncthreads();   // (s_base: thread 0's atomic has returned)
+    const uint32_t n_comp = s_ncomp;
+    const uint32_t base = s_base;
+    const bool in_lds = T <= (uint32_t)ATOM_RUNS && n_comp <= (uint32_t)ATOM_COMPS;   // block-uniform
+    if (in_lds) {
+        // every run finds its root; the roots' places among the components go where the parents were
+        uint32_t my_root[ATOM_RUNS / 256];
+#pragma unroll
+        for (int k = 0; k < ATOM_RUNS / 256; ++k) { const uint32_t i = (uint32_t)tid + 256u * k; my_root[k] = i < T ? lds_find(s_par, i) : 0u; }
+        __syncthreads();
+        for (uint32_t c = tid; c < n_comp; c += 256u) s_par[s_root[c]] = 0x80000000u | c;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < ATOM_RUNS / 256; ++k) { const uint32_t i = (uint32_t)tid + 256u * k; if (i < T && !(s_par[i] & 0x80000000u)) s_par[i] = s_par[my_root[k]]; }
+        __syncthreads();   // s_par[i] = 0x80000000 | component of run i
+    }
+    // ---- the runs' records: a thread per row.  LDS path: folded into the components' accumulators (integer adds: any order);
+    //      otherwise stored run by run (the generic kernels' tables) ----
+    for (int w = tid; w < W; w += 256) {
+        const unsigned long long m = s_m[w];
+        job.mask[vd.word_base + w] = m;
+        job.run_base[vd.word_base + w] = base + s_rb[w];
+        if (m == 0ull) continue;
+        const int sl = w / dr, rl = w - sl * dr;
+        float v[NARROW_ROW];
+        const bool narrow = dc <= NARROW_ROW;
+        if (narrow) {
+#pragma unroll
+            for (int k = 0; k < NARROW_ROW; ++k) v[k] = ((m >> k) & 1ull) ? fetch_wrapped(g, dens, vd.org[0] + k, vd.org[1] + rl, vd.org[2] + sl) : 0.0f;
+        }
+        uint64_t todo = run_starts(m);
+        uint32_t k = s_rb[w];
+        while (todo) {
+            const int ra = ctz64(todo);
+            todo &= todo - 1;
+            const RunRecord rec = atom_run_record(job, g, dens, vd, rl, sl, ra, run_end_of(m, ra), narrow ? v : nullptr);
+            if (in_lds) {
+                const uint32_t c = s_par[k] & 0x7fffffffu;
+                atomicAdd(&s_accn[c], rec.n);
+                atomicAdd(&s_acc[0][c], (unsigned long long)rec.fs.rho);
+                atomicAdd(&s_acc[1][c], (unsigned long long)rec.fs.c_lo); atomicAdd(&s_acc[2][c], (unsigned long long)rec.fs.c_hi);
+                atomicAdd(&s_acc[3][c], (unsigned long long)rec.fs.r_lo); atomicAdd(&s_acc[4][c], (unsigned long long)rec.fs.r_hi);
+                atomicAdd(&s_acc[5][c], (unsigned long long)rec.fs.s_lo); atomicAdd(&s_acc[6][c], (unsigned long long)rec.fs.s_hi);
+                atomicAdd(&s_acc[7][c], (unsigned long long)rec.c); atomicAdd(&s_acc[8][c], (unsigned long long)rec.r); atomicAdd(&s_acc[9][c], (unsigned long long)rec.s);
+                atomicMin(&s_key[c], rec.key);
+                // (what the accessors read of a run: its root -- and a count that says the id is in use)
+                job.parent[base + k] = (int32_t)(base + s_root[c]);
+                job.r_n[base + k] = rec.n;
+            } else {
+                atom_store_record(job, base + k, rec);
+            }
+            ++k;
+        }
+    }
+    __syncthreads();
+    if (in_lds) {   // ---- one record per blob, its first key painted (k_resolve's result + k_paint_keys) ----
+        for (uint32_t c = tid; c < n_comp; c += 256u) {
+            const uint32_t id = base + s_root[c];
+            FixSums fs;
+            fs.rho = (long long)s_acc[0][c];
+            fs.c_lo = (long long)s_acc[1][c]; fs.c_hi = (long long)s_acc[2][c];
+            fs.r_lo = (long long)s_acc[3][c]; fs.r_hi = (long long)s_acc[4][c];
+            fs.s_lo = (long long)s_acc[5][c]; fs.s_hi = (long long)s_acc[6][c];
+            job.r_n[id] = s_accn[c];
+            fix_store(job, id, fs);
+            job.r_c[id] = (long long)s_acc[7][c]; job.r_r[id] = (long long)s_acc[8][c]; job.r_s[id] = (long long)s_acc[9][c];
+            job.r_key[id] = s_key[c];
+            paint_key(job, s_key[c]);
+        }
+        return;
+    }
+    // ---- a volume beyond the LDS tables: the generic kernels' phases on the job's global tables ----
+    // (the records and parents of the volume are in L2 behind the barrier above: the unions' atomics find them)
+    for (int t = tid; t < 4 * W; t += 256) {
+        const int w = t >> 2, nb = t & 3;
+        const unsigned long long m = s_m[w];
+        if (m == 0ull) continue;
+        const int sl = w / dr, rl = w - sl * dr;
+        const int r2 = rl + (nb == 3 ? 1 : (nb == 2 ? 0 : -1)), s2 = sl + (nb == 0 ? 0 : -1);
+        if (r2 < 0 || r2 >= dr || s2 < 0) continue;
+        const int w2 = s2 * dr + r2;
+        const unsigned long long nm = s_m[w2];
+        if (nm == 0ull) continue;
+        const uint32_t nbase = base + s_rb[w2];
+        uint64_t todo = run_starts(m);
+        uint32_t k = 0;
+        while (todo) {
+            const int ra = ctz64(todo);
+            todo &= todo - 1;
+            const int rb = run_end_of(m, ra);
+            const int me = (int)(base + s_rb[w] + k);
+            ++k;
+            int lo = ra - 1, hi = rb + 1;
+            if (lo < 0) lo = 0;
+            if (hi > 63) hi = 63;
+            uint64_t hit = nm & (bits_below(hi + 1) & ~bits_below(lo));
+            while (hit) {
+                const int p = ctz64(hit);
+                int st;
+                const uint32_t other = run_of_bit(nm, nbase, p, &st);
+                uf_unite2(job.parent, me, (int)other);
+                hit &= ~bits_below(run_end_of(nm, st) + 1);
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (see the head of this kernel: the finds below must see what the atomics left)
+    for (uint32_t i0 = (uint32_t)(tid & ~63); i0 < T; i0 += 256u)   // (k_resolve; wave-uniform trip count)
+        resolve_wave(job, base + i0 + (uint32_t)lane, i0 + (uint32_t)lane < T, lane);
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (uint32_t i = (uint32_t)tid; i < T; i += 256u) {   // (k_paint_keys)
+        const uint32_t id = base + i;
+        if (job.parent[id] != (int32_t)id || job.r_n[id] == 0u) continue;
+        paint_key(job, job.r_key[id]);
     }
 }
 

@@ -145,33 +145,6 @@ __device__ __forceinline__ void kernarg_prefetch() {
 }
 static_assert(sizeof(Job) + sizeof(TileDims) + 16 > 0x1c0 && sizeof(Job) + sizeof(TileDims) + 16 <= 0x200, "eight 64-byte lines of kernel arguments");
 
-// Lock-free union in an LDS parent table (parent[x] <= x, roots point at themselves): find both roots, hang the larger
-// under the smaller with an atomic min; if the larger was no root any more, carry on with its new parent.
-// (find splits the path it walks: every node on it is re-pointed at its grandparent with a plain store.  A store that
-//  overwrites a concurrent hook of a NON-root loses nothing: whoever hooks a non-root goes on to unite its old parent.)
-__device__ __forceinline__ uint32_t lds_find(uint32_t *parent, uint32_t x) {
-    uint32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    while (p != x) {
-        const uint32_t gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        x = p;
-        p = gp;
-    }
-    return x;
-}
-__device__ __forceinline__ void lds_unite(uint32_t *parent, uint32_t a, uint32_t b) {
-    while (true) {
-        a = lds_find(parent, a);
-        b = lds_find(parent, b);
-        if (a == b) return;
-        const uint32_t hi = a > b ? a : b, lo = a > b ? b : a;
-        const uint32_t old = atomicMin(&parent[hi], lo);
-        if (old == hi) return;
-        a = old;
-        b = lo;
-    }
-}
-
 // Generic labelling of a tile k_tile_label could not hold in LDS ("unit tile"): every run is its own component with its own
 // record (wave prefix sums per word, as k_run_index), ids from the job's counters above the per-tile ranges; the pairs of such a
 // tile are then ALL united globally.  Called by the tile's own workgroup of k_face_merge (round 3: this used to be 128 extra
