@@ -173,6 +173,7 @@ struct pdbeda_map {
 };
 
 struct pdbeda_bloblist {
+    std::vector<AtomBox> host_boxes;   // a per-atom sphere batch whose boxes the host made: box of atom a (else empty)
     pdbeda_ctx *ctx = nullptr;
     pdbeda_map *map = nullptr;
     Arena arena;
@@ -1221,7 +1222,9 @@ static size_t job_carve(Job &job, char *base, int n_vols, int64_t total_words, i
 }
 
 // Enqueue the labelling engine on a job whose masks are already painted.
-static int engine_enqueue(pdbeda_ctx *ctx, pdbeda_map *m, Job &job, int64_t max_runs, bool labelled = false) {   // labelled: k_atom_engine has done everything up to the painted keys
+// labelled: k_atom_engine has done everything up to the painted keys.  unordered: the caller takes the roots' rows as they come (k_resolve hands them
+// out) and writes its results itself (pdbeda_aggregate_cloud's union job: k_union_finish) -- no keys painted, no ranks, no blob table
+static int engine_enqueue(pdbeda_ctx *ctx, pdbeda_map *m, Job &job, int64_t max_runs, bool labelled = false, bool unordered = false) {
     hipStream_t st = ctx->stream;
     // per-run kernels are grid-stride over the ACTUAL run count (read on the device)
     const unsigned run_grid = grid_for(max_runs, 256, 2048);
@@ -1233,11 +1236,11 @@ static int engine_enqueue(pdbeda_ctx *ctx, pdbeda_map *m, Job &job, int64_t max_
             else hipLaunchKernelGGL(k_run_index<256>, dim3(grid_for(job.total_words, 256, 1ll << 30)), dim3(256), 0, st, job, m->dens, m->geom_dev);
         }
         { PROF(ctx, "k_union"); hipLaunchKernelGGL(k_union, dim3(grid_for(job.total_words * 4, 256, 1ll << 30)), dim3(256), 0, st, job); }
-        { PROF(ctx, "k_resolve"); hipLaunchKernelGGL(k_resolve, dim3(run_grid), dim3(256), 0, st, job); }
-        { PROF(ctx, "k_paint_keys"); hipLaunchKernelGGL(k_paint_keys, dim3(run_grid), dim3(256), 0, st, job); }
+        { PROF(ctx, "k_resolve"); hipLaunchKernelGGL(k_resolve, dim3(run_grid), dim3(256), 0, st, job, unordered ? 1 : 0); }
+        if (!unordered) { PROF(ctx, "k_paint_keys"); hipLaunchKernelGGL(k_paint_keys, dim3(run_grid), dim3(256), 0, st, job); }
     }
     // (k_emit also runs for an empty job: its first block publishes the blob count)
-    { PROF(ctx, "k_emit"); hipLaunchKernelGGL(k_emit, dim3(job.total_words > 0 ? std::min(run_grid, 512u) : 1u), dim3(256), 0, st, job, m->geom_dev); }
+    if (!unordered) { PROF(ctx, "k_emit"); hipLaunchKernelGGL(k_emit, dim3(job.total_words > 0 ? std::min(run_grid, 512u) : 1u), dim3(256), 0, st, job, m->geom_dev); }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -1755,6 +1758,7 @@ struct GroupSetup {
     Counters *d_ctr = nullptr;
     int64_t total_words = 0, total_keys = 0;
     bool host_totals = false;   // the totals are the host's (per-atom spheres): nobody waited for the device's -- k_make_vols checks them
+    std::vector<AtomBox> host_boxes;   // per-atom spheres: the boxes the host made (kept on the list: aggregateCloud's union volumes are boxes around them)
     bool atom_engine = false;   // per-atom spheres whose boxes the host made, every box one mask word a row and at most ATOM_WORDS rows: ONE launch labels the batch (k_atom_engine)
     // staged inputs whose copy into the device scratch has not been launched yet: grouped_job's k_job_init does it (one launch less), flush_pending for everybody else
     const char *pend_src = nullptr;
@@ -1890,6 +1894,7 @@ static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, con
             float cached_rad = NAN;
             int32_t R[3] = {0, 0, 0};
             bool small_boxes = true;
+            gs->host_boxes.resize((size_t)n_items);
             for (int64_t a = 0; a < n_items; ++a) {
                 if (!(radii[a] == cached_rad)) {
                     const double rad = (double)radii[a];
@@ -1908,6 +1913,7 @@ static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, con
                 }
                 if (empty) { for (int k = 0; k < 3; ++k) { bx.lo[k] = 0; bx.hi[k] = -1; } }
                 boxes[a] = bx;
+                gs->host_boxes[(size_t)a] = bx;
                 VolDesc vd;
                 memset(&vd, 0, sizeof vd);
                 for (int k = 0; k < 3 && !empty; ++k) { vd.org[k] = bx.lo[k]; vd.dim[k] = bx.hi[k] - bx.lo[k] + 1; }
@@ -1920,6 +1926,7 @@ static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, con
                 words += (int64_t)vd.row_words * vd.dim[1] * vd.dim[2];
                 keys += (int64_t)vd.dim[0] * vd.dim[1] * vd.dim[2];
             }
+            if (!(words == totals[0] && keys == totals[1])) gs->host_boxes.clear();
             if (words == totals[0] && keys == totals[1]) {      // (they are: both follow from the radii; a mismatch takes the device's path below)
                 memset(ctr0, 0, sizeof *ctr0);
                 ctr0->total_words = words;
@@ -1963,7 +1970,8 @@ static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, con
 }
 
 // Paint the group volumes and enqueue the labelling engine on them; the input scratch is recycled in stream order.
-static int grouped_job(pdbeda_map *m, GroupSetup &gs, int64_t n_items, int64_t n_groups, bool spheres, float cutoff, pdbeda_bloblist **out, const PoolPaint *pool = nullptr) {
+static int grouped_job(pdbeda_map *m, GroupSetup &gs, int64_t n_items, int64_t n_groups, bool spheres, float cutoff, pdbeda_bloblist **out, const PoolPaint *pool = nullptr,
+                       bool unordered = false) {
     pdbeda_ctx *ctx = m->ctx;
     const int64_t max_runs = gs.total_keys / 2 + gs.total_words + 1;
     if (gs.pend_bytes && m->fix_mul == 0.0 && !m->fix_refused) {
@@ -2013,7 +2021,7 @@ static int grouped_job(pdbeda_map *m, GroupSetup &gs, int64_t n_items, int64_t n
             { PROF(ctx, "k_list_paint"); hipLaunchKernelGGL(k_list_paint, dim3(grid_for(n_items, 256)), dim3(256), 0, st, gs.d_crs, gs.d_item_group, n_items, job.vols, job.mask); }
         e = hipGetLastError();
     }
-    if (e == hipSuccess) rc = engine_enqueue(ctx, m, job, max_runs, fused_atoms);
+    if (e == hipSuccess) rc = engine_enqueue(ctx, m, job, max_runs, fused_atoms, unordered);
     // (the inputs are consumed by the paint kernel: whoever gets their arena next is enqueued behind it on this stream)
     arena_put(ctx, gs.in_arena);
     if (e != hipSuccess || rc) {
@@ -2025,6 +2033,7 @@ static int grouped_job(pdbeda_map *m, GroupSetup &gs, int64_t n_items, int64_t n
     bl->arena = arena;
     bl->vol_lo = 0;
     bl->vol_hi = (int)n_groups;
+    bl->host_boxes.swap(gs.host_boxes);
     *out = bl;
     return PDBEDA_OK;
 }
@@ -2316,6 +2325,10 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
     *out = res;
     if (n == 0) return PDBEDA_OK;
     hipStream_t st = ctx->stream;
+    // PDBEDA_CLOUD_TRACE=1 (experiments): the sizes of the two jobs and the host-side phases of this call on stderr
+    static const bool cloud_trace = [] { const char *e = getenv("PDBEDA_CLOUD_TRACE"); return e && e[0] && e[0] != '0'; }();
+    const double t_call = now_s();
+    double t_wait1 = 0.0, t_pooled = 0.0;
 
     // ---- 1. the clouds of every atom: one sphere batch, a group per atom (findAberrantBlobs, 603) ----
     pdbeda_bloblist *clouds = nullptr;
@@ -2332,6 +2345,7 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
     int rc = list_stats_one_trip(clouds, 4 * n + 64, c_n, c_tot, c_cen, c_grp);   // (an atom has one to three clouds: the count and the table in one wait)
     if (rc) return bail(rc, clouds, nullptr);
     const int64_t nb = (int64_t)c_n.size();
+    t_wait1 = now_s();
     // the voxel lists of the clouds (what the pooled voxels and the overlap tests are gathered from) are made by the device
     // while the host decides what to pool
     rc = list_materialise_voxels(clouds);
@@ -2445,17 +2459,33 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
     std::vector<VolDesc> union_vols((size_t)n_groups);
     {
         std::vector<int64_t> lo(3 * (size_t)n_groups, INT64_MAX), hi(3 * (size_t)n_groups, INT64_MIN);
+        const bool have_boxes = (int64_t)cow->host_boxes.size() == n;      // (the sphere job's own boxes, made by the host with the same statements: two xyz2crs per pooled cloud were 0.06 ms here)
+        int64_t last_a = -1;
+        bool cur_empty = false;
+        int64_t blo[3] = {0, 0, 0}, bhi[3] = {0, 0, 0};
         for (int64_t p = 0; p < n_pool; ++p) {
             const int64_t a = at->alias[pool_atom[(size_t)p]];          // (the clouds are those of the coordinate's last atom: its coordinate, its radius)
-            const double rad = (double)at->radius[a];
-            const double o[3] = {m->geom.origin[0] + rad, m->geom.origin[1] + rad, m->geom.origin[2] + rad};
-            int32_t C[3], R[3];
-            xyz2crs(m->geom, at->xyz + 3 * a, C);
-            xyz2crs(m->geom, o, R);
+            if (a != last_a) {
+                if (have_boxes) {
+                    const AtomBox &bx = cow->host_boxes[(size_t)a];
+                    for (int k = 0; k < 3; ++k) { blo[k] = bx.lo[k]; bhi[k] = bx.hi[k]; }
+                    cur_empty = bx.hi[0] < bx.lo[0];      // (an empty box holds no voxel: it has no cloud, it is not pooled -- unreachable)
+                } else {
+                    cur_empty = false;
+                    const double rad = (double)at->radius[a];
+                    const double o[3] = {m->geom.origin[0] + rad, m->geom.origin[1] + rad, m->geom.origin[2] + rad};
+                    int32_t C[3], R[3];
+                    xyz2crs(m->geom, at->xyz + 3 * a, C);
+                    xyz2crs(m->geom, o, R);
+                    for (int k = 0; k < 3; ++k) { blo[k] = (int64_t)C[k] - R[k] - 1; bhi[k] = (int64_t)C[k] + R[k]; }
+                }
+                last_a = a;
+            }
+            if (cur_empty) continue;
             for (int g : {(int)pool_group[(size_t)p], n_rg})
                 for (int k = 0; k < 3; ++k) {
-                    lo[3 * (size_t)g + k] = std::min<int64_t>(lo[3 * (size_t)g + k], (int64_t)C[k] - R[k] - 1);
-                    hi[3 * (size_t)g + k] = std::max<int64_t>(hi[3 * (size_t)g + k], (int64_t)C[k] + R[k]);
+                    lo[3 * (size_t)g + k] = std::min<int64_t>(lo[3 * (size_t)g + k], blo[k]);
+                    hi[3 * (size_t)g + k] = std::max<int64_t>(hi[3 * (size_t)g + k], bhi[k]);
                 }
         }
         for (int g = 0; g < n_groups; ++g) {
@@ -2531,27 +2561,74 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
     }
     if (rc) { arena_put(ctx, gs.in_arena); arena_put(ctx, aux); return bail(rc, clouds, nullptr); }
     pdbeda_bloblist *uni = nullptr;
-    rc = grouped_job(m, gs, 2 * V, n_groups, false, 0.0f, &uni, fused_paint ? &paint : nullptr);
-    if (rc) { arena_put(ctx, aux); return bail(rc, clouds, nullptr); }
-    { PROF(ctx, "k_pool_component"); hipLaunchKernelGGL(k_pool_component, dim3(grid_for(2 * n_pool, 256)), dim3(256), 0, st, uni->job, cow->crs_dev, cow->offsets_dev, d_pool_cloud,
-                                                        d_pool_group, (int)n_pool, n_rg, d_comp); }
-    e = hipGetLastError();
-    if (e != hipSuccess) return fail_dev(e, uni);
+    t_pooled = now_s();
+    // The union job's results: rows of its blobs, the row of the component that holds each pooled cloud, the pairs' touch flags.  The
+    // host orders the rows by the pooled clouds they hold (below), not by key: the job runs UNORDERED (no k_paint_keys, no k_emit) and its
+    // last launch writes the results straight into the pinned block (k_union_finish; four launches -- keys, ranks, components, pack --
+    // before).  Without room in the block (or with PDBEDA_COPY_KERNELS=0: kernels do not write host memory then) the ordered form serves.
+    const int64_t u_cap = 2 * n_pool + 64;      // (a union component holds at least one pooled cloud, per kind)
     std::vector<int32_t> comp(2 * (size_t)n_pool);
     std::vector<unsigned int> touch((size_t)n_pairs);
-    // (the pairs' touch flags and the pooled clouds' components are neighbours in the aux arena: one copy brings both)
-    const size_t tail_bytes = (size_t)((char *)(d_comp + 2 * n_pool) - (char *)d_touch);
-    std::vector<char> tail((tail_bytes + 3) & ~(size_t)3);
-    const D2HItem tail_item = {tail.data(), d_touch, tail.size()};      // (whole words: the pack kernel copies words; the carve's padding covers the round-up)
     std::vector<int64_t> u_n;
     std::vector<double> u_tot, u_cen;
     std::vector<int32_t> u_grp;
-    rc = list_stats_one_trip(uni, 2 * n_pool + 64, u_n, u_tot, u_cen, u_grp, &tail_item);   // (synchronises: comp / touch land with the statistics; a union component holds at least one pooled cloud)
-    arena_put(ctx, aux);
-    if (rc) return bail(rc, clouds, uni);
-    if (n_pairs > 0) memcpy(touch.data(), tail.data(), 4 * (size_t)n_pairs);
-    memcpy(comp.data(), tail.data() + ((char *)d_comp - (char *)d_touch), 8 * (size_t)n_pool);
+    const size_t fin_bytes = align_up(sizeof(Counters), 64) + align_up(8 * (size_t)u_cap, 64) * 2 + align_up(24 * (size_t)u_cap, 64) + align_up(4 * (size_t)u_cap, 64) +
+                             align_up(4 * (size_t)std::max<int64_t>(n_pairs, 1), 64) + align_up(8 * (size_t)n_pool, 64);
+    static const bool unordered_on = [] { const char *e = getenv("PDBEDA_UNORDERED_UNION"); return !(e && e[0] == '0'); }();      // (A/B switch)
+    const bool unordered = unordered_on && fused_paint && copy_kernels() && ctx->pinned && ctx->pinned_used + fin_bytes <= ctx->pinned_cap;
+    rc = grouped_job(m, gs, 2 * V, n_groups, false, 0.0f, &uni, fused_paint ? &paint : nullptr, unordered);
+    if (rc) { arena_put(ctx, aux); return bail(rc, clouds, nullptr); }
+    if (unordered) {
+        u_n.resize((size_t)u_cap); u_tot.resize((size_t)u_cap); u_cen.resize(3 * (size_t)u_cap); u_grp.resize((size_t)u_cap);
+        Counters u_ctr;
+        memset(&u_ctr, 0, sizeof u_ctr);
+        char *blk = ctx->pinned + ctx->pinned_used;
+        size_t off = 0;
+        auto take = [&](void *dst, size_t bytes) { char *p = blk + off; if (bytes) ctx->pending.push_back({dst, ctx->pinned_used + off, bytes}); off += align_up(std::max<size_t>(bytes, 1), 64); return p; };
+        UnionFinish fin;
+        memset(&fin, 0, sizeof fin);
+        fin.src_crs = cow->crs_dev; fin.src_off = cow->offsets_dev; fin.pool_cloud = d_pool_cloud; fin.pool_group = d_pool_group;
+        fin.n_pool = (int)n_pool; fin.domain_group = n_rg; fin.touch = d_touch; fin.n_pairs = (int)n_pairs; fin.cap = (unsigned int)u_cap;
+        fin.out_ctr = reinterpret_cast<Counters *>(take(&u_ctr, sizeof u_ctr));
+        fin.out_n = reinterpret_cast<long long *>(take(u_n.data(), 8 * (size_t)u_cap));
+        fin.out_total = reinterpret_cast<double *>(take(u_tot.data(), 8 * (size_t)u_cap));
+        fin.out_centroid = reinterpret_cast<double *>(take(u_cen.data(), 24 * (size_t)u_cap));
+        fin.out_group = reinterpret_cast<int32_t *>(take(u_grp.data(), 4 * (size_t)u_cap));
+        fin.out_touch = reinterpret_cast<unsigned int *>(take(touch.data(), 4 * (size_t)n_pairs));
+        fin.out_comp = reinterpret_cast<int32_t *>(take(comp.data(), 8 * (size_t)n_pool));
+        ctx->pinned_used += off;
+        const int64_t fin_threads = std::max<int64_t>(std::max<int64_t>(uni->job.run_cap, 2 * n_pool), n_pairs);
+        { PROF(ctx, "k_union_finish"); hipLaunchKernelGGL(k_union_finish, dim3(grid_for(fin_threads, 256, 1024)), dim3(256), 0, st, uni->job, m->geom_dev, fin); }
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail_dev(e, uni);
+        e = ctx_sync(ctx);      // (the one wait of the union job: everything above lands in the host's arrays)
+        arena_put(ctx, aux);
+        if (e != hipSuccess) return bail(fail(ctx, ctx->timed_out ? PDBEDA_ERR_TIMEOUT : PDBEDA_ERR_DEVICE, "aggregate cloud: %s", ctx->timed_out ? ctx->err.c_str() : hipGetErrorString(e)), clouds, uni);
+        if (u_ctr.unit_wait_failed) return bail(fail(ctx, PDBEDA_ERR_DEVICE, "aggregate cloud: a pooled voxel lies outside its group's volume"), clouds, uni);
+        if ((int64_t)u_ctr.n_blobs > u_cap) return bail(fail(ctx, PDBEDA_ERR_STATE, "aggregate cloud: more union components than pooled clouds"), clouds, uni);
+        const size_t nb_u = u_ctr.n_blobs;
+        u_n.resize(nb_u); u_tot.resize(nb_u); u_cen.resize(3 * nb_u); u_grp.resize(nb_u);
+    } else {
+        { PROF(ctx, "k_pool_component"); hipLaunchKernelGGL(k_pool_component, dim3(grid_for(2 * n_pool, 256)), dim3(256), 0, st, uni->job, cow->crs_dev, cow->offsets_dev, d_pool_cloud,
+                                                            d_pool_group, (int)n_pool, n_rg, d_comp); }
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail_dev(e, uni);
+        // (the pairs' touch flags and the pooled clouds' components are neighbours in the aux arena: one copy brings both)
+        const size_t tail_bytes = (size_t)((char *)(d_comp + 2 * n_pool) - (char *)d_touch);
+        std::vector<char> tail((tail_bytes + 3) & ~(size_t)3);
+        const D2HItem tail_item = {tail.data(), d_touch, tail.size()};      // (whole words: the pack kernel copies words; the carve's padding covers the round-up)
+        rc = list_stats_one_trip(uni, u_cap, u_n, u_tot, u_cen, u_grp, &tail_item);   // (synchronises: comp / touch land with the statistics)
+        arena_put(ctx, aux);
+        if (rc) return bail(rc, clouds, uni);
+        if (n_pairs > 0) memcpy(touch.data(), tail.data(), 4 * (size_t)n_pairs);
+        memcpy(comp.data(), tail.data() + ((char *)d_comp - (char *)d_touch), 8 * (size_t)n_pool);
+    }
     const int64_t nu = (int64_t)u_n.size();
+    if (cloud_trace)
+        fprintf(stderr, "aggregate_cloud: %lld atoms, %lld clouds, %lld pooled clouds (%lld voxels), %d residue groups + the domain group: %lld mask words, %lld keys, %lld union blobs; "
+                        "ms: clouds enqueued + waited %.3f, host pooling %.3f, union job enqueued + waited %.3f\n",
+                (long long)n, (long long)nb, (long long)n_pool, (long long)V, n_rg, (long long)union_totals[0], (long long)union_totals[1], (long long)nu,
+                1e3 * (t_wait1 - t_call), 1e3 * (t_pooled - t_wait1), 1e3 * (now_s() - t_pooled));
     pdbeda_bloblist_free(uni);
     pdbeda_bloblist_free(clouds);
     if (rc) { delete res; *out = nullptr; return rc; }

@@ -312,6 +312,60 @@ __device__ inline void narrow_run_records(const JobRef &job, const Geom &g, cons
     }
 }
 
+// The same records for a SPARSE word of a wide row -- at most SPARSE_BITS set voxels among its 64: the words of aggregateCloud's union
+// job (a residue's or the whole domain's pooled voxels in a box that spans the structure: 32 k words of which a quarter hold a few
+// short runs each) -- by ONE thread: the set voxels' densities are fetched together, the runs' sums are plain sequential fp64 sums in
+// voxel order.  The wave-per-word loop of k_run_index spends two wave scans and a memory round trip per word, one word after the
+// other (16 words a wave: 35 us for that job, round 6); here every word of a block goes at once.
+constexpr int SPARSE_BITS = 16;
+template <typename JobRef>
+__device__ inline void sparse_run_records(const JobRef &job, const Geom &g, const float *__restrict__ dens, const VolDesc &vd, uint64_t mw,
+                                          int wq, int rl, int sl, uint32_t rec0) {
+    const int rawc0 = vd.org[0] + wq * 64, rawr = vd.org[1] + rl, raws = vd.org[2] + sl;
+    float v[SPARSE_BITS];
+    int pos[SPARSE_BITS];
+    {
+        uint64_t t = mw;
+#pragma unroll
+        for (int k = 0; k < SPARSE_BITS; ++k) {
+            const bool have = t != 0ull;
+            pos[k] = have ? ctz64(t) : 64;
+            v[k] = have ? fetch_wrapped(g, dens, rawc0 + pos[k], rawr, raws) : 0.0f;
+            t &= t - 1ull;      // (0 - 1 & 0 = 0)
+        }
+    }
+    uint32_t idx = rec0;
+    int first = -1, prev = -2;
+    double s_rho = 0.0, s_rl = 0.0;
+    auto flush = [&]() {
+        const int len = prev - first + 1;
+        job.parent[idx] = (int32_t)idx;
+        job.r_n[idx] = (uint32_t)len;
+        fix_store(job, idx, fix_sums(fix_of(s_rho, job.fix_mul), fix_of(s_rl, job.fix_mul), 0, 0, rawc0, rawr, raws));
+        const long long a0 = (long long)rawc0 + first;
+        job.r_c[idx] = (long long)len * a0 + (long long)len * (len - 1) / 2;
+        job.r_r[idx] = (long long)len * rawr;
+        job.r_s[idx] = (long long)len * raws;
+        const int64_t key_in = ((int64_t)(wq * 64 + first) * vd.dim[1] + rl) * vd.dim[2] + sl;
+        job.r_key[idx] = (unsigned long long)(vd.key_base + key_in);
+        if (job.kpar) job.kpar[idx] = ((unsigned long long)(((uint32_t)vd.group << 31) | (uint32_t)key_in) << 32) | idx;
+        ++idx;
+    };
+#pragma unroll
+    for (int k = 0; k < SPARSE_BITS; ++k) {
+        if (pos[k] < 64) {
+            if (pos[k] != prev + 1) {
+                if (first >= 0) flush();
+                first = pos[k]; s_rho = 0.0; s_rl = 0.0;
+            }
+            s_rho += (double)v[k];
+            s_rl += (double)v[k] * (double)pos[k];
+            prev = pos[k];
+        }
+    }
+    if (first >= 0) flush();
+}
+
 // ------------------------------------------------------------------------------------
 // Run indexing + per-run statistics.  Block = 256 threads = one chunk of WPB words (256, or 64 for a job of few words:
 // the union job of an aggregateCloud has 40 k wide, sparse words -- 164 blocks of 256 words left a third of the chip idle
@@ -361,7 +415,7 @@ __global__ void __launch_bounds__(256) k_run_index(Job job, const float *__restr
     // (every thread searches for its own word's volume: the per-word loop below is serial)
     VolDesc my_vd;
     int wq = 0, rl = 0, sl = 0;
-    bool narrow = false;
+    bool narrow = false, sparse = false;
     if (m != 0ull) {
         my_vd = job.vols[find_vol(job.vols, job.n_vols, w)];
         const int64_t rem = w - my_vd.word_base;
@@ -370,13 +424,15 @@ __global__ void __launch_bounds__(256) k_run_index(Job job, const float *__restr
         rl = (int)(row % my_vd.dim[1]);
         sl = (int)(row / my_vd.dim[1]);
         narrow = my_vd.dim[0] <= NARROW_ROW;
-        if (narrow) s_mask[tid] = 0ull;      // the thread's own work; the wave-per-word loop below skips it
+        sparse = !narrow && popc64(m) <= SPARSE_BITS;
+        if (narrow || sparse) s_mask[tid] = 0ull;      // the thread's own work; the wave-per-word loop below skips it
         else { s_off[tid] = off; s_vd[tid] = my_vd; s_row[tid][0] = wq; s_row[tid][1] = rl; s_row[tid][2] = sl; }
     }
     __syncthreads();
 
     const Geom &g = *gp;
     if (narrow) narrow_run_records(job, g, dens, my_vd, m, rl, sl, off);
+    else if (sparse) sparse_run_records(job, g, dens, my_vd, m, wq, rl, sl, off);
     // the words of my wave that are left, as a bit per slot
     uint64_t todo = 0ull;
     {
@@ -541,6 +597,9 @@ __device__ inline uint32_t run_of_bit(uint64_t nm, uint32_t base, int p, int *st
 // word): one memory round trip before the unions instead of one or two per neighbour; a union is a chain of dependent
 // trips, so the rows of a word go side by side (round 4: a thread per word with loads on demand was 2 x 65-80 us of an
 // aggregateCloud, most of it in a union job of 40 k words = 164 blocks).
+// (Round 6, measured and dropped: optimistic hooks -- uf_hook, one atomic min where both runs are still roots -- as in the cross-tile merge:
+//  43 -> 64 us for the union job of a 2 000-atom entry; the runs of a cloud touch each other many times over, and a hook that finds its
+//  target taken walks down one level per trip where two finds that read cached parents compress the path.)
 __global__ void __launch_bounds__(256) k_union(Job job) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t w = t >> 2;
@@ -615,11 +674,24 @@ __device__ inline uint32_t n_components(const JobRef &job) { return job.comps_ar
 // first and ONE lane sends the nine atomics (a 200-run atom cloud used to send 200 x 9 to the same cache line, where they
 // serialise).
 // (one wave's share: component i of the lane, or none -- every lane of the wave must call)
-__device__ inline void resolve_wave(const Job &job, uint32_t i, bool valid, int lane) {
+// slots: the roots take table rows in the order they come (one atomic per wave): the UNORDERED form of a job whose caller does not
+// read its blobs in key order -- aggregateCloud's union job, whose rows the host orders by the pooled clouds they hold -- and which
+// therefore needs neither the painted keys nor the ranks (k_paint_keys, k_emit: two launches)
+__device__ inline void resolve_wave(const Job &job, uint32_t i, bool valid, int lane, bool slots = false) {
     int root = -1;
+    bool is_root = false;
     if (valid) {
         root = uf_find(job.parent, (int)i);
-        if (root == (int)i) root = -1; else job.parent[i] = root;
+        if (root == (int)i) { root = -1; is_root = true; } else job.parent[i] = root;
+    }
+    if (slots) {
+        const unsigned long long roots = __ballot(is_root);
+        if (roots) {
+            uint32_t first = 0;
+            if (lane == ctz64(roots)) first = atomicAdd(&job.ctr->n_blobs, (uint32_t)popc64(roots));
+            first = __shfl(first, ctz64(roots));
+            if (is_root) job.r_rank[i] = first + (uint32_t)popc64(roots & bits_below(lane));
+        }
     }
     uint32_t n = 0;
     FixSums sum = fix_zero();
@@ -661,12 +733,12 @@ __device__ inline void resolve_wave(const Job &job, uint32_t i, bool valid, int 
         }
     }
 }
-__global__ void __launch_bounds__(256) k_resolve(Job job) {
+__global__ void __launch_bounds__(256) k_resolve(Job job, int slots) {
     const uint32_t n_runs = n_components(job);
     const int lane = lane_id();
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_runs; i0 += stride)      // (wave-uniform trip count)
-        resolve_wave(job, i0 + (uint32_t)lane, i0 + (uint32_t)lane < n_runs, lane);
+        resolve_wave(job, i0 + (uint32_t)lane, i0 + (uint32_t)lane < n_runs, lane, slots != 0);
 }
 
 // A root paints its first key: the bit, the byte counter of the bit's 256-key cell, the 16-bit counter of its 2048-key bucket.
@@ -1850,6 +1922,51 @@ __global__ void __launch_bounds__(256) k_pool_component(Job job, const int32_t *
     const uint32_t run = job.run_base[w] + run_ordinal(run_starts(job.mask[w]), lc & 63);
     const uint32_t comp = job.comp_of_run ? job.comp_of_run[run] : run;
     out[i] = (int32_t)job.r_rank[(uint32_t)job.parent[comp]];
+}
+
+// The last launch of aggregateCloud's union job in its UNORDERED form (round 6; k_paint_keys, k_emit, k_pool_component and the pack of
+// the results were four): behind k_resolve(slots) every root holds its blob's final sums and a table row of its own, so ONE grid
+//   * writes the roots' rows -- voxels, total density, density-weighted centroid (emit_row_ranked's arithmetic), group --,
+//   * looks up the row of the component that holds each pooled cloud, per union kind (k_pool_component),
+//   * copies the bonded pairs' touch flags and the job's counters
+// STRAIGHT into the context's pinned block, where the host reads them after its one wait for this job.
+struct UnionFinish {
+    const int32_t *src_crs; const int64_t *src_off;                 // the clouds' voxel lists
+    const int32_t *pool_cloud, *pool_group; int n_pool, domain_group;
+    const unsigned int *touch; int n_pairs;
+    Counters *out_ctr; long long *out_n; double *out_total, *out_centroid; int32_t *out_group; unsigned int *out_touch; int32_t *out_comp;
+    unsigned int cap;                                               // rows the host's arrays hold (a union component holds a pooled cloud: 2 n_pool bound them)
+};
+__global__ void __launch_bounds__(256) k_union_finish(Job job, const Geom *__restrict__ gp, UnionFinish a) {
+    const uint32_t n_runs = n_components(job);
+    const uint32_t stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const Geom &g = *gp;
+    for (uint32_t i = t0; i < n_runs; i += stride) {
+        if (job.parent[i] != (int32_t)i) continue;
+        const uint32_t row = job.r_rank[i];
+        if (row >= a.cap) continue;      // (cannot happen: see cap)
+        const uint32_t n_vox = job.r_n[i];
+        const FixSums fs = fix_load(job, i);
+        const double tot_q = (double)fs.rho, rc = fix_moment(fs.c_lo, fs.c_hi), rr = fix_moment(fs.r_lo, fs.r_hi), rs = fix_moment(fs.s_lo, fs.s_hi);
+        const double wc[3] = {rc / tot_q, rr / tot_q, rs / tot_q};   // (the quantum cancels)
+        double xyz[3];
+        crs2xyz_frac(g, wc, xyz);
+        a.out_n[row] = (long long)n_vox;
+        a.out_total[row] = tot_q / job.fix_mul;      // (a power of two: exact)
+        a.out_centroid[3 * row + 0] = xyz[0]; a.out_centroid[3 * row + 1] = xyz[1]; a.out_centroid[3 * row + 2] = xyz[2];
+        a.out_group[row] = job.vols[find_vol_by_key(job.vols, job.n_vols, (int64_t)job.r_key[i])].group;
+    }
+    for (uint32_t i = t0; i < 2u * (uint32_t)a.n_pool; i += stride) {
+        const int kind = i >= (uint32_t)a.n_pool ? 1 : 0, p = kind ? (int)i - a.n_pool : (int)i;
+        const int64_t v = a.src_off[a.pool_cloud[p]];
+        const VolDesc vd = job.vols[kind ? a.domain_group : a.pool_group[p]];
+        const int lc = a.src_crs[3 * v] - vd.org[0], lr = a.src_crs[3 * v + 1] - vd.org[1], ls = a.src_crs[3 * v + 2] - vd.org[2];
+        const int64_t w = vd.word_base + ((int64_t)ls * vd.dim[1] + lr) * vd.row_words + (lc >> 6);
+        const uint32_t run = job.run_base[w] + run_ordinal(run_starts(job.mask[w]), lc & 63);
+        a.out_comp[i] = (int32_t)job.r_rank[(uint32_t)job.parent[run]];
+    }
+    for (uint32_t i = t0; i < (uint32_t)a.n_pairs; i += stride) a.out_touch[i] = a.touch[i];
+    if (t0 == 0) *a.out_ctr = *job.ctr;
 }
 
 // One 16-bit digit of a radix select over the masked voxels of the unique box (see pdbeda_abs_select_hist).

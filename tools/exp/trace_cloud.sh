@@ -11,8 +11,8 @@ f = glob.glob("gpurun_out/trace_cloud/**/t_kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0] for r in rows]
 # the last aggregateCloud ends with the last k_pool_component; its first launch is the copy kernel in front of the last but one k_sphere_paint
-last = max(i for i, n in enumerate(names) if n == "k_pool_component")
-paints = [i for i in range(last) if names[i] == "k_sphere_paint"]
+last = max(i for i, n in enumerate(names) if n in ("k_pool_component", "k_union_finish"))      # (round 6: the union job ends in k_union_finish)
+paints = [i for i in range(last) if names[i] in ("k_sphere_paint", "k_atom_engine")]
 start = (paints[-1] - 1) if paints else last - 30
 t0 = int(rows[max(start, 0)]["Start_Timestamp"])
 for r, n in list(zip(rows, names))[max(start, 0):last + 3]:
