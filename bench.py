@@ -151,6 +151,22 @@ def analysis_leg(ctx, case="c2_bench_entry", reps=5):
             "note": "single host thread + one stream; checked here against the reference's result on the same entry (Cython path, one core, build container)"}
 
 
+def cpu_share():
+    """CPUs this process may really use: the affinity mask, cut down to the cgroup's CPU quota when there is one (cpu.max "quota period": the GPU
+    boxes of this pool give a 16-CPU quota under an affinity mask of all 256 logical CPUs -- a pool of 128 processes there delivers 16 CPUs' worth
+    and spends the rest throttled; round 6)."""
+    cores = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, period = fh.read().split()
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        pass
+    return (max(1, min(cores, int(quota + 0.5))) if quota else cores), cores, quota
+
+
 def link_rate(torch):
     """Pinned host -> HBM copy of 64 MiB, the best of six batches of five copies: GB/s."""
     pin = torch.empty(16 << 20, dtype=torch.float32).pin_memory()
@@ -354,11 +370,11 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
         cpu_pool = None
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             from oracle import cpu_entry
-            cores = len(os.sched_getaffinity(0))
+            cores, affinity, quota = cpu_share()
             tasks = [(l.density_path, l.n_residues, l.seed, l.edge, l.spacing) for l in loaders]
             tasks = [tasks[i % len(tasks)] for i in range(max(len(tasks), 2 * cores))]
             cpu_pool = cpu_entry.multiple_baseline(tasks, cores, seconds=args.cpu_seconds)
-            cpu_pool.update({"cores": cores, "kind": "port", "unit": "entries/min", "value": cpu_pool["entries_per_min"],
+            cpu_pool.update({"cores": cores, "affinity_cpus": affinity, "cgroup_cpu_quota": quota, "kind": "port", "unit": "entries/min", "value": cpu_pool["entries_per_min"],
                              "sample": "%d x %d^3 entries (%d atoms) per pass, repeated for %.0f s: read the 2Fo-Fc CCP4 file, numpy-tree mean / std, aggregateCloud "
                                        "(flattening + oracle composite + statistics tail), the entry's diffs -- multiprocessing.Pool(%d), one entry per task"
                                        % (len(tasks), args.entry_size, n_atoms, cpu_pool["seconds"], cores)})

@@ -236,6 +236,8 @@ static int fail(pdbeda_ctx *ctx, int code, const char *fmt, ...) {
 
 // Wait for the context's stream: plain hipStreamSynchronize, or (watchdog armed) a timed query loop; then deliver the
 // staged device -> host results.
+// (round 6, measured and dropped: polling the stream for the first 300 us of a wait without a watchdog instead of hipStreamSynchronize at once --
+//  the analysis entry 3.07 against 3.02 ms, the pools inside their noise: the runtime's own wait is not where an entry's waits lose time)
 static hipError_t ctx_wait(pdbeda_ctx *ctx) {
     if (ctx->timed_out) return hipErrorNotReady;
     if (ctx->timeout_s <= 0.0) return hipStreamSynchronize(ctx->stream);
@@ -2328,7 +2330,7 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
     // PDBEDA_CLOUD_TRACE=1 (experiments): the sizes of the two jobs and the host-side phases of this call on stderr
     static const bool cloud_trace = [] { const char *e = getenv("PDBEDA_CLOUD_TRACE"); return e && e[0] && e[0] != '0'; }();
     const double t_call = now_s();
-    double t_wait1 = 0.0, t_pooled = 0.0;
+    double t_wait1 = 0.0, t_pooled = 0.0, t_marks[6] = {0, 0, 0, 0, 0, 0};
 
     // ---- 1. the clouds of every atom: one sphere batch, a group per atom (findAberrantBlobs, 603) ----
     pdbeda_bloblist *clouds = nullptr;
@@ -2351,6 +2353,7 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
     rc = list_materialise_voxels(clouds);
     if (rc) return bail(rc, clouds, nullptr);
 
+    t_marks[0] = now_s();
     // ---- 2. host: centroid-distance cut-off, best cloud, pool (604-642) ----
     std::vector<int64_t> first((size_t)n + 1, 0);       // clouds of atom a: [first[a], first[a + 1])  (sorted by group)
     for (int64_t c = 0; c < nb; ++c) first[(size_t)c_grp[(size_t)c] + 1]++;
@@ -2369,6 +2372,7 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
     }
     const double cutoff = np_median_h(centroidDistances) + 2.5 * np_std_h(centroidDistances);
     res->totals[3] = cutoff;
+    t_marks[1] = now_s();
     std::vector<int32_t> pool_cloud, pool_atom;
     pool_cloud.reserve((size_t)nb); pool_atom.reserve((size_t)nb);
     res->atom_idx.reserve((size_t)n); res->atom_total.reserve((size_t)n); res->atom_nvox.reserve((size_t)n);
@@ -2393,6 +2397,7 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
     }
     const int64_t n_pool = (int64_t)pool_cloud.size();
     if (n_pool == 0) { pdbeda_bloblist_free(clouds); return PDBEDA_OK; }
+    t_marks[2] = now_s();
 
     // ---- 3. device: pooled voxels -> union job (a group per residue + the domain group) ----
     pdbeda_bloblist *cow = owner_of(clouds);
@@ -2426,6 +2431,7 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
         }
     }
     const int64_t n_pairs = (int64_t)pair_a.size();
+    t_marks[3] = now_s();
 
     GroupSetup gs;
     rc = group_alloc(ctx, 2 * V, n_groups, &gs);
@@ -2508,6 +2514,7 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
             union_totals[1] += (int64_t)vd.dim[0] * vd.dim[1] * vd.dim[2];
         }
     }
+    t_marks[4] = now_s();
     const bool host_sized = !ctx->debug_shrink_totals && union_totals[0] < (1ll << 31) && union_totals[1] < (1ll << 40);   // (absurd boxes, or the debug hook that wants the device's own sizing: the waiting path sizes and reports)
     hipError_t e;
     std::vector<char> block(upload_bytes, 0);      // (staged: the copy below reads a pinned block or, too large for that, has finished reading when it returns)
@@ -2626,9 +2633,10 @@ extern "C" int pdbeda_aggregate_cloud(pdbeda_map *m, const pdbeda_cloud_atoms *a
     const int64_t nu = (int64_t)u_n.size();
     if (cloud_trace)
         fprintf(stderr, "aggregate_cloud: %lld atoms, %lld clouds, %lld pooled clouds (%lld voxels), %d residue groups + the domain group: %lld mask words, %lld keys, %lld union blobs; "
-                        "ms: clouds enqueued + waited %.3f, host pooling %.3f, union job enqueued + waited %.3f\n",
+                        "ms: clouds enqueued + waited %.3f, host pooling %.3f (voxel lists enqueued %.3f, distances + cut-off %.3f, pool loop %.3f, groups + pairs %.3f, arenas + volumes %.3f, block + staging %.3f), union job enqueued + waited %.3f\n",
                 (long long)n, (long long)nb, (long long)n_pool, (long long)V, n_rg, (long long)union_totals[0], (long long)union_totals[1], (long long)nu,
-                1e3 * (t_wait1 - t_call), 1e3 * (t_pooled - t_wait1), 1e3 * (now_s() - t_pooled));
+                1e3 * (t_wait1 - t_call), 1e3 * (t_pooled - t_wait1), 1e3 * (t_marks[0] - t_wait1), 1e3 * (t_marks[1] - t_marks[0]), 1e3 * (t_marks[2] - t_marks[1]),
+                1e3 * (t_marks[3] - t_marks[2]), 1e3 * (t_marks[4] - t_marks[3]), 1e3 * (t_pooled - t_marks[4]), 1e3 * (now_s() - t_pooled));
     pdbeda_bloblist_free(uni);
     pdbeda_bloblist_free(clouds);
     if (rc) { delete res; *out = nullptr; return rc; }
