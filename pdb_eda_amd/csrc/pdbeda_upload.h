@@ -78,6 +78,15 @@ inline size_t file_chunk_alone_bytes() {
     }();
     return v;
 }
+// the first two rounds of a load's chunks (PDBEDA_FILE_RAMP_KB="a,b": experiments)
+inline size_t ramp_bytes(int round) {
+    static const std::pair<size_t, size_t> v = [] {
+        long a = 256, b = 1024;
+        if (const char *e = getenv("PDBEDA_FILE_RAMP_KB")) { long x = 0, y = 0; if (sscanf(e, "%ld,%ld", &x, &y) == 2 && x >= 16 && y >= 16) { a = x; b = y; } }
+        return std::make_pair((size_t)a << 10, (size_t)b << 10);
+    }();
+    return round == 0 ? v.first : v.second;
+}
 inline unsigned reader_spins() { static const unsigned v = (unsigned)env_long("PDBEDA_READER_SPINS", 4); return v; }
 inline double stall_seconds() { static const double v = [] { const char *e = getenv("PDBEDA_SLOT_STALL_S"); return e ? atof(e) : 2.0; }(); return v; }
 inline bool upload_trace() { static const bool v = [] { const char *e = getenv("PDBEDA_UPLOAD_TRACE"); return e && e[0] && e[0] != '0'; }(); return v; }
@@ -228,7 +237,7 @@ struct UploadEngine {
         const size_t full = active.fetch_add(1) == 0 ? file_chunk_alone_bytes() : file_chunk_bytes();
         for (size_t pos = 0, k = 0; pos < ld.need; ++k) {
             const size_t round = k / (size_t)n_readers;
-            const size_t len = std::min(ld.need - pos, round == 0 ? std::min(full, (size_t)256 << 10) : (round == 1 ? std::min(full, (size_t)1 << 20) : full));
+            const size_t len = std::min(ld.need - pos, round == 0 ? std::min(full, ramp_bytes(0)) : (round == 1 ? std::min(full, ramp_bytes(1)) : full));
             ld.pieces.emplace_back(pos, len);
             pos += len;
         }
