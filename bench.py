@@ -167,6 +167,30 @@ def cpu_share():
     return (max(1, min(cores, int(quota + 0.5))) if quota else cores), cores, quota
 
 
+def host_contention():
+    """The committed phantom-ranks runs (tools/exp/phantom_ranks.py, profiles/r*_phantom_ranks_*.json): the real rank's entries/min beside k phantom ranks
+    that do the host half of a rank's work -- and the cgroup's throttling beside it.  Not re-measured here (two minutes of pools); carried from profiles/."""
+    import glob
+    rows, quota = [], None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_phantom_ranks_*.json"))):
+        try:
+            with open(path) as fh:
+                d = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        quota = d.get("cgroup_before", {}).get("cpu.max", quota)
+        for r in d.get("rows", []):
+            rows.append({"file": os.path.basename(path), "phantom_ranks": r.get("phantom_ranks"), "phantom_processes": r.get("phantom_processes"),
+                         "both_maps_k_per_min": round(r.get("both_maps_entries_per_min", 0.0) / 1e3, 1), "lazy_k_per_min": round(r.get("lazy_diff_map_entries_per_min", 0.0) / 1e3, 1),
+                         "phantom_memory_passes_GBs": round(r.get("host_memory_passes_GBs", 0.0)), "cgroup_cpu_busy": round(r.get("cgroup_cpu_busy", 0.0), 1),
+                         "cgroup_periods_throttled": r.get("cgroup_periods_throttled")})
+    if not rows:
+        return None
+    return {"rows": rows, "cgroup_cpu_max": quota,
+            "note": "committed runs of tools/exp/phantom_ranks.py on one box of this pool: a 16-CPU cgroup quota (cpu.max) that one rank's pool half fills -- every row with a phantom is "
+                    "throttled, so the real rank's loss measures the quota, not host-memory contention; the 8-rank host side needs an 8-GPU node (DESIGN.md section 6)"}
+
+
 def link_rate(torch):
     """Pinned host -> HBM copy of 64 MiB, the best of six batches of five copies: GB/s."""
     pin = torch.empty(16 << 20, dtype=torch.float32).pin_memory()
@@ -394,6 +418,7 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
                                   "note": "the same entry list with the product's default loader: the Fo-Fc file's header is read, its grid would follow on first use "
                                           "and nothing in the record of `pdb_eda multiple` uses it (32 MB per entry over PCIe instead of 64); same records"},
                 "cpu_baseline": cpu_pool,
+                "host_contention": host_contention() if rank == 0 else None,
                 "cold_pass": cold,
                 "page_cache": "warm for `entries_per_min`: the files were written by this process moments earlier and every one is read again on each pass; "
                               "`cold_pass` is one pass after the files' pages were dropped",

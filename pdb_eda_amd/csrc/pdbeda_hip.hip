@@ -2011,7 +2011,13 @@ static int grouped_job(pdbeda_map *m, GroupSetup &gs, int64_t n_items, int64_t n
     const bool fused_atoms = spheres && gs.atom_engine && n_items > 0 && n_items == n_groups;
     if (e == hipSuccess && fused_atoms) {   // a per-atom batch of small boxes: paint, run index, unions, resolve and key painting in one launch
         PROF(ctx, "k_atom_engine");
-        hipLaunchKernelGGL(k_atom_engine, dim3((unsigned)n_items), dim3(256), 0, st, job, m->geom_dev, m->dens, gs.d_xyz, gs.d_radii, gs.d_boxes, cutoff);
+        // (PDBEDA_DEBUG_ATOM_CAPS="runs,comps": tests shrink the LDS tables' use so that small inputs run the kernel's global-table path)
+        static const std::pair<int, int> caps = [] {
+            int r = ATOM_RUNS, c = ATOM_COMPS;
+            if (const char *e = getenv("PDBEDA_DEBUG_ATOM_CAPS")) { int x = 0, y = 0; if (sscanf(e, "%d,%d", &x, &y) == 2) { r = std::max(0, std::min(x, ATOM_RUNS)); c = std::max(0, std::min(y, ATOM_COMPS)); } }
+            return std::make_pair(r, c);
+        }();
+        hipLaunchKernelGGL(k_atom_engine, dim3((unsigned)n_items), dim3(256), 0, st, job, m->geom_dev, m->dens, gs.d_xyz, gs.d_radii, gs.d_boxes, cutoff, caps.first, caps.second);
         e = hipGetLastError();
     } else if (e == hipSuccess && n_items > 0) {
         if (spheres)

@@ -1570,7 +1570,7 @@ __device__ __forceinline__ void atom_store_record(const Job &job, uint32_t idx, 
 
 __global__ void __launch_bounds__(256) k_atom_engine(Job job, const Geom *__restrict__ gp, const float *__restrict__ dens,
                                                      const double *__restrict__ xyz, const float *__restrict__ radii,
-                                                     const AtomBox *__restrict__ boxes, float cutoff) {
+                                                     const AtomBox *__restrict__ boxes, float cutoff, int run_cap, int comp_cap) {   // (the caps: ATOM_RUNS / ATOM_COMPS; tests shrink them -- PDBEDA_DEBUG_ATOM_CAPS -- so that small inputs take the global-table path)
     __shared__ unsigned long long s_m[ATOM_WORDS];
     __shared__ uint32_t s_rb[ATOM_WORDS];     // first run of the row, counted from the volume's first run
     __shared__ uint32_t s_par[ATOM_RUNS];     // LDS path: parent of run k of the volume; after the numbering of the roots: component of the run
@@ -1641,7 +1641,7 @@ __global__ void __launch_bounds__(256) k_atom_engine(Job job, const Geom *__rest
     const uint32_t T = s_carry;   // runs of the volume (block-uniform)
     // (the id range: one returning atomic per volume, in flight while the unions run in LDS)
     if (tid == 0) s_base = T ? atomicAdd(&job.ctr->n_runs, T) : 0u;
-    if (T <= (uint32_t)ATOM_RUNS) {
+    if (T <= (uint32_t)run_cap) {
         // ---- LDS path: unions on an LDS parent table ----
         for (uint32_t i = tid; i < T; i += 256u) s_par[i] = i;
         __syncthreads();
@@ -1679,7 +1679,7 @@ __global__ void __launch_bounds__(256) k_atom_engine(Job job, const Geom *__rest
         __syncthreads();
         // the roots take component numbers (the smallest run id of a blob is its root: parents point downwards)
         for (uint32_t i = tid; i < T; i += 256u)
-            if (s_par[i] == i) { const uint32_t c = atomicAdd(&s_ncomp, 1u); if (c < (uint32_t)ATOM_COMPS) s_root[c] = i; }
+            if (s_par[i] == i) { const uint32_t c = atomicAdd(&s_ncomp, 1u); if (c < (uint32_t)comp_cap) s_root[c] = i; }
         for (int c = tid; c < ATOM_COMPS; c += 256) {
 #pragma unroll
             for (int f = 0; f < 10; ++f) s_acc[f][c] = 0ull;
@@ -1690,7 +1690,7 @@ __global__ void __launch_bounds__(256) k_atom_engine(Job job, const Geom *__rest
     __syncthreads();   // (s_base: thread 0's atomic has returned)
     const uint32_t n_comp = s_ncomp;
     const uint32_t base = s_base;
-    const bool in_lds = T <= (uint32_t)ATOM_RUNS && n_comp <= (uint32_t)ATOM_COMPS;   // block-uniform
+    const bool in_lds = T <= (uint32_t)run_cap && n_comp <= (uint32_t)comp_cap;   // block-uniform
     if (in_lds) {
         // every run finds its root; the roots' places among the components go where the parents were
         uint32_t my_root[ATOM_RUNS / 256];

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import VOXEL_CASES, GOLDEN, load_case, blobs_from_record, crs_set
+from conftest import VOXEL_CASES, GOLDEN, ROOT, load_case, blobs_from_record, crs_set
 
 pytestmark = pytest.mark.gpu
 
@@ -794,3 +794,53 @@ def test_borrowed_device_buffer(tmp_path):
     script.write_text(BORROWED_WORKER % {"root": os.path.dirname(os.path.dirname(os.path.abspath(__file__)))})
     proc = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=280)
     assert proc.returncode == 0 and "borrowed ok" in proc.stdout, proc.stderr[-3000:]
+
+
+ATOM_ENGINE_WORKER = r'''
+import json, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from pdb_eda_amd import _native, ccp4, synthetic
+ctx = _native.Context(0)
+out = []
+for shape, seed, spacing, radii, nsd in (((40, 44, 48), 31, 0.5, (0.8, 1.6, 3.4), 0.3), ((36, 40, 52), 32, 0.35, (1.0, 2.4, 5.2), 1.0), ((30, 30, 30), 33, 0.5, (3.5,), 0.0)):
+    g = synthetic.smooth_noise(shape, seed, 1.0)
+    spec = synthetic.MapSpec(ncrs=shape[::-1], spacing=spacing)
+    header = ccp4.DensityHeader.fromFileHeader(synthetic.ccp4_header_bytes(spec))
+    m = _native.DeviceMap(ctx, g, header.geometry())
+    mean, std = m.stats()
+    rng = np.random.default_rng(seed)
+    lo, hi = np.array(header.crs2xyzCoord([2, 2, 2])), np.array(header.crs2xyzCoord([shape[2] - 3, shape[1] - 3, shape[0] - 3]))
+    xyz = lo + rng.random((40, 3)) * (hi - lo)
+    rad = np.array([radii[k %% len(radii)] for k in range(40)], dtype=np.float32)
+    bl = m.sphere_blobs(xyz, rad, np.arange(41), mean + nsd * std if nsd else 0.0)
+    st = bl.stats()
+    crs, off = bl.voxels()
+    lists = [sorted(map(tuple, crs[a:b].tolist())) for a, b in zip(off[:-1], off[1:])]
+    out.append({"n": st["n"].tolist(), "key": st["firstKey"].tolist(), "group": st["group"].tolist(), "total": [float.hex(float(x)) for x in st["totalDensity"]],
+                "centroid": [float.hex(float(x)) for x in st["centroid"].ravel()], "voxels": lists})
+    bl.free(); m.free()
+json.dump(out, open(%(out)r, "w"))
+'''
+
+
+@pytest.mark.timeout(300)
+def test_atom_engine_paths_agree(tmp_path):
+    """Round 6: a per-atom sphere batch is labelled by one launch (k_atom_engine).  Its three ways through a volume -- the LDS tables, the
+    kernel's own global-table path for a volume beyond them (forced here by shrinking the tables' use: PDBEDA_DEBUG_ATOM_CAPS), and the five
+    generic kernels (boxes beyond one word a row or 512 rows, or PDBEDA_ATOM_ENGINE=0) -- give the same blobs to the last bit: counts, first
+    keys, groups, sums, centroids, voxel sets.  Radii from 0.8 to 5.2 A at 0.35 / 0.5 A spacing (rows of 6 to 32 voxels, boxes of 36 to
+    1 024 rows), cutoffs from 0 (every voxel of the sphere) to 1 sigma of noise (hundreds of runs, dozens of blobs in a box)."""
+    import json
+    import subprocess
+    import sys
+    outs = []
+    for k, env_extra in enumerate(({}, {"PDBEDA_DEBUG_ATOM_CAPS": "0,0"}, {"PDBEDA_DEBUG_ATOM_CAPS": "24,3"}, {"PDBEDA_ATOM_ENGINE": "0"})):
+        out, script = tmp_path / ("out%d.json" % k), tmp_path / ("worker%d.py" % k)
+        script.write_text(ATOM_ENGINE_WORKER % {"root": ROOT, "out": str(out)})
+        proc = subprocess.run([sys.executable, str(script)], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=280)
+        assert proc.returncode == 0, proc.stderr[-3000:]
+        outs.append(json.loads(out.read_text()))
+    assert sum(len(c["n"]) for c in outs[0]) > 200 and max(max(c["n"]) for c in outs[0]) > 1000
+    for k in (1, 2, 3):
+        assert outs[k] == outs[0], k
