@@ -222,6 +222,14 @@ def multiple_leg(args, pool, rank, local_rank, world, barrier, dist, torch):
         # page cache: a pass over the list reads 125 x 64 MB = 8 GB, beyond any last-level cache (16 files = 1 GB were re-read 13 x)
         distinct = max(1, min(args.entry_files, args.entries))
         generated = max(1, min(args.entry_generated, distinct))
+        try:      # (N ranks write N x 8 GB into one /tmp: a rank takes at most its share of two thirds of the free space)
+            pair_bytes = 2 * (4 * args.entry_size ** 3 + 1024)
+            room = int(shutil.disk_usage(tmp).free * 2 / 3 / max(world, 1) / pair_bytes)
+            if room < distinct:
+                print("bench.py: /tmp holds %d of the %d file pairs per rank: fewer distinct names" % (max(room, generated), distinct), file=sys.stderr)
+                distinct = max(generated, min(distinct, room))
+        except OSError:
+            pass
         # entry 0 of every rank is the configs[3] entry the REFERENCE was run on (synthetic.BIG_CASES["c3_multiple_entry"]: 200^3, 100
         # residues, seed 0): its records are checked against the reference's numbers after every pool has returned
         golden_case = synthetic.BIG_CASES["c3_multiple_entry"]
