@@ -662,7 +662,7 @@ static int map_create(pdbeda_ctx *ctx, const float *host, const float *dev, cons
     Arena scratch;
     bool have_scratch = false;
     if (with_stats) {
-        if (arena_get(ctx, 8 * (size_t)std::max<int64_t>(m->n_vox / NP_CHUNK, 1), &scratch) == 0) {
+        if (arena_get(ctx, 24 * (size_t)std::max<int64_t>(m->n_vox / NP_CHUNK, 1), &scratch) == 0) {
             have_scratch = true;
             if (stats_enqueue(m, reinterpret_cast<double *>(scratch.base), st_host, range, true) != 0) e = hipErrorUnknown;
         } else {
@@ -849,7 +849,7 @@ static int upload_file_impl(pdbeda_ctx *ctx, const char *path, int64_t offset, i
     Arena scratch;
     bool have_scratch = false;
     if (with_stats) {
-        if (arena_get(ctx, 8 * (size_t)std::max<int64_t>(n_vox / NP_CHUNK, 1), &scratch) == 0) {
+        if (arena_get(ctx, 24 * (size_t)std::max<int64_t>(n_vox / NP_CHUNK, 1), &scratch) == 0) {
             have_scratch = true;
             if (stats_enqueue(m, reinterpret_cast<double *>(scratch.base), host, range, true) != 0) e = hipErrorUnknown;
         } else {
@@ -1007,25 +1007,40 @@ extern "C" int pdbeda_map_invalidate(pdbeda_map *m) {
 // mean and std in numpy's own summation tree (k_np_chunk_sums / k_np_final): == np.mean / np.std, not merely close -- and, while
 // the map's range is not known yet, the range pass behind them (range_enqueue): everything queued, nothing waited for.
 // chunk_sums: 8 * max(n_vox / NP_CHUNK, 1) bytes of device scratch; host[2] / range[2] are filled at the next ctx_sync.
+// chunk_sums: scratch of 3 x max(n_vox / NP_CHUNK, 1) doubles (the chunks' numpy sums; with want_range their range partials behind them).
+// Round 6: with want_range the range rides in the mean's pass (k_np_chunk_sums / k_np_final, mode 0) and the LAST launch of the chain writes mean,
+// std and range straight into the pinned block: four launches where there were seven (two range kernels and a copy), and one pass over the map less.
 static int stats_enqueue(pdbeda_map *m, double *chunk_sums, double host[2], double range[2], bool want_range) {
     pdbeda_ctx *ctx = m->ctx;
-    // (mean / std in the first two of the eight result slots behind the partial sums, the range in slots 4 / 5: with the range
-    //  pass behind them, ONE copy of six doubles brings both)
+    // (mean / std in the first two of the eight result slots behind the partial sums, the range in slots 4 / 5)
     double *res = ctx->partials + 2 * N_PARTIAL;
     const int64_t n_full = m->n_vox / NP_CHUNK;
+    const int64_t n_chunks = std::max<int64_t>(n_full, 1);
     hipStream_t st = ctx->stream;
+    // the results' place in the pinned block (kernels write host memory only with PDBEDA_COPY_KERNELS, the default)
+    double *host_out = nullptr;
+    if (want_range && copy_kernels() && ctx->pinned && ctx->pinned_used + 64 <= ctx->pinned_cap) {
+        host_out = reinterpret_cast<double *>(ctx->pinned + ctx->pinned_used);
+        ctx->pending.push_back({host, ctx->pinned_used, 2 * sizeof(double)});
+        ctx->pending.push_back({range, ctx->pinned_used + 4 * sizeof(double), 2 * sizeof(double)});
+        ctx->pinned_used += 64;
+    }
+    double *r_sum = want_range ? chunk_sums + n_chunks : nullptr, *r_max = want_range ? chunk_sums + 2 * n_chunks : nullptr;
     for (int mode = 0; mode < 2; ++mode) {
-        if (n_full > 0) { PROF(ctx, "k_np_chunk_sums"); hipLaunchKernelGGL(k_np_chunk_sums, dim3((unsigned)std::min<int64_t>(n_full, 1 << 16)), dim3(256), 0, st, m->dens, n_full, mode, res, chunk_sums); }
-        { PROF(ctx, "k_np_final"); hipLaunchKernelGGL(k_np_final, dim3(1), dim3(256), 0, st, m->dens, m->n_vox, n_full, mode, res, chunk_sums, mode, res + mode); }
+        const bool with_range = want_range && mode == 0;
+        if (n_full > 0) { PROF(ctx, "k_np_chunk_sums"); hipLaunchKernelGGL(k_np_chunk_sums, dim3((unsigned)std::min<int64_t>(n_full, 1 << 16)), dim3(256), 0, st, m->dens, n_full, mode, res, chunk_sums,
+                                                                           with_range ? r_sum : (double *)nullptr, with_range ? r_max : (double *)nullptr); }
+        { PROF(ctx, "k_np_final"); hipLaunchKernelGGL(k_np_final, dim3(1), dim3(256), 0, st, m->dens, m->n_vox, n_full, mode, res, chunk_sums, mode, res + mode,
+                                                      with_range && n_full > 0 ? r_sum : (const double *)nullptr, with_range && n_full > 0 ? r_max : (const double *)nullptr,
+                                                      with_range ? res + 4 : (double *)nullptr, want_range && mode == 1 ? res + 4 : (const double *)nullptr, mode == 1 ? host_out : (double *)nullptr); }
     }
     HIP_TRY(ctx, hipGetLastError());
+    if (host_out) return 0;
     if (!want_range) {
         HIP_TRY(ctx, d2h(ctx, host, res, 2 * sizeof(double)));
         return 0;
     }
-    const int rc_range = range_enqueue(m, nullptr);
-    if (rc_range) return rc_range;
-    // one copy of the six doubles into the staging block, delivered to the caller's two arrays at the next ctx_sync
+    // (no room in the pinned block, or the runtime's copies asked for: one copy of the six doubles, or two)
     if (ctx->pinned && ctx->pinned_used + 64 <= ctx->pinned_cap) {
         HIP_TRY(ctx, copy_kernels() ? copy_by_kernel(ctx, ctx->pinned + ctx->pinned_used, res, 6 * sizeof(double))
                                     : hipMemcpyAsync(ctx->pinned + ctx->pinned_used, res, 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1046,7 +1061,7 @@ extern "C" int pdbeda_map_stats(pdbeda_map *m, double *mean, double *std) {
     const int64_t n_full = m->n_vox / NP_CHUNK;
     double host[2], range[2] = {0.0, 0.0};
     const bool want_range = m->fix_mul == 0.0 && !m->fix_refused;   // the quantum of the map's blob sums, in the same wait
-    int rc = with_scratch(ctx, 8 * (size_t)std::max<int64_t>(n_full, 1), [&](char *base) -> int {
+    int rc = with_scratch(ctx, 24 * (size_t)std::max<int64_t>(n_full, 1), [&](char *base) -> int {
         return stats_enqueue(m, reinterpret_cast<double *>(base), host, range, want_range);
     });
     if (rc) return rc;

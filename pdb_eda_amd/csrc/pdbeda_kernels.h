@@ -2133,10 +2133,14 @@ __device__ __forceinline__ double np_elem(float v, int mode, double shift) {
     return d;
 }
 
+// range_sum / range_max (round 6; nullable, mode 0): per chunk, sum |x| and max |x| of the same 8192 values -- the range pass of a fresh map (the quantum
+// of its blob sums) rides in the mean's pass over the map instead of a pass and two launches of its own (k_range_partials, k_range_final)
 __global__ void __launch_bounds__(256) k_np_chunk_sums(const float *__restrict__ x, int64_t n_full, int mode, const double *__restrict__ mean_p,
-                                                       double *__restrict__ chunk_sums) {
+                                                       double *__restrict__ chunk_sums, double *__restrict__ range_sum, double *__restrict__ range_max) {
     __shared__ __attribute__((aligned(16))) float s_x[64 * NP_LSTRIDE];
     __shared__ double s_node[8];
+    __shared__ double s_rs[4];
+    __shared__ float s_rm[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double shift = mode == 1 ? mean_p[0] : 0.0;
     for (int64_t chunk = blockIdx.x; chunk < n_full; chunk += gridDim.x) {   // block-uniform
@@ -2149,7 +2153,21 @@ __global__ void __launch_bounds__(256) k_np_chunk_sums(const float *__restrict__
             const int idx = 4 * (tid + 256 * k);
             *reinterpret_cast<float4 *>(&s_x[(idx >> 7) * NP_LSTRIDE + (idx & 127)]) = v[k];
         }
+        if (range_sum) {   // (block-uniform; a fixed order: thread, then the shuffle tree, then the waves in order)
+            double acc = 0.0;
+            float mx = 0.0f;
+            auto take = [&](float q) { const float a = fabsf(q); if (a < INFINITY) { acc += (double)a; mx = a > mx ? a : mx; } else mx = INFINITY; };   // (a NaN or an infinity makes the maximum infinite: the host refuses such a map)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { take(v[k].x); take(v[k].y); take(v[k].z); take(v[k].w); }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { acc += __shfl_down(acc, off); const float o = __shfl_down(mx, off); mx = o > mx ? o : mx; }
+            if (lane == 0) { s_rs[wv] = acc; s_rm[wv] = mx; }
+        }
         __syncthreads();
+        if (range_sum && tid == 0) {
+            range_sum[chunk] = ((s_rs[0] + s_rs[1]) + s_rs[2]) + s_rs[3];
+            range_max[chunk] = (double)fmaxf(fmaxf(s_rm[0], s_rm[1]), fmaxf(s_rm[2], s_rm[3]));
+        }
         double node[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -2167,8 +2185,13 @@ __global__ void __launch_bounds__(256) k_np_chunk_sums(const float *__restrict__
     }
 }
 
+// range_sum / range_max / range_out (round 6; nullable, mode 0): the chunks' range partials folded in index order, the tail's added -> range_out[0] = sum |x|,
+// range_out[1] = max |x|.  host_out (nullable): six doubles -- mean_p[0] or this launch's result, this launch's result, -, -, and the range (this launch's, or range_in) -- written
+// straight into the context's pinned block by the LAST launch of the chain (a copy launch of its own before).
 __global__ void __launch_bounds__(256) k_np_final(const float *__restrict__ x, int64_t n, int64_t n_full, int mode, const double *__restrict__ mean_p,
-                                                  const double *__restrict__ chunk_sums, int take_sqrt, double *__restrict__ out) {
+                                                  const double *__restrict__ chunk_sums, int take_sqrt, double *__restrict__ out,
+                                                  const double *__restrict__ range_sum, const double *__restrict__ range_max, double *__restrict__ range_out,
+                                                  const double *__restrict__ range_in, double *__restrict__ host_out) {
     // The tail's recursion tree as a heap in LDS (node i -> 2i, 2i + 1): a right child is at most l / 2 + 7.5 long, so from 8 191 elements
     // the lengths are <= 4 103, 2 059, 1 037, 526, 270, 142, 78: every node of level 7 (ids 128..255) is a leaf.  Built level by level, leaves
     // summed by eight lanes each, combined level by level (left + right): round 5 -- one thread walking explicit stacks (private arrays =
@@ -2238,10 +2261,36 @@ __global__ void __launch_bounds__(256) k_np_final(const float *__restrict__ x, i
         }
         __syncthreads();
     }
+    double r_total = 0.0, r_max = 0.0;
+    if (range_out) {   // (block-uniform) the range: the tail's magnitudes by a fixed tree, the chunks' partials in index order behind them
+        __shared__ double s_rpart[4], s_rmax[4];
+        double acc = 0.0, mx = 0.0;
+        for (int i = tid; i < rem; i += 256) { const float a = fabsf(s_tail[i]); if (a < INFINITY) { acc += (double)a; mx = (double)a > mx ? (double)a : mx; } else mx = INFINITY; }
+        if (range_max)
+            for (int64_t k = tid; k < n_full; k += 256) { const double q = range_max[k]; mx = q > mx ? q : mx; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_down(mx, off); mx = o > mx ? o : mx; }
+        if ((tid & 63) == 0) s_rmax[tid >> 6] = mx;
+        const double tail_sum = block_sum(acc, s_rpart);   // (its barrier also publishes s_rmax)
+        if (tid == 0) {
+            r_total = tail_sum;
+            if (range_sum)
+                for (int64_t k = 0; k < n_full; ++k) r_total += range_sum[k];
+            r_max = fmax(fmax(s_rmax[0], s_rmax[1]), fmax(s_rmax[2], s_rmax[3]));
+            range_out[0] = r_total; range_out[1] = r_max;
+        }
+    }
     if (tid == 0) {
         if (rem > 0) total += s_val[1];
         const double v = total / (double)n;
-        out[0] = take_sqrt ? __dsqrt_rn(v) : v;
+        const double res = take_sqrt ? __dsqrt_rn(v) : v;
+        out[0] = res;
+        if (host_out) {
+            host_out[0] = mode == 1 ? mean_p[0] : res;
+            host_out[1] = res;
+            host_out[4] = range_out ? r_total : (range_in ? range_in[0] : 0.0);      // (range_in: what an earlier launch of the chain left in range_out)
+            host_out[5] = range_out ? r_max : (range_in ? range_in[1] : 0.0);
+        }
     }
 }
 
