@@ -1249,7 +1249,8 @@ static int engine_enqueue(pdbeda_ctx *ctx, pdbeda_map *m, Job &job, int64_t max_
         {   // few words in large volumes: a quarter of the words a block, four times the blocks (the loop over a wave's words is
             // serial; the rows of many small volumes -- atom spheres -- are mostly narrow: a thread each, 256 to the block)
             PROF(ctx, "k_run_index");
-            if (job.total_words < 256ll * 2048 && job.total_words > 64ll * job.n_vols) hipLaunchKernelGGL(k_run_index<64>, dim3(grid_for(job.total_words, 64, 1ll << 30)), dim3(256), 0, st, job, m->dens, m->geom_dev);
+            static const int force_wpb = [] { const char *e = getenv("PDBEDA_RUNINDEX_WPB"); return e ? atoi(e) : 0; }();   // (experiments: 64 / 256)
+            if (force_wpb != 256 && (force_wpb == 64 || (job.total_words < 256ll * 2048 && job.total_words > 64ll * job.n_vols))) hipLaunchKernelGGL(k_run_index<64>, dim3(grid_for(job.total_words, 64, 1ll << 30)), dim3(256), 0, st, job, m->dens, m->geom_dev);
             else hipLaunchKernelGGL(k_run_index<256>, dim3(grid_for(job.total_words, 256, 1ll << 30)), dim3(256), 0, st, job, m->dens, m->geom_dev);
         }
         { PROF(ctx, "k_union"); hipLaunchKernelGGL(k_union, dim3(grid_for(job.total_words * 4, 256, 1ll << 30)), dim3(256), 0, st, job); }
