@@ -1869,6 +1869,86 @@ static int group_setup(pdbeda_map *m, const double *xyz, const float *radii, con
     // [C - R - 1, C + R] with R = xyz2crs(origin + radius) -- its SIZE follows from the radius alone, so the host knows the
     // job's mask words and keys without asking the device (the round trip for the totals was one of an entry's host waits).
     // The inputs go through the pinned staging buffer, so nothing here needs the caller's arrays after the call returns.
+    // Round 6: GROUPED spheres (a residue's atoms: the residue region tables, RSCC / RSR) get their boxes and volumes from the host too -- a group's
+    // volume is the box around its atoms' boxes, which is what k_atom_boxes' atomic min / max and k_make_vols make of them on the device (the same
+    // xyz2crs, the same int32 arithmetic): k_init_bounds, k_atom_boxes, k_make_vols, the copy of their totals and the WAIT for it go (four launches and
+    // one of an entry's waits per grouped call).  PDBEDA_HOST_BOXES=0: the device makes them, as for the per-atom batches.
+    if (xyz && n_items > 0 && n_groups > 0 && n_groups < n_items) {
+        static const bool host_boxes_g = [] { const char *e = getenv("PDBEDA_HOST_BOXES"); return !(e && e[0] == '0'); }();
+        bool sane = true;
+        for (int64_t a = 0; a < n_items && sane; ++a) sane = radii[a] >= 0.0f && std::isfinite(radii[a]);
+        const size_t row = (size_t)((char *)(gs->d_ctr + 1) - gs->in_arena.base), row_need = (row + 63) & ~(size_t)63;
+        if (sane && host_boxes_g && copy_kernels() && !ctx->debug_shrink_totals && (char *)gs->d_xyz == gs->in_arena.base && ctx->pinned && row <= ((size_t)1 << 20) &&
+            ctx->pinned_used + row_need <= ctx->pinned_cap) {
+            char *stage = ctx->pinned + ctx->pinned_used;
+            memcpy(stage + ((char *)gs->d_xyz - gs->in_arena.base), xyz, 24 * (size_t)n_items);
+            memcpy(stage + ((char *)gs->d_radii - gs->in_arena.base), radii, 4 * (size_t)n_items);
+            memcpy(stage + ((char *)gs->d_item_group - gs->in_arena.base), item_group.data(), 4 * (size_t)n_items);
+            AtomBox *boxes = reinterpret_cast<AtomBox *>(stage + ((char *)gs->d_boxes - gs->in_arena.base));
+            VolDesc *vols = reinterpret_cast<VolDesc *>(stage + ((char *)gs->d_vols - gs->in_arena.base));
+            Counters *ctr0 = reinterpret_cast<Counters *>(stage + ((char *)gs->d_ctr - gs->in_arena.base));
+            std::vector<int32_t> glo(3 * (size_t)n_groups, INT32_MAX), ghi(3 * (size_t)n_groups, INT32_MIN);
+            float cached_rad = NAN;
+            int32_t R[3] = {0, 0, 0};
+            for (int64_t a = 0; a < n_items; ++a) {
+                if (!(radii[a] == cached_rad)) {
+                    const double rad = (double)radii[a];
+                    const double o[3] = {m->geom.origin[0] + rad, m->geom.origin[1] + rad, m->geom.origin[2] + rad};
+                    xyz2crs(m->geom, o, R);
+                    cached_rad = radii[a];
+                }
+                int32_t C[3];
+                xyz2crs(m->geom, xyz + 3 * a, C);
+                AtomBox bx;
+                bool empty = false;
+                for (int k = 0; k < 3; ++k) {      // (int32 arithmetic as in k_atom_boxes)
+                    bx.lo[k] = C[k] - R[k] - 1;
+                    bx.hi[k] = C[k] + R[k];
+                    empty = empty || bx.hi[k] < bx.lo[k];
+                }
+                if (empty) { for (int k = 0; k < 3; ++k) { bx.lo[k] = 0; bx.hi[k] = -1; } }
+                boxes[a] = bx;
+                if (!empty) {
+                    const size_t g = (size_t)item_group[(size_t)a];
+                    for (int k = 0; k < 3; ++k) { glo[3 * g + k] = std::min(glo[3 * g + k], bx.lo[k]); ghi[3 * g + k] = std::max(ghi[3 * g + k], bx.hi[k]); }
+                }
+            }
+            int64_t words = 0, keys = 0;
+            bool fits = true;
+            for (int64_t g = 0; g < n_groups; ++g) {      // (k_make_vols)
+                VolDesc vd;
+                memset(&vd, 0, sizeof vd);
+                bool empty = false;
+                for (int k = 0; k < 3; ++k) empty = empty || ghi[3 * (size_t)g + k] < glo[3 * (size_t)g + k];
+                for (int k = 0; k < 3 && !empty; ++k) {
+                    const int64_t d = (int64_t)ghi[3 * (size_t)g + k] - glo[3 * (size_t)g + k] + 1;
+                    fits = fits && d < (1ll << 30);
+                    vd.org[k] = glo[3 * (size_t)g + k];
+                    vd.dim[k] = (int32_t)d;
+                }
+                vd.row_words = (vd.dim[0] + 63) / 64;
+                vd.group = (int32_t)g;
+                vd.word_base = words;
+                vd.key_base = keys;
+                vols[g] = vd;
+                words += (int64_t)vd.row_words * vd.dim[1] * vd.dim[2];
+                keys += (int64_t)vd.dim[0] * vd.dim[1] * vd.dim[2];
+                fits = fits && words < (1ll << 40) && keys < (1ll << 46);
+            }
+            if (fits) {
+                memset(ctr0, 0, sizeof *ctr0);
+                ctr0->total_words = words;
+                ctr0->total_keys = keys;
+                gs->pend_src = stage; gs->pend_dst = gs->in_arena.base; gs->pend_bytes = (row + 15) & ~(size_t)15;
+                ctx->pinned_used += row_need;
+                gs->total_words = words;
+                gs->total_keys = keys;
+                gs->host_totals = true;
+                if (gs->total_words >= (1ll << 31) * 2) return fail(ctx, PDBEDA_ERR_ARGUMENT, "sphere batch too large (%lld mask words)", (long long)gs->total_words);
+                return 0;
+            }
+        }
+    }
     if (xyz && n_items > 0 && n_groups == n_items) {
         bool per_atom = true;
         for (int64_t g = 0; g <= n_groups && per_atom; ++g) per_atom = group_offsets[g] == g;

@@ -485,7 +485,14 @@ an.aggregateCloud()
 out = {"ratio": an.densityElectronRatio, "voxels": an.numVoxelsAggregated, "density": an.totalAggregatedDensity,
        "medians": {k: {t: float(v) for t, v in d.items()} for k, d in an.medians.items()},
        "residues": [[r[1], r[3], r[4], r[5], r[6]] + list(r[7]) for r in an.residueCloudDescriptions],
-       "atoms": an.calculateAtomRegionDiscrepancies(3.5, 3.0), "blobs": [list(map(repr, row)) for row in an.calculateAtomSpecificBlobStatistics(an.greenBlobList)]}
+       "atoms": an.calculateAtomRegionDiscrepancies(3.5, 3.0), "blobs": [list(map(repr, row)) for row in an.calculateAtomSpecificBlobStatistics(an.greenBlobList)],
+       # (groups of several atoms -- a residue's: round 6 makes their boxes and volumes on the host too, PDBEDA_HOST_BOXES=0 on the device)
+       "residue_regions": an.calculateResidueRegionDiscrepancies(3.5, 3.0), "residue_density": an.calculateResidueRegionDensity(2.0)}
+cols = structure.columns(st)
+off = np.concatenate([[0], np.cumsum(np.bincount(cols.res_of_atom, minlength=len(cols.residues)))]).astype(np.int64)
+gb = d0._map.sphere_blobs(cols.coord, np.full(len(cols.atoms), 1.4, dtype=np.float32), off, float(d0.meanDensity + 1.5 * d0.stdDensity))
+gst = gb.stats()
+out["grouped_blobs"] = {"n": gst["n"].tolist(), "key": gst["firstKey"].tolist(), "group": gst["group"].tolist(), "total": [float.hex(float(x)) for x in gst["totalDensity"]]}
 json.dump(out, open(%(out)r, "w"), default=lambda o: o.tolist() if hasattr(o, "tolist") else repr(o))
 '''
 
@@ -507,6 +514,6 @@ def test_the_ab_switches_change_no_result(tmp_path):
         proc = subprocess.run([sys.executable, str(script)], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=280)
         assert proc.returncode == 0, proc.stderr[-3000:]
         outs.append(json.loads(out.read_text()))
-    assert outs[0]["voxels"] > 0 and len(outs[0]["atoms"]) > 100 and len(outs[0]["blobs"]) > 5
+    assert outs[0]["voxels"] > 0 and len(outs[0]["atoms"]) > 100 and len(outs[0]["blobs"]) > 5 and len(outs[0]["residue_regions"]) > 20 and len(outs[0]["grouped_blobs"]["n"]) > 20
     assert all(o == outs[0] for o in outs[1:])
 
