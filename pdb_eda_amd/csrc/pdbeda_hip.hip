@@ -626,7 +626,8 @@ static int fill_geom(pdbeda_ctx *ctx, const pdbeda_geometry *in, Geom *g) {
     return 0;
 }
 
-static int stats_enqueue(pdbeda_map *m, double *chunk_sums, double host[2], double range[2], bool want_range);
+static int stats_enqueue(pdbeda_map *m, double *chunk_sums, double host[2], double range[2], bool want_range, bool with_geom = false);
+static bool stats_carries_geom(const pdbeda_map *m) { return m->n_vox / NP_CHUNK > 0; }      // (the chain's first launch exists: it brings the geometry along when asked to)
 static void range_apply(pdbeda_map *m, const double range[2]);
 
 static int map_create(pdbeda_ctx *ctx, const float *host, const float *dev, const pdbeda_geometry *geom, pdbeda_map **out, double *mean = nullptr, double *std = nullptr) {
@@ -655,16 +656,17 @@ static int map_create(pdbeda_ctx *ctx, const float *host, const float *dev, cons
     } else {
         m->dens = dev;
     }
-    if (e == hipSuccess) e = h2d_one(ctx, m->geom_dev, &m->geom, sizeof(Geom));
-    // (an uploaded map with its statistics from the same wait: see upload_file_impl)
+    // (an uploaded map with its statistics from the same wait: see upload_file_impl; the geometry rides in the statistics' first launch then)
     const bool with_stats = (mean || std) && host && e == hipSuccess;
+    const bool geom_in_stats = with_stats && stats_carries_geom(m);
+    if (e == hipSuccess && !geom_in_stats) e = h2d_one(ctx, m->geom_dev, &m->geom, sizeof(Geom));
     double st_host[2] = {0.0, 0.0}, range[2] = {0.0, 0.0};
     Arena scratch;
     bool have_scratch = false;
     if (with_stats) {
         if (arena_get(ctx, 24 * (size_t)std::max<int64_t>(m->n_vox / NP_CHUNK, 1), &scratch) == 0) {
             have_scratch = true;
-            if (stats_enqueue(m, reinterpret_cast<double *>(scratch.base), st_host, range, true) != 0) e = hipErrorUnknown;
+            if (stats_enqueue(m, reinterpret_cast<double *>(scratch.base), st_host, range, true, geom_in_stats) != 0) e = hipErrorUnknown;
         } else {
             e = hipErrorOutOfMemory;
         }
@@ -836,7 +838,8 @@ static int upload_file_impl(pdbeda_ctx *ctx, const char *path, int64_t offset, i
     m->own_dens = true;
     const char *why = nullptr;
     hipError_t e = engine_copy(ctx, engine, fd, offset, nullptr, (char *)d, need, &why);   // (first: the stream is idle, its query says so at once)
-    if (e == hipSuccess) e = h2d_one(ctx, m->geom_dev, &m->geom, sizeof(Geom));
+    const bool geom_in_stats = (mean || std) && stats_carries_geom(m);      // (the statistics' first launch brings the geometry along: a copy launch less)
+    if (e == hipSuccess && !geom_in_stats) e = h2d_one(ctx, m->geom_dev, &m->geom, sizeof(Geom));
     close(fd);
     if (e == hipSuccess && !why && byteswap) {
         hipLaunchKernelGGL(k_byteswap32, dim3(grid_for(n_vox, 256, 8192)), dim3(256), 0, ctx->stream, (uint32_t *)d, n_vox);
@@ -851,7 +854,7 @@ static int upload_file_impl(pdbeda_ctx *ctx, const char *path, int64_t offset, i
     if (with_stats) {
         if (arena_get(ctx, 24 * (size_t)std::max<int64_t>(n_vox / NP_CHUNK, 1), &scratch) == 0) {
             have_scratch = true;
-            if (stats_enqueue(m, reinterpret_cast<double *>(scratch.base), host, range, true) != 0) e = hipErrorUnknown;
+            if (stats_enqueue(m, reinterpret_cast<double *>(scratch.base), host, range, true, geom_in_stats) != 0) e = hipErrorUnknown;
         } else {
             e = hipErrorOutOfMemory;
         }
@@ -1010,7 +1013,8 @@ extern "C" int pdbeda_map_invalidate(pdbeda_map *m) {
 // chunk_sums: scratch of 3 x max(n_vox / NP_CHUNK, 1) doubles (the chunks' numpy sums; with want_range their range partials behind them).
 // Round 6: with want_range the range rides in the mean's pass (k_np_chunk_sums / k_np_final, mode 0) and the LAST launch of the chain writes mean,
 // std and range straight into the pinned block: four launches where there were seven (two range kernels and a copy), and one pass over the map less.
-static int stats_enqueue(pdbeda_map *m, double *chunk_sums, double host[2], double range[2], bool want_range) {
+// with_geom: the first launch of the chain also writes the map's geometry struct to the device (a kernel argument by value; callers check stats_carries_geom)
+static int stats_enqueue(pdbeda_map *m, double *chunk_sums, double host[2], double range[2], bool want_range, bool with_geom) {
     pdbeda_ctx *ctx = m->ctx;
     // (mean / std in the first two of the eight result slots behind the partial sums, the range in slots 4 / 5)
     double *res = ctx->partials + 2 * N_PARTIAL;
@@ -1029,7 +1033,8 @@ static int stats_enqueue(pdbeda_map *m, double *chunk_sums, double host[2], doub
     for (int mode = 0; mode < 2; ++mode) {
         const bool with_range = want_range && mode == 0;
         if (n_full > 0) { PROF(ctx, "k_np_chunk_sums"); hipLaunchKernelGGL(k_np_chunk_sums, dim3((unsigned)std::min<int64_t>(n_full, 1 << 16)), dim3(256), 0, st, m->dens, n_full, mode, res, chunk_sums,
-                                                                           with_range ? r_sum : (double *)nullptr, with_range ? r_max : (double *)nullptr); }
+                                                                           with_range ? r_sum : (double *)nullptr, with_range ? r_max : (double *)nullptr,
+                                                                           m->geom, with_geom && mode == 0 ? m->geom_dev : (Geom *)nullptr); }
         { PROF(ctx, "k_np_final"); hipLaunchKernelGGL(k_np_final, dim3(1), dim3(256), 0, st, m->dens, m->n_vox, n_full, mode, res, chunk_sums, mode, res + mode,
                                                       with_range && n_full > 0 ? r_sum : (const double *)nullptr, with_range && n_full > 0 ? r_max : (const double *)nullptr,
                                                       with_range ? res + 4 : (double *)nullptr, want_range && mode == 1 ? res + 4 : (const double *)nullptr, mode == 1 ? host_out : (double *)nullptr); }

@@ -2136,13 +2136,15 @@ __device__ __forceinline__ double np_elem(float v, int mode, double shift) {
 // range_sum / range_max (round 6; nullable, mode 0): per chunk, sum |x| and max |x| of the same 8192 values -- the range pass of a fresh map (the quantum
 // of its blob sums) rides in the mean's pass over the map instead of a pass and two launches of its own (k_range_partials, k_range_final)
 __global__ void __launch_bounds__(256) k_np_chunk_sums(const float *__restrict__ x, int64_t n_full, int mode, const double *__restrict__ mean_p,
-                                                       double *__restrict__ chunk_sums, double *__restrict__ range_sum, double *__restrict__ range_max) {
+                                                       double *__restrict__ chunk_sums, double *__restrict__ range_sum, double *__restrict__ range_max,
+                                                       Geom geom_val, Geom *__restrict__ geom_out) {   // geom_out (nullable): the map's geometry, by value -- a copy launch of its own before
     __shared__ __attribute__((aligned(16))) float s_x[64 * NP_LSTRIDE];
     __shared__ double s_node[8];
     __shared__ double s_rs[4];
     __shared__ float s_rm[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double shift = mode == 1 ? mean_p[0] : 0.0;
+    if (geom_out && blockIdx.x == 0 && tid == 0) *geom_out = geom_val;      // (nothing of this chain reads it; the jobs behind it on the stream do)
     for (int64_t chunk = blockIdx.x; chunk < n_full; chunk += gridDim.x) {   // block-uniform
         const float4 *src = reinterpret_cast<const float4 *>(x + chunk * NP_CHUNK);
         float4 v[8];
