@@ -2180,6 +2180,39 @@ extern "C" int pdbeda_region_sums(pdbeda_map *m, const double *xyz, const float 
     GroupSetup gs;
     int rc = group_setup(m, xyz, radii, nullptr, n_atoms, group_offsets, n_groups, &gs);
     if (rc) { arena_put(ctx, gs.in_arena); return rc; }
+    std::vector<unsigned long long> h_cnt(n_groups);
+    std::vector<unsigned int> h_inv(n_groups);
+    {   // a group per atom whose inputs the host staged (coordinates, radii, host-made volumes in the pinned block): ONE launch, no mask (k_atom_region)
+        static const bool atom_region_on = [] { const char *e = getenv("PDBEDA_ATOM_REGION"); return !(e && e[0] == '0'); }();      // (A/B switch)
+        const size_t out_bytes = 3 * align_up(8 * (size_t)n_groups, 64) + align_up(4 * (size_t)n_groups, 64);
+        if (atom_region_on && n_groups == n_atoms && gs.pend_bytes && !gs.host_boxes.empty() && copy_kernels() && ctx->pinned && ctx->pinned_used + out_bytes <= ctx->pinned_cap) {
+            char *blk = ctx->pinned + ctx->pinned_used;
+            size_t off = 0;
+            auto take = [&](void *dst, size_t bytes) { char *p = blk + off; if (dst && bytes) ctx->pending.push_back({dst, ctx->pinned_used + off, bytes}); off += align_up(std::max<size_t>(bytes, 1), 64); return p; };
+            double *o_pos = reinterpret_cast<double *>(take(pos, 8 * (size_t)n_groups));
+            double *o_neg = reinterpret_cast<double *>(take(neg, 8 * (size_t)n_groups));
+            unsigned long long *o_cnt = reinterpret_cast<unsigned long long *>(take(h_cnt.data(), 8 * (size_t)n_groups));
+            unsigned int *o_inv = reinterpret_cast<unsigned int *>(take(h_inv.data(), 4 * (size_t)n_groups));
+            ctx->pinned_used += off;
+            // (the staged row mirrors the scratch arena: the same offsets)
+            const char *stage = gs.pend_src;
+            const double *s_xyz = reinterpret_cast<const double *>(stage + ((char *)gs.d_xyz - gs.in_arena.base));
+            const float *s_rad = reinterpret_cast<const float *>(stage + ((char *)gs.d_radii - gs.in_arena.base));
+            const VolDesc *s_vols = reinterpret_cast<const VolDesc *>(stage + ((char *)gs.d_vols - gs.in_arena.base));
+            gs.pend_bytes = 0;
+            { PROF(ctx, "k_atom_region"); hipLaunchKernelGGL(k_atom_region, dim3((unsigned)std::min<int64_t>(n_groups, 65536)), dim3(256), 0, ctx->stream, m->geom_dev, m->dens, s_xyz, s_rad,
+                                                            s_vols, (int)n_groups, cutoff, o_pos, o_neg, o_cnt, o_inv); }
+            hipError_t e1 = hipGetLastError();
+            if (e1 == hipSuccess) e1 = ctx_sync(ctx);
+            arena_put(ctx, gs.in_arena);
+            if (e1 != hipSuccess) return fail(ctx, PDBEDA_ERR_DEVICE, "region sums: %s", hipGetErrorString(e1));
+            for (int64_t g = 0; g < n_groups; ++g) {
+                if (n_region) n_region[g] = (int64_t)h_cnt[g];
+                if (valid) valid[g] = h_inv[g] ? 0 : 1;
+            }
+            return PDBEDA_OK;
+        }
+    }
     const int64_t tw = std::max<int64_t>(gs.total_words, 1);
     Arena a;
     rc = arena_get(ctx, align_up(8 * tw) + 3 * align_up(8 * n_groups) + align_up(4 * n_groups), &a);
@@ -2207,8 +2240,6 @@ extern "C" int pdbeda_region_sums(pdbeda_map *m, const double *xyz, const float 
                            (int)n_groups, mask, gs.total_words, cutoff, d_pos, d_neg, d_cnt, d_inv); }
         e = hipGetLastError();
     }
-    std::vector<unsigned long long> h_cnt(n_groups);
-    std::vector<unsigned int> h_inv(n_groups);
     Counters setup;
     memset(&setup, 0, sizeof setup);
     if (e == hipSuccess) {

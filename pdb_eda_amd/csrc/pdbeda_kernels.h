@@ -1887,6 +1887,66 @@ __global__ void __launch_bounds__(256) k_region_reduce(const Geom *__restrict__ 
 // pooled voxels, 663-687) plus ONE extra group holding everything pooled (the domain clouds, 692-712).
 // ------------------------------------------------------------------------------------
 // Thread per gathered voxel: item i < V goes to the residue group of its cloud's atom, item V + i to the domain group.
+// Round 6: the regional sums of a PER-ATOM batch (calculateAtomRegionDensity / Discrepancy: a group per atom) in ONE launch.  A group of one atom needs
+// no mask -- nothing is united, no voxel is shared -- so the sphere test of k_sphere_paint (cutoff 0: the distance alone) and the sums of k_region_reduce
+// run in one pass over the atom's box: the same voxel -> thread mapping, the same order of the fp64 additions, the same reduction tree, hence the same
+// sums to the last bit (PDBEDA_ATOM_REGION=0: the four launches, A/B).  Inputs (coordinates, radii, the host-made volumes) are read where the host staged
+// them, in the pinned block -- a workgroup reads ITS atom's 80 bytes over the link once --, results are written there: no input copy, no zeroing, no pack.
+__global__ void __launch_bounds__(256) k_atom_region(const Geom *__restrict__ gp, const float *__restrict__ dens, const double *__restrict__ xyz,
+                                                     const float *__restrict__ radii, const VolDesc *__restrict__ vols, int n_vols, float cutoff,
+                                                     double *__restrict__ pos, double *__restrict__ neg, unsigned long long *__restrict__ cnt,
+                                                     unsigned int *__restrict__ invalid) {
+    __shared__ double s_p[4], s_q[4];
+    __shared__ unsigned int s_n[4], s_bad[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const Geom &g = *gp;
+    const double cut = (double)cutoff;
+    for (int v = blockIdx.x; v < n_vols; v += gridDim.x) {
+        const VolDesc vd = vols[v];
+        const double px = xyz[3 * v], py = xyz[3 * v + 1], pz = xyz[3 * v + 2], rad = (double)radii[v];
+        const unsigned dc = (unsigned)vd.dim[0], dr = (unsigned)vd.dim[1];
+        const unsigned nvox = dc * dr * (unsigned)vd.dim[2];
+        double p = 0.0, q = 0.0;
+        unsigned int n = 0;
+        bool bad = false;
+        for (unsigned i0 = tid; i0 < nvox; i0 += 1024) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned i = i0 + 256u * u;
+                if (i >= nvox) continue;
+                const unsigned row = i / dc, c = i - row * dc, sl = row / dr, rl = row - sl * dr;
+                const int rc = vd.org[0] + (int)c, rr = vd.org[1] + (int)rl, rs = vd.org[2] + (int)sl;
+                double w[3];
+                crs2xyz(g, rc, rr, rs, w);
+                const double dx = w[0] - px, dy = w[1] - py, dz = w[2] - pz;
+                if (!(__dsqrt_rn((dx * dx + dy * dy) + dz * dz) <= rad)) continue;      // (k_sphere_paint at cutoff 0: inside the sphere)
+                bool ok = true;
+                const double d = (double)fetch_wrapped(g, dens, rc, rr, rs, &ok);
+                ++n;
+                if (d > cut) p += d;
+                if (d < -cut) q += d;
+                bad = bad || !ok;
+            }
+        }
+        const unsigned long long any_bad = __ballot(bad);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            p += __shfl_down(p, off);
+            q += __shfl_down(q, off);
+            n += __shfl_down(n, off);
+        }
+        if (lane == 0) { s_p[wv] = p; s_q[wv] = q; s_n[wv] = n; s_bad[wv] = any_bad ? 1u : 0u; }
+        __syncthreads();
+        if (tid == 0) {
+            pos[v] = ((s_p[0] + s_p[1]) + s_p[2]) + s_p[3];
+            neg[v] = ((s_q[0] + s_q[1]) + s_q[2]) + s_q[3];
+            cnt[v] = (unsigned long long)(s_n[0] + s_n[1] + s_n[2] + s_n[3]);
+            invalid[v] = s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3];
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void __launch_bounds__(256) k_pool_gather(const int32_t *__restrict__ src_crs, const int64_t *__restrict__ src_off,
                                                      const int32_t *__restrict__ pool_cloud, const int64_t *__restrict__ pool_voff,
                                                      const int32_t *__restrict__ pool_group, int n_pool, int64_t V, int domain_group,

@@ -507,8 +507,9 @@ def test_the_ab_switches_change_no_result(tmp_path):
     import sys
     outs = []
     # (round 6: PDBEDA_ATOM_ENGINE=0 -- the five generic kernels instead of the one fused launch for per-atom sphere batches;
-    #  PDBEDA_UNORDERED_UNION=0 -- aggregateCloud's union job with painted keys, ranks and a packed blob table instead of k_union_finish)
-    for k, env_extra in enumerate(({}, {"PDBEDA_COPY_KERNELS": "0"}, {"PDBEDA_HOST_BOXES": "0"}, {"PDBEDA_ATOM_ENGINE": "0"}, {"PDBEDA_UNORDERED_UNION": "0"})):
+    #  PDBEDA_UNORDERED_UNION=0 -- aggregateCloud's union job with painted keys, ranks and a packed blob table instead of k_union_finish;
+    #  PDBEDA_ATOM_REGION=0 -- per-atom regional sums by paint + reduce + pack instead of the one fused launch)
+    for k, env_extra in enumerate(({}, {"PDBEDA_COPY_KERNELS": "0"}, {"PDBEDA_HOST_BOXES": "0"}, {"PDBEDA_ATOM_ENGINE": "0"}, {"PDBEDA_UNORDERED_UNION": "0"}, {"PDBEDA_ATOM_REGION": "0"})):
         out, script = tmp_path / ("out%d.json" % k), tmp_path / ("worker%d.py" % k)
         script.write_text(AB_WORKER % {"root": ROOT, "out": str(out)})
         proc = subprocess.run([sys.executable, str(script)], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=280)
