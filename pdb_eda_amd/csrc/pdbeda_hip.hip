@@ -455,6 +455,29 @@ static hipError_t d2h_many(pdbeda_ctx *ctx, const D2HItem *items, int n_items) {
 // ------------------------------------------------------------------------------------
 // Small batched helpers: stage host arrays through a scratch arena
 // ------------------------------------------------------------------------------------
+// Round 6: small results and single-touch inputs without copy launches.  pinned_out: a result array that a kernel writes STRAIGHT into the context's pinned
+// block (delivered to `dst` by the next ctx_sync); pinned_in: an input that every thread reads once, staged in the pinned block and read by the kernel over the
+// link.  nullptr: no room, or PDBEDA_COPY_KERNELS=0 (kernels do not touch host memory then) -- the caller stages on the device and copies as before.
+// (An input that threads read many times -- the atoms of a nearest-atom search -- belongs in device memory: a copy launch is cheaper than the link.)
+template <typename T>
+static T *pinned_out(pdbeda_ctx *ctx, T *dst, size_t count) {
+    const size_t bytes = sizeof(T) * count, need = (bytes + 63) & ~(size_t)63;
+    if (!copy_kernels() || !ctx->pinned || !dst || bytes == 0 || ctx->pinned_used + need > ctx->pinned_cap) return nullptr;
+    T *p = reinterpret_cast<T *>(ctx->pinned + ctx->pinned_used);
+    ctx->pending.push_back({dst, ctx->pinned_used, bytes});
+    ctx->pinned_used += need;
+    return p;
+}
+template <typename T>
+static const T *pinned_in(pdbeda_ctx *ctx, const T *src, size_t count) {
+    const size_t bytes = sizeof(T) * count, need = (bytes + 63) & ~(size_t)63;
+    if (!copy_kernels() || !ctx->pinned || !src || bytes == 0 || ctx->pinned_used + need > ctx->pinned_cap) return nullptr;
+    T *p = reinterpret_cast<T *>(ctx->pinned + ctx->pinned_used);
+    memcpy(p, src, bytes);
+    ctx->pinned_used += need;
+    return p;
+}
+
 template <typename Fn>
 static int with_scratch(pdbeda_ctx *ctx, size_t bytes, Fn fn) {
     Arena a;
@@ -1116,9 +1139,11 @@ extern "C" int pdbeda_point_density(pdbeda_map *m, const int32_t *crs, int64_t n
         Carver cv(base);
         int32_t *d_crs = cv.take<int32_t>(3 * n);
         double *d_out = cv.take<double>(n);
-        HIP_TRY(ctx, h2d_one(ctx, d_crs, crs, (size_t)(12 * n)));
-        hipLaunchKernelGGL(k_point_density, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->geom_dev, m->dens, d_crs, n, d_out, (uint8_t *)nullptr);
-        HIP_TRY(ctx, d2h(ctx, out, d_out, 8 * n));
+        const int32_t *in = pinned_in(ctx, crs, (size_t)(3 * n));
+        if (!in) { HIP_TRY(ctx, h2d_one(ctx, d_crs, crs, (size_t)(12 * n))); in = d_crs; }
+        double *res = pinned_out(ctx, out, (size_t)n);
+        hipLaunchKernelGGL(k_point_density, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->geom_dev, m->dens, in, n, res ? res : d_out, (uint8_t *)nullptr);
+        if (!res) HIP_TRY(ctx, d2h(ctx, out, d_out, 8 * n));
         return 0;
     });
 }
@@ -1132,9 +1157,11 @@ extern "C" int pdbeda_valid_crs(pdbeda_map *m, const int32_t *crs, int64_t n, ui
         Carver cv(base);
         int32_t *d_crs = cv.take<int32_t>(3 * n);
         uint8_t *d_out = cv.take<uint8_t>(n);
-        HIP_TRY(ctx, h2d_one(ctx, d_crs, crs, (size_t)(12 * n)));
-        hipLaunchKernelGGL(k_point_density, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->geom_dev, m->dens, d_crs, n, (double *)nullptr, d_out);
-        HIP_TRY(ctx, d2h(ctx, out, d_out, n));
+        const int32_t *in = pinned_in(ctx, crs, (size_t)(3 * n));
+        if (!in) { HIP_TRY(ctx, h2d_one(ctx, d_crs, crs, (size_t)(12 * n))); in = d_crs; }
+        uint8_t *res = pinned_out(ctx, out, (size_t)n);
+        hipLaunchKernelGGL(k_point_density, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->geom_dev, m->dens, in, n, (double *)nullptr, res ? res : d_out);
+        if (!res) HIP_TRY(ctx, d2h(ctx, out, d_out, n));
         return 0;
     });
 }
@@ -1148,9 +1175,11 @@ extern "C" int pdbeda_crs2xyz(pdbeda_map *m, const int32_t *crs, int64_t n, doub
         Carver cv(base);
         int32_t *d_crs = cv.take<int32_t>(3 * n);
         double *d_xyz = cv.take<double>(3 * n);
-        HIP_TRY(ctx, h2d_one(ctx, d_crs, crs, (size_t)(12 * n)));
-        hipLaunchKernelGGL(k_crs2xyz, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->geom_dev, d_crs, n, d_xyz);
-        HIP_TRY(ctx, d2h(ctx, xyz, d_xyz, 24 * n));
+        const int32_t *in = pinned_in(ctx, crs, (size_t)(3 * n));
+        if (!in) { HIP_TRY(ctx, h2d_one(ctx, d_crs, crs, (size_t)(12 * n))); in = d_crs; }
+        double *res = pinned_out(ctx, xyz, (size_t)(3 * n));
+        hipLaunchKernelGGL(k_crs2xyz, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->geom_dev, in, n, res ? res : d_xyz);
+        if (!res) HIP_TRY(ctx, d2h(ctx, xyz, d_xyz, 24 * n));
         return 0;
     });
 }
@@ -1164,9 +1193,11 @@ extern "C" int pdbeda_xyz2crs(pdbeda_map *m, const double *xyz, int64_t n, int32
         Carver cv(base);
         double *d_xyz = cv.take<double>(3 * n);
         int32_t *d_crs = cv.take<int32_t>(3 * n);
-        HIP_TRY(ctx, h2d_one(ctx, d_xyz, xyz, (size_t)(24 * n)));
-        hipLaunchKernelGGL(k_xyz2crs, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->geom_dev, d_xyz, n, d_crs);
-        HIP_TRY(ctx, d2h(ctx, crs, d_crs, 12 * n));
+        const double *in = pinned_in(ctx, xyz, (size_t)(3 * n));
+        if (!in) { HIP_TRY(ctx, h2d_one(ctx, d_xyz, xyz, (size_t)(24 * n))); in = d_xyz; }
+        int32_t *res = pinned_out(ctx, crs, (size_t)(3 * n));
+        hipLaunchKernelGGL(k_xyz2crs, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, m->geom_dev, in, n, res ? res : d_crs);
+        if (!res) HIP_TRY(ctx, d2h(ctx, crs, d_crs, 12 * n));
         return 0;
     });
 }
@@ -2323,17 +2354,20 @@ extern "C" int pdbeda_symmetry_atoms(pdbeda_ctx *ctx, const double *xyz, int64_t
             const H2DItem in[5] = {{d_xyz, xyz, (size_t)(24 * n_atoms)}, {d_rot, rot, (size_t)(96 * n_ops)}, {d_ortho, ortho, 72}, {d_lo, bbox_lo, 24}, {d_hi, bbox_hi, 24}};
             HIP_TRY(ctx, h2d_row(ctx, in, 5));      // (one copy: the five sit in a row)
         }
-        { PROF(ctx, "k_symmetry_keep"); hipLaunchKernelGGL(k_symmetry_keep, dim3(grid_for(total, 256)), dim3(256), 0, st, d_xyz, n_atoms, d_rot, (int)n_ops, d_ortho, d_lo, d_hi, d_keep); }
-        HIP_TRY(ctx, d2h(ctx, h_keep.data(), d_keep, 8 * n_words));
+        unsigned long long *r_keep = pinned_out(ctx, h_keep.data(), (size_t)n_words);
+        { PROF(ctx, "k_symmetry_keep"); hipLaunchKernelGGL(k_symmetry_keep, dim3(grid_for(total, 256)), dim3(256), 0, st, d_xyz, n_atoms, d_rot, (int)n_ops, d_ortho, d_lo, d_hi, r_keep ? r_keep : d_keep); }
+        if (!r_keep) HIP_TRY(ctx, d2h(ctx, h_keep.data(), d_keep, 8 * n_words));
         HIP_TRY(ctx, ctx_sync(ctx));
         for (int64_t w = 0; w < n_words; ++w)
             for (unsigned long long bits = h_keep[(size_t)w]; bits; bits &= bits - 1) picked.push_back(64 * w + __builtin_ctzll(bits));
         const int64_t n = (int64_t)picked.size();
         if (n == 0 || n > cap || !out_xyz) return 0;
         h_xyz.resize(3 * (size_t)n);
-        HIP_TRY(ctx, h2d_one(ctx, d_picked, picked.data(), (size_t)(8 * n)));
-        { PROF(ctx, "k_symmetry_pick"); hipLaunchKernelGGL(k_symmetry_pick, dim3(grid_for(n, 256)), dim3(256), 0, st, d_xyz, n_atoms, d_rot, (int)n_ops, d_ortho, d_lo, d_hi, d_picked, n, d_out); }
-        HIP_TRY(ctx, d2h(ctx, h_xyz.data(), d_out, 24 * n));
+        const int64_t *in_picked = pinned_in(ctx, picked.data(), (size_t)n);      // (a survivor's number is read by its own thread, once)
+        if (!in_picked) { HIP_TRY(ctx, h2d_one(ctx, d_picked, picked.data(), (size_t)(8 * n))); in_picked = d_picked; }
+        double *r_out = pinned_out(ctx, h_xyz.data(), 3 * (size_t)n);
+        { PROF(ctx, "k_symmetry_pick"); hipLaunchKernelGGL(k_symmetry_pick, dim3(grid_for(n, 256)), dim3(256), 0, st, d_xyz, n_atoms, d_rot, (int)n_ops, d_ortho, d_lo, d_hi, in_picked, n, r_out ? r_out : d_out); }
+        if (!r_out) HIP_TRY(ctx, d2h(ctx, h_xyz.data(), d_out, 24 * n));
         return 0;
     });
     if (rc) return rc;
@@ -2366,9 +2400,11 @@ extern "C" int pdbeda_nearest_atom(pdbeda_ctx *ctx, const double *centroids, int
             const H2DItem in[2] = {{d_c, centroids, (size_t)(24 * n_centroids)}, {d_a, atom_xyz, (size_t)(24 * n_atoms)}};
             HIP_TRY(ctx, h2d_row(ctx, in, 2));
         }
-        hipLaunchKernelGGL(k_nearest_atom, dim3((unsigned)n_centroids), dim3(256), 0, st, d_c, d_a, n_atoms, d_i, d_d);
-        HIP_TRY(ctx, d2h(ctx, index, d_i, 8 * n_centroids));
-        HIP_TRY(ctx, d2h(ctx, distance, d_d, 8 * n_centroids));
+        int64_t *r_i = pinned_out(ctx, index, (size_t)n_centroids);
+        double *r_d = pinned_out(ctx, distance, (size_t)n_centroids);
+        hipLaunchKernelGGL(k_nearest_atom, dim3((unsigned)n_centroids), dim3(256), 0, st, d_c, d_a, n_atoms, r_i ? r_i : d_i, r_d ? r_d : d_d);
+        if (!r_i) HIP_TRY(ctx, d2h(ctx, index, d_i, 8 * n_centroids));
+        if (!r_d) HIP_TRY(ctx, d2h(ctx, distance, d_d, 8 * n_centroids));
         return 0;
     });
 }
